@@ -1,0 +1,125 @@
+/*
+ * wavemamba_hip.h - C ABI of libwavemamba_hip.so, the MI355X (gfx950) implementation of the
+ * Wave-Mamba hot path: Haar DWT/IWT over NCHW feature maps, the selective-scan recurrence, and the
+ * SS2D four-direction scan core.
+ *
+ * The reference (AlexZou14/Wave-Mamba, citations into /root/reference/) is pure Python; its only
+ * FFI on this path is the pybind module `selective_scan_cuda.{fwd,bwd}` of the third-party package
+ * `mamba_ssm`, reached through `selective_scan_fn` (basicsr/archs/wavemamba_arch.py:6, :383,
+ * :465-471).  Each entry point below names the reference interface it replaces.  The Python host
+ * side (wave-mamba_amd/ops.py) binds these symbols with ctypes and mirrors the reference's
+ * operator surface (same names, argument meaning, error behaviour).
+ *
+ * Conventions
+ *   - Plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise.
+ *   - Ownership: the caller allocates every input, output and workspace buffer.  The library never
+ *     allocates or frees device memory and keeps no state between calls (profiling hooks aside).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls only enqueue work;
+ *     they never synchronise the host.
+ *   - Return value: WM_OK (0) on success; a negative WM_E* code for argument errors; a positive
+ *     value is a hipError_t from the launch.  wm_strerror() renders either.
+ *   - Tensors are dense, row-major ("contiguous") in the stated shape unless a stride is given.
+ *   - dtype codes: WM_F32 = 0 (float), WM_BF16 = 1 (bfloat16 storage, fp32 arithmetic unless noted).
+ */
+#ifndef WAVEMAMBA_HIP_H
+#define WAVEMAMBA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WM_OK 0
+#define WM_EINVAL (-1)      /* bad shape / size argument */
+#define WM_ENULL (-2)       /* required pointer is NULL */
+#define WM_EALIGN (-3)      /* pointer not aligned to the element size */
+#define WM_EWORKSPACE (-4)  /* workspace too small */
+#define WM_EUNSUPPORTED (-5)/* argument combination not implemented */
+
+#define WM_F32 0
+#define WM_BF16 1
+
+/* ABI version of this header (bumped on any signature change). */
+int wm_abi_version(void);
+const char* wm_strerror(int code);
+
+/* --------------------------------------------------------------------------------------------
+ * Haar DWT.  Replaces dwt_init(x) -> (x_LL, x_HL, x_LH, x_HH), wavemamba_arch.py:97-110
+ * (DWT.forward :138-139, called from DownFRG.forward :973).
+ *   x  (B, C, H, W)  H, W even   ->  ll, hl, lh, hh  each (B, C, H/2, W/2), same dtype as x.
+ * bf16: every add rounds to bf16 like the reference's eager bf16 tensor arithmetic.
+ * wm_dwt2d_bwd: gradient of the above; (dll, dhl, dlh, dhh) -> dx (B, C, H, W).
+ * -------------------------------------------------------------------------------------------- */
+int wm_dwt2d_fwd(const void* x, void* ll, void* hl, void* lh, void* hh,
+                 int B, int C, int H, int W, int dtype, void* stream);
+int wm_dwt2d_bwd(const void* dll, const void* dhl, const void* dlh, const void* dhh, void* dx,
+                 int B, int C, int H, int W, int dtype, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Haar IWT.  Replaces iwt_init(x) -> h, wavemamba_arch.py:113-130 (IWT.forward :147-148, called
+ * from upFRG.forward :1006 on cat([x_l, h_out_conv(x_h)], dim=1)).
+ * The reference takes one (B, 4C, h, w) tensor whose channel blocks are [x1 | x2 | x3 | x4].  Here
+ * each block is its own base pointer with its own batch stride (in elements), so the caller can
+ * pass the concatenated tensor (x_k = x + k*C*h*w, stride 4*C*h*w) or the un-concatenated pair
+ * (x1 = x_l, stride C*h*w;  x2..x4 = x_h + {0,1,2}*C*h*w, stride 3*C*h*w) without a copy.
+ *   out (B, C, 2h, 2w) is ALWAYS fp32 (reference :122-123), whatever `dtype` the inputs have.
+ * wm_idwt2d_bwd: dout (B, C, 2h, 2w) fp32 -> d1..d4 (same addressing, element type `dtype`).
+ * -------------------------------------------------------------------------------------------- */
+int wm_idwt2d_fwd(const void* x1, const void* x2, const void* x3, const void* x4,
+                  int64_t bs1, int64_t bs2, int64_t bs3, int64_t bs4,
+                  float* out, int B, int C, int h, int w, int dtype, void* stream);
+int wm_idwt2d_bwd(const float* dout, void* d1, void* d2, void* d3, void* d4,
+                  int64_t bs1, int64_t bs2, int64_t bs3, int64_t bs4,
+                  int B, int C, int h, int w, int dtype, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Selective scan.  Replaces mamba_ssm's
+ *   selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+ *                     return_last_state=False)
+ * as called at wavemamba_arch.py:465-471 (fp32 in / out / state, asserted at :472).
+ *   u, delta, z, out : (batch, dim, L) fp32          A : (dim, N) fp32
+ *   Bm, Cm           : (batch, G, N, L) fp32, dim % G == 0, channel d reads group d / (dim / G)
+ *   D, delta_bias    : (dim) fp32 or NULL            z : NULL = no gate (out = y), else y*silu(z)
+ *   last_state       : (batch, dim, N) fp32 or NULL
+ *   1 <= N <= 32.
+ *   delta' = softplus(delta + delta_bias) if delta_softplus else delta + delta_bias
+ *   h_t = exp(delta'_t A) h_{t-1} + delta'_t B_t u_t ;  y_t = <C_t, h_t> + D u_t
+ * The sequence is split into chunks scanned in parallel (local reduce -> carry scan -> local scan);
+ * `workspace` holds the per-chunk (decay product, end state) pairs; query its size first.
+ * -------------------------------------------------------------------------------------------- */
+size_t wm_selscan_fwd_workspace_bytes(int batch, int dim, int L, int N, int G);
+int wm_selscan_fwd(const float* u, const float* delta, const float* A, const float* Bm,
+                   const float* Cm, const float* D, const float* z, const float* delta_bias,
+                   float* out, float* last_state, void* workspace, size_t workspace_bytes,
+                   int batch, int dim, int L, int N, int G, int delta_softplus, void* stream);
+
+/* Backward of the above (mamba_ssm's selective_scan_cuda.bwd, reached by autograd in training,
+ * basicsr/models/femasr_model.py:181).  z is not supported (the reference passes z=None, :467).
+ *   dy (batch, dim, L) -> du, ddelta (batch, dim, L); dB, dC (batch, G, N, L);
+ *   dA (dim, N), dD (dim) or NULL, dbias (dim) or NULL.  All outputs are OVERWRITTEN.
+ */
+size_t wm_selscan_bwd_workspace_bytes(int batch, int dim, int L, int N, int G);
+int wm_selscan_bwd(const float* u, const float* delta, const float* A, const float* Bm,
+                   const float* Cm, const float* D, const float* delta_bias, const float* dy,
+                   float* du, float* ddelta, float* dA, float* dB, float* dC, float* dD,
+                   float* dbias, void* workspace, size_t workspace_bytes,
+                   int batch, int dim, int L, int N, int G, int delta_softplus, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Profiling hooks used by bench.py (HIP events recorded on the launch stream around each kernel
+ * class).  Disabled by default; when disabled the library records nothing.
+ *   kernel ids: 0 dwt/analysis, 1 iwt/synthesis, 2 scan chunk-reduce, 3 scan carry,
+ *               4 scan chunk-scan (the dominant kernel), 5 scan bwd
+ * wm_prof_collect synchronises the recorded events (host-blocking) and returns, per kernel id,
+ * the number of launches and their summed duration in milliseconds since wm_prof_enable(1).
+ * -------------------------------------------------------------------------------------------- */
+#define WM_PROF_NKERNELS 8
+void wm_prof_enable(int on);
+int wm_prof_collect(int* launches /*[WM_PROF_NKERNELS]*/, double* total_ms /*[WM_PROF_NKERNELS]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVEMAMBA_HIP_H */

@@ -1,0 +1,140 @@
+"""CPU: the re-built WaveMamba arch (host logic, registry surface, state-dict layout, seeded init)
+against goldens captured from the reference, with the C oracle installed as the ops backend.
+The product backend is HIP-only; installing the oracle here is test infrastructure."""
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, assert_close
+from oracle import oracle
+import wave_mamba_amd as wm
+from wave_mamba_amd.archs import wavemamba_arch as arch
+
+SHIPPED = dict(in_chn=3, wf=32, n_l_blocks=[1, 2, 4], n_h_blocks=[1, 1, 2], ffn_scale=2.0)
+
+
+@pytest.fixture()
+def oracle_backend():
+    prev = arch.set_ops_backend(oracle)
+    yield
+    arch.set_ops_backend(prev)
+
+
+@pytest.fixture(scope="module")
+def meta():
+    with open(os.path.join(GOLDEN, "model_shipped_meta.json")) as f:
+        return json.load(f)
+
+
+def gen(seed):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return g
+
+
+def test_registry_surface():
+    assert "WaveMamba" in wm.ARCH_REGISTRY
+    net = wm.build_network(dict(type="WaveMamba", in_chn=3, wf=8, n_l_blocks=[1, 1, 1],
+                                n_h_blocks=[1, 1, 1], ffn_scale=2.0, some_ignored_kwarg=1))
+    assert isinstance(net, wm.WaveMamba) and hasattr(net, "restoration_network")
+    for meth in ("forward", "test", "test_tile", "check_image_size", "encode_and_decode", "print_network"):
+        assert callable(getattr(net, meth))
+    with pytest.raises(TypeError):
+        wm.WaveMamba(3, 8)                       # keyword-only like the reference (:1068-1070)
+    with pytest.raises(AssertionError):          # name uniqueness (registry.py:38-41)
+        wm.ARCH_REGISTRY.register(wm.WaveMamba)
+    with pytest.raises(KeyError):
+        wm.ARCH_REGISTRY.get("UWMamba")          # the LOL yaml's unregistered type
+
+
+def test_state_dict_layout_and_seeded_init(meta):
+    torch.manual_seed(0)
+    net = wm.WaveMamba(**SHIPPED)
+    sd = net.state_dict()
+    assert sum(p.numel() for p in net.parameters()) == meta["n_params"] == 1512718
+    assert list(sd.keys()) == list(meta["keys"].keys())            # same keys, same order (591)
+    for k, shape in meta["keys"].items():
+        assert list(sd[k].shape) == shape, k
+    # seeded init reproduces the reference's weights bit for bit (float64 fingerprints)
+    for k, (s, a) in meta["init_fingerprint"].items():
+        v = sd[k].double()
+        assert float(v.sum()) == s and float(v.abs().sum()) == a, f"init of {k} differs"
+
+
+def test_product_backend_refuses_cpu_tensors():
+    # no silent CPU fallback in the product path
+    with pytest.raises(RuntimeError):
+        wm.ops.dwt_init(torch.zeros(1, 1, 4, 4))
+    with pytest.raises(RuntimeError):
+        wm.ops.selective_scan_fn(torch.zeros(1, 4, 8), torch.zeros(1, 4, 8), -torch.ones(4, 2),
+                                 torch.zeros(1, 1, 2, 8), torch.zeros(1, 1, 2, 8))
+
+
+def test_tiny_model_with_reference_weights(golden, oracle_backend):
+    g = golden("model_tiny")
+    net = wm.WaveMamba(in_chn=3, wf=8, n_l_blocks=[1, 1, 2], n_h_blocks=[1, 1, 1], ffn_scale=2.0).eval()
+    missing = net.load_state_dict({k[2:]: v for k, v in g.items() if k.startswith("p.")}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    with torch.no_grad():
+        y = net(g["x"])
+    assert_close(y, g["y"], 1e-5, "tiny model output")
+
+
+@pytest.mark.parametrize("tag,hw", [("32x64", (32, 64)), ("128x128", (128, 128)), ("256x256", (256, 256))])
+def test_shipped_config_forward(golden, meta, oracle_backend, tag, hw):
+    torch.manual_seed(0)
+    net = wm.WaveMamba(**SHIPPED).eval()
+    x = torch.rand(1, 3, *hw, generator=gen(1234))
+    with torch.no_grad():
+        y = net.restoration_network(x)        # the attribute inference_wavemamba.py:109 calls
+    assert_close(y, golden("model_shipped")[f"y_{tag}"], 1e-5, f"shipped {tag}")
+    s, m, a = meta[f"out_stats_{tag}"]
+    assert abs(float(y.sum()) - s) <= 1e-4 * abs(s)
+
+
+def test_lfss_block(golden, oracle_backend):
+    g = golden("lfss_block")
+    blk = arch.LFSSBlock(32, expand=2.0).eval()
+    blk.load_state_dict({k[2:]: v for k, v in g.items() if k.startswith("p.")}, strict=True)
+    with torch.no_grad():
+        y = blk(g["x"], [8, 12])
+    assert_close(y, g["y"], 1e-5, "LFSSBlock")
+
+
+def test_training_step_gradients(meta, oracle_backend):
+    """optimize_parameters of the reference trainer (femasr_model.py:157-185): L1 + 0.1*FFT-L1."""
+    torch.manual_seed(0)
+    net = wm.WaveMamba(**SHIPPED).train()
+    lq = torch.rand(2, 3, 64, 64, generator=gen(1234))
+    gt = torch.rand(2, 3, 64, 64, generator=gen(4321))
+    pred = net(lq)
+    l_pix = F.l1_loss(pred, gt)
+    pf, gf = torch.fft.rfft2(pred), torch.fft.rfft2(gt)
+    l_fft = 0.1 * F.l1_loss(torch.stack([pf.real, pf.imag], -1), torch.stack([gf.real, gf.imag], -1))
+    (l_pix + l_fft).backward()
+    assert abs(float(l_pix) - meta["train_losses"][0]) < 1e-5
+    assert abs(float(l_fft) - meta["train_losses"][1]) < 1e-4
+    worst = 0.0
+    for k, p in net.named_parameters():
+        assert p.grad is not None, f"{k} got no gradient"
+        s, a = meta["grad_fingerprint"][k]
+        got = float(p.grad.double().abs().sum())
+        worst = max(worst, abs(got - a) / max(a, 1e-12))
+    assert worst < 2e-3, f"worst abs-sum grad deviation {worst:.3e}"
+
+
+def test_check_image_size_and_tiling(oracle_backend):
+    torch.manual_seed(0)
+    net = wm.WaveMamba(in_chn=3, wf=8, n_l_blocks=[1, 1, 1], n_h_blocks=[1, 1, 1], ffn_scale=2.0).eval()
+    x = torch.rand(1, 3, 30, 45)
+    xp = net.check_image_size(x)
+    assert xp.shape == (1, 3, 32, 48)
+    assert torch.equal(xp[:, :, :30, :45], x)
+    assert torch.equal(xp[:, :, 30:, :45], x[:, :, [28, 27], :])      # reflect padding
+    y = net.test(xp)
+    assert y.shape == xp.shape and not y.requires_grad
+    yt = net.test_tile(xp, tile_size=16, tile_pad=8)
+    assert yt.shape == xp.shape

@@ -1,0 +1,71 @@
+"""ctypes binding of libwavemamba_hip.so (C ABI declared in include/wavemamba_hip.h).
+
+The product path has NO fallback: if the library is missing or fails to load, every op raises.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libwavemamba_hip.so")
+
+WM_F32, WM_BF16 = 0, 1
+WM_PROF_NKERNELS = 8
+ABI_VERSION = 1
+
+_c = ctypes
+_p, _i, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
+
+# name -> (restype, argtypes); mirrors include/wavemamba_hip.h one to one
+SIGNATURES = {
+    "wm_abi_version": (_i, []),
+    "wm_strerror": (_c.c_char_p, [_i]),
+    "wm_dwt2d_fwd": (_i, [_p] * 5 + [_i] * 5 + [_p]),
+    "wm_dwt2d_bwd": (_i, [_p] * 5 + [_i] * 5 + [_p]),
+    "wm_idwt2d_fwd": (_i, [_p] * 4 + [_i64] * 4 + [_p] + [_i] * 5 + [_p]),
+    "wm_idwt2d_bwd": (_i, [_p] * 5 + [_i64] * 4 + [_i] * 5 + [_p]),
+    "wm_selscan_fwd_workspace_bytes": (_sz, [_i] * 5),
+    "wm_selscan_fwd": (_i, [_p] * 10 + [_p, _sz] + [_i] * 6 + [_p]),
+    "wm_selscan_bwd_workspace_bytes": (_sz, [_i] * 5),
+    "wm_selscan_bwd": (_i, [_p] * 15 + [_p, _sz] + [_i] * 6 + [_p]),
+    "wm_prof_enable": (None, [_i]),
+    "wm_prof_collect": (_i, [_c.POINTER(_i), _c.POINTER(_c.c_double)]),
+}
+
+_lib = None
+
+
+class WaveMambaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises WaveMambaHipError if it is absent - never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WaveMambaHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). The Wave-Mamba hot path has no CPU or PyTorch fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise WaveMambaHipError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise WaveMambaHipError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.wm_abi_version() != ABI_VERSION:
+        raise WaveMambaHipError(f"ABI mismatch: library {lib.wm_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    """Non-zero status -> RuntimeError (the reference raises RuntimeError on shape errors)."""
+    if code != 0:
+        msg = load().wm_strerror(code).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {code})")

@@ -1,0 +1,545 @@
+"""WaveMamba for MI355X: the reference's `ARCH_REGISTRY` entry, re-built on the HIP hot path.
+
+Boundary contract (citations into /root/reference/basicsr/archs/wavemamba_arch.py):
+  * registered under the name `WaveMamba` (:1066); ctor `WaveMamba(*, in_chn, wf, n_l_blocks,
+    n_h_blocks, ffn_scale, **ignore_kwargs)` (:1068-1075); attribute `restoration_network`
+    (:1077, used directly by inference_wavemamba.py:109); methods forward / test / test_tile /
+    check_image_size / encode_and_decode / print_network (:1079-1176);
+  * identical state-dict keys and shapes (591 for the shipped config), so reference-format
+    checkpoints `torch.load(p)['params']` load unchanged (inference_wavemamba.py:77);
+  * modules are created in the reference's order, so `torch.manual_seed(s)` + construction yields
+    the reference's initial weights bit for bit (checked by tests against committed fingerprints).
+
+Hot path (the part that is NOT PyTorch): the three Haar DWTs and three IWTs per forward
+(DownFRG / upFRG) and the 14 selective scans (one per LFSSBlock) go to hand-written gfx950 kernels
+through `wave_mamba_amd.ops`.  Everything else (HFEBlock branch, small convs, LayerNorms) stays on
+PyTorch-ROCm as SURVEY.md section 8 scopes it.
+
+This file can be dropped into a `basicsr/archs/` folder: the auto-scan (`archs/__init__.py:12-16`)
+imports every `*_arch.py`, and the registry resolution in `registry.py` then binds to the real
+`basicsr.utils.registry.ARCH_REGISTRY`.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+try:                                                   # inside the wave_mamba_amd package
+    from .. import ops as _hip_ops
+    from ..registry import ARCH_REGISTRY
+except ImportError:                                    # dropped into basicsr/archs/
+    import wave_mamba_amd.ops as _hip_ops
+    from basicsr.utils.registry import ARCH_REGISTRY
+
+
+class _OpsBackend:
+    """Where the hot-path operators come from.  The product backend is the HIP library; tests and
+    bench.py's cpu_baseline leg may install the CPU oracle here to check / time the same network.
+    Nothing in this package ever installs anything but the HIP backend."""
+    impl = _hip_ops
+
+
+def set_ops_backend(backend):
+    """Install an object exposing dwt_init, iwt_init_pair, selective_scan_fn (test infrastructure)."""
+    prev = _OpsBackend.impl
+    _OpsBackend.impl = backend
+    return prev
+
+
+def get_ops_backend():
+    return _OpsBackend.impl
+
+
+# ================================================================================================
+# Low-frequency branch: SS2D / LFSSBlock
+# ================================================================================================
+class DWT(nn.Module):
+    """Haar analysis (reference :133-139)."""
+
+    def forward(self, x):
+        return _OpsBackend.impl.dwt_init(x)
+
+
+class IWT(nn.Module):
+    """Haar synthesis (reference :142-148); also accepts the un-concatenated (x_l, x_h) pair."""
+
+    def forward(self, x, x_h=None):
+        if x_h is None:
+            return _OpsBackend.impl.iwt_init(x)
+        return _OpsBackend.impl.iwt_init_pair(x, x_h)
+
+
+class ffn(nn.Module):
+    """Gated depth-wise conv feed-forward of LFSSBlock (reference :214-231)."""
+
+    def __init__(self, num_feat, ffn_expand=2):
+        super().__init__()
+        hidden = num_feat * ffn_expand
+        self.conv1 = nn.Conv2d(num_feat, hidden, kernel_size=1)
+        self.conv2 = nn.Conv2d(hidden, hidden, kernel_size=3, padding=1, groups=hidden)
+        self.conv3 = nn.Conv2d(hidden // 2, num_feat, kernel_size=1)
+
+    def forward(self, x):
+        gate, value = self.conv2(self.conv1(x)).chunk(2, dim=1)
+        return self.conv3(F.gelu(gate) * value)
+
+
+class SS2D(nn.Module):
+    """Four-direction selective-scan block (reference :316-497).
+
+    Parameter names, shapes and initialisers follow :345-386 / :389-444 exactly:
+      in_proj.weight (2D_in, C) | conv2d.{weight (D_in,1,3,3), bias} | x_proj_weight (4, R+2N, D_in)
+      dt_projs_weight (4, D_in, R) | dt_projs_bias (4, D_in) | A_logs (4 D_in, N) | Ds (4 D_in)
+      out_norm.{weight,bias} (D_in) | out_proj.weight (C, D_in)
+    """
+
+    def __init__(self, d_model, d_state=16, d_conv=3, expand=2, dt_rank="auto", dt_min=0.001,
+                 dt_max=0.1, dt_init="random", dt_scale=1.0, dt_init_floor=1e-4, dropout=0.0,
+                 conv_bias=True, bias=False, device=None, dtype=None, **kwargs):
+        super().__init__()
+        fk = {"device": device, "dtype": dtype}
+        self.d_model, self.d_state, self.d_conv, self.expand = d_model, d_state, d_conv, expand
+        self.d_inner = int(expand * d_model)
+        self.dt_rank = math.ceil(d_model / 16) if dt_rank == "auto" else dt_rank
+        K = 4
+
+        self.in_proj = nn.Linear(d_model, 2 * self.d_inner, bias=bias, **fk)
+        self.conv2d = nn.Conv2d(self.d_inner, self.d_inner, kernel_size=d_conv, padding=(d_conv - 1) // 2,
+                                groups=self.d_inner, bias=conv_bias, **fk)
+        self.act = nn.SiLU()
+
+        # per-direction projections, stacked into single parameters (:357-378)
+        xp = [nn.Linear(self.d_inner, self.dt_rank + 2 * d_state, bias=False, **fk) for _ in range(K)]
+        self.x_proj_weight = nn.Parameter(torch.stack([m.weight for m in xp], dim=0))
+        dtp = [self.dt_init(self.dt_rank, self.d_inner, dt_scale, dt_init, dt_min, dt_max, dt_init_floor, **fk)
+               for _ in range(K)]
+        self.dt_projs_weight = nn.Parameter(torch.stack([m.weight for m in dtp], dim=0))
+        self.dt_projs_bias = nn.Parameter(torch.stack([m.bias for m in dtp], dim=0))
+
+        self.A_logs = self.A_log_init(d_state, self.d_inner, copies=K, merge=True)
+        self.Ds = self.D_init(self.d_inner, copies=K, merge=True)
+
+        self.out_norm = nn.LayerNorm(self.d_inner)
+        self.out_proj = nn.Linear(self.d_inner, d_model, bias=bias, **fk)
+        self.dropout = nn.Dropout(dropout) if dropout > 0.0 else None
+
+    # ---- initialisers (:389-444) ------------------------------------------------------------
+    @staticmethod
+    def dt_init(dt_rank, d_inner, dt_scale=1.0, dt_init="random", dt_min=0.001, dt_max=0.1,
+                dt_init_floor=1e-4, **fk):
+        proj = nn.Linear(dt_rank, d_inner, bias=True, **fk)
+        std = dt_rank ** -0.5 * dt_scale
+        if dt_init == "constant":
+            nn.init.constant_(proj.weight, std)
+        elif dt_init == "random":
+            nn.init.uniform_(proj.weight, -std, std)
+        else:
+            raise NotImplementedError
+        # bias = softplus^-1(dt), dt log-uniform in [dt_min, dt_max]
+        dt = torch.exp(torch.rand(d_inner, **fk) * (math.log(dt_max) - math.log(dt_min))
+                       + math.log(dt_min)).clamp(min=dt_init_floor)
+        with torch.no_grad():
+            proj.bias.copy_(dt + torch.log(-torch.expm1(-dt)))
+        proj.bias._no_reinit = True
+        return proj
+
+    @staticmethod
+    def A_log_init(d_state, d_inner, copies=1, device=None, merge=True):
+        A_log = torch.log(torch.arange(1, d_state + 1, dtype=torch.float32, device=device))
+        A_log = A_log.repeat(d_inner, 1).contiguous()                 # S4D-real: A[d, n] = n + 1
+        if copies > 1:
+            A_log = A_log.unsqueeze(0).repeat(copies, 1, 1)
+            if merge:
+                A_log = A_log.flatten(0, 1)
+        A_log = nn.Parameter(A_log)
+        A_log._no_weight_decay = True
+        return A_log
+
+    @staticmethod
+    def D_init(d_inner, copies=1, device=None, merge=True):
+        D = torch.ones(d_inner, device=device)
+        if copies > 1:
+            D = D.unsqueeze(0).repeat(copies, 1)
+            if merge:
+                D = D.flatten(0, 1)
+        D = nn.Parameter(D)
+        D._no_weight_decay = True
+        return D
+
+    # ---- forward ----------------------------------------------------------------------------
+    def forward_core(self, x):
+        """x (B, D_in, H, W) -> four (B, D_in, L) tensors in row-major l (reference :446-478)."""
+        ops = _OpsBackend.impl
+        if hasattr(ops, "ss2d_core"):
+            return ops.ss2d_core(x, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias,
+                                 self.A_logs, self.Ds)
+        B, D, H, W = x.shape
+        L, K, N, R = H * W, 4, self.d_state, self.dt_rank
+        row = x.reshape(B, D, L)
+        col = x.transpose(2, 3).reshape(B, D, L)                      # l = w*H + h
+        fwd = torch.stack([row, col], dim=1)                          # (B, 2, D, L)
+        xs = torch.cat([fwd, fwd.flip(-1)], dim=1)                    # (B, 4, D, L)
+        x_dbl = torch.einsum("bkdl,kcd->bkcl", xs, self.x_proj_weight)
+        dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
+        dts = torch.einsum("bkrl,kdr->bkdl", dts, self.dt_projs_weight)
+        out = ops.selective_scan_fn(
+            xs.float().reshape(B, K * D, L), dts.contiguous().float().reshape(B, K * D, L),
+            -torch.exp(self.A_logs.float()), Bs.float(), Cs.float(), self.Ds.float(), z=None,
+            delta_bias=self.dt_projs_bias.float().reshape(-1), delta_softplus=True,
+            return_last_state=False).reshape(B, K, D, L)
+        assert out.dtype == torch.float32
+        back = out[:, 2:4].flip(-1)
+        y_col = out[:, 1].reshape(B, D, W, H).transpose(2, 3).reshape(B, D, L)
+        y_col_back = back[:, 1].reshape(B, D, W, H).transpose(2, 3).reshape(B, D, L)
+        return out[:, 0], back[:, 0], y_col, y_col_back
+
+    def forward(self, x, **kwargs):
+        B, H, W, C = x.shape
+        x, z = self.in_proj(x).chunk(2, dim=-1)
+        x = self.act(self.conv2d(x.permute(0, 3, 1, 2).contiguous()))
+        y1, y2, y3, y4 = self.forward_core(x)
+        assert y1.dtype == torch.float32
+        y = (y1 + y2 + y3 + y4).transpose(1, 2).contiguous().view(B, H, W, -1)
+        y = self.out_norm(y) * F.silu(z)
+        y = self.out_proj(y)
+        return self.dropout(y) if self.dropout is not None else y
+
+
+class LFSSBlock(nn.Module):
+    """LN -> SS2D -> scaled skip; LN -> gated conv ffn -> scaled skip, on (B, HW, C) (:499-528)."""
+
+    def __init__(self, hidden_dim=0, drop_path=0.0, norm_layer=None, attn_drop_rate=0.0, d_state=16,
+                 expand=2.0, **kwargs):
+        super().__init__()
+        if drop_path:
+            raise NotImplementedError("stochastic depth is unused by the reference (rate 0, :513)")
+        self.ln_1 = norm_layer(hidden_dim) if norm_layer is not None else nn.LayerNorm(hidden_dim, eps=1e-6)
+        self.self_attention = SS2D(d_model=hidden_dim, d_state=d_state, expand=expand,
+                                   dropout=attn_drop_rate, **kwargs)
+        self.drop_path = nn.Identity()
+        self.skip_scale = nn.Parameter(torch.ones(hidden_dim))
+        self.conv_blk = ffn(hidden_dim)
+        self.ln_2 = nn.LayerNorm(hidden_dim)
+        self.skip_scale2 = nn.Parameter(torch.ones(hidden_dim))
+
+    def forward(self, input, x_size):
+        B, L, C = input.shape
+        tok = input.view(B, x_size[0], x_size[1], C)
+        tok = tok * self.skip_scale + self.drop_path(self.self_attention(self.ln_1(tok)))
+        mix = self.conv_blk(self.ln_2(tok).permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1)
+        tok = tok * self.skip_scale2 + mix
+        return tok.reshape(B, L, C)
+
+
+# ================================================================================================
+# High-frequency branch: HFEBlock family (PyTorch-ROCm; out of HIP scope)
+# ================================================================================================
+class LayerNorm2d(nn.Module):
+    """Per-pixel LayerNorm over channels of an NCHW map, eps 1e-6 (reference :532-569)."""
+
+    def __init__(self, channels, eps=1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(channels))
+        self.bias = nn.Parameter(torch.zeros(channels))
+        self.eps = eps
+
+    def forward(self, x):
+        mu = x.mean(1, keepdim=True)
+        var = (x - mu).pow(2).mean(1, keepdim=True)
+        y = (x - mu) / (var + self.eps).sqrt()
+        return self.weight.view(1, -1, 1, 1) * y + self.bias.view(1, -1, 1, 1)
+
+
+def nearest_candidate_maps(maps, candidates, num_matches):
+    """Channel matching (reference :618-666): for every channel of `maps` (B, C, HW) find its
+    L2-nearest channel of `candidates`; keep the `num_matches` channels whose nearest distance is
+    smallest (original channel order) and return the matched candidate maps (B, num_matches, HW)."""
+    dist = torch.cdist(maps, candidates)                            # (B, C, C)
+    best_val, best_idx = dist.topk(k=1, largest=False)
+    best_val, best_idx = best_val.squeeze(-1), best_idx.squeeze(-1)
+    if num_matches is None or num_matches == -1:
+        num_matches = maps.size(1)
+    if num_matches < maps.size(1):
+        rank = best_val.argsort(dim=1).argsort(dim=1)               # rank of each channel's distance
+        best_idx = best_idx.masked_select(rank < num_matches).reshape(maps.size(0), num_matches)
+    gather_idx = best_idx.unsqueeze(-1).expand(-1, -1, candidates.size(2))
+    return torch.gather(candidates, 1, gather_idx)
+
+
+class Matching(nn.Module):
+    def __init__(self, dim=32, match_factor=1):
+        super().__init__()
+        self.num_matching = int(dim / match_factor)
+
+    def forward(self, x, perception):
+        b, c, h, w = x.shape
+        matched = nearest_candidate_maps(x.flatten(2), perception.flatten(2), self.num_matching)
+        return matched.reshape(b, self.num_matching, h, w)
+
+
+class PAConv(nn.Module):
+    """Pixel-attention conv: k4(k3(x) * sigmoid(k2(x))) (reference :683-700)."""
+
+    def __init__(self, nf, k_size=3):
+        super().__init__()
+        self.k2 = nn.Conv2d(nf, nf, 1)
+        self.sigmoid = nn.Sigmoid()
+        self.k3 = nn.Conv2d(nf, nf, kernel_size=k_size, padding=(k_size - 1) // 2, bias=False)
+        self.k4 = nn.Conv2d(nf, nf // 2, kernel_size=k_size, padding=(k_size - 1) // 2, bias=False)
+
+    def forward(self, x):
+        return self.k4(self.k3(x) * self.sigmoid(self.k2(x)))
+
+
+class Matching_transformation(nn.Module):
+    def __init__(self, dim=32, match_factor=1, ffn_expansion_factor=1, bias=True):
+        super().__init__()
+        self.num_matching = int(dim / match_factor)
+        self.channel = dim
+        self.matching = Matching(dim=dim, match_factor=match_factor)
+        self.paconv = PAConv(dim * 2)
+
+    def forward(self, x, perception):
+        return self.paconv(torch.cat([x, self.matching(x, perception)], dim=1))
+
+
+class FeedForward(nn.Module):
+    """HFE feed-forward (reference :721-751)."""
+
+    def __init__(self, dim=32, match_factor=4, ffn_expansion_factor=1, bias=True, ffn_matching=True):
+        super().__init__()
+        self.num_matching = int(dim / match_factor)
+        self.channel = dim
+        self.matching = ffn_matching
+        hidden = int(dim * ffn_expansion_factor)
+        self.project_in = nn.Sequential(
+            nn.Conv2d(dim, hidden, 1, bias=bias),
+            nn.Conv2d(hidden, dim, kernel_size=3, stride=1, padding=1, groups=dim, bias=bias))
+        if self.matching is True:
+            self.matching_transformation = Matching_transformation(
+                dim=dim, match_factor=match_factor, ffn_expansion_factor=ffn_expansion_factor, bias=bias)
+        self.project_out = nn.Sequential(
+            nn.Conv2d(dim, hidden, kernel_size=3, stride=1, padding=1, groups=dim, bias=bias),
+            nn.GELU(),
+            nn.Conv2d(hidden, dim, 1, bias=bias))
+
+    def forward(self, x, perception):
+        y = self.project_in(x)
+        if perception is not None:
+            y = self.matching_transformation(y, perception)
+        return self.project_out(y)
+
+
+class CMTAttention(nn.Module):
+    """Transposed (channel) attention with channel-matched queries (reference :756-798)."""
+
+    def __init__(self, dim, num_heads, match_factor=4, ffn_expansion_factor=1, scale_factor=8, bias=True,
+                 attention_matching=True):
+        super().__init__()
+        self.num_heads = num_heads
+        self.temperature = nn.Parameter(torch.ones(num_heads, 1, 1))
+        self.qkv = nn.Conv2d(dim, dim * 3, kernel_size=1, bias=bias)
+        self.qkv_dwconv = nn.Conv2d(dim * 3, dim * 3, kernel_size=3, stride=1, padding=1, groups=dim * 3,
+                                    bias=bias)
+        self.project_out = nn.Conv2d(dim, dim, kernel_size=1, bias=bias)
+        self.matching = attention_matching
+        if self.matching is True:
+            self.matching_transformation = Matching_transformation(
+                dim=dim, match_factor=match_factor, ffn_expansion_factor=ffn_expansion_factor, bias=bias)
+
+    def forward(self, x, perception):
+        b, c, h, w = x.shape
+        q, k, v = self.qkv_dwconv(self.qkv(x)).chunk(3, dim=1)
+        if self.matching is True:
+            q = self.matching_transformation(q, perception)
+        heads = self.num_heads
+        q = F.normalize(q.reshape(b, heads, c // heads, h * w), dim=-1)
+        k = F.normalize(k.reshape(b, heads, c // heads, h * w), dim=-1)
+        v = v.reshape(b, heads, c // heads, h * w)
+        attn = ((q @ k.transpose(-2, -1)) * self.temperature).softmax(dim=-1)
+        return self.project_out((attn @ v).reshape(b, c, h, w))
+
+
+class HFEBlock(nn.Module):
+    """High-frequency enhancement block (reference :822-854); `perception` is the low-freq map."""
+
+    def __init__(self, dim=48, num_heads=1, match_factor=4, ffn_expansion_factor=1, bias=True,
+                 attention_matching=True, ffn_matching=True, ffn_restormer=False):
+        super().__init__()
+        if ffn_restormer:
+            raise NotImplementedError("ffn_restormer=True is never instantiated by the reference UNet")
+        self.dim = dim
+        self.norm1 = LayerNorm2d(dim)
+        self.attn = CMTAttention(dim=dim, num_heads=num_heads, match_factor=match_factor,
+                                 ffn_expansion_factor=ffn_expansion_factor, bias=bias,
+                                 attention_matching=attention_matching)
+        self.norm2 = LayerNorm2d(dim)
+        self.ffn_restormer = ffn_restormer
+        self.ffn = FeedForward(dim=dim, match_factor=match_factor, ffn_expansion_factor=ffn_expansion_factor,
+                               bias=bias, ffn_matching=ffn_matching)
+        self.LayerNorm = LayerNorm2d(dim)
+
+    def forward(self, x, perception):
+        p = self.LayerNorm(perception)
+        x = x + self.attn(self.norm1(x), p)
+        return x + self.ffn(self.norm2(x), p)
+
+
+class SKFF(nn.Module):
+    """Selective-kernel fusion of the three detail sub-bands (reference :923-959)."""
+
+    def __init__(self, in_channels, height=3, reduction=8, bias=False):
+        super().__init__()
+        self.height = height
+        d = max(int(in_channels / reduction), 4)
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.conv_du = nn.Sequential(nn.Conv2d(in_channels, d, 1, padding=0, bias=bias), nn.PReLU())
+        self.fcs = nn.ModuleList([nn.Conv2d(d, in_channels, kernel_size=1, stride=1, bias=bias)
+                                  for _ in range(height)])
+        self.softmax = nn.Softmax(dim=1)
+
+    def forward(self, inp_feats):
+        b, c = inp_feats[0].shape[:2]
+        stack = torch.stack(list(inp_feats), dim=1)                    # (B, height, C, H, W)
+        squeeze = self.conv_du(self.avg_pool(stack.sum(dim=1)))
+        weights = torch.cat([fc(squeeze) for fc in self.fcs], dim=1).view(b, self.height, c, 1, 1)
+        return (stack * self.softmax(weights)).sum(dim=1)
+
+
+# ================================================================================================
+# Wavelet U-Net
+# ================================================================================================
+def _tokens(x):        # (B, C, H, W) -> (B, HW, C)
+    return x.flatten(2).transpose(1, 2).contiguous()
+
+
+def _maps(t, h, w):    # (B, HW, C) -> (B, C, H, W)
+    return t.transpose(1, 2).reshape(t.shape[0], t.shape[2], h, w).contiguous()
+
+
+class DownFRG(nn.Module):
+    """DWT -> low-freq LFSS stack + high-freq SKFF/HFE stack (reference :962-985)."""
+
+    def __init__(self, dim, n_l_blocks=1, n_h_blocks=1, expand=2):
+        super().__init__()
+        self.dwt = DWT()
+        self.l_conv = nn.Conv2d(dim * 2, dim, 3, 1, 1)
+        self.l_blk = nn.Sequential(*[LFSSBlock(dim, expand=expand) for _ in range(n_l_blocks)])
+        self.h_fusion = SKFF(dim, height=3, reduction=8)
+        self.h_blk = nn.Sequential(*[HFEBlock(dim, match_factor=1, ffn_expansion_factor=1)
+                                     for _ in range(n_h_blocks)])
+
+    def forward(self, x, x_d):
+        ll, hl, lh, hh = self.dwt(x)
+        h, w = ll.shape[2:]
+        low = _tokens(self.l_conv(torch.cat([ll, x_d], dim=1)))
+        for blk in self.l_blk:
+            low = blk(low, [h, w])
+        low = _maps(low, h, w)
+        high = self.h_fusion([hl, lh, hh])
+        for blk in self.h_blk:
+            high = blk(high, low)
+        return low, high
+
+
+class upFRG(nn.Module):
+    """LFSS stack + HFE stack -> IWT (reference :987-1008)."""
+
+    def __init__(self, dim, n_l_blocks=1, n_h_blocks=1, expand=2):
+        super().__init__()
+        self.iwt = IWT()
+        self.l_blk = nn.Sequential(*[LFSSBlock(dim, expand=expand) for _ in range(n_l_blocks)])
+        self.h_out_conv = nn.Conv2d(dim, dim * 3, 3, 1, 1)
+        self.h_blk = nn.Sequential(*[HFEBlock(dim, match_factor=1, ffn_expansion_factor=1)
+                                     for _ in range(n_h_blocks)])
+
+    def forward(self, x_l, x_h):
+        h, w = x_l.shape[2:]
+        low = _tokens(x_l)
+        for blk in self.l_blk:
+            low = blk(low, [h, w])
+        low = _maps(low, h, w)
+        for blk in self.h_blk:
+            x_h = blk(x_h, low)
+        # reference: iwt(cat([x_l, h_out_conv(x_h)], 1)); the pair form skips the concatenation
+        return self.iwt(low, self.h_out_conv(x_h))
+
+
+class UNet(nn.Module):
+    """Three-level wavelet U-Net (reference :1011-1063)."""
+
+    def __init__(self, in_chn=3, wf=48, n_l_blocks=[1, 1, 2], n_h_blocks=[1, 1, 1], ffn_scale=2):
+        super().__init__()
+        self.ps_down1 = nn.Sequential(nn.PixelUnshuffle(2), nn.Conv2d(4 * in_chn, wf, 1, 1, 0))
+        self.ps_down2 = nn.Sequential(nn.PixelUnshuffle(4), nn.Conv2d(16 * in_chn, wf, 1, 1, 0))
+        self.ps_down3 = nn.Sequential(nn.PixelUnshuffle(8), nn.Conv2d(64 * in_chn, wf, 1, 1, 0))
+        self.conv_01 = nn.Conv2d(in_chn, wf, 3, 1, 1)
+        self.down_group1 = DownFRG(wf, n_l_blocks[0], n_h_blocks[0], expand=ffn_scale)
+        self.down_group2 = DownFRG(wf, n_l_blocks[1], n_h_blocks[1], expand=ffn_scale)
+        self.down_group3 = DownFRG(wf, n_l_blocks[2], n_h_blocks[2], expand=ffn_scale)
+        self.up_group3 = upFRG(wf, n_l_blocks[2], n_h_blocks[2], expand=ffn_scale)
+        self.up_group2 = upFRG(wf, n_l_blocks[1], n_h_blocks[1], expand=ffn_scale)
+        self.up_group1 = upFRG(wf, n_l_blocks[0], n_h_blocks[0], expand=ffn_scale)
+        self.last = nn.Conv2d(wf, in_chn, kernel_size=3, stride=1, padding=1, bias=True)
+
+    def forward(self, x):
+        img = x
+        d1, d2, d3 = self.ps_down1(img), self.ps_down2(img), self.ps_down3(img)
+        low, high1 = self.down_group1(self.conv_01(img), d1)
+        low, high2 = self.down_group2(low, d2)
+        low, high3 = self.down_group3(low, d3)
+        low = self.up_group3(low, high3)
+        low = self.up_group2(low, high2)
+        low = self.up_group1(low, high1)
+        return self.last(low) + img
+
+
+@ARCH_REGISTRY.register()
+class WaveMamba(nn.Module):
+    """Registry entry (reference :1066-1176).  Input NCHW in [0, 1], H and W multiples of 8."""
+
+    scale_factor = 1          # the reference's test_tile reads an undefined self.scale_factor (:1099)
+
+    def __init__(self, *, in_chn, wf, n_l_blocks=[1, 1, 2], n_h_blocks=[1, 1, 1], ffn_scale=2.0,
+                 **ignore_kwargs):
+        super().__init__()
+        self.restoration_network = UNet(in_chn=in_chn, wf=wf, n_l_blocks=n_l_blocks,
+                                        n_h_blocks=n_h_blocks, ffn_scale=ffn_scale)
+
+    def print_network(self, model):
+        print(model)
+        print("The number of parameters: {}".format(sum(p.numel() for p in model.parameters())))
+
+    def encode_and_decode(self, input, current_iter=None):
+        return self.restoration_network(input)
+
+    def check_image_size(self, x, window_size=8):
+        _, _, h, w = x.size()
+        pad_h = (window_size - h % window_size) % window_size
+        pad_w = (window_size - w % window_size) % window_size
+        return F.pad(x, (0, pad_w, 0, pad_h), "reflect")
+
+    @torch.no_grad()
+    def test(self, input):
+        return self.encode_and_decode(input)
+
+    @torch.no_grad()
+    def test_tile(self, input, tile_size=240, tile_pad=16):
+        """Tile-by-tile inference with padded borders (reference :1091-1151, scale factor 1)."""
+        batch, channel, height, width = input.shape
+        s = self.scale_factor
+        output = input.new_zeros((batch, channel, height * s, width * s))
+        for y0 in range(0, height, tile_size):
+            for x0 in range(0, width, tile_size):
+                y1, x1 = min(y0 + tile_size, height), min(x0 + tile_size, width)
+                py0, px0 = max(y0 - tile_pad, 0), max(x0 - tile_pad, 0)
+                py1, px1 = min(y1 + tile_pad, height), min(x1 + tile_pad, width)
+                tile = self.test(input[:, :, py0:py1, px0:px1])
+                oy, ox = (y0 - py0) * s, (x0 - px0) * s
+                output[:, :, y0 * s:y1 * s, x0 * s:x1 * s] = \
+                    tile[:, :, oy:oy + (y1 - y0) * s, ox:ox + (x1 - x0) * s]
+        return output
+
+    def forward(self, input):
+        return self.encode_and_decode(input)

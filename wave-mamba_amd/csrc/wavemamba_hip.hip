@@ -1,0 +1,314 @@
+// wavemamba_hip.hip - C ABI (include/wavemamba_hip.h) over the gfx950 kernels.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC wavemamba_hip.hip -o libwavemamba_hip.so
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <mutex>
+#include <vector>
+
+#include "../../include/wavemamba_hip.h"
+#include "haar.hip.h"
+#include "selscan.hip.h"
+
+namespace wm {
+
+// ------------------------------------------------------------------------------------------------
+// profiling hooks: HIP events on the launch stream around each kernel class
+// ------------------------------------------------------------------------------------------------
+struct Prof {
+    std::mutex mu;
+    bool on = false;
+    std::vector<hipEvent_t> pool;                               // recycled events
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> rec[WM_PROF_NKERNELS];
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e; hipEventCreate(&e); return e;
+    }
+};
+static Prof g_prof;
+
+struct ProfScope {
+    int id; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr; bool active;
+    ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), active(g_prof.on) {
+        if (!active) return;
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        e0 = g_prof.get(); e1 = g_prof.get();
+        hipEventRecord(e0, s);
+    }
+    ~ProfScope() {
+        if (!active) return;
+        hipEventRecord(e1, s);
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        g_prof.rec[id].emplace_back(e0, e1);
+    }
+};
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int launch_status() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? WM_OK : (int)e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Haar launchers
+// ------------------------------------------------------------------------------------------------
+template <typename Tf, typename Ts, bool ROUND>
+static int launch_analysis(const void* full, void* s0, void* s1, void* s2, void* s3, const HaarGeom& g,
+                           bool vec, hipStream_t st) {
+    const dim3 block(64, 4);
+    const int cols = vec ? (g.w + 3) / 4 : g.w;
+    const dim3 grid((unsigned)((g.rows + 3) / 4), (unsigned)((cols + 63) / 64));
+    if (vec)
+        hipLaunchKernelGGL((haar_analysis_kernel<Tf, Ts, ROUND, true>), grid, block, 0, st,
+                           (const Tf*)full, (Ts*)s0, (Ts*)s1, (Ts*)s2, (Ts*)s3, g);
+    else
+        hipLaunchKernelGGL((haar_analysis_kernel<Tf, Ts, ROUND, false>), grid, block, 0, st,
+                           (const Tf*)full, (Ts*)s0, (Ts*)s1, (Ts*)s2, (Ts*)s3, g);
+    return launch_status();
+}
+template <typename Ts, typename Tf, bool ROUND>
+static int launch_synthesis(const void* s0, const void* s1, const void* s2, const void* s3, void* full,
+                            const HaarGeom& g, bool vec, hipStream_t st) {
+    const dim3 block(64, 4);
+    const int cols = vec ? (g.w + 3) / 4 : g.w;
+    const dim3 grid((unsigned)((g.rows + 3) / 4), (unsigned)((cols + 63) / 64));
+    if (vec)
+        hipLaunchKernelGGL((haar_synthesis_kernel<Ts, Tf, ROUND, true>), grid, block, 0, st,
+                           (const Ts*)s0, (const Ts*)s1, (const Ts*)s2, (const Ts*)s3, (Tf*)full, g);
+    else
+        hipLaunchKernelGGL((haar_synthesis_kernel<Ts, Tf, ROUND, false>), grid, block, 0, st,
+                           (const Ts*)s0, (const Ts*)s1, (const Ts*)s2, (const Ts*)s3, (Tf*)full, g);
+    return launch_status();
+}
+
+static int haar_geom(HaarGeom& g, int B, int C, int h, int w, int64_t b0, int64_t b1, int64_t b2,
+                     int64_t b3) {
+    if (B < 0 || C < 0 || h < 0 || w < 0) return WM_EINVAL;
+    g.C = C; g.h = h; g.w = w; g.rows = (long long)B * C * h;
+    g.bs[0] = b0; g.bs[1] = b1; g.bs[2] = b2; g.bs[3] = b3;
+    if ((g.rows + 3) / 4 > 0x7fffffffLL) return WM_EINVAL;
+    return WM_OK;
+}
+// vector path: 4 sub-band columns per thread, every row start / stride 16-byte aligned on the
+// full-res side and 16 B (fp32) / 8 B (bf16) aligned on the sub-band side
+static bool haar_vec_ok(const HaarGeom& g, const void* full, const void* const s[4]) {
+    if (g.w % 4 != 0) return false;
+    if (!aligned16(full)) return false;
+    for (int k = 0; k < 4; ++k)
+        if (!aligned16(s[k]) || (g.bs[k] % 4) != 0) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// selective-scan host side
+// ------------------------------------------------------------------------------------------------
+struct ScanPlan { int NP, wpg, rows, chunk_len, nchunks; size_t ws_bytes; };
+
+static int scan_plan(ScanPlan& pl, int batch, int dim, int L, int N, int G) {
+    if (batch <= 0 || dim <= 0 || L <= 0 || N <= 0 || G <= 0) return WM_EINVAL;
+    if (N > 32) return WM_EUNSUPPORTED;
+    if (dim % G != 0) return WM_EINVAL;
+    const int dpg = dim / G;
+    pl.NP = N <= 16 ? 16 : 32;
+    pl.wpg = (dpg + 63) / 64;
+    const long long rows = (long long)batch * G * pl.wpg;
+    if (rows > 65535) return WM_EUNSUPPORTED;
+    pl.rows = (int)rows;
+    // enough chunks to keep every CU's wave slots busy for several rounds (256 CUs x ~12 resident
+    // single-wave workgroups), but never shorter than 64 steps
+    const long long target_waves = 256LL * 12 * 4;
+    long long want = (target_waves + rows - 1) / rows;           // chunks wanted per wave-row
+    long long cl = ((long long)L + want - 1) / want;
+    cl = ((cl + kTile - 1) / kTile) * kTile;
+    if (cl < 64) cl = 64;
+    pl.chunk_len = (int)cl;
+    pl.nchunks = (int)(((long long)L + cl - 1) / cl);
+    pl.ws_bytes = pl.nchunks > 1 ? (size_t)2 * pl.nchunks * batch * dim * pl.NP * sizeof(float) : 0;
+    return WM_OK;
+}
+
+template <int NP, bool VEC>
+static int scan_launch(const ScanArgs& a, const ScanPlan& pl, hipStream_t st) {
+    const dim3 grid((unsigned)pl.nchunks, (unsigned)pl.rows), block(64);
+    if (pl.nchunks > 1) {
+        {
+            ProfScope ps(2, st);
+            hipLaunchKernelGGL((selscan_chunk_kernel<NP, 1, VEC>), grid, block, 0, st, a);
+        }
+        {
+            ProfScope ps(3, st);
+            const long long nchains = (long long)a.batch * a.dim * NP;
+            hipLaunchKernelGGL(selscan_carry_kernel, dim3((unsigned)((nchains + 63) / 64)), dim3(1024), 0,
+                               st, (const float*)a.wsP, a.wsH, nchains, pl.nchunks);
+        }
+    }
+    {
+        ProfScope ps(4, st);
+        hipLaunchKernelGGL((selscan_chunk_kernel<NP, 3, VEC>), grid, block, 0, st, a);
+    }
+    return launch_status();
+}
+
+}  // namespace wm
+
+using namespace wm;
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int wm_abi_version(void) { return 1; }
+
+const char* wm_strerror(int code) {
+    switch (code) {
+        case WM_OK: return "ok";
+        case WM_EINVAL: return "invalid shape or size argument";
+        case WM_ENULL: return "required pointer is NULL";
+        case WM_EALIGN: return "pointer not aligned to its element size";
+        case WM_EWORKSPACE: return "workspace too small";
+        case WM_EUNSUPPORTED: return "argument combination not supported";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+int wm_dwt2d_fwd(const void* x, void* ll, void* hl, void* lh, void* hh, int B, int C, int H, int W,
+                 int dtype, void* stream) {
+    if (H % 2 != 0 || W % 2 != 0) return WM_EINVAL;        // reference: RuntimeError on odd sizes
+    HaarGeom g;
+    const int64_t bs = (int64_t)C * (H / 2) * (W / 2);
+    int rc = haar_geom(g, B, C, H / 2, W / 2, bs, bs, bs, bs);
+    if (rc) return rc;
+    if (g.rows == 0 || g.w == 0) return WM_OK;
+    if (!x || !ll || !hl || !lh || !hh) return WM_ENULL;
+    const void* s[4] = {ll, hl, lh, hh};
+    const bool vec = haar_vec_ok(g, x, s);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(0, st);
+    if (dtype == WM_F32) return launch_analysis<float, float, false>(x, ll, hl, lh, hh, g, vec, st);
+    if (dtype == WM_BF16) return launch_analysis<bf16_t, bf16_t, true>(x, ll, hl, lh, hh, g, vec, st);
+    return WM_EUNSUPPORTED;
+}
+
+int wm_dwt2d_bwd(const void* dll, const void* dhl, const void* dlh, const void* dhh, void* dx, int B,
+                 int C, int H, int W, int dtype, void* stream) {
+    if (H % 2 != 0 || W % 2 != 0) return WM_EINVAL;
+    HaarGeom g;
+    const int64_t bs = (int64_t)C * (H / 2) * (W / 2);
+    int rc = haar_geom(g, B, C, H / 2, W / 2, bs, bs, bs, bs);
+    if (rc) return rc;
+    if (g.rows == 0 || g.w == 0) return WM_OK;
+    if (!dx || !dll || !dhl || !dlh || !dhh) return WM_ENULL;
+    const void* s[4] = {dll, dhl, dlh, dhh};
+    const bool vec = haar_vec_ok(g, dx, s);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(1, st);
+    // the 2x2 Haar matrix (with the 1/2 scaling) is orthogonal: d(analysis) = synthesis
+    if (dtype == WM_F32) return launch_synthesis<float, float, false>(dll, dhl, dlh, dhh, dx, g, vec, st);
+    if (dtype == WM_BF16) return launch_synthesis<bf16_t, bf16_t, false>(dll, dhl, dlh, dhh, dx, g, vec, st);
+    return WM_EUNSUPPORTED;
+}
+
+int wm_idwt2d_fwd(const void* x1, const void* x2, const void* x3, const void* x4, int64_t bs1,
+                  int64_t bs2, int64_t bs3, int64_t bs4, float* out, int B, int C, int h, int w,
+                  int dtype, void* stream) {
+    HaarGeom g;
+    int rc = haar_geom(g, B, C, h, w, bs1, bs2, bs3, bs4);
+    if (rc) return rc;
+    if (g.rows == 0 || g.w == 0) return WM_OK;
+    if (!x1 || !x2 || !x3 || !x4 || !out) return WM_ENULL;
+    const void* s[4] = {x1, x2, x3, x4};
+    const bool vec = haar_vec_ok(g, out, s);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(1, st);
+    if (dtype == WM_F32) return launch_synthesis<float, float, false>(x1, x2, x3, x4, out, g, vec, st);
+    if (dtype == WM_BF16) return launch_synthesis<bf16_t, float, true>(x1, x2, x3, x4, out, g, vec, st);
+    return WM_EUNSUPPORTED;
+}
+
+int wm_idwt2d_bwd(const float* dout, void* d1, void* d2, void* d3, void* d4, int64_t bs1, int64_t bs2,
+                  int64_t bs3, int64_t bs4, int B, int C, int h, int w, int dtype, void* stream) {
+    HaarGeom g;
+    int rc = haar_geom(g, B, C, h, w, bs1, bs2, bs3, bs4);
+    if (rc) return rc;
+    if (g.rows == 0 || g.w == 0) return WM_OK;
+    if (!dout || !d1 || !d2 || !d3 || !d4) return WM_ENULL;
+    const void* s[4] = {d1, d2, d3, d4};
+    const bool vec = haar_vec_ok(g, dout, s);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(0, st);
+    if (dtype == WM_F32) return launch_analysis<float, float, false>(dout, d1, d2, d3, d4, g, vec, st);
+    if (dtype == WM_BF16) return launch_analysis<float, bf16_t, false>(dout, d1, d2, d3, d4, g, vec, st);
+    return WM_EUNSUPPORTED;
+}
+
+size_t wm_selscan_fwd_workspace_bytes(int batch, int dim, int L, int N, int G) {
+    ScanPlan pl;
+    if (scan_plan(pl, batch, dim, L, N, G) != WM_OK) return 0;
+    return pl.ws_bytes;
+}
+
+int wm_selscan_fwd(const float* u, const float* delta, const float* A, const float* Bm, const float* Cm,
+                   const float* D, const float* z, const float* delta_bias, float* out,
+                   float* last_state, void* workspace, size_t workspace_bytes, int batch, int dim, int L,
+                   int N, int G, int delta_softplus, void* stream) {
+    if (batch == 0 || dim == 0 || L == 0) return (batch < 0 || dim < 0 || L < 0) ? WM_EINVAL : WM_OK;
+    ScanPlan pl;
+    int rc = scan_plan(pl, batch, dim, L, N, G);
+    if (rc) return rc;
+    if (!u || !delta || !A || !Bm || !Cm || !out) return WM_ENULL;
+    if (pl.ws_bytes > 0) {
+        if (!workspace) return WM_ENULL;
+        if (workspace_bytes < pl.ws_bytes) return WM_EWORKSPACE;
+        if (!aligned16(workspace)) return WM_EALIGN;
+    }
+    ScanArgs a;
+    a.u = u; a.delta = delta; a.A = A; a.Bm = Bm; a.Cm = Cm; a.D = D; a.z = z; a.bias = delta_bias;
+    a.out = out; a.last_state = last_state;
+    a.wsP = (float*)workspace;
+    a.wsH = a.wsP ? a.wsP + (size_t)pl.nchunks * batch * dim * pl.NP : nullptr;
+    a.batch = batch; a.dim = dim; a.L = L; a.N = N; a.G = G; a.dpg = dim / G; a.wpg = pl.wpg;
+    a.chunk_len = pl.chunk_len; a.nchunks = pl.nchunks; a.softplus = delta_softplus ? 1 : 0;
+    const bool vec = (L % 4 == 0) && aligned16(u) && aligned16(delta) && aligned16(Bm) && aligned16(Cm) &&
+                     aligned16(out) && (!z || aligned16(z));
+    hipStream_t st = (hipStream_t)stream;
+    if (pl.NP == 16) return vec ? scan_launch<16, true>(a, pl, st) : scan_launch<16, false>(a, pl, st);
+    return vec ? scan_launch<32, true>(a, pl, st) : scan_launch<32, false>(a, pl, st);
+}
+
+size_t wm_selscan_bwd_workspace_bytes(int, int, int, int, int) { return 0; }
+int wm_selscan_bwd(const float*, const float*, const float*, const float*, const float*, const float*,
+                   const float*, const float*, float*, float*, float*, float*, float*, float*, float*,
+                   void*, size_t, int, int, int, int, int, int, void*) {
+    return WM_EUNSUPPORTED;   // implemented in a later milestone
+}
+
+void wm_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.on = on != 0;
+    if (on)
+        for (auto& v : g_prof.rec) {
+            for (auto& pr : v) { g_prof.pool.push_back(pr.first); g_prof.pool.push_back(pr.second); }
+            v.clear();
+        }
+}
+
+int wm_prof_collect(int* launches, double* total_ms) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    for (int k = 0; k < WM_PROF_NKERNELS; ++k) {
+        double tot = 0.0;
+        for (auto& pr : g_prof.rec[k]) {
+            hipError_t e = hipEventSynchronize(pr.second);
+            if (e != hipSuccess) return (int)e;
+            float ms = 0.f;
+            e = hipEventElapsedTime(&ms, pr.first, pr.second);
+            if (e != hipSuccess) return (int)e;
+            tot += ms;
+        }
+        launches[k] = (int)g_prof.rec[k].size();
+        total_ms[k] = tot;
+    }
+    return WM_OK;
+}
+
+}  // extern "C"

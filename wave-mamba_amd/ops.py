@@ -1,0 +1,291 @@
+"""Host-side mirror of the reference's operator surface for the Wave-Mamba hot path.
+
+Same names, argument meaning and error behaviour as the reference
+(/root/reference/basicsr/archs/wavemamba_arch.py):
+
+    dwt_init(x) -> (x_LL, x_HL, x_LH, x_HH)                                   :97-110
+    iwt_init(x) -> h                                                          :113-130
+    selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None,
+                      delta_softplus=False, return_last_state=False)          :6, :465-471
+
+Every op is a torch.autograd.Function over the C ABI of libwavemamba_hip.so (hand-written HIP for
+gfx950).  PyTorch only supplies device memory, the current stream and autograd plumbing.  There is
+NO CPU / eager fallback: a non-CUDA tensor or a missing library raises.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import WM_BF16, WM_F32, check
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_cuda(name, *tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                f"{name}: expected a CUDA (ROCm) tensor, got device '{t.device}'. The Wave-Mamba hot "
+                "path is HIP-only; there is no CPU fallback in the product path.")
+
+
+def _dtype_code(t, name):
+    if t.dtype == torch.float32:
+        return WM_F32
+    if t.dtype == torch.bfloat16:
+        return WM_BF16
+    raise RuntimeError(f"{name}: unsupported dtype {t.dtype} (float32 and bfloat16 are implemented)")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------
+# Haar DWT / IWT
+# ------------------------------------------------------------------------------------------------
+class _DWT(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        _require_cuda("dwt_init", x)
+        if x.dim() != 4:
+            raise RuntimeError(f"dwt_init: expected a 4-D NCHW tensor, got {tuple(x.shape)}")
+        B, C, H, W = x.shape
+        if H % 2 or W % 2:
+            # the reference's strided slices disagree in size for odd H/W -> RuntimeError
+            raise RuntimeError(f"dwt_init: H and W must be even, got {H}x{W}")
+        code = _dtype_code(x, "dwt_init")
+        x = x.contiguous()
+        outs = [torch.empty((B, C, H // 2, W // 2), dtype=x.dtype, device=x.device) for _ in range(4)]
+        with torch.cuda.device(x.device):
+            check(lib.wm_dwt2d_fwd(_ptr(x), *[_ptr(o) for o in outs], B, C, H, W, code, _stream()),
+                  "wm_dwt2d_fwd")
+        ctx.shape = (B, C, H, W)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_ll, g_hl, g_lh, g_hh):
+        lib = _lib.load()
+        B, C, H, W = ctx.shape
+        gs = [g.contiguous() for g in (g_ll, g_hl, g_lh, g_hh)]
+        code = _dtype_code(gs[0], "dwt_init.backward")
+        dx = torch.empty((B, C, H, W), dtype=gs[0].dtype, device=gs[0].device)
+        with torch.cuda.device(dx.device):
+            check(lib.wm_dwt2d_bwd(*[_ptr(g) for g in gs], _ptr(dx), B, C, H, W, code, _stream()),
+                  "wm_dwt2d_bwd")
+        return dx
+
+
+class _IWT(torch.autograd.Function):
+    """Synthesis from four sub-band blocks given as (tensor, channel offset) views of 1 or 2 tensors."""
+
+    @staticmethod
+    def forward(ctx, x_l, x_h):
+        # x_h is None: x_l is the reference's concatenated (B, 4C, h, w) tensor.
+        # else: x_l (B, C, h, w) and x_h (B, 3C, h, w) - upFRG's un-concatenated pair (:1006).
+        lib = _lib.load()
+        _require_cuda("iwt_init", x_l, x_h)
+        x_l = x_l.contiguous()
+        if x_h is None:
+            B, C4, h, w = x_l.shape
+            if C4 % 4:
+                raise RuntimeError(f"iwt_init: channel count {C4} is not a multiple of 4")
+            C = C4 // 4
+            hw = h * w
+            es = x_l.element_size()
+            ptrs = [x_l.data_ptr() + k * C * hw * es for k in range(4)]
+            strides = [4 * C * hw] * 4
+            code = _dtype_code(x_l, "iwt_init")
+        else:
+            x_h = x_h.contiguous()
+            if x_h.dtype != x_l.dtype:
+                raise RuntimeError("iwt_init: x_l and x_h dtypes differ")
+            B, C, h, w = x_l.shape
+            if x_h.shape != (B, 3 * C, h, w):
+                raise RuntimeError(f"iwt_init: x_h shape {tuple(x_h.shape)} != {(B, 3 * C, h, w)}")
+            hw = h * w
+            es = x_h.element_size()
+            ptrs = [x_l.data_ptr()] + [x_h.data_ptr() + k * C * hw * es for k in range(3)]
+            strides = [C * hw] + [3 * C * hw] * 3
+            code = _dtype_code(x_l, "iwt_init")
+        out = torch.empty((B, C, 2 * h, 2 * w), dtype=torch.float32, device=x_l.device)  # always fp32
+        with torch.cuda.device(out.device):
+            check(lib.wm_idwt2d_fwd(*ptrs, *strides, _ptr(out), B, C, h, w, code, _stream()), "wm_idwt2d_fwd")
+        ctx.geom = (B, C, h, w, x_h is None, x_l.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        B, C, h, w, cat, dt = ctx.geom
+        g = g.contiguous().float()
+        hw = h * w
+        code = WM_F32 if dt == torch.float32 else WM_BF16
+        if cat:
+            d_l = torch.empty((B, 4 * C, h, w), dtype=dt, device=g.device)
+            d_h = None
+            es = d_l.element_size()
+            ptrs = [d_l.data_ptr() + k * C * hw * es for k in range(4)]
+            strides = [4 * C * hw] * 4
+        else:
+            d_l = torch.empty((B, C, h, w), dtype=dt, device=g.device)
+            d_h = torch.empty((B, 3 * C, h, w), dtype=dt, device=g.device)
+            es = d_l.element_size()
+            ptrs = [d_l.data_ptr()] + [d_h.data_ptr() + k * C * hw * es for k in range(3)]
+            strides = [C * hw] + [3 * C * hw] * 3
+        with torch.cuda.device(g.device):
+            check(lib.wm_idwt2d_bwd(_ptr(g), *ptrs, *strides, B, C, h, w, code, _stream()), "wm_idwt2d_bwd")
+        return d_l, d_h
+
+
+def dwt_init(x):
+    """Haar analysis of an NCHW map -> (x_LL, x_HL, x_LH, x_HH), each (B, C, H/2, W/2), dtype of x."""
+    return _DWT.apply(x)
+
+
+def iwt_init(x):
+    """Haar synthesis of a (B, 4C, h, w) tensor [x1|x2|x3|x4] -> (B, C, 2h, 2w), always float32."""
+    return _IWT.apply(x, None)
+
+
+def iwt_init_pair(x_l, x_h):
+    """iwt_init(torch.cat([x_l, x_h], dim=1)) without materialising the concatenation."""
+    return _IWT.apply(x_l, x_h)
+
+
+# ------------------------------------------------------------------------------------------------
+# selective scan
+# ------------------------------------------------------------------------------------------------
+def _scan_shapes(u, delta, A, B, C, D, z, delta_bias):
+    if u.dim() != 3:
+        raise RuntimeError(f"selective_scan_fn: u must be (batch, dim, L), got {tuple(u.shape)}")
+    batch, dim, L = u.shape
+    if delta.shape != u.shape:
+        raise RuntimeError(f"selective_scan_fn: delta shape {tuple(delta.shape)} != u shape {tuple(u.shape)}")
+    if A.dim() != 2 or A.shape[0] != dim:
+        raise RuntimeError(f"selective_scan_fn: A must be (dim, N) with dim={dim}, got {tuple(A.shape)}")
+    N = A.shape[1]
+    if B.dim() == 2 or C.dim() == 2:
+        raise NotImplementedError("selective_scan_fn: time-invariant (dim, N) B/C are not implemented; "
+                                  "the reference only uses (batch, G, N, L) B/C (wavemamba_arch.py:459-460)")
+    if B.dim() == 3:
+        B = B.unsqueeze(1)
+    if C.dim() == 3:
+        C = C.unsqueeze(1)
+    G = B.shape[1]
+    if B.shape != (batch, G, N, L) or C.shape != (batch, G, N, L):
+        raise RuntimeError(f"selective_scan_fn: B/C must be (batch, G, N, L) = ({batch}, G, {N}, {L}), "
+                           f"got {tuple(B.shape)} / {tuple(C.shape)}")
+    if dim % G:
+        raise RuntimeError(f"selective_scan_fn: dim {dim} not divisible by the number of groups {G}")
+    for name, t in (("D", D), ("delta_bias", delta_bias)):
+        if t is not None and t.shape != (dim,):
+            raise RuntimeError(f"selective_scan_fn: {name} must be ({dim},), got {tuple(t.shape)}")
+    if z is not None and z.shape != u.shape:
+        raise RuntimeError("selective_scan_fn: z shape must match u")
+    return batch, dim, L, N, G, B, C
+
+
+def _f32c(t):
+    return None if t is None else t.contiguous().float()
+
+
+def _scan_forward(u, delta, A, B, C, D, z, delta_bias, delta_softplus, want_last):
+    lib = _lib.load()
+    batch, dim, L, N, G = u.shape[0], u.shape[1], u.shape[2], A.shape[1], B.shape[1]
+    out = torch.empty_like(u)
+    last = torch.empty((batch, dim, N), dtype=torch.float32, device=u.device) if want_last else None
+    ws_bytes = lib.wm_selscan_fwd_workspace_bytes(batch, dim, L, N, G)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=u.device) if ws_bytes else None
+    with torch.cuda.device(u.device):
+        check(lib.wm_selscan_fwd(_ptr(u), _ptr(delta), _ptr(A), _ptr(B), _ptr(C), _ptr(D), _ptr(z),
+                                 _ptr(delta_bias), _ptr(out), _ptr(last), _ptr(ws), ws_bytes,
+                                 batch, dim, L, N, G, int(bool(delta_softplus)), _stream()),
+              "wm_selscan_fwd")
+    return out, last
+
+
+class _SelectiveScan(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, delta, A, B, C, D, delta_bias, delta_softplus, want_last):
+        out, last = _scan_forward(u, delta, A, B, C, D, None, delta_bias, delta_softplus, want_last)
+        ctx.save_for_backward(u, delta, A, B, C, D, delta_bias)
+        ctx.delta_softplus = bool(delta_softplus)
+        if want_last:
+            ctx.mark_non_differentiable(last)
+            return out, last
+        return out
+
+    @staticmethod
+    def backward(ctx, dout, *unused):
+        lib = _lib.load()
+        u, delta, A, B, C, D, delta_bias = ctx.saved_tensors
+        batch, dim, L = u.shape
+        N, G = A.shape[1], B.shape[1]
+        dout = dout.contiguous().float()
+        du = torch.empty_like(u)
+        ddelta = torch.empty_like(delta)
+        dA = torch.empty_like(A)
+        dB = torch.empty_like(B)
+        dC = torch.empty_like(C)
+        dD = torch.empty_like(D) if D is not None else None
+        dbias = torch.empty_like(delta_bias) if delta_bias is not None else None
+        ws_bytes = lib.wm_selscan_bwd_workspace_bytes(batch, dim, L, N, G)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=u.device) if ws_bytes else None
+        with torch.cuda.device(u.device):
+            check(lib.wm_selscan_bwd(_ptr(u), _ptr(delta), _ptr(A), _ptr(B), _ptr(C), _ptr(D),
+                                     _ptr(delta_bias), _ptr(dout), _ptr(du), _ptr(ddelta), _ptr(dA),
+                                     _ptr(dB), _ptr(dC), _ptr(dD), _ptr(dbias), _ptr(ws), ws_bytes,
+                                     batch, dim, L, N, G, int(ctx.delta_softplus), _stream()),
+                  "wm_selscan_bwd")
+        return du, ddelta, dA, dB, dC, dD, dbias, None, None
+
+
+def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                      return_last_state=False):
+    """Drop-in for mamba_ssm.ops.selective_scan_interface.selective_scan_fn (reference call site
+    wavemamba_arch.py:465-471).  u, delta: (batch, dim, L); A: (dim, N); B, C: (batch, [G,] N, L);
+    D, delta_bias: (dim,).  Computes in fp32, returns `out` in u's dtype (and the fp32 last state
+    (batch, dim, N) when return_last_state).  Differentiable w.r.t. u, delta, A, B, C, D, delta_bias
+    (and z, through eager gating)."""
+    _require_cuda("selective_scan_fn", u, delta, A, B, C, D, z, delta_bias)
+    batch, dim, L, N, G, B4, C4 = _scan_shapes(u, delta, A, B, C, D, z, delta_bias)
+    squeeze_B, squeeze_C = B.dim() == 3, C.dim() == 3
+    in_dtype = u.dtype
+    args = [_f32c(t) for t in (u, delta, A, B4, C4, D, delta_bias)]
+    need_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad
+                                                for t in (u, delta, A, B, C, D, z, delta_bias))
+    if not need_grad:
+        out, last = _scan_forward(args[0], args[1], args[2], args[3], args[4], args[5], _f32c(z),
+                                  args[6], delta_softplus, return_last_state)
+    else:
+        res = _SelectiveScan.apply(*args, bool(delta_softplus), bool(return_last_state))
+        out, last = res if return_last_state else (res, None)
+        if z is not None:
+            out = out * F.silu(z.float())
+    out = out.to(in_dtype)
+    return (out, last) if return_last_state else out
+
+
+# ------------------------------------------------------------------------------------------------
+# profiling hooks (bench.py)
+# ------------------------------------------------------------------------------------------------
+PROF_KERNELS = ("haar_analysis", "haar_synthesis", "selscan_chunk_reduce", "selscan_carry",
+                "selscan_chunk_scan", "selscan_bwd", "ss2d_proj", "reserved")
+
+
+def prof_enable(on=True):
+    _lib.load().wm_prof_enable(int(bool(on)))
+
+
+def prof_collect():
+    """-> {kernel name: (launches, total_ms)} since prof_enable(True); blocks on the recorded events."""
+    import ctypes
+    lib = _lib.load()
+    n = (ctypes.c_int * _lib.WM_PROF_NKERNELS)()
+    ms = (ctypes.c_double * _lib.WM_PROF_NKERNELS)()
+    check(lib.wm_prof_collect(n, ms), "wm_prof_collect")
+    return {PROF_KERNELS[k]: (n[k], ms[k]) for k in range(_lib.WM_PROF_NKERNELS)}
