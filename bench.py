@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py - UHD (3840x2160) images/s of the Wave-Mamba forward on MI355X, with the roofline
+fraction of the dominant hot-path kernel and the CPU-oracle baseline timed beside it.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one forward of the shipped WaveMamba (inference_wavemamba.py:71-75 config, seeded random
+init - checkpoints are not distributed) over one synthetic 1x3x2160x3840 image, reflect-padded to
+2176x3840 exactly as the reference's inference script does (:28-36), input already resident in HBM.
+N > 1: one process per GPU, each an independent replica on its own image (the path shards by image,
+no data-path collective) -> weak scaling; value = N*K images / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import wave_mamba_amd as wm                                     # noqa: E402
+from wave_mamba_amd.archs import wavemamba_arch as arch        # noqa: E402
+
+SHIPPED = dict(in_chn=3, wf=32, n_l_blocks=[1, 2, 4], n_h_blocks=[1, 1, 2], ffn_scale=2.0)
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+SCAN_BYTES_PER_POS = {16: 3584, 32: 4096}   # 4*(3*KD + 2*K*N), KD = 256, K = 4
+
+
+def pad_to(x, mult=128):
+    """inference_wavemamba.py:28-36: reflect-pad bottom/right to a multiple of 128."""
+    h, w = x.shape[-2:]
+    return F.pad(x, (0, (mult - w % mult) % mult, 0, (mult - h % mult) % mult), "reflect")
+
+
+def scan_positions(h, w):
+    """positions scanned per image: 2*(L1 + 2*L2 + 4*L3) for n_l_blocks [1,2,4]."""
+    l1, l2, l3 = (h // 2) * (w // 2), (h // 4) * (w // 4), (h // 8) * (w // 8)
+    return 2 * (l1 + 2 * l2 + 4 * l3)
+
+
+def build_model(device):
+    torch.manual_seed(0)
+    return wm.WaveMamba(**SHIPPED).eval().to(device)
+
+
+def cpu_baseline(sample_hw, uhd_hw, repeats):
+    """The CPU oracle ("port") inside the same network on host cores, on a bounded sample."""
+    from oracle import oracle
+    cores = oracle.usable_cpus()
+    torch.set_num_threads(cores)
+    oracle.set_num_threads(cores)
+    net = build_model("cpu")
+    prev = arch.set_ops_backend(oracle)
+    try:
+        with torch.no_grad():
+            # bounded: shrink the sample until one forward takes < ~8 s on this host
+            while True:
+                x = torch.rand(1, 3, *sample_hw, generator=torch.Generator().manual_seed(1234))
+                t0 = time.perf_counter()
+                y = net.restoration_network(x)                  # warm-up / probe
+                probe = time.perf_counter() - t0
+                if probe < 8.0 or min(sample_hw) <= 128:
+                    break
+                sample_hw = (sample_hw[0] // 2, sample_hw[1] // 2)
+            times = [probe] if probe > 8.0 else []
+            for _ in range(0 if times else repeats):
+                t0 = time.perf_counter()
+                y = net.restoration_network(x)
+                times.append(time.perf_counter() - t0)
+    finally:
+        arch.set_ops_backend(prev)
+    repeats = len(times)
+    t = sorted(times)[len(times) // 2]
+    scale = (uhd_hw[0] * uhd_hw[1]) / (sample_hw[0] * sample_hw[1])
+    return {
+        "value": 1.0 / (t * scale), "unit": "images/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
+        "sample": f"1x3x{sample_hw[0]}x{sample_hw[1]} fp32 forward (median of {repeats}, {t:.2f} s), same "
+                  f"network with the C/OpenMP oracle as hot-path backend + PyTorch-CPU for the rest; "
+                  f"scaled by the padded-area ratio {scale:.2f} to one 2176x3840 image",
+    }, x, y
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, nargs=2, default=[512, 1024])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path is HIP-only (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)          # RCCL on ROCm
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    # CPU baseline first (rank 0, N = 1 only), before the GPU pass
+    cpu, parity = None, None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, xs, ys = cpu_baseline(tuple(args.cpu_sample), (2176, 3840), repeats=3)
+
+    net = build_model(device)
+    img = torch.rand(1, 3, args.height, args.width, generator=torch.Generator().manual_seed(1234 + rank))
+    x = pad_to(img.to(device))
+    hp, wp = x.shape[-2:]
+
+    if cpu is not None:   # parity of the HIP path vs the CPU-oracle path on the very same sample
+        with torch.no_grad():
+            yg = net.restoration_network(xs.to(device)).cpu()
+        tgt = torch.rand(xs.shape, generator=torch.Generator().manual_seed(4321))
+
+        def psnr(a, b):
+            qa, qb = (a.clamp(0, 1) * 255).round(), (b.clamp(0, 1) * 255).round()
+            return float(20 * torch.log10(255.0 / (qa - qb).pow(2).mean().sqrt()))
+        parity = {"rel_l2_vs_cpu_oracle": float((yg - ys).norm() / ys.norm()),
+                  "abs_dpsnr_db": abs(psnr(yg, tgt) - psnr(ys, tgt))}
+
+    def step():
+        with torch.no_grad():
+            out = net.restoration_network(x)
+        return out[:, :, :args.height, :args.width]
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wm.ops.prof_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = wm.ops.prof_collect()
+    wm.ops.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    if rank == 0:
+        n_launch, ms = prof["selscan_chunk_scan"]
+        algo_bytes = SCAN_BYTES_PER_POS[16] * scan_positions(hp, wp) * args.steps    # over all launches
+        achieved = algo_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        scan_ms = sum(prof[k][1] for k in ("selscan_chunk_reduce", "selscan_carry", "selscan_chunk_scan"))
+        haar_ms = prof["haar_analysis"][1] + prof["haar_synthesis"][1]
+        haar_bytes = 2 * (2 * 4 * 32 * hp * wp * (1 + 1 / 4 + 1 / 16)) * args.steps
+        line = {
+            "metric": "UHD (3840x2160) images/sec fwd", "value": world * args.steps / elapsed,
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Wave-Mamba UHD-LL inference config (wf=32, n_l=[1,2,4], n_h=[1,1,2]), "
+                                   f"1x3x{args.height}x{args.width} reflect-padded to {hp}x{wp}, seeded random "
+                                   f"init, one image per GPU per step, replicas (no collective)"},
+            "roofline": {
+                "kernel": "selscan_chunk_kernel<16,3> (selective-scan chunk-scan phase)",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),
+                "algorithmic_bytes_per_launch_avg": algo_bytes / max(n_launch, 1),
+                "whole_scan_op_frac": (algo_bytes / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if scan_ms else None,
+                "haar_frac": (haar_bytes / (haar_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if haar_ms else None,
+                "hot_path_ms_per_step": (scan_ms + haar_ms) / args.steps,
+            },
+            "cpu_baseline": cpu, "parity": parity,
+            "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items() if v[0]},
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

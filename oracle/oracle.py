@@ -43,6 +43,29 @@ def num_threads():
     return lib().oracle_num_threads()
 
 
+def usable_cpus(cap=64):
+    """Host cores this process may really use: affinity mask and cgroup CPU quota, capped (a 256-way
+    OpenMP team on a quota-limited container spends its time spinning, not computing)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, min(n, cap))
+
+
+def set_num_threads(n):
+    lib().oracle_set_num_threads(int(n))
+
+
 def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 

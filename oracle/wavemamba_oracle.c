@@ -43,6 +43,14 @@ int oracle_num_threads(void) {
 #endif
 }
 
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* F.softplus(x) with beta = 1, threshold = 20 (torch semantics) */
 static inline float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 static inline float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }

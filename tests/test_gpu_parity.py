@@ -1,0 +1,258 @@
+"""GPU: the HIP hot path (through the C ABI) against the committed goldens and the CPU oracle.
+
+Bars (BASELINE.json north_star / SURVEY.md 8d): Haar DWT/IWT bit-exact (pure add/sub of halves in
+the reference's operation order); selective scan and anything containing it <= 1e-4 relative
+(l2 and max-abs) per tensor in fp32."""
+import pytest
+import torch
+
+from conftest import assert_close
+from oracle import oracle
+import wave_mamba_amd as wm
+from wave_mamba_amd.archs import wavemamba_arch as arch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4
+
+
+def gen(seed):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return g
+
+
+def cu(*ts):
+    return [None if t is None else t.to(DEV) for t in ts]
+
+
+# ------------------------------------------------------------------------------------------------
+# Haar DWT / IWT
+# ------------------------------------------------------------------------------------------------
+def test_dwt_iwt_golden_bit_exact(golden):
+    g = golden("wavelet")
+    for tag in ("a", "b"):                      # "a": w = 5 (scalar path), "b": w = 6 (scalar path)
+        outs = wm.ops.dwt_init(g[f"{tag}_x"].to(DEV))
+        for name, o in zip(("ll", "hl", "lh", "hh"), outs):
+            assert torch.equal(o.cpu(), g[f"{tag}_{name}"]), f"{tag}_{name}"
+        assert torch.equal(wm.ops.iwt_init(g[f"{tag}_iwt_in"].to(DEV)).cpu(), g[f"{tag}_iwt_out"])
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 8, 16), (1, 32, 64, 96), (3, 5, 6, 10), (1, 1, 2, 2),
+                                   (2, 7, 34, 40), (1, 4, 16, 8200)])
+def test_dwt_iwt_vs_oracle(shape):
+    x = torch.randn(*shape, generator=gen(1))
+    got = wm.ops.dwt_init(x.to(DEV))
+    ref = oracle.dwt_raw(x)
+    for a, b in zip(got, ref):
+        assert torch.equal(a.cpu(), b)
+    y = torch.randn(shape[0], 4 * shape[1], shape[2], shape[3], generator=gen(2))
+    ref_i = oracle.iwt_raw(y)
+    assert torch.equal(wm.ops.iwt_init(y.to(DEV)).cpu(), ref_i)
+    C = shape[1]
+    assert torch.equal(wm.ops.iwt_init_pair(y[:, :C].contiguous().to(DEV), y[:, C:].contiguous().to(DEV)).cpu(),
+                       ref_i)
+
+
+def test_dwt_bf16_matches_reference_rounding(golden):
+    g = golden("wavelet")
+    outs = wm.ops.dwt_init(g["bf16_x"].to(DEV).bfloat16())
+    for name, o in zip(("ll", "hl", "lh", "hh"), outs):
+        assert o.dtype == torch.bfloat16
+        assert torch.equal(o.float().cpu(), g[f"bf16_{name}"]), name
+    rec = wm.ops.iwt_init(torch.cat(outs, 1))
+    assert rec.dtype == torch.float32                       # reference quirk: IWT is always fp32
+    assert torch.equal(rec.cpu(), g["bf16_iwt_out"])
+    # vector path too (w % 4 == 0)
+    x = torch.randn(2, 4, 16, 64, generator=gen(3)).bfloat16()
+    outs = wm.ops.dwt_init(x.to(DEV))
+    a, b = x[:, :, 0::2, :] / 2, x[:, :, 1::2, :] / 2      # eager bf16 arithmetic = the reference's
+    x1, x2, x3, x4 = a[..., 0::2], b[..., 0::2], a[..., 1::2], b[..., 1::2]
+    for got, want in zip(outs, (x1 + x2 + x3 + x4, -x1 - x2 + x3 + x4, -x1 + x2 - x3 + x4, x1 - x2 - x3 + x4)):
+        assert torch.equal(got.cpu(), want)
+
+
+def test_dwt_errors():
+    with pytest.raises(RuntimeError):
+        wm.ops.dwt_init(torch.zeros(1, 1, 5, 4, device=DEV))       # odd H: reference raises too
+    with pytest.raises(RuntimeError):
+        wm.ops.dwt_init(torch.zeros(1, 1, 4, 4))                   # CPU tensor: no fallback
+    assert all(o.numel() == 0 for o in wm.ops.dwt_init(torch.zeros(0, 3, 4, 4, device=DEV)))
+
+
+def test_dwt_iwt_backward_is_the_adjoint():
+    x = torch.randn(2, 6, 12, 20, generator=gen(4)).to(DEV).requires_grad_(True)
+    outs = wm.ops.dwt_init(x)
+    gs = [torch.randn(o.shape, generator=gen(10 + i)).to(DEV) for i, o in enumerate(outs)]
+    (dx,) = torch.autograd.grad(outs, x, gs)
+    assert torch.equal(dx.cpu(), oracle.iwt_raw(torch.cat([g.cpu() for g in gs], 1)))
+    y = torch.randn(2, 24, 6, 10, generator=gen(5)).to(DEV).requires_grad_(True)
+    out = wm.ops.iwt_init(y)
+    g = torch.randn(out.shape, generator=gen(6)).to(DEV)
+    (dy,) = torch.autograd.grad(out, y, g)
+    assert torch.equal(dy.cpu(), torch.cat(oracle.dwt_raw(g.cpu()), 1))
+    yl, yh = y.detach()[:, :6].contiguous().requires_grad_(True), y.detach()[:, 6:].contiguous().requires_grad_(True)
+    dl, dh = torch.autograd.grad(wm.ops.iwt_init_pair(yl, yh), (yl, yh), g)
+    assert torch.equal(torch.cat([dl, dh], 1), dy)
+
+
+def test_dwt_full_size_round_trip_and_energy():
+    # BASELINE config 4 plane size (UHDLOL4K 2160 x 4096), 3 levels; properties instead of an oracle
+    x = torch.randn(1, 32, 2160, 4096, generator=gen(7)).to(DEV)
+    cur, pyramid = x, []
+    for _ in range(3):
+        ll, hl, lh, hh = wm.ops.dwt_init(cur)
+        e_in = cur.double().pow(2).sum()
+        e_out = sum(t.double().pow(2).sum() for t in (ll, hl, lh, hh))
+        assert abs(float(e_out / e_in) - 1.0) < 1e-6          # orthogonal transform
+        pyramid.append((hl, lh, hh))
+        cur = ll
+    for hl, lh, hh in reversed(pyramid):
+        cur = wm.ops.iwt_init(torch.cat([cur, hl, lh, hh], 1))
+    assert float((cur - x).abs().max()) < 5e-6
+    # linearity: DWT(a + 2b) == DWT(a) + 2 DWT(b) up to rounding
+    a, b = x[:, :4, :256, :512].contiguous(), torch.randn(1, 4, 256, 512, generator=gen(8)).to(DEV)
+    for p, q, r in zip(wm.ops.dwt_init(a + 2 * b), wm.ops.dwt_init(a), wm.ops.dwt_init(b)):
+        assert float((p - (q + 2 * r)).abs().max()) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# selective scan forward
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["s16", "sq16", "s32", "d8"])
+def test_scan_golden(golden, tag):
+    g = golden("scan")
+    y = wm.ops.selective_scan_fn(*cu(g[f"{tag}_u"], g[f"{tag}_delta"], g[f"{tag}_A"], g[f"{tag}_B"],
+                                     g[f"{tag}_C"], g[f"{tag}_D"]), None, g[f"{tag}_bias"].to(DEV), True)
+    assert y.dtype == torch.float32
+    assert_close(y, g[f"{tag}_y"], TOL, f"{tag} y")
+
+
+def test_scan_optional_arguments(golden):
+    g = golden("scan")
+    y, last = wm.ops.selective_scan_fn(*cu(g["opt_u"], g["opt_delta"], g["opt_A"], g["opt_B"], g["opt_C"],
+                                           g["opt_D"], g["opt_z"], g["opt_bias"]), True, True)
+    assert_close(y, g["opt_y_full"], TOL, "z-gated y")
+    assert_close(last, g["opt_last_state"], TOL, "last state")
+    y2 = wm.ops.selective_scan_fn(*cu(g["opt_u"], g["opt_delta"].abs() + 0.01, g["opt_A"], g["opt_B"], g["opt_C"]))
+    assert_close(y2, g["opt_y_plain"], TOL, "plain y")
+
+
+def random_scan_case(batch, dim, L, N, G, seed, softplus_bias=-3.0):
+    gg = gen(seed)
+    u = torch.randn(batch, dim, L, generator=gg)
+    delta = 0.5 * torch.randn(batch, dim, L, generator=gg)
+    A = -torch.exp(torch.log(torch.arange(1, N + 1, dtype=torch.float32)).repeat(dim, 1)
+                   + 0.2 * torch.randn(dim, N, generator=gg))
+    Bm = torch.randn(batch, G, N, L, generator=gg)
+    Cm = torch.randn(batch, G, N, L, generator=gg)
+    D = torch.randn(dim, generator=gg)
+    bias = 0.5 * torch.randn(dim, generator=gg) + softplus_bias
+    return u, delta, A, Bm, Cm, D, bias
+
+
+@pytest.mark.parametrize("batch,dim,L,N,G", [
+    (1, 256, 16384, 16, 4),      # BASELINE config 1, level 1 (128 x 128): multi-chunk
+    (2, 256, 4096, 16, 4),
+    (1, 256, 1024, 16, 4),
+    (1, 64, 5000, 16, 1),        # one group of 64
+    (1, 256, 3000, 32, 4),       # d_state 32 (BASELINE config 5 flavour)
+    (2, 96, 777, 16, 1),         # 96 channels per group (wf = 48): 2 waves per group, ragged; L % 4 != 0
+    (1, 40, 130, 7, 4),          # 10 channels per group, N = 7 (padded), scalar path
+    (3, 8, 1, 4, 2),             # L = 1
+    (1, 128, 66000, 16, 2),      # many chunks, L % 16 != 0
+])
+def test_scan_vs_oracle(batch, dim, L, N, G):
+    case = random_scan_case(batch, dim, L, N, G, seed=batch * 1000 + L)
+    y, last = wm.ops.selective_scan_fn(*cu(*case[:6]), None, case[6].to(DEV), True, True)
+    yr, lr = oracle.selscan_fwd_raw(*case[:6], None, case[6], True, True)
+    assert_close(y, yr, TOL, "y")
+    assert_close(last, lr, TOL, "last_state")
+
+
+def test_scan_stress_inputs():
+    # large positive delta (softplus threshold branch), tiny delta, zero u: no NaN, matches oracle
+    u, delta, A, Bm, Cm, D, bias = random_scan_case(1, 64, 2048, 16, 1, seed=5, softplus_bias=0.0)
+    delta[:, :, 100:110] = 30.0          # softplus(x) = x above 20; exp(dt*A) underflows to 0
+    delta[:, :, 500:600] = -40.0         # dt ~ 4e-18
+    u[:, :, 900:1000] = 0.0
+    y = wm.ops.selective_scan_fn(*cu(u, delta, A, Bm, Cm, D), None, bias.to(DEV), True)
+    assert torch.isfinite(y).all()
+    assert_close(y, oracle.selscan_fwd_raw(u, delta, A, Bm, Cm, D, None, bias, True), TOL, "stress y")
+
+
+def test_scan_errors():
+    u, delta, A, Bm, Cm, D, bias = cu(*random_scan_case(1, 8, 16, 4, 2, seed=1))
+    with pytest.raises(RuntimeError):
+        wm.ops.selective_scan_fn(u, delta[:, :, :8], A, Bm, Cm)
+    with pytest.raises(RuntimeError):
+        wm.ops.selective_scan_fn(u, delta, A, Bm[:, :, :3], Cm)
+    with pytest.raises(RuntimeError):
+        wm.ops.selective_scan_fn(u.cpu(), delta.cpu(), A.cpu(), Bm.cpu(), Cm.cpu())
+    with pytest.raises(NotImplementedError):
+        wm.ops.selective_scan_fn(u, delta, A, A, A)
+
+
+def test_scan_uhd_level1_properties():
+    """BASELINE config 2, level-1 scan at full size (B=1, KD=256, L=2,088,960): the oracle on all
+    channels would take minutes, so check (a) 8 channels of every group against the oracle and
+    (b) linearity in u on the full tensor."""
+    L, dim, N, G = 1088 * 1920, 256, 16, 4
+    gg = torch.Generator(device=DEV)
+    gg.manual_seed(11)
+    u = torch.randn(1, dim, L, generator=gg, device=DEV)
+    delta = 0.5 * torch.randn(1, dim, L, generator=gg, device=DEV)
+    Bm = torch.randn(1, G, N, L, generator=gg, device=DEV)
+    Cm = torch.randn(1, G, N, L, generator=gg, device=DEV)
+    A = -torch.arange(1, N + 1, dtype=torch.float32, device=DEV).repeat(dim, 1) * \
+        torch.exp(0.2 * torch.randn(dim, N, generator=gg, device=DEV))
+    D = torch.randn(dim, generator=gg, device=DEV)
+    bias = 0.5 * torch.randn(dim, generator=gg, device=DEV) - 4.0
+    y = wm.ops.selective_scan_fn(u, delta, A, Bm, Cm, D, None, bias, True)
+    assert torch.isfinite(y).all()
+    sel = torch.cat([torch.arange(g * 64 + 5, g * 64 + 61, 8) for g in range(G)])       # 7 per group
+    sel = torch.cat([sel, torch.tensor([0, 63, 64, 255])]).sort().values
+    # keep the group structure: pick the same number of channels in every group
+    per_group = [sel[(sel >= g * 64) & (sel < (g + 1) * 64)] for g in range(G)]
+    k = min(len(p) for p in per_group)
+    sel = torch.cat([p[:k] for p in per_group])
+    yr = oracle.selscan_fwd_raw(u[:, sel].cpu(), delta[:, sel].cpu(), A[sel].cpu(), Bm.cpu(), Cm.cpu(),
+                                D[sel].cpu(), None, bias[sel].cpu(), True)
+    assert_close(y[:, sel], yr, TOL, "UHD level-1 subset")
+    u2 = torch.randn(1, dim, L, generator=gg, device=DEV)
+    y2 = wm.ops.selective_scan_fn(u2, delta, A, Bm, Cm, D, None, bias, True)
+    y12 = wm.ops.selective_scan_fn(u + 2 * u2, delta, A, Bm, Cm, D, None, bias, True)
+    assert_close(y12, y + 2 * y2, 1e-5, "linearity in u")
+
+
+# ------------------------------------------------------------------------------------------------
+# network level
+# ------------------------------------------------------------------------------------------------
+def test_tiny_model_golden(golden):
+    g = golden("model_tiny")
+    net = wm.WaveMamba(in_chn=3, wf=8, n_l_blocks=[1, 1, 2], n_h_blocks=[1, 1, 1], ffn_scale=2.0).eval()
+    net.load_state_dict({k[2:]: v for k, v in g.items() if k.startswith("p.")}, strict=True)
+    net = net.to(DEV)
+    with torch.no_grad():
+        y = net(g["x"].to(DEV))
+    assert_close(y, g["y"], TOL, "tiny model")
+
+
+@pytest.mark.parametrize("tag,hw", [("32x64", (32, 64)), ("128x128", (128, 128)), ("256x256", (256, 256))])
+def test_shipped_config_golden(golden, tag, hw):
+    torch.manual_seed(0)
+    net = wm.WaveMamba(in_chn=3, wf=32, n_l_blocks=[1, 2, 4], n_h_blocks=[1, 1, 2], ffn_scale=2.0).eval().to(DEV)
+    x = torch.rand(1, 3, *hw, generator=gen(1234))
+    with torch.no_grad():
+        y = net.restoration_network(x.to(DEV))
+    want = golden("model_shipped")[f"y_{tag}"]
+    assert_close(y, want, TOL, f"shipped {tag}")
+    # PSNR match vs the reference output after the reference's uint8 quantisation
+    # (img_util.py:67-94, comput_psnr_ssim.py:434-438), against a seeded synthetic target
+    tgt = torch.rand(1, 3, *hw, generator=gen(4321))
+
+    def psnr(a, b):
+        qa = (a.clamp(0, 1) * 255).round()
+        qb = (b.clamp(0, 1) * 255).round()
+        return float(20 * torch.log10(255.0 / (qa - qb).pow(2).mean().sqrt()))
+    assert abs(psnr(y.cpu(), tgt) - psnr(want, tgt)) <= 1e-3
