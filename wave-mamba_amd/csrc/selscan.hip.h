@@ -33,9 +33,21 @@
 
 namespace wm {
 
-constexpr int kTile = 16;   // time steps per LDS tile
-constexpr int kRow = 20;    // LDS row stride (floats) of the [64][kTile] tiles: 80 B keeps the
-                            // per-lane ds_read_b128 of 16 consecutive rows on disjoint banks
+#ifndef WM_KTILE
+#define WM_KTILE 16
+#endif
+constexpr int kTile = WM_KTILE;   // time steps per LDS tile (16 -> 64-B, 32 -> 128-B row segments)
+constexpr int kLpr = kTile / 4;   // lanes per tile row (one float4 each)
+constexpr int kRpi = 64 / kLpr;   // tile rows covered by one wave-wide float4 access
+constexpr int kNld = 64 / kRpi;   // such accesses per [64][kTile] tile
+#ifndef WM_KROW
+#define WM_KROW (WM_KTILE + 4)
+#endif
+#ifndef WM_LB_WAVES
+#define WM_LB_WAVES 1
+#endif
+constexpr int kRow = WM_KROW;  // LDS row stride (floats) of the [64][kTile] tiles: 80 B keeps the
+                               // per-lane ds_read_b128 of 16 consecutive rows on disjoint banks
 
 struct ScanArgs {
     const float* u; const float* delta; const float* A; const float* Bm; const float* Cm;
@@ -49,22 +61,37 @@ struct ScanArgs {
     int softplus;
 };
 
-__device__ __forceinline__ float softplus_f(float x) {
-    // F.softplus(beta=1, threshold=20): log1p(exp(x)) below the threshold.  Hardware v_exp_f32 /
-    // v_log_f32 (both base 2, ~1 ulp) with the w = 1 + e compensation for log1p:
-    //   log1p(e) = log(w) * e / (w - 1), exact-cancelling the rounding of 1 + e.
-    const float e = __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
-    const float w = 1.0f + e;
-    const float lp = (w == 1.0f) ? e
-                                 : (__builtin_amdgcn_logf(w) * 0.6931471805599453f) * (e / (w - 1.0f));
-    return x > 20.0f ? x : lp;
+typedef float v2f __attribute__((ext_vector_type(2)));   // operands of v_pk_{mul,add,fma}_f32
+
+// gfx950 issues a plain fp32 VALU op over a wave64 in 4 cycles and a PACKED one (two fp32 per lane)
+// in the same 4 cycles; v_exp_f32 / v_log_f32 / v_rcp_f32 take 8 (tools/microbench.hip).  So all
+// non-transcendental math below is written on float pairs.
+__device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
+__device__ __forceinline__ v2f exp2_2(v2f x) {
+    return (v2f){__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+}
+
+// F.softplus(beta=1, threshold=20) = log1p(exp(x)) below the threshold, on two values at once.
+// Hardware v_exp_f32 / v_log_f32 (base 2, ~1 ulp) with the w = 1 + e compensation of log1p:
+//   log1p(e) = log(w) * e / (w - 1), which cancels the rounding of 1 + e exactly.
+__device__ __forceinline__ v2f softplus2(v2f x) {
+    const v2f e = exp2_2(x * 1.4426950408889634f);
+    const v2f w = e + 1.0f;
+    const v2f wm1 = w - 1.0f;
+    const v2f lg = (v2f){__builtin_amdgcn_logf(w.x), __builtin_amdgcn_logf(w.y)} * 0.6931471805599453f;
+    const v2f rc = (v2f){__builtin_amdgcn_rcpf(wm1.x), __builtin_amdgcn_rcpf(wm1.y)};
+    const v2f lp = lg * (e * rc);
+    v2f r;
+    r.x = x.x > 20.0f ? x.x : (w.x == 1.0f ? e.x : lp.x);
+    r.y = x.y > 20.0f ? x.y : (w.y == 1.0f ? e.y : lp.y);
+    return r;
 }
 
 // PHASE 1: reduce (no C, no y; writes P/H).  PHASE 3: scan (reads H_in, writes y).
 // NP = N padded to 16 or 32 (padded states have A = 0, B = C = 0 -> stay exactly 0).
 // VEC: L % 4 == 0 and 16-byte aligned bases -> float4 global access; else scalar access.
 template <int NP, int PHASE, bool VEC>
-__global__ __launch_bounds__(64) void selscan_chunk_kernel(ScanArgs p) {
+__global__ __launch_bounds__(64, WM_LB_WAVES) void selscan_chunk_kernel(ScanArgs p) {
     __shared__ __attribute__((aligned(16))) float s_u[64 * kRow];
     __shared__ __attribute__((aligned(16))) float s_d[64 * kRow];
     __shared__ __attribute__((aligned(16))) float s_B[kTile * NP];
@@ -85,24 +112,26 @@ __global__ __launch_bounds__(64) void selscan_chunk_kernel(ScanArgs p) {
     const int t_end = min(p.L, t_begin + p.chunk_len);
 
     // per-lane constants
-    float A2[NP];
+    v2f A2[NP / 2];                                   // A * log2(e), as (n, n+1) pairs
 #pragma unroll
-    for (int n = 0; n < NP; ++n)
-        A2[n] = (n < p.N) ? p.A[(long long)d * p.N + n] * 1.4426950408889634f : 0.0f;
+    for (int n = 0; n < NP; ++n) {
+        const float a = (n < p.N) ? p.A[(long long)d * p.N + n] * 1.4426950408889634f : 0.0f;
+        if (n & 1) A2[n / 2].y = a; else A2[n / 2].x = a;
+    }
     const float bias = p.bias ? p.bias[d] : 0.0f;
     const float Dd = (PHASE == 3 && p.D) ? p.D[d] : 0.0f;
 
-    float h[NP];
+    v2f h[NP / 2];                                    // the N states of this lane's channel
     const long long wsrow = ((long long)chunk * p.batch * p.dim + (long long)b * p.dim + d) * NP;
     if (PHASE == 3 && chunk > 0) {
 #pragma unroll
         for (int q = 0; q < NP / 4; ++q) {
             const float4 v = *reinterpret_cast<const float4*>(p.wsH + wsrow + 4 * q);
-            h[4 * q] = v.x; h[4 * q + 1] = v.y; h[4 * q + 2] = v.z; h[4 * q + 3] = v.w;
+            h[2 * q] = (v2f){v.x, v.y}; h[2 * q + 1] = (v2f){v.z, v.w};
         }
     } else {
 #pragma unroll
-        for (int n = 0; n < NP; ++n) h[n] = 0.0f;
+        for (int n = 0; n < NP / 2; ++n) h[n] = splat(0.0f);
     }
     float sum_dt = 0.0f;
 
@@ -114,17 +143,17 @@ __global__ __launch_bounds__(64) void selscan_chunk_kernel(ScanArgs p) {
     const float* zb = (PHASE == 3 && p.z) ? p.z + ((long long)b * p.dim + ch0) * L : nullptr;
 
     // ---- register staging of one tile (prefetched one tile ahead) ---------------------------
-    constexpr int NBQ = (NP * kTile / 4 + 63) / 64;     // float4 per lane for a [NP][16] tile
-    float4 ru[4], rd[4], rB[NBQ], rC[NBQ];
-    const int trow = lane >> 2, tq = lane & 3;           // tile row within a 16-row slab, quad col
+    constexpr int NBQ = (NP + kRpi - 1) / kRpi;         // float4 per lane for a [NP][kTile] tile
+    float4 ru[kNld], rd[kNld], rB[NBQ], rC[NBQ];
+    const int trow = lane / kLpr, tq = lane % kLpr;      // tile row within a slab, quad column
 
     auto fetch = [&](int t0) {
         if constexpr (VEC) {
             const int t = t0 + 4 * tq;
             const bool tin = t < t_end;                  // L % 4 == 0: a quad is all-in or all-out
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 16 * i + trow;
+            for (int i = 0; i < kNld; ++i) {
+                const int r = kRpi * i + trow;
                 const bool ok = tin && r < nch;
                 ru[i] = ok ? *reinterpret_cast<const float4*>(ub + (long long)r * L + t)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -133,7 +162,7 @@ __global__ __launch_bounds__(64) void selscan_chunk_kernel(ScanArgs p) {
             }
 #pragma unroll
             for (int i = 0; i < NBQ; ++i) {
-                const int n = 16 * i + trow;
+                const int n = kRpi * i + trow;
                 const bool ok = tin && n < p.N;
                 rB[i] = ok ? *reinterpret_cast<const float4*>(Bb + (long long)n * L + t)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -156,28 +185,28 @@ __global__ __launch_bounds__(64) void selscan_chunk_kernel(ScanArgs p) {
             };
             const int t = t0 + 4 * tq;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ru[i] = ld4(ub, 16 * i + trow, nch, t);
-                rd[i] = ld4(db, 16 * i + trow, nch, t);
+            for (int i = 0; i < kNld; ++i) {
+                ru[i] = ld4(ub, kRpi * i + trow, nch, t);
+                rd[i] = ld4(db, kRpi * i + trow, nch, t);
             }
 #pragma unroll
             for (int i = 0; i < NBQ; ++i) {
-                rB[i] = ld4(Bb, 16 * i + trow, p.N, t);
-                if (PHASE == 3) rC[i] = ld4(Cb, 16 * i + trow, p.N, t);
+                rB[i] = ld4(Bb, kRpi * i + trow, p.N, t);
+                if (PHASE == 3) rC[i] = ld4(Cb, kRpi * i + trow, p.N, t);
             }
         }
     };
 
     auto stage = [&]() {          // registers -> LDS (u/delta row-major padded, B/C transposed)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 16 * i + trow;
+        for (int i = 0; i < kNld; ++i) {
+            const int r = kRpi * i + trow;
             *reinterpret_cast<float4*>(&s_u[r * kRow + 4 * tq]) = ru[i];
             *reinterpret_cast<float4*>(&s_d[r * kRow + 4 * tq]) = rd[i];
         }
 #pragma unroll
         for (int i = 0; i < NBQ; ++i) {
-            const int n = 16 * i + trow;
+            const int n = kRpi * i + trow;
             if (n < NP) {
                 s_B[(4 * tq + 0) * NP + n] = rB[i].x; s_B[(4 * tq + 1) * NP + n] = rB[i].y;
                 s_B[(4 * tq + 2) * NP + n] = rB[i].z; s_B[(4 * tq + 3) * NP + n] = rB[i].w;
@@ -202,35 +231,33 @@ __global__ __launch_bounds__(64) void selscan_chunk_kernel(ScanArgs p) {
                 const float4 u4 = *reinterpret_cast<const float4*>(&s_u[lane * kRow + 4 * q]);
                 const float4 d4 = *reinterpret_cast<const float4*>(&s_d[lane * kRow + 4 * q]);
                 const float uu[4] = {u4.x, u4.y, u4.z, u4.w};
-                const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+                v2f dta = (v2f){d4.x, d4.y} + bias, dtb = (v2f){d4.z, d4.w} + bias;
+                if (p.softplus) { dta = softplus2(dta); dtb = softplus2(dtb); }
+                const float dts[4] = {dta.x, dta.y, dtb.x, dtb.y};
                 float yy[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int tt = 4 * q + j;
                     if (tt < tl) {
-                        float dt = dd[j] + bias;
-                        if (p.softplus) dt = softplus_f(dt);
+                        const float dt = dts[j];
                         const float ut = uu[j];
-                        const float du = dt * ut;
+                        const v2f dt2 = splat(dt), du2 = splat(dt * ut);
                         if (PHASE == 1) sum_dt += dt;
-                        float Bv[NP], Cv[NP];
+                        v2f y2 = splat(0.0f);
 #pragma unroll
                         for (int r = 0; r < NP / 4; ++r) {
-                            const float4 v = *reinterpret_cast<const float4*>(&s_B[tt * NP + 4 * r]);
-                            Bv[4 * r] = v.x; Bv[4 * r + 1] = v.y; Bv[4 * r + 2] = v.z; Bv[4 * r + 3] = v.w;
+                            const float4 bv = *reinterpret_cast<const float4*>(&s_B[tt * NP + 4 * r]);
+                            const v2f a0 = exp2_2(dt2 * A2[2 * r]);
+                            const v2f a1 = exp2_2(dt2 * A2[2 * r + 1]);
+                            h[2 * r] = a0 * h[2 * r] + du2 * (v2f){bv.x, bv.y};
+                            h[2 * r + 1] = a1 * h[2 * r + 1] + du2 * (v2f){bv.z, bv.w};
                             if (PHASE == 3) {
-                                const float4 c = *reinterpret_cast<const float4*>(&s_C[tt * NP + 4 * r]);
-                                Cv[4 * r] = c.x; Cv[4 * r + 1] = c.y; Cv[4 * r + 2] = c.z; Cv[4 * r + 3] = c.w;
+                                const float4 cv = *reinterpret_cast<const float4*>(&s_C[tt * NP + 4 * r]);
+                                y2 = (v2f){cv.x, cv.y} * h[2 * r] + y2;
+                                y2 = (v2f){cv.z, cv.w} * h[2 * r + 1] + y2;
                             }
                         }
-                        float y = 0.0f;
-#pragma unroll
-                        for (int n = 0; n < NP; ++n) {
-                            const float a = __builtin_amdgcn_exp2f(dt * A2[n]);
-                            h[n] = fmaf(a, h[n], du * Bv[n]);
-                            if (PHASE == 3) y = fmaf(Cv[n], h[n], y);
-                        }
-                        if (PHASE == 3) yy[j] = fmaf(Dd, ut, y);
+                        if (PHASE == 3) yy[j] = fmaf(Dd, ut, y2.x + y2.y);
                     }
                 }
                 if (PHASE == 3)   // y overwrites the consumed u tile (same row, same lane)
@@ -242,8 +269,8 @@ __global__ __launch_bounds__(64) void selscan_chunk_kernel(ScanArgs p) {
         if (PHASE == 3) {         // LDS y tile -> global, 16 B per lane, z-gate fused
             const int t = t0 + 4 * tq;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 16 * i + trow;
+            for (int i = 0; i < kNld; ++i) {
+                const int r = kRpi * i + trow;
                 if (r < nch && t < t_end) {
                     float4 v = *reinterpret_cast<const float4*>(&s_u[r * kRow + 4 * tq]);
                     float* o = ob + (long long)r * L + t;
@@ -275,54 +302,66 @@ __global__ __launch_bounds__(64) void selscan_chunk_kernel(ScanArgs p) {
 #pragma unroll
             for (int q = 0; q < NP / 4; ++q) {
                 *reinterpret_cast<float4*>(p.wsH + wsrow + 4 * q) =
-                    make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
-                *reinterpret_cast<float4*>(p.wsP + wsrow + 4 * q) =
-                    make_float4(__builtin_amdgcn_exp2f(sum_dt * A2[4 * q]),
-                                __builtin_amdgcn_exp2f(sum_dt * A2[4 * q + 1]),
-                                __builtin_amdgcn_exp2f(sum_dt * A2[4 * q + 2]),
-                                __builtin_amdgcn_exp2f(sum_dt * A2[4 * q + 3]));
+                    make_float4(h[2 * q].x, h[2 * q].y, h[2 * q + 1].x, h[2 * q + 1].y);
+                const v2f p0 = exp2_2(splat(sum_dt) * A2[2 * q]), p1 = exp2_2(splat(sum_dt) * A2[2 * q + 1]);
+                *reinterpret_cast<float4*>(p.wsP + wsrow + 4 * q) = make_float4(p0.x, p0.y, p1.x, p1.y);
             }
         }
     } else if (p.last_state && chunk == p.nchunks - 1 && live) {
-        for (int n = 0; n < p.N; ++n) p.last_state[((long long)b * p.dim + d) * p.N + n] = h[n];
+        for (int n = 0; n < p.N; ++n)
+            p.last_state[((long long)b * p.dim + d) * p.N + n] = (n & 1) ? h[n / 2].y : h[n / 2].x;
     }
 }
 
 // Phase 2.  chain = (b*dim + d)*NP + n; ws layout [chunk][chain] so that consecutive lanes touch
-// consecutive words.  A 1024-thread block owns 64 chains; its 16 waves split the chunk range:
-// each wave folds its segment, the segment aggregates are combined through LDS, then each wave
-// re-walks its segment replacing the end state H[c] by the carry-in H_in[c].
+// consecutive words.  A 1024-thread block owns 16 chains x 64 segments of the chunk range (lane =
+// 16 chains x 4 segments, 16 waves): each thread folds its segment (loads batched 8 deep so the
+// dependent FMA chain never waits on memory), the 64 segment aggregates of a chain are combined
+// through LDS, then each thread re-walks its segment replacing the end state H[c] by the carry-in.
+constexpr int kCarrySeg = 64;
 __global__ __launch_bounds__(1024) void selscan_carry_kernel(const float* __restrict__ wsP,
                                                              float* __restrict__ wsH,
                                                              long long nchains, int nchunks) {
-    __shared__ float sP[16][64];
-    __shared__ float sH[16][64];
-    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
-    const long long chain = (long long)blockIdx.x * 64 + lane;
+    __shared__ float sP[kCarrySeg][17];
+    __shared__ float sH[kCarrySeg][17];
+    const int cl = threadIdx.x & 15;                       // chain within the block
+    const int seg = threadIdx.x >> 4;                      // 0..63
+    const long long chain = (long long)blockIdx.x * 16 + cl;
     const bool ok = chain < nchains;
-    const int per = (nchunks + 15) / 16;
+    const int per = (nchunks + kCarrySeg - 1) / kCarrySeg;
     const int c0 = min(nchunks, seg * per), c1 = min(nchunks, c0 + per);
     float P = 1.0f, H = 0.0f;
     if (ok) {
-#pragma unroll 4
-        for (int c = c0; c < c1; ++c) {
-            const float pp = wsP[(long long)c * nchains + chain];
-            const float hh = wsH[(long long)c * nchains + chain];
-            H = fmaf(pp, H, hh);
-            P *= pp;
+        for (int c = c0; c < c1; c += 8) {
+            float pp[8], hh[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool in = c + j < c1;
+                pp[j] = in ? wsP[(long long)(c + j) * nchains + chain] : 1.0f;
+                hh[j] = in ? wsH[(long long)(c + j) * nchains + chain] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { H = fmaf(pp[j], H, hh[j]); P *= pp[j]; }
         }
     }
-    sP[seg][lane] = P; sH[seg][lane] = H;
+    sP[seg][cl] = P; sH[seg][cl] = H;
     __syncthreads();
     float carry = 0.0f;
-    for (int s = 0; s < seg; ++s) carry = fmaf(sP[s][lane], carry, sH[s][lane]);
+    for (int s = 0; s < seg; ++s) carry = fmaf(sP[s][cl], carry, sH[s][cl]);
     if (ok) {
-#pragma unroll 4
-        for (int c = c0; c < c1; ++c) {
-            const float pp = wsP[(long long)c * nchains + chain];
-            const float hh = wsH[(long long)c * nchains + chain];
-            wsH[(long long)c * nchains + chain] = carry;
-            carry = fmaf(pp, carry, hh);
+        for (int c = c0; c < c1; c += 8) {
+            float pp[8], hh[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool in = c + j < c1;
+                pp[j] = in ? wsP[(long long)(c + j) * nchains + chain] : 1.0f;
+                hh[j] = in ? wsH[(long long)(c + j) * nchains + chain] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (c + j < c1) wsH[(long long)(c + j) * nchains + chain] = carry;
+                carry = fmaf(pp[j], carry, hh[j]);
+            }
         }
     }
 }

@@ -116,7 +116,10 @@ static int scan_plan(ScanPlan& pl, int batch, int dim, int L, int N, int G) {
     pl.rows = (int)rows;
     // enough chunks to keep every CU's wave slots busy for several rounds (256 CUs x ~12 resident
     // single-wave workgroups), but never shorter than 64 steps
-    const long long target_waves = 256LL * 12 * 4;
+#ifndef WM_TARGET_WAVES
+#define WM_TARGET_WAVES (256LL * 12 * 4)
+#endif
+    const long long target_waves = WM_TARGET_WAVES;
     long long want = (target_waves + rows - 1) / rows;           // chunks wanted per wave-row
     long long cl = ((long long)L + want - 1) / want;
     cl = ((cl + kTile - 1) / kTile) * kTile;
@@ -138,7 +141,7 @@ static int scan_launch(const ScanArgs& a, const ScanPlan& pl, hipStream_t st) {
         {
             ProfScope ps(3, st);
             const long long nchains = (long long)a.batch * a.dim * NP;
-            hipLaunchKernelGGL(selscan_carry_kernel, dim3((unsigned)((nchains + 63) / 64)), dim3(1024), 0,
+            hipLaunchKernelGGL(selscan_carry_kernel, dim3((unsigned)((nchains + 15) / 16)), dim3(1024), 0,
                                st, (const float*)a.wsP, a.wsH, nchains, pl.nchunks);
         }
     }
