@@ -108,10 +108,20 @@ int wm_selscan_bwd(const float* u, const float* delta, const float* A, const flo
                    int batch, int dim, int L, int N, int G, int delta_softplus, void* stream);
 
 /* --------------------------------------------------------------------------------------------
+ * Depth-wise 3x3 convolution, stride 1, zero padding 1, + bias, + optional SiLU.
+ * Replaces nn.Conv2d(groups=channels) + nn.SiLU of SS2D (wavemamba_arch.py:346-355, :487) and the
+ * ffn's conv2 (:220, :226) in LFSSBlock.  x, y (B, C, H, W) fp32; weight (C, 1, 3, 3); bias (C) or
+ * NULL; act: 0 = none, 1 = SiLU.  Forward only (training keeps the autograd conv).
+ * -------------------------------------------------------------------------------------------- */
+int wm_dwconv3x3_fwd(const float* x, const float* weight, const float* bias, float* y,
+                     int B, int C, int H, int W, int act, void* stream);
+
+/* --------------------------------------------------------------------------------------------
  * Profiling hooks used by bench.py (HIP events recorded on the launch stream around each kernel
  * class).  Disabled by default; when disabled the library records nothing.
  *   kernel ids: 0 dwt/analysis, 1 iwt/synthesis, 2 scan chunk-reduce, 3 scan carry,
- *               4 scan chunk-scan (the dominant kernel), 5 scan bwd
+ *               4 scan chunk-scan (the dominant kernel), 5 scan bwd, 6 ss2d projection,
+ *               7 depth-wise conv
  * wm_prof_collect synchronises the recorded events (host-blocking) and returns, per kernel id,
  * the number of launches and their summed duration in milliseconds since wm_prof_enable(1).
  * -------------------------------------------------------------------------------------------- */

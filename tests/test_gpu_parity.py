@@ -256,3 +256,26 @@ def test_shipped_config_golden(golden, tag, hw):
         qb = (b.clamp(0, 1) * 255).round()
         return float(20 * torch.log10(255.0 / (qa - qb).pow(2).mean().sqrt()))
     assert abs(psnr(y.cpu(), tgt) - psnr(want, tgt)) <= 1e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# depth-wise 3x3 conv (+bias, +SiLU): SS2D.conv2d / ffn.conv2 (reference :346-355, :487, :220)
+# floating-point kernel of a standard op -> PyTorch fp32 CPU conv is the reference
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 64, 32, 48), (2, 5, 7, 9), (1, 3, 1, 1), (1, 8, 130, 260),
+                                   (1, 2, 33, 1030), (1, 96, 17, 64)])
+@pytest.mark.parametrize("act", ["none", "silu"])
+def test_dwconv3x3_vs_torch(shape, act):
+    import torch.nn.functional as F
+    B, C, H, W = shape
+    gg = gen(B * 1000 + W)
+    x = torch.randn(*shape, generator=gg)
+    w = torch.randn(C, 1, 3, 3, generator=gg) * 0.3
+    b = torch.randn(C, generator=gg)
+    ref = F.conv2d(x, w, b, stride=1, padding=1, groups=C)
+    if act == "silu":
+        ref = F.silu(ref)
+    got = wm.ops.dwconv3x3(x.to(DEV), w.to(DEV), b.to(DEV), act)
+    assert_close(got, ref, 1e-5, f"dwconv {shape} {act}")
+    got_nb = wm.ops.dwconv3x3(x.to(DEV), w.to(DEV), None, "none")
+    assert_close(got_nb, F.conv2d(x, w, None, padding=1, groups=C), 1e-5, "dwconv no bias")

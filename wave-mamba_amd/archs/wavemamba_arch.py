@@ -51,6 +51,17 @@ def get_ops_backend():
     return _OpsBackend.impl
 
 
+def _dwconv(conv, x, act="none"):
+    """Depth-wise 3x3 nn.Conv2d (+ optional SiLU).  Inference on the HIP backend goes to the
+    streaming HIP kernel; training (autograd) and the test backends use the PyTorch conv."""
+    ops = _OpsBackend.impl
+    if (hasattr(ops, "dwconv3x3") and x.is_cuda and x.dtype == torch.float32
+            and not (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad))):
+        return ops.dwconv3x3(x, conv.weight, conv.bias, act)
+    y = conv(x)
+    return F.silu(y) if act == "silu" else y
+
+
 # ================================================================================================
 # Low-frequency branch: SS2D / LFSSBlock
 # ================================================================================================
@@ -81,7 +92,7 @@ class ffn(nn.Module):
         self.conv3 = nn.Conv2d(hidden // 2, num_feat, kernel_size=1)
 
     def forward(self, x):
-        gate, value = self.conv2(self.conv1(x)).chunk(2, dim=1)
+        gate, value = _dwconv(self.conv2, self.conv1(x)).chunk(2, dim=1)
         return self.conv3(F.gelu(gate) * value)
 
 
@@ -197,7 +208,7 @@ class SS2D(nn.Module):
     def forward(self, x, **kwargs):
         B, H, W, C = x.shape
         x, z = self.in_proj(x).chunk(2, dim=-1)
-        x = self.act(self.conv2d(x.permute(0, 3, 1, 2).contiguous()))
+        x = _dwconv(self.conv2d, x.permute(0, 3, 1, 2).contiguous(), act="silu")
         y1, y2, y3, y4 = self.forward_core(x)
         assert y1.dtype == torch.float32
         y = (y1 + y2 + y3 + y4).transpose(1, 2).contiguous().view(B, H, W, -1)
@@ -325,10 +336,10 @@ class FeedForward(nn.Module):
             nn.Conv2d(hidden, dim, 1, bias=bias))
 
     def forward(self, x, perception):
-        y = self.project_in(x)
+        y = _dwconv(self.project_in[1], self.project_in[0](x))
         if perception is not None:
             y = self.matching_transformation(y, perception)
-        return self.project_out(y)
+        return self.project_out[2](self.project_out[1](_dwconv(self.project_out[0], y)))
 
 
 class CMTAttention(nn.Module):
@@ -350,7 +361,7 @@ class CMTAttention(nn.Module):
 
     def forward(self, x, perception):
         b, c, h, w = x.shape
-        q, k, v = self.qkv_dwconv(self.qkv(x)).chunk(3, dim=1)
+        q, k, v = _dwconv(self.qkv_dwconv, self.qkv(x)).chunk(3, dim=1)
         if self.matching is True:
             q = self.matching_transformation(q, perception)
         heads = self.num_heads

@@ -1,0 +1,96 @@
+// dwconv.hip.h - depth-wise 3x3 convolution (stride 1, zero padding 1) over NCHW fp32, with bias and
+// an optional fused SiLU, for gfx950.
+//
+// Reference call sites: SS2D.conv2d + SiLU (/root/reference/basicsr/archs/wavemamba_arch.py:346-355,
+// :487) and the gated ffn's conv2 (:220, :226) inside LFSSBlock - both `groups == channels`.  On
+// ROCm these land on MIOpen's dense Winograd kernel (~30x the streaming time at UHD, see
+// profiles/r01/bench_kernel_stats_step_tail.txt); the op is pure bandwidth: 9 FMA per 8 bytes moved.
+//
+// One thread walks a 4-column strip down RH output rows with a 3-row register window, so every
+// input row is fetched once per strip (16-byte loads); the two halo columns come from the
+// neighbouring lanes by wave shuffle (the strip edges of a wave read them from memory).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace wm {
+
+constexpr int kDwRows = 16;     // output rows per thread strip
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+
+template <int ACT /*0 none, 1 silu*/, bool VEC>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ wgt,
+                                                        const float* __restrict__ bias,
+                                                        float* __restrict__ y, int C, int H, int W,
+                                                        long long planes) {
+    const int lane = threadIdx.x;                        // 64 column groups = one wave per strip row
+    const int cg = blockIdx.x * 64 + lane;               // column group (4 columns)
+    const int h0 = (blockIdx.y * 4 + threadIdx.y) * kDwRows;
+    for (long long plane = blockIdx.z; plane < planes; plane += gridDim.z) {
+        const int c = (int)(plane % C);
+        float k[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) k[i] = wgt[c * 9 + i];
+        const float bv = bias ? bias[c] : 0.0f;
+        const float* xp = x + plane * (long long)H * W;
+        float* yp = y + plane * (long long)H * W;
+        const int w0 = cg * 4;
+        const bool colok = w0 < W;                       // whole quad in range when VEC (W % 4 == 0)
+
+        // row(r): 6 values x[r][w0-1 .. w0+4], zero outside the image
+        auto load_row = [&](int r, float (&v)[6]) {
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool rowok = r >= 0 && r < H;
+            if (rowok && colok) {
+                if constexpr (VEC) {
+                    q = *reinterpret_cast<const float4*>(xp + (long long)r * W + w0);
+                } else {
+                    const float* p = xp + (long long)r * W + w0;
+                    q.x = p[0];
+                    if (w0 + 1 < W) q.y = p[1];
+                    if (w0 + 2 < W) q.z = p[2];
+                    if (w0 + 3 < W) q.w = p[3];
+                }
+            }
+            float left = __shfl_up(q.w, 1), right = __shfl_down(q.x, 1);
+            if (lane == 0) left = (rowok && w0 - 1 >= 0 && w0 - 1 < W) ? xp[(long long)r * W + w0 - 1] : 0.0f;
+            if (lane == 63) right = (rowok && w0 + 4 < W) ? xp[(long long)r * W + w0 + 4] : 0.0f;
+            v[0] = left; v[1] = q.x; v[2] = q.y; v[3] = q.z; v[4] = q.w; v[5] = right;
+        };
+
+        if (h0 < H) {                                     // uniform per wave (threadIdx.y, blockIdx.y)
+            float r0[6], r1[6], r2[6];
+            load_row(h0 - 1, r0);
+            load_row(h0, r1);
+            const int hend = min(H, h0 + kDwRows);
+            for (int h = h0; h < hend; ++h) {
+                load_row(h + 1, r2);
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float acc = bv;
+                    acc = fmaf(k[0], r0[j], acc); acc = fmaf(k[1], r0[j + 1], acc); acc = fmaf(k[2], r0[j + 2], acc);
+                    acc = fmaf(k[3], r1[j], acc); acc = fmaf(k[4], r1[j + 1], acc); acc = fmaf(k[5], r1[j + 2], acc);
+                    acc = fmaf(k[6], r2[j], acc); acc = fmaf(k[7], r2[j + 1], acc); acc = fmaf(k[8], r2[j + 2], acc);
+                    o[j] = ACT == 1 ? silu_f(acc) : acc;
+                }
+                if (colok) {
+                    if constexpr (VEC) {
+                        *reinterpret_cast<float4*>(yp + (long long)h * W + w0) = make_float4(o[0], o[1], o[2], o[3]);
+                    } else {
+                        float* p = yp + (long long)h * W + w0;
+                        p[0] = o[0];
+                        if (w0 + 1 < W) p[1] = o[1];
+                        if (w0 + 2 < W) p[2] = o[2];
+                        if (w0 + 3 < W) p[3] = o[3];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; }
+            }
+        }
+    }
+}
+
+}  // namespace wm

@@ -9,6 +9,7 @@
 #include "../../include/wavemamba_hip.h"
 #include "haar.hip.h"
 #include "selscan.hip.h"
+#include "dwconv.hip.h"
 
 namespace wm {
 
@@ -284,6 +285,26 @@ int wm_selscan_bwd(const float*, const float*, const float*, const float*, const
                    const float*, const float*, float*, float*, float*, float*, float*, float*, float*,
                    void*, size_t, int, int, int, int, int, int, void*) {
     return WM_EUNSUPPORTED;   // implemented in a later milestone
+}
+
+int wm_dwconv3x3_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int C,
+                     int H, int W, int act, void* stream) {
+    if (B < 0 || C < 0 || H < 0 || W < 0) return WM_EINVAL;
+    if (act != 0 && act != 1) return WM_EUNSUPPORTED;
+    const long long planes = (long long)B * C;
+    if (planes == 0 || H == 0 || W == 0) return WM_OK;
+    if (!x || !weight || !y) return WM_ENULL;
+    const bool vec = (W % 4 == 0) && aligned16(x) && aligned16(y);
+    const dim3 block(64, 4);
+    const dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 4 * kDwRows - 1) / (4 * kDwRows)),
+                    (unsigned)(planes < 65535 ? planes : 65535));
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(7, st);
+#define WM_DW(ACT, VEC) hipLaunchKernelGGL((dwconv3x3_kernel<ACT, VEC>), grid, block, 0, st, x, weight, bias, y, C, H, W, planes)
+    if (act == 1) { if (vec) WM_DW(1, true); else WM_DW(1, false); }
+    else          { if (vec) WM_DW(0, true); else WM_DW(0, false); }
+#undef WM_DW
+    return launch_status();
 }
 
 void wm_prof_enable(int on) {

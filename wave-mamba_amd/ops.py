@@ -271,10 +271,32 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
 
 
 # ------------------------------------------------------------------------------------------------
+# depth-wise 3x3 convolution (+ bias, + SiLU) - inference path of SS2D.conv2d / ffn.conv2
+# ------------------------------------------------------------------------------------------------
+def dwconv3x3(x, weight, bias=None, act="none"):
+    """F.conv2d(x, weight, bias, stride=1, padding=1, groups=C) [+ SiLU when act == 'silu'] for a
+    (C, 1, 3, 3) weight, NCHW fp32, forward only (no autograd graph is recorded)."""
+    lib = _lib.load()
+    _require_cuda("dwconv3x3", x, weight, bias)
+    B, C, H, W = x.shape
+    if weight.shape != (C, 1, 3, 3):
+        raise RuntimeError(f"dwconv3x3: weight must be ({C}, 1, 3, 3), got {tuple(weight.shape)}")
+    if x.dtype != torch.float32:
+        raise RuntimeError("dwconv3x3: float32 only")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(lib.wm_dwconv3x3_fwd(_ptr(x), _ptr(weight.detach().contiguous()),
+                                   _ptr(None if bias is None else bias.detach().contiguous()), _ptr(y),
+                                   B, C, H, W, {"none": 0, "silu": 1}[act], _stream()), "wm_dwconv3x3_fwd")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
 # profiling hooks (bench.py)
 # ------------------------------------------------------------------------------------------------
 PROF_KERNELS = ("haar_analysis", "haar_synthesis", "selscan_chunk_reduce", "selscan_carry",
-                "selscan_chunk_scan", "selscan_bwd", "ss2d_proj", "reserved")
+                "selscan_chunk_scan", "selscan_bwd", "ss2d_proj", "dwconv3x3")
 
 
 def prof_enable(on=True):
