@@ -108,6 +108,25 @@ int wm_selscan_bwd(const float* u, const float* delta, const float* A, const flo
                    int batch, int dim, int L, int N, int G, int delta_softplus, void* stream);
 
 /* --------------------------------------------------------------------------------------------
+ * Fused SS2D four-direction scan core.  Replaces SS2D.forward_core(x), wavemamba_arch.py:446-478:
+ * direction flatten (:451-452), x_proj / dt_proj einsums (:453-455), the selective scan (:465-471)
+ * and the flips / transposes back (:474-478), without materialising any of the intermediates.
+ *   x (B, D, H, W) fp32;  x_proj_weight (4, R + 2N, D);  dt_projs_weight (4, D, R);
+ *   dt_projs_bias (4, D);  A_logs (4 D, N)  [A = -exp(A_logs)];  Ds (4 D)
+ *   outputs, each (B, D, H*W) in row-major l, in the reference's return order (:478):
+ *     y_row_fwd = out_y[:,0], y_row_rev = flip(out_y[:,2]), y_col_fwd, y_col_rev (column scans,
+ *     transposed back).  merged != 0: only y_row_fwd is written and holds the SUM of the four
+ *     (what SS2D.forward computes next, :490); the other three pointers may be NULL.
+ *   Supported: N <= 16, R <= 4, D <= 64 (else WM_EUNSUPPORTED: use wm_selscan_fwd).
+ * -------------------------------------------------------------------------------------------- */
+size_t wm_ss2d_core_fwd_workspace_bytes(int B, int D, int H, int W, int N, int R);
+int wm_ss2d_core_fwd(const float* x, const float* x_proj_weight, const float* dt_projs_weight,
+                     const float* dt_projs_bias, const float* A_logs, const float* Ds,
+                     float* y_row_fwd, float* y_row_rev, float* y_col_fwd, float* y_col_rev,
+                     int merged, void* workspace, size_t workspace_bytes,
+                     int B, int D, int H, int W, int N, int R, void* stream);
+
+/* --------------------------------------------------------------------------------------------
  * Depth-wise 3x3 convolution, stride 1, zero padding 1, + bias, + optional SiLU.
  * Replaces nn.Conv2d(groups=channels) + nn.SiLU of SS2D (wavemamba_arch.py:346-355, :487) and the
  * ffn's conv2 (:220, :226) in LFSSBlock.  x, y (B, C, H, W) fp32; weight (C, 1, 3, 3); bias (C) or

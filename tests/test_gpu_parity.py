@@ -226,6 +226,66 @@ def test_scan_uhd_level1_properties():
 
 
 # ------------------------------------------------------------------------------------------------
+# fused SS2D four-direction core (reference SS2D.forward_core, :446-478)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["s16", "sq16", "d8"])
+def test_ss2d_core_golden(golden, tag):
+    g = golden("scan")          # captured from the reference's real forward_core
+    args = cu(g[f"{tag}_core_x"], g[f"{tag}_x_proj_weight"], g[f"{tag}_dt_projs_weight"],
+              g[f"{tag}_dt_projs_bias"], g[f"{tag}_A_logs"], g[f"{tag}_Ds"])
+    ys = wm.ops.ss2d_core(*args)
+    for i, y in enumerate(ys):
+        assert_close(y, g[f"{tag}_core_y{i}"], TOL, f"{tag} core y{i}")
+    ysum = wm.ops.ss2d_core(*args, merged=True)
+    assert_close(ysum, sum(g[f"{tag}_core_y{i}"] for i in range(4)), TOL, f"{tag} merged")
+
+
+def random_core_case(B, D, H, W, N, R, seed):
+    gg = gen(seed)
+    x = torch.randn(B, D, H, W, generator=gg)
+    Wx = torch.randn(4, R + 2 * N, D, generator=gg) / D ** 0.5
+    Wdt = torch.randn(4, D, R, generator=gg) * R ** -0.5
+    bias = torch.randn(4, D, generator=gg) * 0.5 - 3.0
+    A_logs = torch.log(torch.arange(1, N + 1, dtype=torch.float32)).repeat(4 * D, 1) + 0.2 * torch.randn(4 * D, N, generator=gg)
+    Ds = torch.randn(4 * D, generator=gg)
+    return x, Wx, Wdt, bias, A_logs, Ds
+
+
+@pytest.mark.parametrize("B,D,H,W,N,R", [
+    (1, 64, 32, 32, 16, 2),      # BASELINE config 1, level 3
+    (1, 64, 64, 64, 16, 2),      # level 2: several chunks / segments
+    (2, 64, 24, 40, 16, 2),      # batch 2, W < 64 (ragged column tile)
+    (1, 64, 40, 136, 16, 2),     # 3 column tiles, last ragged
+    (1, 16, 10, 14, 16, 1),      # wf = 8: d_inner 16, dt_rank 1
+    (1, 48, 9, 7, 8, 3),         # odd sizes (L % 4 != 0 -> scalar paths), N = 8, R = 3
+    (1, 64, 128, 128, 16, 2),    # config 1 level 1: many chunks, several row segments
+])
+def test_ss2d_core_vs_oracle(B, D, H, W, N, R):
+    case = random_core_case(B, D, H, W, N, R, seed=H * 100 + W)
+    want = oracle.ss2d_core_raw(*case)
+    got = wm.ops.ss2d_core(*cu(*case))
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert_close(a, b, TOL, f"core y{i}")
+    assert_close(wm.ops.ss2d_core(*cu(*case), merged=True), sum(want), TOL, "merged")
+
+
+def test_ss2d_core_uhd_level2_against_unfused():
+    """UHD level-2 map (544 x 960, L = 522,240): fused core vs the direction glue + op-boundary scan
+    (itself oracle-checked above) - the oracle would need minutes here."""
+    case = cu(*random_core_case(1, 64, 544, 960, 16, 2, seed=3))
+    x, Wx, Wdt, bias, A_logs, Ds = case
+    ss = arch.SS2D(d_model=32, d_state=16, expand=2.0).to(DEV)
+    with torch.no_grad():
+        ss.x_proj_weight.copy_(Wx); ss.dt_projs_weight.copy_(Wdt); ss.dt_projs_bias.copy_(bias)
+        ss.A_logs.copy_(A_logs); ss.Ds.copy_(Ds)
+        fused = wm.ops.ss2d_core(*case)
+        ss._fused_ok = lambda _x: False                     # force the unfused path
+        unfused = ss.forward_core(x)
+    for i, (a, b) in enumerate(zip(fused, unfused)):
+        assert_close(a, b, TOL, f"UHD-L2 core y{i}")
+
+
+# ------------------------------------------------------------------------------------------------
 # network level
 # ------------------------------------------------------------------------------------------------
 def test_tiny_model_golden(golden):

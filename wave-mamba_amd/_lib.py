@@ -27,6 +27,8 @@ SIGNATURES = {
     "wm_selscan_fwd": (_i, [_p] * 10 + [_p, _sz] + [_i] * 6 + [_p]),
     "wm_selscan_bwd_workspace_bytes": (_sz, [_i] * 5),
     "wm_selscan_bwd": (_i, [_p] * 15 + [_p, _sz] + [_i] * 6 + [_p]),
+    "wm_ss2d_core_fwd_workspace_bytes": (_sz, [_i] * 6),
+    "wm_ss2d_core_fwd": (_i, [_p] * 10 + [_i, _p, _sz] + [_i] * 6 + [_p]),
     "wm_dwconv3x3_fwd": (_i, [_p] * 4 + [_i] * 5 + [_p]),
     "wm_prof_enable": (None, [_i]),
     "wm_prof_collect": (_i, [_c.POINTER(_i), _c.POINTER(_c.c_double)]),

@@ -1,0 +1,502 @@
+// ss2d.hip.h - fused SS2D four-direction scan core for gfx950 (MI355X).
+//
+// Replaces SS2D.forward_core (/root/reference/basicsr/archs/wavemamba_arch.py:446-478):
+//   xs = [x row-major | x column-major | their flips]                         (:451-452)
+//   x_dbl[k] = x_proj_weight[k] . xs[k]  -> split (dt_r | B | C)              (:453-454)
+//   dts[k]   = dt_projs_weight[k] . dt_r                                      (:455)
+//   y[k]     = selective_scan(xs[k], dts[k], -exp(A_logs), B, C, Ds, bias, softplus)   (:465-471)
+//   flips / transposes back to row-major                                      (:474-478)
+// without materialising xs / x_dbl / dts / flips / transposes (9.5 GB of intermediates per
+// LFSSBlock at UHD level 1 in the reference).  Three kernel families:
+//
+//  1. ss2d_proj_kernel - the only GEMM-shaped piece: per position a (4 x (R+2N)) x D_in mat-vec,
+//     i.e. an (136 x 64) x (64 x L) GEMM at the shipped config.  fp32-input MFMA
+//     (v_mfma_f32_16x16x4_f32, exact fp32 = an fmaf chain): A = the stacked weights, kept in VGPRs
+//     for the whole kernel (9 row-tiles x 16 K-steps), B = x read straight from NCHW in fragment
+//     layout (16 lanes x 8 B = one 128-B line per channel row), D = per-position records
+//         rec[b][k][p] = [dt_r(4) | B(16) | C(16)]   (p = row-major position, 144 B, 16-B aligned)
+//     written as 16-byte pieces.  Every direction's record lives at the ROW-MAJOR position, so no
+//     direction ever needs a transposed copy.
+//  2. ss2d_row_kernel (k = 0, 2) - lane = channel, time = row-major l (reversed for k = 2): the
+//     chunked scan of selscan.hip.h with u read from x, dt rebuilt in-register from dt_r
+//     (R FMAs + softplus per step) and B/C taken from the record tile (plain linear LDS copy).
+//  3. ss2d_col_kernel (k = 1, 3) - lanes = 64 adjacent COLUMNS, time = row h (reversed for k = 3):
+//     u loads and y stores are coalesced straight in NCHW, every lane scans its own column segment;
+//     a workgroup (8 waves x 2 channels) shares the record rows through LDS; A / dt weights of a
+//     wave's channels are wave-uniform (SGPR operands of the packed ops).
+//  All three write y in row-major (B, D, L), optionally accumulating (y1+y2+y3+y4 of :490).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "selscan.hip.h"
+
+namespace wm {
+
+constexpr int kRecPad = 4;                 // dt_r slots at the head of a record (R <= 4)
+constexpr int kRS = kRecPad + 32;          // record stride in floats for N <= 16: 36 floats = 144 B
+
+struct Ss2dArgs {
+    const float* x;          // (B, D, H, W)
+    float* rec;              // (B, 4, L, kRS)
+    const float* Wx;         // (4, R + 2N, D)    x_proj_weight
+    const float* Wdt;        // (4, D, R)         dt_projs_weight
+    const float* dtb;        // (4, D)            dt_projs_bias
+    const float* A_logs;     // (4 D, N)
+    const float* Ds;         // (4 D)
+    float* y;                // (B, D, L) output of direction k (row-major positions)
+    float* wsP; float* wsH;  // chunk summaries [chunk][b*D + d][16]
+    int B, D, H, W, L, N, R, k;
+    int chunk_len, nchunks;  // row kernel: steps per chunk along l.  col kernel: rows per segment, W * nseg
+    int nseg;                // col kernel: segments per column
+    int accumulate;          // y += instead of y =
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// 1. projection: records for all four directions (MFMA fp32 16x16x4)
+//    row tiles: tile 0 = dt_r rows (direction k in row group k: rows 4k .. 4k+3, r < R used),
+//               tile 1 + 2k = B rows of direction k, tile 2 + 2k = C rows of direction k.
+// ------------------------------------------------------------------------------------------------
+constexpr int kProjTiles = 9;
+constexpr int kProjKS = 16;                // K-steps of 4 -> D_in <= 64
+
+__global__ __launch_bounds__(256, 1) void ss2d_proj_kernel(Ss2dArgs p, int groups_per_batch) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    const int g4 = lane >> 4, j16 = lane & 15;
+    const int C = p.R + 2 * p.N;
+
+    // A fragments: lane holds A[row = j16][kk = g4] of every (tile, K-step): W[c(row)][d = 4 s + g4]
+    float wfrag[kProjTiles][kProjKS];
+#pragma unroll
+    for (int t = 0; t < kProjTiles; ++t) {
+        int kdir, c;
+        bool ok;
+        if (t == 0) { kdir = j16 >> 2; c = j16 & 3; ok = c < p.R; }
+        else { kdir = (t - 1) >> 1; const int n = j16; ok = n < p.N; c = p.R + ((t - 1) & 1) * p.N + n; }
+#pragma unroll
+        for (int s = 0; s < kProjKS; ++s) {
+            const int d = 4 * s + g4;
+            wfrag[t][s] = (ok && d < p.D) ? p.Wx[((long long)kdir * C + c) * p.D + d] : 0.0f;
+        }
+    }
+
+    const long long L = p.L;
+    const long long total = (long long)p.B * groups_per_batch;          // groups of 32 positions
+    for (long long grp = wave; grp < total; grp += nwaves) {
+        const int b = (int)(grp / groups_per_batch);
+        const long long p0 = (grp - (long long)b * groups_per_batch) * 32;
+        const float* xb = p.x + (long long)b * p.D * L;
+        const long long pj = p0 + 2 * j16;                              // this lane's 2 positions
+        f32x4 acc[kProjTiles][2];
+#pragma unroll
+        for (int t = 0; t < kProjTiles; ++t) { acc[t][0] = (f32x4){0, 0, 0, 0}; acc[t][1] = (f32x4){0, 0, 0, 0}; }
+        float2 xv[kProjKS];
+#pragma unroll
+        for (int s = 0; s < kProjKS; ++s) {
+            const int d = 4 * s + g4;
+            xv[s] = make_float2(0.f, 0.f);
+            if (d < p.D) {
+                const float* q = xb + (long long)d * L + pj;
+                if ((L & 1) == 0) { if (pj < L) xv[s] = *reinterpret_cast<const float2*>(q); }
+                else { if (pj < L) xv[s].x = q[0]; if (pj + 1 < L) xv[s].y = q[1]; }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < kProjKS; ++s) {
+#pragma unroll
+            for (int t = 0; t < kProjTiles; ++t) {
+                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[t][s], xv[s].x, acc[t][0], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[t][s], xv[s].y, acc[t][1], 0, 0, 0);
+            }
+        }
+        // D layout: lane holds rows 4*g4 .. 4*g4+3 of column j16  ->  16-byte pieces of the records
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long long pos = pj + i;
+            if (pos < L) {
+                // tile 0: row group g4 = direction g4, rows = dt_r[0..3]
+                float* r0 = p.rec + (((long long)b * 4 + g4) * L + pos) * kRS;
+                *reinterpret_cast<f32x4*>(r0) = acc[0][i];
+#pragma unroll
+                for (int kd = 0; kd < 4; ++kd) {
+                    float* rk = p.rec + (((long long)b * 4 + kd) * L + pos) * kRS + kRecPad + 4 * g4;
+                    *reinterpret_cast<f32x4*>(rk) = acc[1 + 2 * kd][i];
+                    *reinterpret_cast<f32x4*>(rk + 16) = acc[2 + 2 * kd][i];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2. row-major directions (k = 0 forward, k = 2 reversed): lane = channel
+// ------------------------------------------------------------------------------------------------
+template <int PHASE, bool REV, bool VEC>
+__global__ __launch_bounds__(64) void ss2d_row_kernel(Ss2dArgs p) {
+    constexpr int NP = 16;
+    constexpr int T = 16;                            // steps per tile
+    constexpr int ROW = 20;                          // padded LDS row of the u tile
+    constexpr int NREC4 = (T * kRS / 4 + 63) / 64;   // float4 per lane of a record tile (144 -> 3)
+    __shared__ __attribute__((aligned(16))) float s_u[64 * ROW];
+    __shared__ __attribute__((aligned(16))) float s_rec[T * kRS];
+
+    const int lane = threadIdx.x;
+    const int chunk = blockIdx.x, b = blockIdx.y, k = p.k;
+    const bool live = lane < p.D;
+    const int d = live ? lane : 0;
+    const int kd = k * p.D + d;
+    const long long L = p.L;
+    const int t_begin = chunk * p.chunk_len;
+    const int t_end = min(p.L, t_begin + p.chunk_len);
+
+    v2f A2[NP / 2];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        const float a = (n < p.N) ? -expf(p.A_logs[(long long)kd * p.N + n]) * 1.4426950408889634f : 0.0f;
+        if (n & 1) A2[n / 2].y = a; else A2[n / 2].x = a;
+    }
+    float wdt[kRecPad];
+#pragma unroll
+    for (int r = 0; r < kRecPad; ++r) wdt[r] = (r < p.R) ? p.Wdt[(long long)kd * p.R + r] : 0.0f;
+    const float bias = p.dtb[kd];
+    const float Dd = p.Ds[kd];
+
+    v2f h[NP / 2];
+    const long long wsrow = ((long long)chunk * p.B * p.D + (long long)b * p.D + d) * NP;
+    if (PHASE == 3 && chunk > 0) {
+#pragma unroll
+        for (int q = 0; q < NP / 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(p.wsH + wsrow + 4 * q);
+            h[2 * q] = (v2f){v.x, v.y}; h[2 * q + 1] = (v2f){v.z, v.w};
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < NP / 2; ++n) h[n] = splat(0.0f);
+    }
+    float sum_dt = 0.0f;
+
+    const float* xb = p.x + (long long)b * p.D * L;
+    const float* recb = p.rec + ((long long)b * 4 + k) * L * kRS;
+    float* yb = (PHASE == 3) ? p.y + (long long)b * p.D * L : nullptr;
+
+    float4 ru[4], rr[NREC4];
+    const int trow = lane >> 2, tq = lane & 3;
+
+    // tile at step t0 covers positions plo .. plo+15 (column c <-> position plo + c);
+    // step tt uses column tt (forward) or 15 - tt (reversed)
+    auto tile_lo = [&](int t0) -> long long { return REV ? (L - 16 - t0) : (long long)t0; };
+
+    auto fetch = [&](int t0) {
+        const long long plo = tile_lo(t0);
+        const int tl = min(T, t_end - t0);
+        const int c_lo = REV ? T - tl : 0, c_hi = REV ? T : tl;          // valid columns [c_lo, c_hi)
+        const int c = 4 * tq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 16 * i + trow;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < p.D) {
+                const float* q = xb + (long long)r * L + plo + c;
+                if constexpr (VEC) {
+                    if (c >= c_lo && c < c_hi) v = *reinterpret_cast<const float4*>(q);
+                } else {
+                    if (c + 0 >= c_lo && c + 0 < c_hi) v.x = q[0];
+                    if (c + 1 >= c_lo && c + 1 < c_hi) v.y = q[1];
+                    if (c + 2 >= c_lo && c + 2 < c_hi) v.z = q[2];
+                    if (c + 3 >= c_lo && c + 3 < c_hi) v.w = q[3];
+                }
+            }
+            ru[i] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NREC4; ++j) {
+            const int f = lane + 64 * j;                       // float4 index inside the record tile
+            const int col = (4 * f) / kRS;
+            rr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < T * kRS / 4 && col >= c_lo && col < c_hi)
+                rr[j] = *reinterpret_cast<const float4*>(recb + plo * kRS + 4 * f);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(&s_u[(16 * i + trow) * ROW + 4 * tq]) = ru[i];
+#pragma unroll
+        for (int j = 0; j < NREC4; ++j) {
+            const int f = lane + 64 * j;
+            if (f < T * kRS / 4) *reinterpret_cast<float4*>(&s_rec[4 * f]) = rr[j];
+        }
+    };
+
+    fetch(t_begin);
+    for (int t0 = t_begin; t0 < t_end; t0 += T) {
+        stage();
+        __syncthreads();
+        if (t0 + T < t_end) fetch(t0 + T);
+        const int tl = min(T, t_end - t0);
+
+#pragma unroll
+        for (int q = 0; q < T / 4; ++q) {
+            if (4 * q < tl) {
+                const int cq = REV ? 3 - q : q;                          // column quad of this step quad
+                const float4 u4 = *reinterpret_cast<const float4*>(&s_u[lane * ROW + 4 * cq]);
+                const float uu[4] = {REV ? u4.w : u4.x, REV ? u4.z : u4.y, REV ? u4.y : u4.z, REV ? u4.x : u4.w};
+                float dts[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = REV ? 15 - (4 * q + j) : 4 * q + j;
+                    const float4 dr = *reinterpret_cast<const float4*>(&s_rec[col * kRS]);
+                    dts[j] = fmaf(wdt[3], dr.w, fmaf(wdt[2], dr.z, fmaf(wdt[1], dr.y, fmaf(wdt[0], dr.x, bias))));
+                }
+                const v2f sa = softplus2((v2f){dts[0], dts[1]}), sb = softplus2((v2f){dts[2], dts[3]});
+                dts[0] = sa.x; dts[1] = sa.y; dts[2] = sb.x; dts[3] = sb.y;
+                float yy[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int tt = 4 * q + j;
+                    if (tt < tl) {
+                        const int col = REV ? 15 - tt : tt;
+                        const float dt = dts[j], ut = uu[j];
+                        const v2f dt2 = splat(dt), du2 = splat(dt * ut);
+                        if (PHASE == 1) sum_dt += dt;
+                        v2f y2 = splat(0.0f);
+                        const float* rc = &s_rec[col * kRS + kRecPad];
+#pragma unroll
+                        for (int r = 0; r < NP / 4; ++r) {
+                            const float4 bv = *reinterpret_cast<const float4*>(rc + 4 * r);
+                            const v2f a0 = exp2_2(dt2 * A2[2 * r]);
+                            const v2f a1 = exp2_2(dt2 * A2[2 * r + 1]);
+                            h[2 * r] = a0 * h[2 * r] + du2 * (v2f){bv.x, bv.y};
+                            h[2 * r + 1] = a1 * h[2 * r + 1] + du2 * (v2f){bv.z, bv.w};
+                            if (PHASE == 3) {
+                                const float4 cv = *reinterpret_cast<const float4*>(rc + NP + 4 * r);
+                                y2 = (v2f){cv.x, cv.y} * h[2 * r] + y2;
+                                y2 = (v2f){cv.z, cv.w} * h[2 * r + 1] + y2;
+                            }
+                        }
+                        if (PHASE == 3) yy[j] = fmaf(Dd, ut, y2.x + y2.y);
+                    }
+                }
+                if (PHASE == 3)
+                    *reinterpret_cast<float4*>(&s_u[lane * ROW + 4 * cq]) =
+                        REV ? make_float4(yy[3], yy[2], yy[1], yy[0]) : make_float4(yy[0], yy[1], yy[2], yy[3]);
+            }
+        }
+        __syncthreads();
+        if (PHASE == 3) {
+            const long long plo = tile_lo(t0);
+            const int c_lo = REV ? T - tl : 0, c_hi = REV ? T : tl;
+            const int c = 4 * tq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * i + trow;
+                if (r < p.D) {
+                    const float4 v = *reinterpret_cast<const float4*>(&s_u[r * ROW + c]);
+                    float* o = yb + (long long)r * L + plo + c;
+                    if constexpr (VEC) {
+                        if (c >= c_lo && c < c_hi) {
+                            float4 w = v;
+                            if (p.accumulate) { const float4 e = *reinterpret_cast<const float4*>(o); w.x += e.x; w.y += e.y; w.z += e.z; w.w += e.w; }
+                            *reinterpret_cast<float4*>(o) = w;
+                        }
+                    } else {
+                        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (c + j >= c_lo && c + j < c_hi) o[j] = p.accumulate ? o[j] + vv[j] : vv[j];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    if (PHASE == 1 && live) {
+#pragma unroll
+        for (int q = 0; q < NP / 4; ++q) {
+            *reinterpret_cast<float4*>(p.wsH + wsrow + 4 * q) =
+                make_float4(h[2 * q].x, h[2 * q].y, h[2 * q + 1].x, h[2 * q + 1].y);
+            const v2f p0 = exp2_2(splat(sum_dt) * A2[2 * q]), p1 = exp2_2(splat(sum_dt) * A2[2 * q + 1]);
+            *reinterpret_cast<float4*>(p.wsP + wsrow + 4 * q) = make_float4(p0.x, p0.y, p1.x, p1.y);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3. column-major directions (k = 1 forward, k = 3 reversed): lanes = 64 adjacent columns
+//    scan order l = w*H + h: time tau = h (k=1) or H-1-h (k=3); column order omega = w or W-1-w;
+//    chunk = (omega, segment of tau), chunk index = omega * nseg + seg.
+// ------------------------------------------------------------------------------------------------
+constexpr int kColT = 4;        // record rows per LDS batch
+constexpr int kColCH = 2;       // channels per wave
+constexpr int kColWaves = 8;    // waves per workgroup -> 16 channels per workgroup
+
+template <int PHASE, bool REV>
+__global__ __launch_bounds__(64 * kColWaves) void ss2d_col_kernel(Ss2dArgs p) {
+    constexpr int NP = 16;
+    __shared__ __attribute__((aligned(16))) float s_rec[kColT * 64 * kRS];     // 36,864 B
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = p.k;
+    const int w0 = blockIdx.x * 64;
+    const int seg = blockIdx.y;
+    const int cgroups = (p.D + kColCH * kColWaves - 1) / (kColCH * kColWaves);
+    const int b = blockIdx.z / cgroups;
+    const int d0 = (blockIdx.z % cgroups) * (kColCH * kColWaves) + wv * kColCH;   // wave-uniform
+    const int w = w0 + lane;
+    const bool colok = w < p.W;
+    const int H = p.H, W = p.W;
+    const long long L = p.L;
+    const int tau_begin = seg * p.chunk_len;
+    const int tau_end = min(H, tau_begin + p.chunk_len);
+
+    // wave-uniform per-channel constants (scalar registers)
+    v2f A2[kColCH][NP / 2];
+    float wdt[kColCH][kRecPad], bias[kColCH], Dd[kColCH];
+    bool chok[kColCH];
+#pragma unroll
+    for (int c = 0; c < kColCH; ++c) {
+        const int d = d0 + c;
+        chok[c] = d < p.D;
+        const int kd = k * p.D + (chok[c] ? d : 0);
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+            const float a = (n < p.N) ? -expf(p.A_logs[(long long)kd * p.N + n]) * 1.4426950408889634f : 0.0f;
+            if (n & 1) A2[c][n / 2].y = a; else A2[c][n / 2].x = a;
+        }
+#pragma unroll
+        for (int r = 0; r < kRecPad; ++r) wdt[c][r] = (r < p.R) ? p.Wdt[(long long)kd * p.R + r] : 0.0f;
+        bias[c] = p.dtb[kd];
+        Dd[c] = p.Ds[kd];
+    }
+
+    const int omega = REV ? W - 1 - w : w;
+    const long long chunk = (long long)omega * p.nseg + seg;
+    v2f h[kColCH][NP / 2];
+    float sum_dt[kColCH];
+#pragma unroll
+    for (int c = 0; c < kColCH; ++c) {
+        sum_dt[c] = 0.0f;
+        const long long wsrow = (chunk * p.B * p.D + (long long)b * p.D + d0 + c) * NP;
+        if (PHASE == 3 && colok && chok[c] && chunk > 0) {
+#pragma unroll
+            for (int q = 0; q < NP / 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(p.wsH + wsrow + 4 * q);
+                h[c][2 * q] = (v2f){v.x, v.y}; h[c][2 * q + 1] = (v2f){v.z, v.w};
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < NP / 2; ++n) h[c][n] = splat(0.0f);
+        }
+    }
+
+    const float* recb = p.rec + ((long long)b * 4 + k) * L * kRS;
+    constexpr int NTH = 64 * kColWaves;
+    constexpr int NR4 = (kColT * 64 * kRS / 4 + NTH - 1) / NTH;        // float4 per thread per batch (3)
+    float4 rr[NR4];
+    float ur[kColCH][kColT];
+
+    auto row_of = [&](int tau) { return REV ? H - 1 - tau : tau; };
+    auto fetch = [&](int tau0) {
+#pragma unroll
+        for (int j = 0; j < NR4; ++j) {
+            const int f = threadIdx.x + NTH * j;                     // float4 index in the batch
+            const int i = f / (64 * kRS / 4);                         // batch row
+            const int fr = f - i * (64 * kRS / 4);
+            const int col = (4 * fr) / kRS;
+            rr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < kColT && tau0 + i < tau_end && w0 + col < W)
+                rr[j] = *reinterpret_cast<const float4*>(recb + ((long long)row_of(tau0 + i) * W + w0) * kRS + 4 * fr);
+        }
+#pragma unroll
+        for (int c = 0; c < kColCH; ++c)
+#pragma unroll
+            for (int i = 0; i < kColT; ++i)
+                ur[c][i] = (colok && chok[c] && tau0 + i < tau_end)
+                               ? p.x[(((long long)b * p.D + d0 + c) * H + row_of(tau0 + i)) * W + w] : 0.0f;
+    };
+
+    fetch(tau_begin);
+    for (int tau0 = tau_begin; tau0 < tau_end; tau0 += kColT) {
+#pragma unroll
+        for (int j = 0; j < NR4; ++j) {
+            const int f = threadIdx.x + NTH * j;
+            if (f < kColT * 64 * kRS / 4) *reinterpret_cast<float4*>(&s_rec[4 * f]) = rr[j];
+        }
+        float uc[kColCH][kColT];
+#pragma unroll
+        for (int c = 0; c < kColCH; ++c)
+#pragma unroll
+            for (int i = 0; i < kColT; ++i) uc[c][i] = ur[c][i];
+        __syncthreads();
+        if (tau0 + kColT < tau_end) fetch(tau0 + kColT);
+
+#pragma unroll
+        for (int i = 0; i < kColT; ++i) {
+            if (tau0 + i < tau_end) {                                  // uniform
+                const float* rc = &s_rec[(i * 64 + lane) * kRS];
+                const float4 dr = *reinterpret_cast<const float4*>(rc);
+                float4 bq[NP / 4], cq[NP / 4];
+#pragma unroll
+                for (int r = 0; r < NP / 4; ++r) {
+                    bq[r] = *reinterpret_cast<const float4*>(rc + kRecPad + 4 * r);
+                    if (PHASE == 3) cq[r] = *reinterpret_cast<const float4*>(rc + kRecPad + NP + 4 * r);
+                }
+                float dtv[kColCH];
+#pragma unroll
+                for (int c = 0; c < kColCH; ++c)
+                    dtv[c] = fmaf(wdt[c][3], dr.w, fmaf(wdt[c][2], dr.z, fmaf(wdt[c][1], dr.y, fmaf(wdt[c][0], dr.x, bias[c]))));
+                static_assert(kColCH == 2, "softplus pairing assumes two channels per wave");
+                const v2f sp = softplus2((v2f){dtv[0], dtv[1]});
+                dtv[0] = sp.x; dtv[1] = sp.y;
+                const int hrow = row_of(tau0 + i);
+#pragma unroll
+                for (int c = 0; c < kColCH; ++c) {
+                    const float dt = dtv[c], ut = uc[c][i];
+                    const v2f dt2 = splat(dt), du2 = splat(dt * ut);
+                    if (PHASE == 1) sum_dt[c] += dt;
+                    v2f y2 = splat(0.0f);
+#pragma unroll
+                    for (int r = 0; r < NP / 4; ++r) {
+                        const v2f a0 = exp2_2(dt2 * A2[c][2 * r]);
+                        const v2f a1 = exp2_2(dt2 * A2[c][2 * r + 1]);
+                        h[c][2 * r] = a0 * h[c][2 * r] + du2 * (v2f){bq[r].x, bq[r].y};
+                        h[c][2 * r + 1] = a1 * h[c][2 * r + 1] + du2 * (v2f){bq[r].z, bq[r].w};
+                        if (PHASE == 3) {
+                            y2 = (v2f){cq[r].x, cq[r].y} * h[c][2 * r] + y2;
+                            y2 = (v2f){cq[r].z, cq[r].w} * h[c][2 * r + 1] + y2;
+                        }
+                    }
+                    if (PHASE == 3 && colok && chok[c]) {
+                        float* o = p.y + (((long long)b * p.D + d0 + c) * H + hrow) * W + w;
+                        const float yv = fmaf(Dd[c], ut, y2.x + y2.y);
+                        *o = p.accumulate ? *o + yv : yv;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (PHASE == 1 && colok) {
+#pragma unroll
+        for (int c = 0; c < kColCH; ++c) {
+            if (!chok[c]) continue;
+            const long long wsrow = (chunk * p.B * p.D + (long long)b * p.D + d0 + c) * NP;
+#pragma unroll
+            for (int q = 0; q < NP / 4; ++q) {
+                *reinterpret_cast<float4*>(p.wsH + wsrow + 4 * q) =
+                    make_float4(h[c][2 * q].x, h[c][2 * q].y, h[c][2 * q + 1].x, h[c][2 * q + 1].y);
+                const v2f p0 = exp2_2(splat(sum_dt[c]) * A2[c][2 * q]);
+                const v2f p1 = exp2_2(splat(sum_dt[c]) * A2[c][2 * q + 1]);
+                *reinterpret_cast<float4*>(p.wsP + wsrow + 4 * q) = make_float4(p0.x, p0.y, p1.x, p1.y);
+            }
+        }
+    }
+}
+
+}  // namespace wm

@@ -10,6 +10,7 @@
 #include "haar.hip.h"
 #include "selscan.hip.h"
 #include "dwconv.hip.h"
+#include "ss2d.hip.h"
 
 namespace wm {
 
@@ -151,6 +152,79 @@ static int scan_launch(const ScanArgs& a, const ScanPlan& pl, hipStream_t st) {
         hipLaunchKernelGGL((selscan_chunk_kernel<NP, 3, VEC>), grid, block, 0, st, a);
     }
     return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused SS2D core host side
+// ------------------------------------------------------------------------------------------------
+struct Ss2dPlan {
+    int row_chunk, row_nchunks;            // k = 0, 2
+    int col_seg, col_nseg; long long col_nchunks;   // k = 1, 3
+    size_t rec_bytes, ws_half_bytes, total_bytes;
+};
+
+static int ss2d_plan(Ss2dPlan& pl, int B, int D, int H, int W, int N, int R) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || N <= 0 || R <= 0) return WM_EINVAL;
+    if (N > 16 || R > kRecPad || D > 64) return WM_EUNSUPPORTED;
+    const long long L = (long long)H * W;
+    if (L > 0x7fffffffLL) return WM_EUNSUPPORTED;
+    // row directions: one wave per (batch, chunk)
+    long long want = (256LL * 12 * 4 + B - 1) / B;
+    long long cl = (L + want - 1) / want;
+    cl = ((cl + 15) / 16) * 16;
+    if (cl < 64) cl = 64;
+    pl.row_chunk = (int)cl;
+    pl.row_nchunks = (int)((L + cl - 1) / cl);
+    // column directions: one 16-wave workgroup per (64-column tile, segment, batch, 32-channel group)
+    const int coltiles = (W + 63) / 64, cgroups = (D + kColCH * kColWaves - 1) / (kColCH * kColWaves);
+    long long nseg = (1536 + (long long)coltiles * B * cgroups - 1) / ((long long)coltiles * B * cgroups);
+    if (nseg < 1) nseg = 1;
+    long long sl = (H + nseg - 1) / nseg;
+    sl = ((sl + kColT - 1) / kColT) * kColT;
+    if (sl < 16) sl = 16;
+    pl.col_seg = (int)sl;
+    pl.col_nseg = (int)((H + sl - 1) / sl);
+    pl.col_nchunks = (long long)W * pl.col_nseg;
+    if (pl.col_nchunks > 0x7fffffffLL) return WM_EUNSUPPORTED;
+    pl.rec_bytes = (size_t)B * 4 * L * kRS * sizeof(float);
+    const long long maxchunks = pl.col_nchunks > pl.row_nchunks ? pl.col_nchunks : pl.row_nchunks;
+    pl.ws_half_bytes = (size_t)maxchunks * B * D * 16 * sizeof(float);
+    pl.total_bytes = pl.rec_bytes + 2 * pl.ws_half_bytes;
+    return WM_OK;
+}
+
+template <bool REV>
+static void ss2d_launch_row(Ss2dArgs a, const Ss2dPlan& pl, bool vec, hipStream_t st) {
+    a.chunk_len = pl.row_chunk; a.nchunks = pl.row_nchunks; a.nseg = 0;
+    const dim3 grid((unsigned)pl.row_nchunks, (unsigned)a.B), block(64);
+    if (pl.row_nchunks > 1) {
+        { ProfScope ps(2, st);
+          if (vec) hipLaunchKernelGGL((ss2d_row_kernel<1, REV, true>), grid, block, 0, st, a);
+          else hipLaunchKernelGGL((ss2d_row_kernel<1, REV, false>), grid, block, 0, st, a); }
+        { ProfScope ps(3, st);
+          const long long nchains = (long long)a.B * a.D * 16;
+          hipLaunchKernelGGL(selscan_carry_kernel, dim3((unsigned)((nchains + 15) / 16)), dim3(1024), 0, st,
+                             (const float*)a.wsP, a.wsH, nchains, pl.row_nchunks); }
+    }
+    ProfScope ps(4, st);
+    if (vec) hipLaunchKernelGGL((ss2d_row_kernel<3, REV, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((ss2d_row_kernel<3, REV, false>), grid, block, 0, st, a);
+}
+
+template <bool REV>
+static void ss2d_launch_col(Ss2dArgs a, const Ss2dPlan& pl, hipStream_t st) {
+    a.chunk_len = pl.col_seg; a.nseg = pl.col_nseg; a.nchunks = (int)pl.col_nchunks;
+    const int cgroups = (a.D + kColCH * kColWaves - 1) / (kColCH * kColWaves);
+    const dim3 grid((unsigned)((a.W + 63) / 64), (unsigned)pl.col_nseg, (unsigned)(a.B * cgroups)), block(64 * kColWaves);
+    if (pl.col_nchunks > 1) {
+        { ProfScope ps(2, st); hipLaunchKernelGGL((ss2d_col_kernel<1, REV>), grid, block, 0, st, a); }
+        { ProfScope ps(3, st);
+          const long long nchains = (long long)a.B * a.D * 16;
+          hipLaunchKernelGGL(selscan_carry_kernel, dim3((unsigned)((nchains + 15) / 16)), dim3(1024), 0, st,
+                             (const float*)a.wsP, a.wsH, nchains, (int)pl.col_nchunks); }
+    }
+    ProfScope ps(4, st);
+    hipLaunchKernelGGL((ss2d_col_kernel<3, REV>), grid, block, 0, st, a);
 }
 
 }  // namespace wm
@@ -304,6 +378,53 @@ int wm_dwconv3x3_fwd(const float* x, const float* weight, const float* bias, flo
     if (act == 1) { if (vec) WM_DW(1, true); else WM_DW(1, false); }
     else          { if (vec) WM_DW(0, true); else WM_DW(0, false); }
 #undef WM_DW
+    return launch_status();
+}
+
+size_t wm_ss2d_core_fwd_workspace_bytes(int B, int D, int H, int W, int N, int R) {
+    Ss2dPlan pl;
+    if (ss2d_plan(pl, B, D, H, W, N, R) != WM_OK) return 0;
+    return pl.total_bytes;
+}
+
+int wm_ss2d_core_fwd(const float* x, const float* x_proj_weight, const float* dt_projs_weight,
+                     const float* dt_projs_bias, const float* A_logs, const float* Ds, float* y_row_fwd,
+                     float* y_row_rev, float* y_col_fwd, float* y_col_rev, int merged, void* workspace,
+                     size_t workspace_bytes, int B, int D, int H, int W, int N, int R, void* stream) {
+    if (B == 0 || D == 0 || H == 0 || W == 0) return (B < 0 || D < 0 || H < 0 || W < 0) ? WM_EINVAL : WM_OK;
+    Ss2dPlan pl;
+    int rc = ss2d_plan(pl, B, D, H, W, N, R);
+    if (rc) return rc;
+    if (!x || !x_proj_weight || !dt_projs_weight || !dt_projs_bias || !A_logs || !Ds || !y_row_fwd) return WM_ENULL;
+    if (!merged && (!y_row_rev || !y_col_fwd || !y_col_rev)) return WM_ENULL;
+    if (!workspace) return WM_ENULL;
+    if (workspace_bytes < pl.total_bytes) return WM_EWORKSPACE;
+    if (!aligned16(workspace)) return WM_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    Ss2dArgs a;
+    a.x = x; a.rec = (float*)workspace; a.Wx = x_proj_weight; a.Wdt = dt_projs_weight; a.dtb = dt_projs_bias;
+    a.A_logs = A_logs; a.Ds = Ds;
+    a.wsP = (float*)((char*)workspace + pl.rec_bytes);
+    a.wsH = (float*)((char*)workspace + pl.rec_bytes + pl.ws_half_bytes);
+    a.B = B; a.D = D; a.H = H; a.W = W; a.L = H * W; a.N = N; a.R = R;
+    a.k = 0; a.y = y_row_fwd; a.accumulate = 0; a.chunk_len = 0; a.nchunks = 0; a.nseg = 0;
+    {
+        ProfScope ps(6, st);
+        const int groups = (a.L + 31) / 32;
+        long long waves = (long long)B * groups;
+        int blocks = (int)((waves + 3) / 4);
+        if (blocks > 256 * 2) blocks = 256 * 2;                     // persistent: weights stay in VGPRs
+        hipLaunchKernelGGL(ss2d_proj_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, groups);
+    }
+    const bool vec = (a.L % 4 == 0) && aligned16(x) && aligned16(y_row_fwd) && (merged || aligned16(y_row_rev));
+    a.k = 0; a.y = y_row_fwd; a.accumulate = 0;
+    ss2d_launch_row<false>(a, pl, vec, st);
+    a.k = 2; a.y = merged ? y_row_fwd : y_row_rev; a.accumulate = merged;
+    ss2d_launch_row<true>(a, pl, vec, st);
+    a.k = 1; a.y = merged ? y_row_fwd : y_col_fwd; a.accumulate = merged;
+    ss2d_launch_col<false>(a, pl, st);
+    a.k = 3; a.y = merged ? y_row_fwd : y_col_rev; a.accumulate = merged;
+    ss2d_launch_col<true>(a, pl, st);
     return launch_status();
 }
 

@@ -271,6 +271,40 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
 
 
 # ------------------------------------------------------------------------------------------------
+# fused SS2D four-direction core (forward / inference)
+# ------------------------------------------------------------------------------------------------
+def ss2d_core_supported(d_inner, d_state, dt_rank):
+    """Shapes the fused HIP core covers (else: direction glue + selective_scan_fn)."""
+    return d_inner <= 64 and d_state <= 16 and dt_rank <= 4
+
+
+def ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, merged=False):
+    """SS2D.forward_core (reference wavemamba_arch.py:446-478) in one call.
+    x (B, D, H, W) fp32 -> (y_row_fwd, y_row_rev, y_col_fwd, y_col_rev), each (B, D, H*W) in
+    row-major l - the reference's return order; merged=True returns their sum (what :490 computes).
+    Forward only (no autograd graph)."""
+    lib = _lib.load()
+    _require_cuda("ss2d_core", x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
+    B, D, H, W = x.shape
+    K, C, D2 = x_proj_weight.shape
+    R, N = dt_projs_weight.shape[2], A_logs.shape[1]
+    if K != 4 or D2 != D or C != R + 2 * N or dt_projs_weight.shape != (4, D, R) or A_logs.shape[0] != 4 * D:
+        raise RuntimeError("ss2d_core: inconsistent parameter shapes")
+    if not ss2d_core_supported(D, N, R):
+        raise NotImplementedError(f"ss2d_core: d_inner={D}, d_state={N}, dt_rank={R} outside the fused kernel's range")
+    f = [t.detach().contiguous().float() for t in (x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)]
+    L = H * W
+    outs = [torch.empty((B, D, L), dtype=torch.float32, device=x.device) for _ in range(1 if merged else 4)]
+    ws_bytes = lib.wm_ss2d_core_fwd_workspace_bytes(B, D, H, W, N, R)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    ptrs = [_ptr(o) for o in outs] + [None] * (4 - len(outs))
+    with torch.cuda.device(x.device):
+        check(lib.wm_ss2d_core_fwd(*[_ptr(t) for t in f], *ptrs, int(bool(merged)), _ptr(ws), ws_bytes,
+                                   B, D, H, W, N, R, _stream()), "wm_ss2d_core_fwd")
+    return outs[0] if merged else tuple(outs)
+
+
+# ------------------------------------------------------------------------------------------------
 # depth-wise 3x3 convolution (+ bias, + SiLU) - inference path of SS2D.conv2d / ffn.conv2
 # ------------------------------------------------------------------------------------------------
 def dwconv3x3(x, weight, bias=None, act="none"):
