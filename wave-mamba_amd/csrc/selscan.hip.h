@@ -366,4 +366,43 @@ __global__ __launch_bounds__(1024) void selscan_carry_kernel(const float* __rest
     }
 }
 
+// Two-level carry for long chunk sequences (column scans have one chunk sequence entry per image
+// column and segment: tens of thousands).  Thread = (chain, segment of kCarrySegLen chunks), fully
+// independent, 256-B coalesced rows:
+//   fold  : segment aggregate (P, H) -> segP/segH [segment][chain]
+//   (selscan_carry_kernel on the aggregates turns segH into the per-segment carry-in)
+//   apply : re-walk the segment from its carry-in, replacing H[c] by H_in[c]
+constexpr int kCarrySegLen = 32;
+template <bool APPLY>
+__global__ __launch_bounds__(256) void selscan_carry_seg_kernel(const float* __restrict__ wsP,
+                                                                float* __restrict__ wsH,
+                                                                float* __restrict__ segP,
+                                                                float* __restrict__ segH,
+                                                                long long nchains, int nchunks, int nsegs) {
+    const long long chain = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int seg = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (chain >= nchains || seg >= nsegs) return;
+    const int c0 = seg * kCarrySegLen, c1 = min(nchunks, c0 + kCarrySegLen);
+    float P = 1.0f, H = APPLY ? segH[(long long)seg * nchains + chain] : 0.0f;
+    for (int c = c0; c < c1; c += 8) {
+        float pp[8], hh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool in = c + j < c1;
+            pp[j] = in ? wsP[(long long)(c + j) * nchains + chain] : 1.0f;
+            hh[j] = in ? wsH[(long long)(c + j) * nchains + chain] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (APPLY && c + j < c1) wsH[(long long)(c + j) * nchains + chain] = H;
+            H = fmaf(pp[j], H, hh[j]);
+            P *= pp[j];
+        }
+    }
+    if (!APPLY) {
+        segP[(long long)seg * nchains + chain] = P;
+        segH[(long long)seg * nchains + chain] = H;
+    }
+}
+
 }  // namespace wm

@@ -22,7 +22,7 @@
 //     (R FMAs + softplus per step) and B/C taken from the record tile (plain linear LDS copy).
 //  3. ss2d_col_kernel (k = 1, 3) - lanes = 64 adjacent COLUMNS, time = row h (reversed for k = 3):
 //     u loads and y stores are coalesced straight in NCHW, every lane scans its own column segment;
-//     a workgroup (8 waves x 2 channels) shares the record rows through LDS; A / dt weights of a
+//     a workgroup (4 waves x 2 channels) shares the record rows through LDS; A / dt weights of a
 //     wave's channels are wave-uniform (SGPR operands of the packed ops).
 //  All three write y in row-major (B, D, L), optionally accumulating (y1+y2+y3+y4 of :490).
 #pragma once
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64) void ss2d_row_kernel(Ss2dArgs p) {
     const float* recb = p.rec + ((long long)b * 4 + k) * L * kRS;
     float* yb = (PHASE == 3) ? p.y + (long long)b * p.D * L : nullptr;
 
-    float4 ru[4], rr[NREC4];
+    float4 ru[4], rr[NREC4], ry[4];                 // ry: previous directions' y (accumulate mode)
     const int trow = lane >> 2, tq = lane & 3;
 
     // tile at step t0 covers positions plo .. plo+15 (column c <-> position plo + c);
@@ -210,6 +210,21 @@ __global__ __launch_bounds__(64) void ss2d_row_kernel(Ss2dArgs p) {
                 }
             }
             ru[i] = v;
+            if (PHASE == 3) {
+                float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.accumulate && r < p.D) {
+                    const float* q = yb + (long long)r * L + plo + c;
+                    if constexpr (VEC) {
+                        if (c >= c_lo && c < c_hi) e = *reinterpret_cast<const float4*>(q);
+                    } else {
+                        if (c + 0 >= c_lo && c + 0 < c_hi) e.x = q[0];
+                        if (c + 1 >= c_lo && c + 1 < c_hi) e.y = q[1];
+                        if (c + 2 >= c_lo && c + 2 < c_hi) e.z = q[2];
+                        if (c + 3 >= c_lo && c + 3 < c_hi) e.w = q[3];
+                    }
+                }
+                ry[i] = e;
+            }
         }
 #pragma unroll
         for (int j = 0; j < NREC4; ++j) {
@@ -220,10 +235,13 @@ __global__ __launch_bounds__(64) void ss2d_row_kernel(Ss2dArgs p) {
                 rr[j] = *reinterpret_cast<const float4*>(recb + plo * kRS + 4 * f);
         }
     };
+    float4 yold[4];
     auto stage = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
             *reinterpret_cast<float4*>(&s_u[(16 * i + trow) * ROW + 4 * tq]) = ru[i];
+            if (PHASE == 3) yold[i] = ry[i];
+        }
 #pragma unroll
         for (int j = 0; j < NREC4; ++j) {
             const int f = lane + 64 * j;
@@ -296,17 +314,15 @@ __global__ __launch_bounds__(64) void ss2d_row_kernel(Ss2dArgs p) {
                 if (r < p.D) {
                     const float4 v = *reinterpret_cast<const float4*>(&s_u[r * ROW + c]);
                     float* o = yb + (long long)r * L + plo + c;
+                    const float4 e = yold[i];
                     if constexpr (VEC) {
-                        if (c >= c_lo && c < c_hi) {
-                            float4 w = v;
-                            if (p.accumulate) { const float4 e = *reinterpret_cast<const float4*>(o); w.x += e.x; w.y += e.y; w.z += e.z; w.w += e.w; }
-                            *reinterpret_cast<float4*>(o) = w;
-                        }
+                        if (c >= c_lo && c < c_hi)
+                            *reinterpret_cast<float4*>(o) = make_float4(v.x + e.x, v.y + e.y, v.z + e.z, v.w + e.w);
                     } else {
-                        const float vv[4] = {v.x, v.y, v.z, v.w};
+                        const float vv[4] = {v.x + e.x, v.y + e.y, v.z + e.z, v.w + e.w};
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            if (c + j >= c_lo && c + j < c_hi) o[j] = p.accumulate ? o[j] + vv[j] : vv[j];
+                            if (c + j >= c_lo && c + j < c_hi) o[j] = vv[j];
                     }
                 }
             }
@@ -330,12 +346,24 @@ __global__ __launch_bounds__(64) void ss2d_row_kernel(Ss2dArgs p) {
 //    scan order l = w*H + h: time tau = h (k=1) or H-1-h (k=3); column order omega = w or W-1-w;
 //    chunk = (omega, segment of tau), chunk index = omega * nseg + seg.
 // ------------------------------------------------------------------------------------------------
-constexpr int kColT = 4;        // record rows per LDS batch
+#ifndef WM_COLT
+#define WM_COLT 4
+#endif
+#ifndef WM_COLWAVES
+#define WM_COLWAVES 4
+#endif
+#ifndef WM_COL_LB
+#define WM_COL_LB 1
+#endif
+#ifndef WM_COL_WGS
+#define WM_COL_WGS 1024
+#endif
+constexpr int kColT = WM_COLT;  // record rows per LDS batch
 constexpr int kColCH = 2;       // channels per wave
-constexpr int kColWaves = 8;    // waves per workgroup -> 16 channels per workgroup
+constexpr int kColWaves = WM_COLWAVES;   // waves per workgroup -> 2 * kColWaves channels per workgroup
 
 template <int PHASE, bool REV>
-__global__ __launch_bounds__(64 * kColWaves) void ss2d_col_kernel(Ss2dArgs p) {
+__global__ __launch_bounds__(64 * kColWaves, WM_COL_LB) void ss2d_col_kernel(Ss2dArgs p) {
     constexpr int NP = 16;
     __shared__ __attribute__((aligned(16))) float s_rec[kColT * 64 * kRS];     // 36,864 B
 
@@ -365,7 +393,10 @@ __global__ __launch_bounds__(64 * kColWaves) void ss2d_col_kernel(Ss2dArgs p) {
         const int kd = k * p.D + (chok[c] ? d : 0);
 #pragma unroll
         for (int n = 0; n < NP; ++n) {
-            const float a = (n < p.N) ? -expf(p.A_logs[(long long)kd * p.N + n]) * 1.4426950408889634f : 0.0f;
+            float a = (n < p.N) ? -expf(p.A_logs[(long long)kd * p.N + n]) * 1.4426950408889634f : 0.0f;
+            // wave-uniform, but v_pk_mul_f32 cannot take an SGPR pair: pin the value in a VGPR once
+            // (otherwise the compiler re-copies SGPR -> VGPR at every use, 16 v_mov per step)
+            asm volatile("" : "+v"(a));
             if (n & 1) A2[c][n / 2].y = a; else A2[c][n / 2].x = a;
         }
 #pragma unroll
@@ -399,6 +430,7 @@ __global__ __launch_bounds__(64 * kColWaves) void ss2d_col_kernel(Ss2dArgs p) {
     constexpr int NR4 = (kColT * 64 * kRS / 4 + NTH - 1) / NTH;        // float4 per thread per batch (3)
     float4 rr[NR4];
     float ur[kColCH][kColT];
+    float yr[kColCH][kColT];        // previous directions' y (accumulate mode), fetched with u
 
     auto row_of = [&](int tau) { return REV ? H - 1 - tau : tau; };
     auto fetch = [&](int tau0) {
@@ -416,8 +448,12 @@ __global__ __launch_bounds__(64 * kColWaves) void ss2d_col_kernel(Ss2dArgs p) {
         for (int c = 0; c < kColCH; ++c)
 #pragma unroll
             for (int i = 0; i < kColT; ++i)
-                ur[c][i] = (colok && chok[c] && tau0 + i < tau_end)
-                               ? p.x[(((long long)b * p.D + d0 + c) * H + row_of(tau0 + i)) * W + w] : 0.0f;
+            {
+                const bool ok = colok && chok[c] && tau0 + i < tau_end;
+                const long long off = (((long long)b * p.D + d0 + c) * H + row_of(tau0 + i)) * W + w;
+                ur[c][i] = ok ? p.x[off] : 0.0f;
+                yr[c][i] = (PHASE == 3 && ok && p.accumulate) ? p.y[off] : 0.0f;
+            }
     };
 
     fetch(tau_begin);
@@ -427,11 +463,11 @@ __global__ __launch_bounds__(64 * kColWaves) void ss2d_col_kernel(Ss2dArgs p) {
             const int f = threadIdx.x + NTH * j;
             if (f < kColT * 64 * kRS / 4) *reinterpret_cast<float4*>(&s_rec[4 * f]) = rr[j];
         }
-        float uc[kColCH][kColT];
+        float uc[kColCH][kColT], yc[kColCH][kColT];
 #pragma unroll
         for (int c = 0; c < kColCH; ++c)
 #pragma unroll
-            for (int i = 0; i < kColT; ++i) uc[c][i] = ur[c][i];
+            for (int i = 0; i < kColT; ++i) { uc[c][i] = ur[c][i]; yc[c][i] = yr[c][i]; }
         __syncthreads();
         if (tau0 + kColT < tau_end) fetch(tau0 + kColT);
 
@@ -473,8 +509,7 @@ __global__ __launch_bounds__(64 * kColWaves) void ss2d_col_kernel(Ss2dArgs p) {
                     }
                     if (PHASE == 3 && colok && chok[c]) {
                         float* o = p.y + (((long long)b * p.D + d0 + c) * H + hrow) * W + w;
-                        const float yv = fmaf(Dd[c], ut, y2.x + y2.y);
-                        *o = p.accumulate ? *o + yv : yv;
+                        *o = fmaf(Dd[c], ut, y2.x + y2.y) + yc[c][i];
                     }
                 }
             }

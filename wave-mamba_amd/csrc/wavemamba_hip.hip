@@ -106,6 +106,27 @@ static bool haar_vec_ok(const HaarGeom& g, const void* full, const void* const s
 // ------------------------------------------------------------------------------------------------
 struct ScanPlan { int NP, wpg, rows, chunk_len, nchunks; size_t ws_bytes; };
 
+static inline long long carry_nsegs(long long nchunks) { return (nchunks + kCarrySegLen - 1) / kCarrySegLen; }
+
+// phase 2 over [nchunks][nchains] summaries; `seg` = scratch for 2 * carry_nsegs(nchunks) * nchains floats
+static void launch_carry(float* wsP, float* wsH, float* seg, long long nchains, int nchunks, hipStream_t st) {
+    ProfScope ps(3, st);
+    const dim3 cgrid((unsigned)((nchains + 15) / 16)), cblock(1024);
+    if (nchunks <= 1024 || !seg) {
+        hipLaunchKernelGGL(selscan_carry_kernel, cgrid, cblock, 0, st, (const float*)wsP, wsH, nchains, nchunks);
+        return;
+    }
+    const int nsegs = (int)carry_nsegs(nchunks);
+    float* segP = seg;
+    float* segH = seg + (size_t)nsegs * nchains;
+    const dim3 grid((unsigned)((nchains + 63) / 64), (unsigned)((nsegs + 3) / 4)), block(256);
+    hipLaunchKernelGGL((selscan_carry_seg_kernel<false>), grid, block, 0, st, (const float*)wsP, wsH, segP, segH,
+                       nchains, nchunks, nsegs);
+    hipLaunchKernelGGL(selscan_carry_kernel, cgrid, cblock, 0, st, (const float*)segP, segH, nchains, nsegs);
+    hipLaunchKernelGGL((selscan_carry_seg_kernel<true>), grid, block, 0, st, (const float*)wsP, wsH, segP, segH,
+                       nchains, nchunks, nsegs);
+}
+
 static int scan_plan(ScanPlan& pl, int batch, int dim, int L, int N, int G) {
     if (batch <= 0 || dim <= 0 || L <= 0 || N <= 0 || G <= 0) return WM_EINVAL;
     if (N > 32) return WM_EUNSUPPORTED;
@@ -128,7 +149,7 @@ static int scan_plan(ScanPlan& pl, int batch, int dim, int L, int N, int G) {
     if (cl < 64) cl = 64;
     pl.chunk_len = (int)cl;
     pl.nchunks = (int)(((long long)L + cl - 1) / cl);
-    pl.ws_bytes = pl.nchunks > 1 ? (size_t)2 * pl.nchunks * batch * dim * pl.NP * sizeof(float) : 0;
+    pl.ws_bytes = pl.nchunks > 1 ? (size_t)2 * (pl.nchunks + carry_nsegs(pl.nchunks)) * batch * dim * pl.NP * sizeof(float) : 0;
     return WM_OK;
 }
 
@@ -140,12 +161,8 @@ static int scan_launch(const ScanArgs& a, const ScanPlan& pl, hipStream_t st) {
             ProfScope ps(2, st);
             hipLaunchKernelGGL((selscan_chunk_kernel<NP, 1, VEC>), grid, block, 0, st, a);
         }
-        {
-            ProfScope ps(3, st);
-            const long long nchains = (long long)a.batch * a.dim * NP;
-            hipLaunchKernelGGL(selscan_carry_kernel, dim3((unsigned)((nchains + 15) / 16)), dim3(1024), 0,
-                               st, (const float*)a.wsP, a.wsH, nchains, pl.nchunks);
-        }
+        const long long nchains = (long long)a.batch * a.dim * NP;
+        launch_carry(a.wsP, a.wsH, a.wsH + (size_t)pl.nchunks * nchains, nchains, pl.nchunks, st);
     }
     {
         ProfScope ps(4, st);
@@ -160,7 +177,7 @@ static int scan_launch(const ScanArgs& a, const ScanPlan& pl, hipStream_t st) {
 struct Ss2dPlan {
     int row_chunk, row_nchunks;            // k = 0, 2
     int col_seg, col_nseg; long long col_nchunks;   // k = 1, 3
-    size_t rec_bytes, ws_half_bytes, total_bytes;
+    size_t rec_bytes, ws_half_bytes, seg_bytes, total_bytes;
 };
 
 static int ss2d_plan(Ss2dPlan& pl, int B, int D, int H, int W, int N, int R) {
@@ -177,7 +194,7 @@ static int ss2d_plan(Ss2dPlan& pl, int B, int D, int H, int W, int N, int R) {
     pl.row_nchunks = (int)((L + cl - 1) / cl);
     // column directions: one 16-wave workgroup per (64-column tile, segment, batch, 32-channel group)
     const int coltiles = (W + 63) / 64, cgroups = (D + kColCH * kColWaves - 1) / (kColCH * kColWaves);
-    long long nseg = (1536 + (long long)coltiles * B * cgroups - 1) / ((long long)coltiles * B * cgroups);
+    long long nseg = (WM_COL_WGS + (long long)coltiles * B * cgroups - 1) / ((long long)coltiles * B * cgroups);
     if (nseg < 1) nseg = 1;
     long long sl = (H + nseg - 1) / nseg;
     sl = ((sl + kColT - 1) / kColT) * kColT;
@@ -189,41 +206,36 @@ static int ss2d_plan(Ss2dPlan& pl, int B, int D, int H, int W, int N, int R) {
     pl.rec_bytes = (size_t)B * 4 * L * kRS * sizeof(float);
     const long long maxchunks = pl.col_nchunks > pl.row_nchunks ? pl.col_nchunks : pl.row_nchunks;
     pl.ws_half_bytes = (size_t)maxchunks * B * D * 16 * sizeof(float);
-    pl.total_bytes = pl.rec_bytes + 2 * pl.ws_half_bytes;
+    pl.seg_bytes = (size_t)2 * carry_nsegs(maxchunks) * B * D * 16 * sizeof(float);
+    pl.total_bytes = pl.rec_bytes + 2 * pl.ws_half_bytes + pl.seg_bytes;
     return WM_OK;
 }
 
 template <bool REV>
-static void ss2d_launch_row(Ss2dArgs a, const Ss2dPlan& pl, bool vec, hipStream_t st) {
+static void ss2d_launch_row(Ss2dArgs a, const Ss2dPlan& pl, bool vec, float* seg, hipStream_t st) {
     a.chunk_len = pl.row_chunk; a.nchunks = pl.row_nchunks; a.nseg = 0;
     const dim3 grid((unsigned)pl.row_nchunks, (unsigned)a.B), block(64);
     if (pl.row_nchunks > 1) {
-        { ProfScope ps(2, st);
+        { ProfScope ps(10, st);
           if (vec) hipLaunchKernelGGL((ss2d_row_kernel<1, REV, true>), grid, block, 0, st, a);
           else hipLaunchKernelGGL((ss2d_row_kernel<1, REV, false>), grid, block, 0, st, a); }
-        { ProfScope ps(3, st);
-          const long long nchains = (long long)a.B * a.D * 16;
-          hipLaunchKernelGGL(selscan_carry_kernel, dim3((unsigned)((nchains + 15) / 16)), dim3(1024), 0, st,
-                             (const float*)a.wsP, a.wsH, nchains, pl.row_nchunks); }
+        launch_carry(a.wsP, a.wsH, seg, (long long)a.B * a.D * 16, pl.row_nchunks, st);
     }
-    ProfScope ps(4, st);
+    ProfScope ps(8, st);
     if (vec) hipLaunchKernelGGL((ss2d_row_kernel<3, REV, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((ss2d_row_kernel<3, REV, false>), grid, block, 0, st, a);
 }
 
 template <bool REV>
-static void ss2d_launch_col(Ss2dArgs a, const Ss2dPlan& pl, hipStream_t st) {
+static void ss2d_launch_col(Ss2dArgs a, const Ss2dPlan& pl, float* seg, hipStream_t st) {
     a.chunk_len = pl.col_seg; a.nseg = pl.col_nseg; a.nchunks = (int)pl.col_nchunks;
     const int cgroups = (a.D + kColCH * kColWaves - 1) / (kColCH * kColWaves);
     const dim3 grid((unsigned)((a.W + 63) / 64), (unsigned)pl.col_nseg, (unsigned)(a.B * cgroups)), block(64 * kColWaves);
     if (pl.col_nchunks > 1) {
-        { ProfScope ps(2, st); hipLaunchKernelGGL((ss2d_col_kernel<1, REV>), grid, block, 0, st, a); }
-        { ProfScope ps(3, st);
-          const long long nchains = (long long)a.B * a.D * 16;
-          hipLaunchKernelGGL(selscan_carry_kernel, dim3((unsigned)((nchains + 15) / 16)), dim3(1024), 0, st,
-                             (const float*)a.wsP, a.wsH, nchains, (int)pl.col_nchunks); }
+        { ProfScope ps(11, st); hipLaunchKernelGGL((ss2d_col_kernel<1, REV>), grid, block, 0, st, a); }
+        launch_carry(a.wsP, a.wsH, seg, (long long)a.B * a.D * 16, (int)pl.col_nchunks, st);
     }
-    ProfScope ps(4, st);
+    ProfScope ps(9, st);
     hipLaunchKernelGGL((ss2d_col_kernel<3, REV>), grid, block, 0, st, a);
 }
 
@@ -418,13 +430,14 @@ int wm_ss2d_core_fwd(const float* x, const float* x_proj_weight, const float* dt
     }
     const bool vec = (a.L % 4 == 0) && aligned16(x) && aligned16(y_row_fwd) && (merged || aligned16(y_row_rev));
     a.k = 0; a.y = y_row_fwd; a.accumulate = 0;
-    ss2d_launch_row<false>(a, pl, vec, st);
+    float* seg = (float*)((char*)workspace + pl.rec_bytes + 2 * pl.ws_half_bytes);
+    ss2d_launch_row<false>(a, pl, vec, seg, st);
     a.k = 2; a.y = merged ? y_row_fwd : y_row_rev; a.accumulate = merged;
-    ss2d_launch_row<true>(a, pl, vec, st);
+    ss2d_launch_row<true>(a, pl, vec, seg, st);
     a.k = 1; a.y = merged ? y_row_fwd : y_col_fwd; a.accumulate = merged;
-    ss2d_launch_col<false>(a, pl, st);
+    ss2d_launch_col<false>(a, pl, seg, st);
     a.k = 3; a.y = merged ? y_row_fwd : y_col_rev; a.accumulate = merged;
-    ss2d_launch_col<true>(a, pl, st);
+    ss2d_launch_col<true>(a, pl, seg, st);
     return launch_status();
 }
 

@@ -330,7 +330,8 @@ def dwconv3x3(x, weight, bias=None, act="none"):
 # profiling hooks (bench.py)
 # ------------------------------------------------------------------------------------------------
 PROF_KERNELS = ("haar_analysis", "haar_synthesis", "selscan_chunk_reduce", "selscan_carry",
-                "selscan_chunk_scan", "selscan_bwd", "ss2d_proj", "dwconv3x3")
+                "selscan_chunk_scan", "selscan_bwd", "ss2d_proj", "dwconv3x3",
+                "ss2d_row_scan", "ss2d_col_scan", "ss2d_row_reduce", "ss2d_col_reduce")
 
 
 def prof_enable(on=True):
