@@ -136,6 +136,29 @@ int wm_dwconv3x3_fwd(const float* x, const float* weight, const float* bias, flo
                      int B, int C, int H, int W, int act, void* stream);
 
 /* --------------------------------------------------------------------------------------------
+ * LFSSBlock / SS2D per-position glue around the scan core, fused (forward only; C in {8,16,32},
+ * inner width D = 2C, ffn hidden = 2C).  Token tensors are (B, L, C) rows unless the *_nchw flag
+ * says (B, C, L); plane tensors are (B, D, L).  Reference lines: wavemamba_arch.py
+ *   wm_lfss_in_fwd  : ln_1 (:524) + in_proj (:483) + chunk (:484) + NHWC->NCHW (:486)
+ *                     tok -> x (conv input), z (gate)
+ *   wm_lfss_mid_fwd : transpose (:491) + out_norm (:492) + *silu(z) (:493) + out_proj (:494)
+ *                     + skip_scale residual (:525) + ln_2 + ffn.conv1 (:526, :226)
+ *                     ysum, z, tok -> tok1, f (input of ffn.conv2)
+ *   wm_lfss_out_fwd : gelu gate (:227-228) + ffn.conv3 (:230) + skip_scale2 residual (:526)
+ *                     fc, tok1 -> out
+ * -------------------------------------------------------------------------------------------- */
+int wm_lfss_in_fwd(const float* tok, int tok_nchw, const float* ln_w, const float* ln_b, float ln_eps,
+                   const float* in_proj_weight, float* x, float* z, int B, int64_t L, int C, void* stream);
+int wm_lfss_mid_fwd(const float* ysum, const float* z, const float* tok, int tok_nchw,
+                    const float* out_norm_w, const float* out_norm_b, float out_norm_eps,
+                    const float* out_proj_weight, const float* skip_scale,
+                    const float* ln2_w, const float* ln2_b, float ln2_eps,
+                    const float* conv1_weight, const float* conv1_bias,
+                    float* tok1, float* f, int B, int64_t L, int C, void* stream);
+int wm_lfss_out_fwd(const float* fc, const float* tok1, const float* conv3_weight, const float* conv3_bias,
+                    const float* skip_scale2, float* out, int out_nchw, int B, int64_t L, int C, void* stream);
+
+/* --------------------------------------------------------------------------------------------
  * Profiling hooks used by bench.py (HIP events recorded on the launch stream around each kernel
  * class).  Disabled by default; when disabled the library records nothing.
  *   kernel ids: 0 dwt/analysis, 1 iwt/synthesis, 2 scan chunk-reduce, 3 scan carry,

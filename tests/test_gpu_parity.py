@@ -286,6 +286,39 @@ def test_ss2d_core_uhd_level2_against_unfused():
 
 
 # ------------------------------------------------------------------------------------------------
+# whole LFSSBlock on the HIP path (reference LFSSBlock.forward, :520-528)
+# ------------------------------------------------------------------------------------------------
+def test_lfss_block_golden(golden):
+    g = golden("lfss_block")            # input/output/weights captured from the reference's LFSSBlock
+    blk = arch.LFSSBlock(32, expand=2.0).eval()
+    blk.load_state_dict({k[2:]: v for k, v in g.items() if k.startswith("p.")}, strict=True)
+    blk = blk.to(DEV)
+    with torch.no_grad():
+        assert blk._fused_ok(g["x"].to(DEV))
+        y = blk(g["x"].to(DEV), [8, 12])
+    assert_close(y, g["y"], TOL, "LFSSBlock (fused HIP path)")
+
+
+@pytest.mark.parametrize("C,H,W", [(32, 40, 72), (16, 17, 23), (8, 64, 64)])
+def test_lfss_block_fused_vs_module_path(C, H, W):
+    """fused block kernels vs the same block evaluated through the PyTorch modules + HIP scan."""
+    torch.manual_seed(C)
+    blk = arch.LFSSBlock(C, expand=2.0).eval().to(DEV)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+        x = torch.randn(2, H * W, C, device=DEV)
+        fused = blk(x, [H, W])
+        saved = arch.LFSSBlock._fused_ok
+        arch.LFSSBlock._fused_ok = lambda self, t: False
+        try:
+            ref = blk(x, [H, W])
+        finally:
+            arch.LFSSBlock._fused_ok = saved
+    assert_close(fused, ref, TOL, f"LFSSBlock C={C}")
+
+
+# ------------------------------------------------------------------------------------------------
 # network level
 # ------------------------------------------------------------------------------------------------
 def test_tiny_model_golden(golden):

@@ -29,6 +29,10 @@ SIGNATURES = {
     "wm_selscan_bwd": (_i, [_p] * 15 + [_p, _sz] + [_i] * 6 + [_p]),
     "wm_ss2d_core_fwd_workspace_bytes": (_sz, [_i] * 6),
     "wm_ss2d_core_fwd": (_i, [_p] * 10 + [_i, _p, _sz] + [_i] * 6 + [_p]),
+    "wm_lfss_in_fwd": (_i, [_p, _i, _p, _p, _c.c_float, _p, _p, _p, _i, _i64, _i, _p]),
+    "wm_lfss_mid_fwd": (_i, [_p, _p, _p, _i, _p, _p, _c.c_float, _p, _p, _p, _p, _c.c_float, _p, _p, _p, _p,
+                             _i, _i64, _i, _p]),
+    "wm_lfss_out_fwd": (_i, [_p] * 6 + [_i, _i, _i64, _i, _p]),
     "wm_dwconv3x3_fwd": (_i, [_p] * 4 + [_i] * 5 + [_p]),
     "wm_prof_enable": (None, [_i]),
     "wm_prof_collect": (_i, [_c.POINTER(_i), _c.POINTER(_c.c_double)]),

@@ -249,8 +249,22 @@ class LFSSBlock(nn.Module):
         self.ln_2 = nn.LayerNorm(hidden_dim)
         self.skip_scale2 = nn.Parameter(torch.ones(hidden_dim))
 
+    def _fused_ok(self, x):
+        """Whole-block HIP path: inference on the HIP backend for the kernel's shape range."""
+        ops = _OpsBackend.impl
+        ss = self.self_attention
+        if not (hasattr(ops, "lfss_block_forward") and x.is_cuda and x.dtype == torch.float32):
+            return False
+        if torch.is_grad_enabled() and (x.requires_grad or self.skip_scale.requires_grad):
+            return False
+        if ss.dropout is not None or ss.in_proj.bias is not None or ss.out_proj.bias is not None:
+            return False
+        return ops.lfss_block_supported(ss.d_model, ss.d_inner, ss.d_state, ss.dt_rank, self.conv_blk.conv1.out_channels)
+
     def forward(self, input, x_size):
         B, L, C = input.shape
+        if self._fused_ok(input):
+            return _OpsBackend.impl.lfss_block_forward(input, x_size, self)
         tok = input.view(B, x_size[0], x_size[1], C)
         tok = tok * self.skip_scale + self.drop_path(self.self_attention(self.ln_1(tok)))
         mix = self.conv_blk(self.ln_2(tok).permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1)

@@ -11,6 +11,7 @@
 #include "selscan.hip.h"
 #include "dwconv.hip.h"
 #include "ss2d.hip.h"
+#include "lfss.hip.h"
 
 namespace wm {
 
@@ -439,6 +440,49 @@ int wm_ss2d_core_fwd(const float* x, const float* x_proj_weight, const float* dt
     a.k = 3; a.y = merged ? y_row_fwd : y_col_rev; a.accumulate = merged;
     ss2d_launch_col<true>(a, pl, seg, st);
     return launch_status();
+}
+
+#define WM_LFSS_DISPATCH(KERNEL, ...)                                                              \
+    do {                                                                                           \
+        const long long total = (long long)B * L;                                                  \
+        if (total == 0) return WM_OK;                                                              \
+        const dim3 grid((unsigned)((total + 255) / 256)), block(256);                              \
+        hipStream_t st = (hipStream_t)stream;                                                      \
+        ProfScope ps(5, st);                                                                       \
+        if (C == 32) hipLaunchKernelGGL((KERNEL<32>), grid, block, 0, st, __VA_ARGS__);            \
+        else if (C == 16) hipLaunchKernelGGL((KERNEL<16>), grid, block, 0, st, __VA_ARGS__);       \
+        else if (C == 8) hipLaunchKernelGGL((KERNEL<8>), grid, block, 0, st, __VA_ARGS__);         \
+        else return WM_EUNSUPPORTED;                                                               \
+        return launch_status();                                                                    \
+    } while (0)
+
+int wm_lfss_in_fwd(const float* tok, int tok_nchw, const float* ln_w, const float* ln_b, float ln_eps,
+                   const float* in_proj_weight, float* x, float* z, int B, int64_t L, int C, void* stream) {
+    if (B < 0 || L < 0) return WM_EINVAL;
+    if (B && L && (!tok || !ln_w || !ln_b || !in_proj_weight || !x || !z)) return WM_ENULL;
+    if (!tok_nchw && !aligned16(tok)) return WM_EALIGN;
+    WM_LFSS_DISPATCH(lfss_in_kernel, tok, tok_nchw, ln_w, ln_b, ln_eps, in_proj_weight, x, z, B, (long long)L);
+}
+
+int wm_lfss_mid_fwd(const float* ysum, const float* z, const float* tok, int tok_nchw, const float* out_norm_w,
+                    const float* out_norm_b, float out_norm_eps, const float* out_proj_weight,
+                    const float* skip_scale, const float* ln2_w, const float* ln2_b, float ln2_eps,
+                    const float* conv1_weight, const float* conv1_bias, float* tok1, float* f, int B, int64_t L,
+                    int C, void* stream) {
+    if (B < 0 || L < 0) return WM_EINVAL;
+    if (B && L && (!ysum || !z || !tok || !out_norm_w || !out_norm_b || !out_proj_weight || !skip_scale || !ln2_w ||
+                   !ln2_b || !conv1_weight || !conv1_bias || !tok1 || !f)) return WM_ENULL;
+    if ((!tok_nchw && !aligned16(tok)) || !aligned16(tok1)) return WM_EALIGN;
+    WM_LFSS_DISPATCH(lfss_mid_kernel, ysum, z, tok, tok_nchw, out_norm_w, out_norm_b, out_norm_eps, out_proj_weight,
+                     skip_scale, ln2_w, ln2_b, ln2_eps, conv1_weight, conv1_bias, tok1, f, B, (long long)L);
+}
+
+int wm_lfss_out_fwd(const float* fc, const float* tok1, const float* conv3_weight, const float* conv3_bias,
+                    const float* skip_scale2, float* out, int out_nchw, int B, int64_t L, int C, void* stream) {
+    if (B < 0 || L < 0) return WM_EINVAL;
+    if (B && L && (!fc || !tok1 || !conv3_weight || !conv3_bias || !skip_scale2 || !out)) return WM_ENULL;
+    if (!aligned16(tok1) || (!out_nchw && !aligned16(out))) return WM_EALIGN;
+    WM_LFSS_DISPATCH(lfss_out_kernel, fc, tok1, conv3_weight, conv3_bias, skip_scale2, out, out_nchw, B, (long long)L);
 }
 
 void wm_prof_enable(int on) {

@@ -305,6 +305,57 @@ def ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, merg
 
 
 # ------------------------------------------------------------------------------------------------
+# LFSSBlock forward, fused (inference): lfss_in -> dwconv+SiLU -> ss2d core -> lfss_mid -> dwconv -> lfss_out
+# ------------------------------------------------------------------------------------------------
+def lfss_block_supported(C, d_inner, d_state, dt_rank, ffn_hidden):
+    return C in (8, 16, 32) and d_inner == 2 * C and ffn_hidden == 2 * C and ss2d_core_supported(d_inner, d_state, dt_rank)
+
+
+def _w(t):
+    return t.detach().contiguous().float()
+
+
+def lfss_block_forward(tok, x_size, blk, tok_nchw=False, out_nchw=False):
+    """LFSSBlock.forward (reference wavemamba_arch.py:520-528) on the HIP path, forward only.
+    tok: (B, L, C) tokens, or (B, C, H, W) when tok_nchw.  `blk` supplies the parameters (an LFSSBlock
+    module: ln_1, self_attention, skip_scale, conv_blk, ln_2, skip_scale2).  Returns (B, L, C) tokens or
+    (B, C, H, W) when out_nchw."""
+    lib = _lib.load()
+    _require_cuda("lfss_block_forward", tok)
+    H, W = x_size
+    L = H * W
+    ss, ff = blk.self_attention, blk.conv_blk
+    C, D = ss.d_model, ss.d_inner
+    B = tok.shape[0]
+    tok = tok.contiguous().float()
+    dev = tok.device
+    st = _stream()
+    x = torch.empty((B, D, H, W), dtype=torch.float32, device=dev)
+    z = torch.empty((B, D, L), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.wm_lfss_in_fwd(_ptr(tok), int(tok_nchw), _ptr(_w(blk.ln_1.weight)), _ptr(_w(blk.ln_1.bias)),
+                                 float(blk.ln_1.eps), _ptr(_w(ss.in_proj.weight)), _ptr(x), _ptr(z), B, L, C, st),
+              "wm_lfss_in_fwd")
+    xc = dwconv3x3(x, ss.conv2d.weight, ss.conv2d.bias, "silu")
+    ysum = ss2d_core(xc, ss.x_proj_weight, ss.dt_projs_weight, ss.dt_projs_bias, ss.A_logs, ss.Ds, merged=True)
+    tok1 = torch.empty((B, L, C), dtype=torch.float32, device=dev)
+    f = torch.empty((B, D, H, W), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.wm_lfss_mid_fwd(_ptr(ysum), _ptr(z), _ptr(tok), int(tok_nchw), _ptr(_w(ss.out_norm.weight)),
+                                  _ptr(_w(ss.out_norm.bias)), float(ss.out_norm.eps), _ptr(_w(ss.out_proj.weight)),
+                                  _ptr(_w(blk.skip_scale)), _ptr(_w(blk.ln_2.weight)), _ptr(_w(blk.ln_2.bias)),
+                                  float(blk.ln_2.eps), _ptr(_w(ff.conv1.weight)), _ptr(_w(ff.conv1.bias)),
+                                  _ptr(tok1), _ptr(f), B, L, C, st), "wm_lfss_mid_fwd")
+    fc = dwconv3x3(f, ff.conv2.weight, ff.conv2.bias, "none")
+    out = torch.empty((B, C, H, W) if out_nchw else (B, L, C), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.wm_lfss_out_fwd(_ptr(fc), _ptr(tok1), _ptr(_w(ff.conv3.weight)), _ptr(_w(ff.conv3.bias)),
+                                  _ptr(_w(blk.skip_scale2)), _ptr(out), int(out_nchw), B, L, C, st),
+              "wm_lfss_out_fwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # depth-wise 3x3 convolution (+ bias, + SiLU) - inference path of SS2D.conv2d / ffn.conv2
 # ------------------------------------------------------------------------------------------------
 def dwconv3x3(x, weight, bias=None, act="none"):
@@ -330,7 +381,7 @@ def dwconv3x3(x, weight, bias=None, act="none"):
 # profiling hooks (bench.py)
 # ------------------------------------------------------------------------------------------------
 PROF_KERNELS = ("haar_analysis", "haar_synthesis", "selscan_chunk_reduce", "selscan_carry",
-                "selscan_chunk_scan", "selscan_bwd", "ss2d_proj", "dwconv3x3",
+                "selscan_chunk_scan", "lfss_glue", "ss2d_proj", "dwconv3x3",
                 "ss2d_row_scan", "ss2d_col_scan", "ss2d_row_reduce", "ss2d_col_reduce")
 
 
