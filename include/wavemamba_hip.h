@@ -164,11 +164,11 @@ int wm_lfss_out_fwd(const float* fc, const float* tok1, const float* conv3_weigh
  *   kernel ids: 0 dwt/analysis, 1 iwt/synthesis, 2 scan chunk-reduce, 3 scan carry,
  *               4 scan chunk-scan (the dominant kernel), 5 scan bwd, 6 ss2d projection,
  *               7 depth-wise conv, 8 ss2d row chunk-scan, 9 ss2d col chunk-scan,
- *               10 ss2d row chunk-reduce, 11 ss2d col chunk-reduce
+ *               10 ss2d row chunk-reduce, 11 ss2d col chunk-reduce, 12 selective-scan backward (all phases)
  * wm_prof_collect synchronises the recorded events (host-blocking) and returns, per kernel id,
  * the number of launches and their summed duration in milliseconds since wm_prof_enable(1).
  * -------------------------------------------------------------------------------------------- */
-#define WM_PROF_NKERNELS 12
+#define WM_PROF_NKERNELS 13
 void wm_prof_enable(int on);
 int wm_prof_collect(int* launches /*[WM_PROF_NKERNELS]*/, double* total_ms /*[WM_PROF_NKERNELS]*/);
 

@@ -47,5 +47,9 @@ def rel_err(a, b):
 
 def assert_close(a, b, tol=1e-4, what=""):
     assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} != {tuple(b.shape)}"
+    a, b = a.detach(), b.detach()
+    if float(b.abs().max()) == 0.0:            # all-zero reference: absolute check (rounding residue only)
+        assert float(a.abs().max()) <= 1e-6, f"{what}: expected zeros, max abs {float(a.abs().max()):.3e}"
+        return
     l2, mx = rel_err(a, b)
     assert l2 <= tol and mx <= tol, f"{what}: rel l2 {l2:.3e}, rel max {mx:.3e} > {tol:g}"

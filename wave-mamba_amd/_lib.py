@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WAVEMAMBA_HIP_LIB") or os.path.join(HERE, "libwavemamba_hip.so")  # env: A/B builds
 
 WM_F32, WM_BF16 = 0, 1
-WM_PROF_NKERNELS = 12
+WM_PROF_NKERNELS = 13
 ABI_VERSION = 1
 
 _c = ctypes

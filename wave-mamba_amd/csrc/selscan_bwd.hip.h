@@ -1,0 +1,451 @@
+// selscan_bwd.hip.h - backward of the chunked selective scan for gfx950 (MI355X).
+//
+// Replaces mamba_ssm's selective_scan_cuda.bwd, reached by autograd through selective_scan_fn in
+// training (/root/reference/basicsr/models/femasr_model.py:181 -> wavemamba_arch.py:465-471).
+// Math (derived from the forward definition), a_t = exp(dt_t A):
+//   g_t   = C_t dy_t + a_{t+1} g_{t+1}                     adjoint state, reverse recurrence
+//   dC_t  = sum_d dy_t h_t          dB_t = sum_d g_t dt_t u_t           (sums over the group's channels)
+//   du_t  = dt_t <g_t, B_t> + D dy_t
+//   ddt_t = <g_t, A a_t h_{t-1} + B_t u_t>,  a_t h_{t-1} = h_t - dt_t B_t u_t
+//   dA    = sum_t g_t a_t h_{t-1} dt_t      dD = sum_t dy_t u_t
+//   ddelta_t = ddt_t * sigmoid(delta_t + bias)  (softplus; 1 above the threshold)    dbias = sum_t ddelta_t
+//
+// Same mapping as the forward (lane = channel, states in registers, B/C wave-uniform from LDS) and the
+// same L-split: chunks of 16 steps, each an independent single-wave workgroup:
+//   bwd-reduce : one forward pass per chunk -> P = prod a, H = local end state (forward carry) AND
+//                G = sum_s (prod_{r<=s} a_r) C_s dy_s, the chunk's contribution to the adjoint carry
+//                (forward-computable, so forward and adjoint summaries cost ONE pass of exponentials)
+//   carry      : the forward carry scan on H, and the same scan on the chunk-mirrored (P, G) arrays
+//   bwd-chunk  : forward sweep from H_in storing the state at every 4th step in LDS; then the four
+//                sub-tiles in reverse: recompute h_t and a_t for 4 steps into registers, walk them
+//                backwards.  dB/dC need a sum over the 64 lanes for 2N values per step: butterfly
+//                v_permlane32_swap -> v_permlane16_swap -> 4 DPP row-rotate adds (no LDS, no
+//                ds_bpermute).  dA / dD / dbias are per-chunk partials reduced by a last kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "selscan.hip.h"
+
+namespace wm {
+
+constexpr int kBT = 16;            // steps per backward chunk (= one LDS tile)
+constexpr int kBS = 4;             // steps per register sub-tile
+constexpr int kBRow = 20;          // padded LDS row
+constexpr int kPartPad = 4;        // per-(chunk, channel) partial record: NP (dA) + [dD, dbias, 0, 0]
+
+struct ScanBwdArgs {
+    const float *u, *delta, *A, *Bm, *Cm, *D, *bias, *dy;
+    float *du, *ddelta, *dB, *dC;
+    float *wsP, *wsH;              // forward summaries   [chunk][chain]
+    float *wsPr, *wsG;             // adjoint summaries   [nchunks-1-chunk][chain]
+    float *part;                   // [chunk][batch*dim][NP + kPartPad]
+    int batch, dim, L, N, G, dpg, wpg, nchunks, softplus, atomic_bc;
+};
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float row_sum16(float x) {       // every lane of a 16-lane row gets the row sum
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x128, 0xf, 0xf, false));  // row_ror:8
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x124, 0xf, 0xf, false));
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x122, 0xf, 0xf, false));
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x121, 0xf, 0xf, false));
+    return x;
+}
+// 32 per-lane values -> their sums over the 64 lanes; afterwards every lane of 16-lane row r holds
+// the totals of values 8r .. 8r+7 in out[0..7].
+__device__ __forceinline__ void wave_reduce32(const float (&v)[32], float (&out)[8]) {
+    float r1[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const u32x2 s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j]), __float_as_uint(v[j + 16]), false, false);
+        r1[j] = __uint_as_float(s.x) + __uint_as_float(s.y);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const u32x2 s = __builtin_amdgcn_permlane16_swap(__float_as_uint(r1[j]), __float_as_uint(r1[j + 8]), false, false);
+        out[j] = row_sum16(__uint_as_float(s.x) + __uint_as_float(s.y));
+    }
+}
+
+struct BwdTileIdx { int b, g, nch, ch0; bool live; int d; };
+__device__ __forceinline__ BwdTileIdx bwd_decode(const ScanBwdArgs& p, int wr, int lane) {
+    BwdTileIdx r;
+    const int sub = wr % p.wpg; wr /= p.wpg;
+    r.g = wr % p.G; r.b = wr / p.G;
+    r.nch = min(64, p.dpg - sub * 64);
+    r.ch0 = r.g * p.dpg + sub * 64;
+    r.live = lane < r.nch;
+    r.d = r.ch0 + (r.live ? lane : 0);
+    return r;
+}
+
+// cooperative load of one [64 rows][16 steps] tile (rows = this wave's channels) into LDS
+template <bool VEC>
+__device__ __forceinline__ void bwd_load_rows(const float* __restrict__ base, long long L, int t0, int t_end,
+                                              int nch, int lane, float* __restrict__ s) {
+    const int trow = lane >> 2, tq = lane & 3, t = t0 + 4 * tq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 16 * i + trow;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < nch) {
+            const float* q = base + (long long)r * L + t;
+            if constexpr (VEC) { if (t < t_end) v = *reinterpret_cast<const float4*>(q); }
+            else {
+                if (t + 0 < t_end) v.x = q[0];
+                if (t + 1 < t_end) v.y = q[1];
+                if (t + 2 < t_end) v.z = q[2];
+                if (t + 3 < t_end) v.w = q[3];
+            }
+        }
+        *reinterpret_cast<float4*>(&s[r * kBRow + 4 * tq]) = v;
+    }
+}
+// [N rows][16 steps] -> LDS transposed [16 steps][NP]
+template <int NP, bool VEC>
+__device__ __forceinline__ void bwd_load_bc(const float* __restrict__ base, long long L, int t0, int t_end,
+                                            int N, int lane, float* __restrict__ s) {
+    const int trow = lane >> 2, tq = lane & 3, t = t0 + 4 * tq;
+#pragma unroll
+    for (int i = 0; i < NP / 16; ++i) {
+        const int n = 16 * i + trow;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N) {
+            const float* q = base + (long long)n * L + t;
+            if constexpr (VEC) { if (t < t_end) v = *reinterpret_cast<const float4*>(q); }
+            else {
+                if (t + 0 < t_end) v.x = q[0];
+                if (t + 1 < t_end) v.y = q[1];
+                if (t + 2 < t_end) v.z = q[2];
+                if (t + 3 < t_end) v.w = q[3];
+            }
+        }
+        s[(4 * tq + 0) * NP + n] = v.x; s[(4 * tq + 1) * NP + n] = v.y;
+        s[(4 * tq + 2) * NP + n] = v.z; s[(4 * tq + 3) * NP + n] = v.w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bwd-reduce: forward (P, H) and adjoint (G) chunk summaries in one pass
+// ------------------------------------------------------------------------------------------------
+template <int NP, bool VEC>
+__global__ __launch_bounds__(64) void selscan_bwd_reduce_kernel(ScanBwdArgs p) {
+    __shared__ __attribute__((aligned(16))) float s_u[64 * kBRow], s_d[64 * kBRow], s_dy[64 * kBRow];
+    __shared__ __attribute__((aligned(16))) float s_B[kBT * NP], s_C[kBT * NP];
+    const int lane = threadIdx.x, chunk = blockIdx.x;
+    const BwdTileIdx ix = bwd_decode(p, blockIdx.y, lane);
+    const long long L = p.L;
+    const int t0 = chunk * kBT, t_end = min(p.L, t0 + kBT), tl = t_end - t0;
+
+    v2f A2[NP / 2];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        const float a = (n < p.N) ? p.A[(long long)ix.d * p.N + n] * 1.4426950408889634f : 0.0f;
+        if (n & 1) A2[n / 2].y = a; else A2[n / 2].x = a;
+    }
+    const float bias = p.bias ? p.bias[ix.d] : 0.0f;
+    const long long rowbase = ((long long)ix.b * p.dim + ix.ch0) * L;
+    const long long bcbase = ((long long)ix.b * p.G + ix.g) * p.N * L;
+    bwd_load_rows<VEC>(p.u + rowbase, L, t0, t_end, ix.nch, lane, s_u);
+    bwd_load_rows<VEC>(p.delta + rowbase, L, t0, t_end, ix.nch, lane, s_d);
+    bwd_load_rows<VEC>(p.dy + rowbase, L, t0, t_end, ix.nch, lane, s_dy);
+    bwd_load_bc<NP, VEC>(p.Bm + bcbase, L, t0, t_end, p.N, lane, s_B);
+    bwd_load_bc<NP, VEC>(p.Cm + bcbase, L, t0, t_end, p.N, lane, s_C);
+    __syncthreads();
+
+    v2f h[NP / 2], pf[NP / 2], gl[NP / 2];
+#pragma unroll
+    for (int n = 0; n < NP / 2; ++n) { h[n] = splat(0.f); pf[n] = splat(1.f); gl[n] = splat(0.f); }
+#pragma unroll
+    for (int q = 0; q < kBT / 4; ++q) {
+        if (4 * q < tl) {
+            const float4 u4 = *reinterpret_cast<const float4*>(&s_u[lane * kBRow + 4 * q]);
+            const float4 d4 = *reinterpret_cast<const float4*>(&s_d[lane * kBRow + 4 * q]);
+            const float4 y4 = *reinterpret_cast<const float4*>(&s_dy[lane * kBRow + 4 * q]);
+            const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, yy[4] = {y4.x, y4.y, y4.z, y4.w};
+            v2f da = (v2f){d4.x, d4.y} + bias, db = (v2f){d4.z, d4.w} + bias;
+            if (p.softplus) { da = softplus2(da); db = softplus2(db); }
+            const float dts[4] = {da.x, da.y, db.x, db.y};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tt = 4 * q + j;
+                if (tt < tl) {
+                    const v2f dt2 = splat(dts[j]), du2 = splat(dts[j] * uu[j]), dy2 = splat(yy[j]);
+#pragma unroll
+                    for (int r = 0; r < NP / 4; ++r) {
+                        const float4 bv = *reinterpret_cast<const float4*>(&s_B[tt * NP + 4 * r]);
+                        const float4 cv = *reinterpret_cast<const float4*>(&s_C[tt * NP + 4 * r]);
+                        const v2f a0 = exp2_2(dt2 * A2[2 * r]), a1 = exp2_2(dt2 * A2[2 * r + 1]);
+                        h[2 * r] = a0 * h[2 * r] + du2 * (v2f){bv.x, bv.y};
+                        h[2 * r + 1] = a1 * h[2 * r + 1] + du2 * (v2f){bv.z, bv.w};
+                        pf[2 * r] *= a0; pf[2 * r + 1] *= a1;
+                        gl[2 * r] = pf[2 * r] * (dy2 * (v2f){cv.x, cv.y}) + gl[2 * r];
+                        gl[2 * r + 1] = pf[2 * r + 1] * (dy2 * (v2f){cv.z, cv.w}) + gl[2 * r + 1];
+                    }
+                }
+            }
+        }
+    }
+    if (ix.live) {
+        const long long chains = (long long)p.batch * p.dim * NP;
+        const long long row = ((long long)ix.b * p.dim + ix.d) * NP;
+        const long long f = (long long)chunk * chains + row, m = (long long)(p.nchunks - 1 - chunk) * chains + row;
+#pragma unroll
+        for (int q = 0; q < NP / 4; ++q) {
+            const float4 P4 = make_float4(pf[2 * q].x, pf[2 * q].y, pf[2 * q + 1].x, pf[2 * q + 1].y);
+            *reinterpret_cast<float4*>(p.wsP + f + 4 * q) = P4;
+            *reinterpret_cast<float4*>(p.wsPr + m + 4 * q) = P4;
+            *reinterpret_cast<float4*>(p.wsH + f + 4 * q) = make_float4(h[2 * q].x, h[2 * q].y, h[2 * q + 1].x, h[2 * q + 1].y);
+            *reinterpret_cast<float4*>(p.wsG + m + 4 * q) = make_float4(gl[2 * q].x, gl[2 * q].y, gl[2 * q + 1].x, gl[2 * q + 1].y);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bwd-chunk: the gradients of one 16-step chunk
+// ------------------------------------------------------------------------------------------------
+template <int NP, bool VEC>
+__global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
+    constexpr int NSUB = kBT / kBS;
+    __shared__ __attribute__((aligned(16))) float s_u[64 * kBRow], s_d[64 * kBRow], s_dy[64 * kBRow];
+    __shared__ __attribute__((aligned(16))) float s_B[kBT * NP], s_C[kBT * NP];
+    __shared__ __attribute__((aligned(16))) float s_hs[NSUB * NP * 64];       // state at the start of each sub-tile
+    __shared__ __attribute__((aligned(16))) float s_red[2 * NP * kBRow];      // dB rows then dC rows, [value][step]
+    const int lane = threadIdx.x, chunk = blockIdx.x;
+    const BwdTileIdx ix = bwd_decode(p, blockIdx.y, lane);
+    const long long L = p.L;
+    const int t0 = chunk * kBT, t_end = min(p.L, t0 + kBT), tl = t_end - t0;
+
+    v2f A2[NP / 2];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        const float a = (n < p.N) ? p.A[(long long)ix.d * p.N + n] * 1.4426950408889634f : 0.0f;
+        if (n & 1) A2[n / 2].y = a; else A2[n / 2].x = a;
+    }
+    const float bias = p.bias ? p.bias[ix.d] : 0.0f;
+    const float Dd = p.D ? p.D[ix.d] : 0.0f;
+    const long long rowbase = ((long long)ix.b * p.dim + ix.ch0) * L;
+    const long long bcbase = ((long long)ix.b * p.G + ix.g) * p.N * L;
+    bwd_load_rows<VEC>(p.u + rowbase, L, t0, t_end, ix.nch, lane, s_u);
+    bwd_load_rows<VEC>(p.delta + rowbase, L, t0, t_end, ix.nch, lane, s_d);
+    bwd_load_rows<VEC>(p.dy + rowbase, L, t0, t_end, ix.nch, lane, s_dy);
+    bwd_load_bc<NP, VEC>(p.Bm + bcbase, L, t0, t_end, p.N, lane, s_B);
+    bwd_load_bc<NP, VEC>(p.Cm + bcbase, L, t0, t_end, p.N, lane, s_C);
+
+    const long long chains = (long long)p.batch * p.dim * NP;
+    const long long row = ((long long)ix.b * p.dim + ix.d) * NP;
+    v2f h[NP / 2], gacc[NP / 2];
+#pragma unroll
+    for (int q = 0; q < NP / 4; ++q) {
+        float4 hv = make_float4(0.f, 0.f, 0.f, 0.f), gv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ix.live && p.nchunks > 1) {
+            hv = *reinterpret_cast<const float4*>(p.wsH + (long long)chunk * chains + row + 4 * q);
+            gv = *reinterpret_cast<const float4*>(p.wsG + (long long)(p.nchunks - 1 - chunk) * chains + row + 4 * q);
+        }
+        h[2 * q] = (v2f){hv.x, hv.y}; h[2 * q + 1] = (v2f){hv.z, hv.w};
+        gacc[2 * q] = (v2f){gv.x, gv.y}; gacc[2 * q + 1] = (v2f){gv.z, gv.w};
+    }
+    __syncthreads();
+
+    // dt for the 16 steps (registers) + forward sweep storing the sub-tile start states
+    float dts[kBT];
+#pragma unroll
+    for (int q = 0; q < kBT / 4; ++q) {
+        const float4 d4 = *reinterpret_cast<const float4*>(&s_d[lane * kBRow + 4 * q]);
+        v2f da = (v2f){d4.x, d4.y} + bias, db = (v2f){d4.z, d4.w} + bias;
+        if (p.softplus) { da = softplus2(da); db = softplus2(db); }
+        dts[4 * q] = da.x; dts[4 * q + 1] = da.y; dts[4 * q + 2] = db.x; dts[4 * q + 3] = db.y;
+    }
+#pragma unroll
+    for (int st = 0; st < NSUB; ++st) {
+#pragma unroll
+        for (int n = 0; n < NP / 2; ++n) {
+            s_hs[(st * NP + 2 * n) * 64 + lane] = h[n].x;
+            s_hs[(st * NP + 2 * n + 1) * 64 + lane] = h[n].y;
+        }
+        if (st < NSUB - 1) {
+#pragma unroll
+            for (int j = 0; j < kBS; ++j) {
+                const int tt = st * kBS + j;
+                if (tt < tl) {
+                    const v2f dt2 = splat(dts[tt]), du2 = splat(dts[tt] * s_u[lane * kBRow + tt]);
+#pragma unroll
+                    for (int r = 0; r < NP / 4; ++r) {
+                        const float4 bv = *reinterpret_cast<const float4*>(&s_B[tt * NP + 4 * r]);
+                        h[2 * r] = exp2_2(dt2 * A2[2 * r]) * h[2 * r] + du2 * (v2f){bv.x, bv.y};
+                        h[2 * r + 1] = exp2_2(dt2 * A2[2 * r + 1]) * h[2 * r + 1] + du2 * (v2f){bv.z, bv.w};
+                    }
+                }
+            }
+        }
+    }
+
+    v2f dA[NP / 2];
+#pragma unroll
+    for (int n = 0; n < NP / 2; ++n) dA[n] = splat(0.f);
+    float dDp = 0.0f, dbp = 0.0f;
+
+#pragma unroll
+    for (int st = NSUB - 1; st >= 0; --st) {
+        if (st * kBS >= tl) continue;
+        // recompute h_t and a_t for the sub-tile's 4 steps into registers
+        v2f hh[kBS][NP / 2], aa[kBS][NP / 2];
+        v2f hc[NP / 2];
+#pragma unroll
+        for (int n = 0; n < NP / 2; ++n)
+            hc[n] = (v2f){s_hs[(st * NP + 2 * n) * 64 + lane], s_hs[(st * NP + 2 * n + 1) * 64 + lane]};
+#pragma unroll
+        for (int j = 0; j < kBS; ++j) {
+            const int tt = st * kBS + j;
+            const float dt = dts[tt];                                // (steps beyond tl: dt of zero padding, unused)
+            const v2f dt2 = splat(dt), du2 = splat(dt * s_u[lane * kBRow + tt]);
+#pragma unroll
+            for (int r = 0; r < NP / 4; ++r) {
+                const float4 bv = *reinterpret_cast<const float4*>(&s_B[tt * NP + 4 * r]);
+                aa[j][2 * r] = exp2_2(dt2 * A2[2 * r]);
+                aa[j][2 * r + 1] = exp2_2(dt2 * A2[2 * r + 1]);
+                hc[2 * r] = aa[j][2 * r] * hc[2 * r] + du2 * (v2f){bv.x, bv.y};
+                hc[2 * r + 1] = aa[j][2 * r + 1] * hc[2 * r + 1] + du2 * (v2f){bv.z, bv.w};
+                hh[j][2 * r] = hc[2 * r]; hh[j][2 * r + 1] = hc[2 * r + 1];
+            }
+        }
+#pragma unroll
+        for (int j = kBS - 1; j >= 0; --j) {
+            const int tt = st * kBS + j;
+            if (tt < tl) {
+                const float dt = dts[tt], ut = s_u[lane * kBRow + tt], dyt = s_dy[lane * kBRow + tt];
+                const float xraw = s_d[lane * kBRow + tt] + bias;
+                const v2f dt2 = splat(dt), du2 = splat(dt * ut), dy2 = splat(dyt);
+                v2f sdu = splat(0.f), sdt = splat(0.f);
+                float prod[2 * NP];                                   // [0, NP): dB products, [NP, 2NP): dC products
+#pragma unroll
+                for (int r = 0; r < NP / 4; ++r) {
+                    const float4 bv = *reinterpret_cast<const float4*>(&s_B[tt * NP + 4 * r]);
+                    const float4 cv = *reinterpret_cast<const float4*>(&s_C[tt * NP + 4 * r]);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int n2 = 2 * r + e;
+                        const v2f B2 = e ? (v2f){bv.z, bv.w} : (v2f){bv.x, bv.y};
+                        const v2f C2 = e ? (v2f){cv.z, cv.w} : (v2f){cv.x, cv.y};
+                        const v2f g = C2 * dy2 + gacc[n2];            // g_t
+                        const v2f ahp = hh[j][n2] - du2 * B2;         // a_t h_{t-1}
+                        const v2f gah = g * ahp;
+                        dA[n2] = gah * dt2 + dA[n2];
+                        sdt = gah * (A2[n2] * 0.6931471805599453f) + sdt;     // A = A2 * ln 2
+                        sdu = g * B2 + sdu;
+                        const v2f pb = g * du2, pc = hh[j][n2] * dy2;
+                        prod[2 * n2] = pb.x; prod[2 * n2 + 1] = pb.y;
+                        prod[NP + 2 * n2] = pc.x; prod[NP + 2 * n2 + 1] = pc.y;
+                        gacc[n2] = aa[j][n2] * g;                      // a_t g_t, carried to step t-1
+                    }
+                }
+                const float sb = sdu.x + sdu.y;
+                const float ddt = (sdt.x + sdt.y) + ut * sb;
+                const float dut = fmaf(dt, sb, Dd * dyt);
+                float dd = ddt;
+                if (p.softplus) dd = xraw > 20.0f ? ddt : ddt / (1.0f + __expf(-xraw));
+                dDp = fmaf(dyt, ut, dDp);
+                dbp += dd;
+                s_dy[lane * kBRow + tt] = dut;                        // du_t takes dy_t's slot
+                s_d[lane * kBRow + tt] = dd;                          // ddelta_t takes delta_t's slot
+                // channel sums of the 2N products (dead lanes hold zeros: their u, dy rows are zero-filled)
+#pragma unroll
+                for (int half = 0; half < NP / 16; ++half) {
+                    float v[32], o[8];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { v[i] = prod[16 * half + i]; v[16 + i] = prod[NP + 16 * half + i]; }
+                    wave_reduce32(v, o);
+                    if ((lane & 15) == 0) {
+                        const int rowg = lane >> 4;                   // row r holds values 8r .. 8r+7
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int val = 8 * rowg + i;             // 0..15 -> dB n, 16..31 -> dC n
+                            const int n = 16 * half + (val & 15);
+                            s_red[((val >> 4) * NP + n) * kBRow + tt] = o[i];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- write back: du, ddelta rows; dB, dC rows; per-chunk partials --------------------------------
+    {
+        const int trow = lane >> 2, tq = lane & 3, t = t0 + 4 * tq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 16 * i + trow;
+            if (r < ix.nch && t < t_end) {
+                const float4 a = *reinterpret_cast<const float4*>(&s_dy[r * kBRow + 4 * tq]);
+                const float4 b = *reinterpret_cast<const float4*>(&s_d[r * kBRow + 4 * tq]);
+                float* o1 = p.du + rowbase + (long long)r * L + t;
+                float* o2 = p.ddelta + rowbase + (long long)r * L + t;
+                if constexpr (VEC) { *reinterpret_cast<float4*>(o1) = a; *reinterpret_cast<float4*>(o2) = b; }
+                else {
+                    const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (t + j < t_end) { o1[j] = av[j]; o2[j] = bv[j]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NP / 16; ++i) {
+            const int rr = 16 * i + trow;                              // 0..NP-1: dB n, NP..2NP-1: dC n
+            const int n = rr % NP;
+            if (n < p.N) {
+                float* base = (rr < NP ? p.dB : p.dC) + bcbase + (long long)n * L + t;
+                const float4 v = *reinterpret_cast<const float4*>(&s_red[rr * kBRow + 4 * tq]);
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+                if (p.atomic_bc) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (t + j < t_end) atomicAdd(base + j, vv[j]);
+                } else if constexpr (VEC) {
+                    if (t < t_end) *reinterpret_cast<float4*>(base) = v;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (t + j < t_end) base[j] = vv[j];
+                }
+            }
+        }
+    }
+    if (ix.live) {
+        float* pr = p.part + ((long long)chunk * p.batch * p.dim + (long long)ix.b * p.dim + ix.d) * (NP + kPartPad);
+#pragma unroll
+        for (int q = 0; q < NP / 4; ++q)
+            *reinterpret_cast<float4*>(pr + 4 * q) = make_float4(dA[2 * q].x, dA[2 * q].y, dA[2 * q + 1].x, dA[2 * q + 1].y);
+        *reinterpret_cast<float4*>(pr + NP) = make_float4(dDp, dbp, 0.f, 0.f);
+    }
+}
+
+// dA (dim, N), dD (dim), dbias (dim) = sums of the per-chunk partials over chunks and batch.
+// One block per channel: NP + kPartPad columns x 8 row-groups, LDS tree over the row-groups.
+__global__ __launch_bounds__(256) void selscan_bwd_finish_kernel(const float* __restrict__ part, float* __restrict__ dA,
+                                                                 float* __restrict__ dD, float* __restrict__ dbias,
+                                                                 int batch, int dim, int N, int NPP, int nchunks) {
+    __shared__ float s[8][40];
+    const int d = blockIdx.x, col = threadIdx.x % 32, grp = threadIdx.x / 32;       // NPP <= 36 handled in 2 sweeps
+    for (int c0 = 0; c0 < NPP; c0 += 32) {
+        const int j = c0 + col;
+        float acc = 0.0f;
+        if (j < NPP)
+            for (long long i = grp; i < (long long)nchunks * batch; i += 8) {
+                const long long c = i / batch, b = i - c * batch;
+                acc += part[((c * batch + b) * dim + d) * NPP + j];
+            }
+        s[grp][col] = acc;
+        __syncthreads();
+        if (grp == 0 && j < NPP) {
+            float t = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) t += s[g][col];
+            const int NP = NPP - kPartPad;
+            if (j < N) dA[(long long)d * N + j] = t;
+            else if (j == NP && dD) dD[d] = t;
+            else if (j == NP + 1 && dbias) dbias[d] = t;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace wm

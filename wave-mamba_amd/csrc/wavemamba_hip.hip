@@ -9,6 +9,7 @@
 #include "../../include/wavemamba_hip.h"
 #include "haar.hip.h"
 #include "selscan.hip.h"
+#include "selscan_bwd.hip.h"
 #include "dwconv.hip.h"
 #include "ss2d.hip.h"
 #include "lfss.hip.h"
@@ -367,11 +368,86 @@ int wm_selscan_fwd(const float* u, const float* delta, const float* A, const flo
     return vec ? scan_launch<32, true>(a, pl, st) : scan_launch<32, false>(a, pl, st);
 }
 
-size_t wm_selscan_bwd_workspace_bytes(int, int, int, int, int) { return 0; }
-int wm_selscan_bwd(const float*, const float*, const float*, const float*, const float*, const float*,
-                   const float*, const float*, float*, float*, float*, float*, float*, float*, float*,
-                   void*, size_t, int, int, int, int, int, int, void*) {
-    return WM_EUNSUPPORTED;   // implemented in a later milestone
+}  // extern "C" (templates below need C++ linkage)
+namespace wm {
+struct BwdPlan { int NP, wpg, rows, nchunks; long long chains; size_t arr_bytes, seg_bytes, part_bytes, total; };
+static int bwd_plan(BwdPlan& pl, int batch, int dim, int L, int N, int G) {
+    if (batch <= 0 || dim <= 0 || L <= 0 || N <= 0 || G <= 0) return WM_EINVAL;
+    if (N > 32) return WM_EUNSUPPORTED;
+    if (dim % G != 0) return WM_EINVAL;
+    pl.NP = N <= 16 ? 16 : 32;
+    pl.wpg = (dim / G + 63) / 64;
+    const long long rows = (long long)batch * G * pl.wpg;
+    if (rows > 65535) return WM_EUNSUPPORTED;
+    pl.rows = (int)rows;
+    pl.nchunks = (L + kBT - 1) / kBT;
+    pl.chains = (long long)batch * dim * pl.NP;
+    pl.arr_bytes = (size_t)pl.nchunks * pl.chains * sizeof(float);
+    pl.seg_bytes = (size_t)2 * carry_nsegs(pl.nchunks) * pl.chains * sizeof(float);
+    pl.part_bytes = (size_t)pl.nchunks * batch * dim * (pl.NP + kPartPad) * sizeof(float);
+    pl.total = 4 * pl.arr_bytes + pl.seg_bytes + pl.part_bytes;
+    return WM_OK;
+}
+
+template <int NP, bool VEC>
+static int bwd_launch(const ScanBwdArgs& a, const BwdPlan& pl, float* seg, float* dA, float* dD, float* dbias,
+                      hipStream_t st) {
+    const dim3 grid((unsigned)pl.nchunks, (unsigned)pl.rows), block(64);
+    ProfScope ps(12, st);
+    if (pl.nchunks > 1) {
+        hipLaunchKernelGGL((selscan_bwd_reduce_kernel<NP, VEC>), grid, block, 0, st, a);
+        launch_carry(a.wsP, a.wsH, seg, pl.chains, pl.nchunks, st);
+        launch_carry(a.wsPr, a.wsG, seg, pl.chains, pl.nchunks, st);
+    }
+    hipLaunchKernelGGL((selscan_bwd_chunk_kernel<NP, VEC>), grid, block, 0, st, a);
+    hipLaunchKernelGGL(selscan_bwd_finish_kernel, dim3((unsigned)a.dim), dim3(256), 0, st, (const float*)a.part, dA, dD,
+                       dbias, a.batch, a.dim, a.N, NP + kPartPad, pl.nchunks);
+    return launch_status();
+}
+
+}  // namespace wm
+extern "C" {
+size_t wm_selscan_bwd_workspace_bytes(int batch, int dim, int L, int N, int G) {
+    BwdPlan pl;
+    if (bwd_plan(pl, batch, dim, L, N, G) != WM_OK) return 0;
+    return pl.total;
+}
+
+int wm_selscan_bwd(const float* u, const float* delta, const float* A, const float* Bm, const float* Cm,
+                   const float* D, const float* delta_bias, const float* dy, float* du, float* ddelta,
+                   float* dA, float* dB, float* dC, float* dD, float* dbias, void* workspace,
+                   size_t workspace_bytes, int batch, int dim, int L, int N, int G, int delta_softplus,
+                   void* stream) {
+    if (batch == 0 || dim == 0 || L == 0) return (batch < 0 || dim < 0 || L < 0) ? WM_EINVAL : WM_OK;
+    BwdPlan pl;
+    int rc = bwd_plan(pl, batch, dim, L, N, G);
+    if (rc) return rc;
+    if (!u || !delta || !A || !Bm || !Cm || !dy || !du || !ddelta || !dA || !dB || !dC) return WM_ENULL;
+    if (!workspace) return WM_ENULL;
+    if (workspace_bytes < pl.total) return WM_EWORKSPACE;
+    if (!aligned16(workspace)) return WM_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    ScanBwdArgs a;
+    a.u = u; a.delta = delta; a.A = A; a.Bm = Bm; a.Cm = Cm; a.D = D; a.bias = delta_bias; a.dy = dy;
+    a.du = du; a.ddelta = ddelta; a.dB = dB; a.dC = dC;
+    char* w = (char*)workspace;
+    a.wsP = (float*)w; a.wsH = (float*)(w + pl.arr_bytes); a.wsPr = (float*)(w + 2 * pl.arr_bytes);
+    a.wsG = (float*)(w + 3 * pl.arr_bytes);
+    float* seg = (float*)(w + 4 * pl.arr_bytes);
+    a.part = (float*)(w + 4 * pl.arr_bytes + pl.seg_bytes);
+    a.batch = batch; a.dim = dim; a.L = L; a.N = N; a.G = G; a.dpg = dim / G; a.wpg = pl.wpg;
+    a.nchunks = pl.nchunks; a.softplus = delta_softplus ? 1 : 0; a.atomic_bc = pl.wpg > 1 ? 1 : 0;
+    if (a.atomic_bc) {
+        const size_t nb = (size_t)batch * G * N * L * sizeof(float);
+        hipError_t e = hipMemsetAsync(dB, 0, nb, st);
+        if (e == hipSuccess) e = hipMemsetAsync(dC, 0, nb, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    const bool vec = (L % 4 == 0) && aligned16(u) && aligned16(delta) && aligned16(Bm) && aligned16(Cm) &&
+                     aligned16(dy) && aligned16(du) && aligned16(ddelta) && aligned16(dB) && aligned16(dC);
+    if (pl.NP == 16) return vec ? bwd_launch<16, true>(a, pl, seg, dA, dD, dbias, st)
+                                : bwd_launch<16, false>(a, pl, seg, dA, dD, dbias, st);
+    return vec ? bwd_launch<32, true>(a, pl, seg, dA, dD, dbias, st) : bwd_launch<32, false>(a, pl, seg, dA, dD, dbias, st);
 }
 
 int wm_dwconv3x3_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int C,

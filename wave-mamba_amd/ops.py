@@ -382,7 +382,7 @@ def dwconv3x3(x, weight, bias=None, act="none"):
 # ------------------------------------------------------------------------------------------------
 PROF_KERNELS = ("haar_analysis", "haar_synthesis", "selscan_chunk_reduce", "selscan_carry",
                 "selscan_chunk_scan", "lfss_glue", "ss2d_proj", "dwconv3x3",
-                "ss2d_row_scan", "ss2d_col_scan", "ss2d_row_reduce", "ss2d_col_reduce")
+                "ss2d_row_scan", "ss2d_col_scan", "ss2d_row_reduce", "ss2d_col_reduce", "selscan_bwd")
 
 
 def prof_enable(on=True):
