@@ -61,10 +61,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kProjTiles = 9;
 constexpr int kProjKS = 16;                // K-steps of 4 -> D_in <= 64
 
-__global__ __launch_bounds__(256, 1) void ss2d_proj_kernel(Ss2dArgs p, int groups_per_batch) {
+__global__ __launch_bounds__(128, 1) void ss2d_proj_kernel(Ss2dArgs p, int groups_per_batch) {
+    __shared__ __attribute__((aligned(16))) float s_out[2 * 4 * 32 * kRS];       // 2 waves x 18,432 B
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * 4;
+    const int wave = blockIdx.x * 2 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 2;
     const int g4 = lane >> 4, j16 = lane & 15;
     const int C = p.R + 2 * p.N;
 
@@ -85,25 +86,47 @@ __global__ __launch_bounds__(256, 1) void ss2d_proj_kernel(Ss2dArgs p, int group
 
     const long long L = p.L;
     const long long total = (long long)p.B * groups_per_batch;          // groups of 32 positions
+    // common case (D_in == 64, even L): unconditional 8-byte loads with clamped addresses - per-load
+    // predication costs more issue slots than the MFMAs it feeds (one wave per SIMD hides nothing)
+    const bool fast = (p.D == 4 * kProjKS) && ((L & 1) == 0) && L >= 2;
+    auto load_x = [&](long long grp, float2 (&v)[kProjKS]) {
+        if (fast) {
+            const long long gc = grp < total ? grp : total - 1;
+            const int bb = (int)(gc / groups_per_batch);
+            long long pc = (gc - (long long)bb * groups_per_batch) * 32 + 2 * j16;
+            pc = pc < L - 2 ? pc : L - 2;
+            const float* q = p.x + ((long long)bb * p.D + g4) * L + pc;
+#pragma unroll
+            for (int s = 0; s < kProjKS; ++s) v[s] = *reinterpret_cast<const float2*>(q + (long long)(4 * s) * L);
+            return;
+        }
+        const int b = (int)(grp / groups_per_batch);
+        const long long pj = (grp - (long long)b * groups_per_batch) * 32 + 2 * j16;
+        const float* xb = p.x + (long long)b * p.D * L;
+#pragma unroll
+        for (int s = 0; s < kProjKS; ++s) {
+            const int d = 4 * s + g4;
+            v[s] = make_float2(0.f, 0.f);
+            if (grp < total && d < p.D) {
+                const float* q = xb + (long long)d * L + pj;
+                if ((L & 1) == 0) { if (pj < L) v[s] = *reinterpret_cast<const float2*>(q); }
+                else { if (pj < L) v[s].x = q[0]; if (pj + 1 < L) v[s].y = q[1]; }
+            }
+        }
+    };
+    float2 xnext[kProjKS];
+    load_x(wave, xnext);
     for (long long grp = wave; grp < total; grp += nwaves) {
         const int b = (int)(grp / groups_per_batch);
         const long long p0 = (grp - (long long)b * groups_per_batch) * 32;
-        const float* xb = p.x + (long long)b * p.D * L;
         const long long pj = p0 + 2 * j16;                              // this lane's 2 positions
         f32x4 acc[kProjTiles][2];
 #pragma unroll
         for (int t = 0; t < kProjTiles; ++t) { acc[t][0] = (f32x4){0, 0, 0, 0}; acc[t][1] = (f32x4){0, 0, 0, 0}; }
         float2 xv[kProjKS];
 #pragma unroll
-        for (int s = 0; s < kProjKS; ++s) {
-            const int d = 4 * s + g4;
-            xv[s] = make_float2(0.f, 0.f);
-            if (d < p.D) {
-                const float* q = xb + (long long)d * L + pj;
-                if ((L & 1) == 0) { if (pj < L) xv[s] = *reinterpret_cast<const float2*>(q); }
-                else { if (pj < L) xv[s].x = q[0]; if (pj + 1 < L) xv[s].y = q[1]; }
-            }
-        }
+        for (int s = 0; s < kProjKS; ++s) xv[s] = xnext[s];
+        load_x(grp + nwaves, xnext);                                    // in flight under the MFMAs below
 #pragma unroll
         for (int s = 0; s < kProjKS; ++s) {
 #pragma unroll
@@ -112,20 +135,32 @@ __global__ __launch_bounds__(256, 1) void ss2d_proj_kernel(Ss2dArgs p, int group
                 acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[t][s], xv[s].y, acc[t][1], 0, 0, 0);
             }
         }
-        // D layout: lane holds rows 4*g4 .. 4*g4+3 of column j16  ->  16-byte pieces of the records
+        // D layout: lane holds rows 4*g4 .. 4*g4+3 of column j16.  Assemble the 4 x 32 records of this
+        // group in the wave's private LDS slab, then write each direction's 32 x 144 B as ONE contiguous
+        // 4608-B run of 16-byte stores (direct stores would be 16-B pieces at a 144-B stride).
+        float* slab = s_out + (threadIdx.x >> 6) * (4 * 32 * kRS);
+        __builtin_amdgcn_wave_barrier();                  // previous iteration's reads are done (in-order LDS)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const long long pos = pj + i;
-            if (pos < L) {
-                // tile 0: row group g4 = direction g4, rows = dt_r[0..3]
-                float* r0 = p.rec + (((long long)b * 4 + g4) * L + pos) * kRS;
-                *reinterpret_cast<f32x4*>(r0) = acc[0][i];
+            const int pl = 2 * j16 + i;
+            *reinterpret_cast<f32x4*>(&slab[(g4 * 32 + pl) * kRS]) = acc[0][i];     // dt_r of direction g4
 #pragma unroll
-                for (int kd = 0; kd < 4; ++kd) {
-                    float* rk = p.rec + (((long long)b * 4 + kd) * L + pos) * kRS + kRecPad + 4 * g4;
-                    *reinterpret_cast<f32x4*>(rk) = acc[1 + 2 * kd][i];
-                    *reinterpret_cast<f32x4*>(rk + 16) = acc[2 + 2 * kd][i];
-                }
+            for (int kd = 0; kd < 4; ++kd) {
+                float* rk = &slab[(kd * 32 + pl) * kRS + kRecPad + 4 * g4];
+                *reinterpret_cast<f32x4*>(rk) = acc[1 + 2 * kd][i];
+                *reinterpret_cast<f32x4*>(rk + 16) = acc[2 + 2 * kd][i];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int npos = (int)min((long long)32, L - p0);
+#pragma unroll
+        for (int kd = 0; kd < 4; ++kd) {
+            float* dst = p.rec + (((long long)b * 4 + kd) * L + p0) * kRS;
+#pragma unroll
+            for (int it = 0; it < (32 * kRS / 4 + 63) / 64; ++it) {
+                const int f = lane + 64 * it;
+                if (4 * f < npos * kRS)
+                    *reinterpret_cast<f32x4*>(dst + 4 * f) = *reinterpret_cast<const f32x4*>(&slab[kd * 32 * kRS + 4 * f]);
             }
         }
     }
@@ -231,7 +266,8 @@ __global__ __launch_bounds__(64) void ss2d_row_kernel(Ss2dArgs p) {
             const int f = lane + 64 * j;                       // float4 index inside the record tile
             const int col = (4 * f) / kRS;
             rr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < T * kRS / 4 && col >= c_lo && col < c_hi)
+            const bool used = PHASE == 3 || (4 * f - col * kRS) < kRecPad + NP;    // reduce phase: no C
+            if (f < T * kRS / 4 && col >= c_lo && col < c_hi && used)
                 rr[j] = *reinterpret_cast<const float4*>(recb + plo * kRS + 4 * f);
         }
     };
@@ -370,11 +406,19 @@ __global__ __launch_bounds__(64 * kColWaves, WM_COL_LB) void ss2d_col_kernel(Ss2
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int k = p.k;
-    const int w0 = blockIdx.x * 64;
-    const int seg = blockIdx.y;
+    // XCD-aware block order.  The `cgroups` workgroups that scan different channels of the SAME
+    // (column tile, segment, batch) read the same record rows; workgroup q is dispatched to XCD q % 8,
+    // so give those workgroups consecutive slots of one XCD: its private L2 then serves the re-reads.
     const int cgroups = (p.D + kColCH * kColWaves - 1) / (kColCH * kColWaves);
-    const int b = blockIdx.z / cgroups;
-    const int d0 = (blockIdx.z % cgroups) * (kColCH * kColWaves) + wv * kColCH;   // wave-uniform
+    const int coltiles = (p.W + 63) / 64;
+    const int ntiles = coltiles * p.nseg * p.B;
+    const int q = blockIdx.x, xcd = q & 7, m = q >> 3;
+    const int tile = (m / cgroups) * 8 + xcd;
+    if (tile >= ntiles) return;
+    const int w0 = (tile % coltiles) * 64;
+    const int seg = (tile / coltiles) % p.nseg;
+    const int b = tile / (coltiles * p.nseg);
+    const int d0 = (m % cgroups) * (kColCH * kColWaves) + wv * kColCH;            // wave-uniform
     const int w = w0 + lane;
     const bool colok = w < p.W;
     const int H = p.H, W = p.W;
@@ -441,7 +485,9 @@ __global__ __launch_bounds__(64 * kColWaves, WM_COL_LB) void ss2d_col_kernel(Ss2
             const int fr = f - i * (64 * kRS / 4);
             const int col = (4 * fr) / kRS;
             rr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < kColT && tau0 + i < tau_end && w0 + col < W)
+            // the reduce phase never reads C: skip the last 64 B of every 144-B record
+            const bool used = PHASE == 3 || (4 * fr - col * kRS) < kRecPad + NP;
+            if (i < kColT && tau0 + i < tau_end && w0 + col < W && used)
                 rr[j] = *reinterpret_cast<const float4*>(recb + ((long long)row_of(tau0 + i) * W + w0) * kRS + 4 * fr);
         }
 #pragma unroll

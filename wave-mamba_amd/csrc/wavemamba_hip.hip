@@ -232,7 +232,8 @@ template <bool REV>
 static void ss2d_launch_col(Ss2dArgs a, const Ss2dPlan& pl, float* seg, hipStream_t st) {
     a.chunk_len = pl.col_seg; a.nseg = pl.col_nseg; a.nchunks = (int)pl.col_nchunks;
     const int cgroups = (a.D + kColCH * kColWaves - 1) / (kColCH * kColWaves);
-    const dim3 grid((unsigned)((a.W + 63) / 64), (unsigned)pl.col_nseg, (unsigned)(a.B * cgroups)), block(64 * kColWaves);
+    const long long ntiles = (long long)((a.W + 63) / 64) * pl.col_nseg * a.B;
+    const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8 * cgroups)), block(64 * kColWaves);    // XCD-aware order, see kernel
     if (pl.col_nchunks > 1) {
         { ProfScope ps(11, st); hipLaunchKernelGGL((ss2d_col_kernel<1, REV>), grid, block, 0, st, a); }
         launch_carry(a.wsP, a.wsH, seg, (long long)a.B * a.D * 16, (int)pl.col_nchunks, st);
@@ -501,9 +502,9 @@ int wm_ss2d_core_fwd(const float* x, const float* x_proj_weight, const float* dt
         ProfScope ps(6, st);
         const int groups = (a.L + 31) / 32;
         long long waves = (long long)B * groups;
-        int blocks = (int)((waves + 3) / 4);
-        if (blocks > 256 * 2) blocks = 256 * 2;                     // persistent: weights stay in VGPRs
-        hipLaunchKernelGGL(ss2d_proj_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, groups);
+        int blocks = (int)((waves + 1) / 2);
+        if (blocks > 256 * 4) blocks = 256 * 4;                     // persistent: weights stay in VGPRs
+        hipLaunchKernelGGL(ss2d_proj_kernel, dim3((unsigned)blocks), dim3(128), 0, st, a, groups);
     }
     const bool vec = (a.L % 4 == 0) && aligned16(x) && aligned16(y_row_fwd) && (merged || aligned16(y_row_rev));
     a.k = 0; a.y = y_row_fwd; a.accumulate = 0;
