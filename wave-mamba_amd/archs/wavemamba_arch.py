@@ -450,6 +450,24 @@ class SKFF(nn.Module):
 # ================================================================================================
 # Wavelet U-Net
 # ================================================================================================
+def _run_lfss_stack(blocks, x):
+    """(B, C, H, W) -> (B, C, H, W) through a stack of LFSSBlocks.  On the fused HIP path the first block
+    reads NCHW and the last writes NCHW, so the `b c h w <-> b (h w) c` rearranges of the reference
+    (:976-979, :998-1001) never materialise; otherwise the reference's token round trip."""
+    h, w = x.shape[2:]
+    blocks = list(blocks)
+    if blocks and all(blk._fused_ok(x) for blk in blocks):
+        ops = _OpsBackend.impl
+        t = x
+        for i, blk in enumerate(blocks):
+            t = ops.lfss_block_forward(t, (h, w), blk, tok_nchw=(i == 0), out_nchw=(i == len(blocks) - 1))
+        return t
+    t = _tokens(x)
+    for blk in blocks:
+        t = blk(t, [h, w])
+    return _maps(t, h, w)
+
+
 def _tokens(x):        # (B, C, H, W) -> (B, HW, C)
     return x.flatten(2).transpose(1, 2).contiguous()
 
@@ -472,11 +490,7 @@ class DownFRG(nn.Module):
 
     def forward(self, x, x_d):
         ll, hl, lh, hh = self.dwt(x)
-        h, w = ll.shape[2:]
-        low = _tokens(self.l_conv(torch.cat([ll, x_d], dim=1)))
-        for blk in self.l_blk:
-            low = blk(low, [h, w])
-        low = _maps(low, h, w)
+        low = _run_lfss_stack(self.l_blk, self.l_conv(torch.cat([ll, x_d], dim=1)))
         high = self.h_fusion([hl, lh, hh])
         for blk in self.h_blk:
             high = blk(high, low)
@@ -495,11 +509,7 @@ class upFRG(nn.Module):
                                      for _ in range(n_h_blocks)])
 
     def forward(self, x_l, x_h):
-        h, w = x_l.shape[2:]
-        low = _tokens(x_l)
-        for blk in self.l_blk:
-            low = blk(low, [h, w])
-        low = _maps(low, h, w)
+        low = _run_lfss_stack(self.l_blk, x_l)
         for blk in self.h_blk:
             x_h = blk(x_h, low)
         # reference: iwt(cat([x_l, h_out_conv(x_h)], 1)); the pair form skips the concatenation
