@@ -101,8 +101,8 @@ class _IWT(torch.autograd.Function):
             code = _dtype_code(x_l, "iwt_init")
         else:
             x_h = x_h.contiguous()
-            if x_h.dtype != x_l.dtype:
-                raise RuntimeError("iwt_init: x_l and x_h dtypes differ")
+            if x_h.dtype != x_l.dtype:           # mixed precision (autocast): the output is fp32 anyway
+                x_l, x_h = x_l.float(), x_h.float()
             B, C, h, w = x_l.shape
             if x_h.shape != (B, 3 * C, h, w):
                 raise RuntimeError(f"iwt_init: x_h shape {tuple(x_h.shape)} != {(B, 3 * C, h, w)}")
