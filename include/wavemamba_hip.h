@@ -159,6 +159,23 @@ int wm_lfss_out_fwd(const float* fc, const float* tok1, const float* conv3_weigh
                     const float* skip_scale2, float* out, int out_nchw, int B, int64_t L, int C, void* stream);
 
 /* --------------------------------------------------------------------------------------------
+ * LayerNorm2d of the HFE branch (first "next" row): per-pixel LayerNorm over the C
+ * channels of an NCHW map, eps inside the square root, biased variance (wavemamba_arch.py:532-569).
+ * x, y (B, C, L) fp32; C in {8, 16, 32}.  Forward only.
+ * -------------------------------------------------------------------------------------------- */
+int wm_layernorm2d_fwd(const float* x, const float* weight, const float* bias, float eps, float* y,
+                       int B, int64_t L, int C, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Channel Gram matrix over the pixel axis (HFE branch): G[b][i][j] = sum_l X[b][i][l] Y[b][j][l],
+ * nx[b][i] = sum_l X^2, ny likewise.  X, Y (B, C, L) fp32, C <= 32; G (B, C, C), nx, ny (B, C) are
+ * overwritten.  Replaces torch.cdist(x, perception) (wavemamba_arch.py:664) and
+ * normalize(q) @ normalize(k)^T (:787-790), both contractions over H*W.
+ * -------------------------------------------------------------------------------------------- */
+int wm_gram_fwd(const float* X, const float* Y, float* G, float* nx, float* ny, int B, int C, int64_t L,
+                void* stream);
+
+/* --------------------------------------------------------------------------------------------
  * Profiling hooks used by bench.py (HIP events recorded on the launch stream around each kernel
  * class).  Disabled by default; when disabled the library records nothing.
  *   kernel ids: 0 dwt/analysis, 1 iwt/synthesis, 2 scan chunk-reduce, 3 scan carry,

@@ -379,6 +379,51 @@ def test_lfss_block_fused_vs_module_path(C, H, W):
 
 
 # ------------------------------------------------------------------------------------------------
+# HFE-branch helpers ("next" row): floating-point kernels of standard ops -> torch fp32
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,H,W", [(32, 33, 47), (16, 8, 8), (8, 5, 130)])
+def test_layernorm2d_vs_torch(C, H, W):
+    ln = arch.LayerNorm2d(C)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(C, generator=gen(1)))
+        ln.bias.copy_(torch.randn(C, generator=gen(2)))
+    x = torch.randn(2, C, H, W, generator=gen(3)) * 3 + 1
+    mu = x.mean(1, keepdim=True)
+    var = (x - mu).pow(2).mean(1, keepdim=True)
+    want = ln.weight.view(1, -1, 1, 1) * ((x - mu) / (var + ln.eps).sqrt()) + ln.bias.view(1, -1, 1, 1)
+    with torch.no_grad():
+        got = ln.to(DEV)(x.to(DEV))
+    assert_close(got, want.detach(), 1e-5, "LayerNorm2d")
+
+
+@pytest.mark.parametrize("B,C,L", [(1, 32, 70000), (2, 32, 4099), (1, 16, 257), (3, 8, 64), (1, 32, 5)])
+def test_gram_vs_torch(B, C, L):
+    x = torch.randn(B, C, L, generator=gen(L)) + 0.3
+    y = torch.randn(B, C, L, generator=gen(L + 1)) - 0.2
+    G, nx, ny = wm.ops.gram(x.to(DEV), y.to(DEV))
+    assert_close(G, (x.double() @ y.double().transpose(1, 2)).float(), 2e-5, "gram")
+    assert_close(nx, x.double().pow(2).sum(-1).float(), 2e-5, "|x|^2")
+    assert_close(ny, y.double().pow(2).sum(-1).float(), 2e-5, "|y|^2")
+
+
+def test_hfe_block_hip_helpers_vs_module_path():
+    """HFEBlock with the HIP helpers (Gram-based matching + attention, LayerNorm2d, depth-wise conv) vs the
+    same block evaluated with the plain PyTorch ops on the GPU."""
+    torch.manual_seed(3)
+    blk = arch.HFEBlock(32, match_factor=1, ffn_expansion_factor=1).eval().to(DEV)
+    x = torch.randn(1, 32, 40, 56, device=DEV)
+    per = torch.randn(1, 32, 40, 56, device=DEV)
+    with torch.no_grad():
+        fast = blk(x, per)
+        prev = arch.set_ops_backend(type("Plain", (), {})())        # a backend without any helper
+        try:
+            ref = blk(x, per)
+        finally:
+            arch.set_ops_backend(prev)
+    assert_close(fast, ref, TOL, "HFEBlock")
+
+
+# ------------------------------------------------------------------------------------------------
 # network level
 # ------------------------------------------------------------------------------------------------
 def test_tiny_model_golden(golden):

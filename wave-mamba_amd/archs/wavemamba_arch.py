@@ -285,17 +285,34 @@ class LayerNorm2d(nn.Module):
         self.eps = eps
 
     def forward(self, x):
+        ops = _OpsBackend.impl
+        if (hasattr(ops, "layernorm2d") and x.is_cuda and x.dtype == torch.float32 and x.shape[1] in (8, 16, 32)
+                and not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad))):
+            return ops.layernorm2d(x, self.weight, self.bias, self.eps)
         mu = x.mean(1, keepdim=True)
         var = (x - mu).pow(2).mean(1, keepdim=True)
         y = (x - mu) / (var + self.eps).sqrt()
         return self.weight.view(1, -1, 1, 1) * y + self.bias.view(1, -1, 1, 1)
 
 
+def _gram_ok(a, b):
+    ops = _OpsBackend.impl
+    return (hasattr(ops, "gram") and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32
+            and a.shape == b.shape and a.shape[1] <= 32
+            and not (torch.is_grad_enabled() and (a.requires_grad or b.requires_grad)))
+
+
 def nearest_candidate_maps(maps, candidates, num_matches):
     """Channel matching (reference :618-666): for every channel of `maps` (B, C, HW) find its
     L2-nearest channel of `candidates`; keep the `num_matches` channels whose nearest distance is
     smallest (original channel order) and return the matched candidate maps (B, num_matches, HW)."""
-    dist = torch.cdist(maps, candidates)                            # (B, C, C)
+    ops = _OpsBackend.impl
+    if _gram_ok(maps, candidates):
+        # d^2 = |x|^2 + |y|^2 - 2 x.y, the same expansion torch.cdist uses for C > 25 (mm mode)
+        G, nx, ny = ops.gram(maps, candidates)
+        dist = (nx.unsqueeze(2) + ny.unsqueeze(1) - 2.0 * G).clamp_min(1e-30).sqrt()
+    else:
+        dist = torch.cdist(maps, candidates)                        # (B, C, C)
     best_val, best_idx = dist.topk(k=1, largest=False)
     best_val, best_idx = best_val.squeeze(-1), best_idx.squeeze(-1)
     if num_matches is None or num_matches == -1:
@@ -394,10 +411,19 @@ class CMTAttention(nn.Module):
         if self.matching is True:
             q = self.matching_transformation(q, perception)
         heads = self.num_heads
-        q = F.normalize(q.reshape(b, heads, c // heads, h * w), dim=-1)
-        k = F.normalize(k.reshape(b, heads, c // heads, h * w), dim=-1)
+        q = q.reshape(b * heads, c // heads, h * w)
+        k = k.reshape(b * heads, c // heads, h * w)
         v = v.reshape(b, heads, c // heads, h * w)
-        attn = ((q @ k.transpose(-2, -1)) * self.temperature).softmax(dim=-1)
+        if _gram_ok(q, k):
+            # normalize(q) @ normalize(k)^T == (q @ k^T) / (max(|q|, eps) max(|k|, eps)): one pass over q, k
+            G, nq, nk = _OpsBackend.impl.gram(q.contiguous(), k.contiguous())
+            scale = nq.sqrt().clamp_min(1e-12).unsqueeze(2) * nk.sqrt().clamp_min(1e-12).unsqueeze(1)
+            attn = (G / scale).reshape(b, heads, c // heads, c // heads)
+        else:
+            qn = F.normalize(q.reshape(b, heads, c // heads, h * w), dim=-1)
+            kn = F.normalize(k.reshape(b, heads, c // heads, h * w), dim=-1)
+            attn = qn @ kn.transpose(-2, -1)
+        attn = (attn * self.temperature).softmax(dim=-1)
         return self.project_out((attn @ v).reshape(b, c, h, w))
 
 

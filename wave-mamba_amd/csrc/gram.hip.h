@@ -1,0 +1,97 @@
+// gram.hip.h - channel Gram matrices over the pixel axis for the HFE branch ("next" row).
+//
+//   G[b][i][j] = sum_l X[b][i][l] * Y[b][j][l]      nx[b][i] = sum_l X[b][i][l]^2      ny likewise
+//
+// serves both channel matching (torch.cdist(x, perception) over H*W-long rows, reference
+// wavemamba_arch.py:659-666: d^2 = |x|^2 + |y|^2 - 2 x.y) and the transposed attention
+// (normalize(q) @ normalize(k)^T, :787-790: G / (|q||k|)).  K = H*W is ~2 M at UHD with M = N = 32:
+// a library GEMM runs one tiny tile with a huge K; here every wave owns a slice of l, feeds
+// fp32 MFMA 16x16x4 straight from 16-byte row loads (both operands use the SAME lane->(row, l)
+// mapping, so no layout shuffling), and the 32x32 partials meet through atomics.  HBM-bound:
+// 2*C*L*4 bytes read once.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace wm {
+
+typedef float gram_f4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void gram32_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                     float* __restrict__ G, float* __restrict__ nx,
+                                                     float* __restrict__ ny, int C, long long L, long long slice) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const long long l_begin = wave * slice, l_end = min(L, l_begin + slice);
+    const float* xb = X + (long long)b * C * L;
+    const float* yb = Y + (long long)b * C * L;
+    const bool vec = (L & 3) == 0;
+
+    gram_f4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[a][c] = (gram_f4){0.f, 0.f, 0.f, 0.f};
+    float sx[2] = {0.f, 0.f}, sy[2] = {0.f, 0.f};
+
+    auto load4 = [&](const float* base, int row, long long l) -> float4 {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < C) {
+            const float* q = base + (long long)row * L + l;
+            if (vec) { if (l < l_end) v = *reinterpret_cast<const float4*>(q); }
+            else {
+                if (l + 0 < l_end) v.x = q[0];
+                if (l + 1 < l_end) v.y = q[1];
+                if (l + 2 < l_end) v.z = q[2];
+                if (l + 3 < l_end) v.w = q[3];
+            }
+        }
+        return v;
+    };
+
+    for (long long l0 = l_begin; l0 < l_end; l0 += 16) {
+        const long long l = l0 + 4 * kq;
+        float4 xa[2], ya[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { xa[h] = load4(xb, i16 + 16 * h, l); ya[h] = load4(yb, i16 + 16 * h, l); }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            sx[h] = fmaf(xa[h].x, xa[h].x, fmaf(xa[h].y, xa[h].y, fmaf(xa[h].z, xa[h].z, fmaf(xa[h].w, xa[h].w, sx[h]))));
+            sy[h] = fmaf(ya[h].x, ya[h].x, fmaf(ya[h].y, ya[h].y, fmaf(ya[h].z, ya[h].z, fmaf(ya[h].w, ya[h].w, sy[h]))));
+        }
+        const float xc[2][4] = {{xa[0].x, xa[0].y, xa[0].z, xa[0].w}, {xa[1].x, xa[1].y, xa[1].z, xa[1].w}};
+        const float yc[2][4] = {{ya[0].x, ya[0].y, ya[0].z, ya[0].w}, {ya[1].x, ya[1].y, ya[1].z, ya[1].w}};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+                    acc[a][bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[a][c], yc[bb][c], acc[a][bb], 0, 0, 0);
+    }
+    // D layout: lane holds rows 4*kq .. 4*kq+3 (i) of column i16 (j)
+    float* Gb = G + (long long)b * C * C;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            const int j = 16 * bb + i16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * a + 4 * kq + r;
+                if (i < C && j < C) atomicAdd(Gb + i * C + j, acc[a][bb][r]);
+            }
+        }
+    // row norms: lanes i16, i16+16, i16+32, i16+48 hold the four l-quarters of row i16
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float vx = sx[h], vy = sy[h];
+        vx += __shfl_xor(vx, 16); vx += __shfl_xor(vx, 32);
+        vy += __shfl_xor(vy, 16); vy += __shfl_xor(vy, 32);
+        const int row = i16 + 16 * h;
+        if (kq == 0 && row < C) { atomicAdd(nx + (long long)b * C + row, vx); atomicAdd(ny + (long long)b * C + row, vy); }
+    }
+}
+
+}  // namespace wm

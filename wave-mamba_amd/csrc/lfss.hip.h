@@ -161,4 +161,28 @@ __global__ __launch_bounds__(256) void lfss_out_kernel(const float* __restrict__
     store_token<C>(out, out_nchw != 0, b, p, L, t);
 }
 
+// ---- LayerNorm2d: per-pixel LayerNorm over the C channels of an NCHW map (reference :532-569) -----------
+// y = w * (x - mean_c) / sqrt(var_c + eps) + b, biased variance - one thread per pixel, planes coalesced.
+template <int C>
+__global__ __launch_bounds__(256) void layernorm2d_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float eps,
+                                                          float* __restrict__ y, int B, long long L) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * L) return;
+    const long long bb = idx / L, p = idx - bb * L;
+    float v[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] = x[(bb * C + c) * L + p];
+    float mean = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) mean += v[c];
+    mean *= (1.0f / C);
+    float var = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { const float d = v[c] - mean; var = fmaf(d, d, var); }
+    const float rstd = 1.0f / sqrtf(var * (1.0f / C) + eps);
+#pragma unroll
+    for (int c = 0; c < C; ++c) y[(bb * C + c) * L + p] = fmaf(w[c], (v[c] - mean) * rstd, b[c]);
+}
+
 }  // namespace wm

@@ -13,6 +13,7 @@
 #include "dwconv.hip.h"
 #include "ss2d.hip.h"
 #include "lfss.hip.h"
+#include "gram.hip.h"
 
 namespace wm {
 
@@ -560,6 +561,36 @@ int wm_lfss_out_fwd(const float* fc, const float* tok1, const float* conv3_weigh
     if (B && L && (!fc || !tok1 || !conv3_weight || !conv3_bias || !skip_scale2 || !out)) return WM_ENULL;
     if (!aligned16(tok1) || (!out_nchw && !aligned16(out))) return WM_EALIGN;
     WM_LFSS_DISPATCH(lfss_out_kernel, fc, tok1, conv3_weight, conv3_bias, skip_scale2, out, out_nchw, B, (long long)L);
+}
+
+int wm_layernorm2d_fwd(const float* x, const float* weight, const float* bias, float eps, float* y, int B,
+                       int64_t L, int C, void* stream) {
+    if (B < 0 || L < 0) return WM_EINVAL;
+    if (B && L && (!x || !weight || !bias || !y)) return WM_ENULL;
+    WM_LFSS_DISPATCH(layernorm2d_kernel, x, weight, bias, eps, y, B, (long long)L);
+}
+
+int wm_gram_fwd(const float* X, const float* Y, float* G, float* nx, float* ny, int B, int C, int64_t L,
+                void* stream) {
+    if (B < 0 || C < 0 || L < 0) return WM_EINVAL;
+    if (C > 32) return WM_EUNSUPPORTED;
+    if (B == 0 || C == 0) return WM_OK;
+    if (!X || !Y || !G || !nx || !ny) return WM_ENULL;
+    if (!aligned16(X) || !aligned16(Y)) return WM_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(G, 0, (size_t)B * C * C * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(nx, 0, (size_t)B * C * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(ny, 0, (size_t)B * C * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    if (L == 0) return WM_OK;
+    long long waves = (L + 2047) / 2048;                       // >= 2048 positions per wave
+    if (waves > 4096) waves = 4096;
+    waves = ((waves + 3) / 4) * 4;
+    long long slice = (L + waves - 1) / waves;
+    slice = ((slice + 15) / 16) * 16;
+    const dim3 grid((unsigned)(waves / 4), (unsigned)B), block(256);
+    hipLaunchKernelGGL(gram32_kernel, grid, block, 0, st, X, Y, G, nx, ny, C, (long long)L, slice);
+    return launch_status();
 }
 
 void wm_prof_enable(int on) {

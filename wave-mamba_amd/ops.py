@@ -356,6 +356,43 @@ def lfss_block_forward(tok, x_size, blk, tok_nchw=False, out_nchw=False):
 
 
 # ------------------------------------------------------------------------------------------------
+# LayerNorm2d (HFE branch, forward only)
+# ------------------------------------------------------------------------------------------------
+def layernorm2d(x, weight, bias, eps):
+    """Per-pixel LayerNorm over channels of an NCHW fp32 map (reference LayerNorm2d, :532-569)."""
+    lib = _lib.load()
+    _require_cuda("layernorm2d", x, weight, bias)
+    B, C, H, W = x.shape
+    if C not in (8, 16, 32) or x.dtype != torch.float32:
+        raise NotImplementedError("layernorm2d: fp32, C in {8, 16, 32}")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(lib.wm_layernorm2d_fwd(_ptr(x), _ptr(_w(weight)), _ptr(_w(bias)), float(eps), _ptr(y), B, H * W, C,
+                                     _stream()), "wm_layernorm2d_fwd")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# channel Gram matrix over pixels (HFE branch, forward only)
+# ------------------------------------------------------------------------------------------------
+def gram(x, y):
+    """x, y (B, C, L) fp32, C <= 32 -> (G (B, C, C) = x @ y^T over L, |x_i|^2 (B, C), |y_j|^2 (B, C))."""
+    lib = _lib.load()
+    _require_cuda("gram", x, y)
+    B, C, L = x.shape
+    if y.shape != x.shape or C > 32 or x.dtype != torch.float32 or y.dtype != torch.float32:
+        raise NotImplementedError("gram: two fp32 (B, C<=32, L) tensors of equal shape")
+    x, y = x.contiguous(), y.contiguous()
+    G = torch.empty((B, C, C), dtype=torch.float32, device=x.device)
+    nx = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    ny = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.wm_gram_fwd(_ptr(x), _ptr(y), _ptr(G), _ptr(nx), _ptr(ny), B, C, L, _stream()), "wm_gram_fwd")
+    return G, nx, ny
+
+
+# ------------------------------------------------------------------------------------------------
 # depth-wise 3x3 convolution (+ bias, + SiLU) - inference path of SS2D.conv2d / ffn.conv2
 # ------------------------------------------------------------------------------------------------
 def dwconv3x3(x, weight, bias=None, act="none"):
