@@ -16,11 +16,14 @@ namespace wm {
 
 typedef float gram_f4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void gram32_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+constexpr int kGramWaves = 8;          // waves per block: their 32x32 partials meet in LDS before the atomics
+__global__ __launch_bounds__(64 * kGramWaves) void gram32_kernel(const float* __restrict__ X, const float* __restrict__ Y,
                                                      float* __restrict__ G, float* __restrict__ nx,
                                                      float* __restrict__ ny, int C, long long L, long long slice) {
     const int lane = threadIdx.x & 63;
-    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ float s_part[kGramWaves][32 * 32 + 64];
+    const int wv = threadIdx.x >> 6;
+    const long long wave = (long long)blockIdx.x * kGramWaves + wv;
     const int b = blockIdx.y;
     const int i16 = lane & 15, kq = lane >> 4;
     const long long l_begin = wave * slice, l_end = min(L, l_begin + slice);
@@ -70,27 +73,35 @@ __global__ __launch_bounds__(256) void gram32_kernel(const float* __restrict__ X
                 for (int bb = 0; bb < 2; ++bb)
                     acc[a][bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[a][c], yc[bb][c], acc[a][bb], 0, 0, 0);
     }
-    // D layout: lane holds rows 4*kq .. 4*kq+3 (i) of column i16 (j)
-    float* Gb = G + (long long)b * C * C;
+    // D layout: lane holds rows 4*kq .. 4*kq+3 (i) of column i16 (j).  Block-level sum in LDS first:
+    // one atomic per output element per BLOCK instead of per wave.
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-            const int j = 16 * bb + i16;
+        for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * a + 4 * kq + r;
-                if (i < C && j < C) atomicAdd(Gb + i * C + j, acc[a][bb][r]);
-            }
-        }
-    // row norms: lanes i16, i16+16, i16+32, i16+48 hold the four l-quarters of row i16
+            for (int r = 0; r < 4; ++r)
+                s_part[wv][(16 * a + 4 * kq + r) * 32 + 16 * bb + i16] = acc[a][bb][r];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         float vx = sx[h], vy = sy[h];
         vx += __shfl_xor(vx, 16); vx += __shfl_xor(vx, 32);
         vy += __shfl_xor(vy, 16); vy += __shfl_xor(vy, 32);
-        const int row = i16 + 16 * h;
-        if (kq == 0 && row < C) { atomicAdd(nx + (long long)b * C + row, vx); atomicAdd(ny + (long long)b * C + row, vy); }
+        if (kq == 0) { s_part[wv][1024 + i16 + 16 * h] = vx; s_part[wv][1056 + i16 + 16 * h] = vy; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * 32 + 64; e += 64 * kGramWaves) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w8 = 0; w8 < kGramWaves; ++w8) t += s_part[w8][e];
+        if (e < 1024) {
+            const int i = e >> 5, j = e & 31;
+            if (i < C && j < C) atomicAdd(G + ((long long)b * C + i) * C + j, t);
+        } else if (e < 1056) {
+            if (e - 1024 < C) atomicAdd(nx + (long long)b * C + (e - 1024), t);
+        } else {
+            if (e - 1056 < C) atomicAdd(ny + (long long)b * C + (e - 1056), t);
+        }
     }
 }
 

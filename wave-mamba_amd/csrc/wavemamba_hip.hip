@@ -583,12 +583,12 @@ int wm_gram_fwd(const float* X, const float* Y, float* G, float* nx, float* ny, 
     if (e == hipSuccess) e = hipMemsetAsync(ny, 0, (size_t)B * C * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
     if (L == 0) return WM_OK;
-    long long waves = (L + 2047) / 2048;                       // >= 2048 positions per wave
+    long long waves = (L + 511) / 512;                         // >= 512 positions per wave
     if (waves > 4096) waves = 4096;
-    waves = ((waves + 3) / 4) * 4;
+    waves = ((waves + kGramWaves - 1) / kGramWaves) * kGramWaves;
     long long slice = (L + waves - 1) / waves;
     slice = ((slice + 15) / 16) * 16;
-    const dim3 grid((unsigned)(waves / 4), (unsigned)B), block(256);
+    const dim3 grid((unsigned)(waves / kGramWaves), (unsigned)B), block(64 * kGramWaves);
     hipLaunchKernelGGL(gram32_kernel, grid, block, 0, st, X, Y, G, nx, ny, C, (long long)L, slice);
     return launch_status();
 }
