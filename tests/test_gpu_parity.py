@@ -378,6 +378,26 @@ def test_lfss_block_fused_vs_module_path(C, H, W):
     assert_close(fused, ref, TOL, f"LFSSBlock C={C}")
 
 
+def test_lfss_block_d_state_32_uses_op_boundary_scan():
+    """BASELINE config 5 flavour: LFSSBlock(32, d_state=32) is outside the fused core's range (N <= 16), so the
+    block runs the direction glue + the drop-in selective_scan_fn (N = 32 kernels).  Checked against the same
+    block on the CPU oracle backend."""
+    torch.manual_seed(5)
+    blk = arch.LFSSBlock(32, d_state=32, expand=2.0).eval()
+    x = torch.randn(1, 48 * 40, 32, generator=gen(9))
+    prev = arch.set_ops_backend(oracle)
+    try:
+        with torch.no_grad():
+            want = blk(x, [48, 40])
+    finally:
+        arch.set_ops_backend(prev)
+    blk = blk.to(DEV)
+    with torch.no_grad():
+        assert not blk._fused_ok(x.to(DEV))
+        got = blk(x.to(DEV), [48, 40])
+    assert_close(got, want, TOL, "LFSSBlock d_state=32")
+
+
 # ------------------------------------------------------------------------------------------------
 # HFE-branch helpers ("next" row, SURVEY 8f rank 1): floating-point kernels of standard ops -> torch fp32
 # ------------------------------------------------------------------------------------------------
