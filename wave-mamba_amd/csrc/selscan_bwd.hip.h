@@ -410,7 +410,8 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
         }
     }
     if (ix.live) {
-        float* pr = p.part + ((long long)chunk * p.batch * p.dim + (long long)ix.b * p.dim + ix.d) * (NP + kPartPad);
+        // layout [b*dim + d][chunk][NP + pad]: the finish kernel streams one channel's partials contiguously
+        float* pr = p.part + (((long long)ix.b * p.dim + ix.d) * p.nchunks + chunk) * (NP + kPartPad);
 #pragma unroll
         for (int q = 0; q < NP / 4; ++q)
             *reinterpret_cast<float4*>(pr + 4 * q) = make_float4(dA[2 * q].x, dA[2 * q].y, dA[2 * q + 1].x, dA[2 * q + 1].y);
@@ -419,32 +420,33 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
 }
 
 // dA (dim, N), dD (dim), dbias (dim) = sums of the per-chunk partials over chunks and batch.
-// One block per channel: NP + kPartPad columns x 8 row-groups, LDS tree over the row-groups.
+// One block per channel streams its [batch][chunk][NPP] partials (contiguous per batch item); a thread
+// keeps a fixed column j = f mod NPP by striding in multiples of NPP, then an LDS tree over the threads.
 __global__ __launch_bounds__(256) void selscan_bwd_finish_kernel(const float* __restrict__ part, float* __restrict__ dA,
                                                                  float* __restrict__ dD, float* __restrict__ dbias,
                                                                  int batch, int dim, int N, int NPP, int nchunks) {
-    __shared__ float s[8][40];
-    const int d = blockIdx.x, col = threadIdx.x % 32, grp = threadIdx.x / 32;       // NPP <= 36 handled in 2 sweeps
-    for (int c0 = 0; c0 < NPP; c0 += 32) {
-        const int j = c0 + col;
-        float acc = 0.0f;
-        if (j < NPP)
-            for (long long i = grp; i < (long long)nchunks * batch; i += 8) {
-                const long long c = i / batch, b = i - c * batch;
-                acc += part[((c * batch + b) * dim + d) * NPP + j];
-            }
-        s[grp][col] = acc;
-        __syncthreads();
-        if (grp == 0 && j < NPP) {
-            float t = 0.0f;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) t += s[g][col];
-            const int NP = NPP - kPartPad;
-            if (j < N) dA[(long long)d * N + j] = t;
-            else if (j == NP && dD) dD[d] = t;
-            else if (j == NP + 1 && dbias) dbias[d] = t;
+    __shared__ float s[256];
+    const int d = blockIdx.x;
+    const int stride = (256 / NPP) * NPP;                   // active threads: a multiple of the record length
+    const int t = threadIdx.x;
+    float acc = 0.0f;
+    if (t < stride) {
+        const long long per = (long long)nchunks * NPP;
+        // gridDim.y blocks share a channel: block y takes every gridDim.y-th stride-sized span
+        for (int b = 0; b < batch; ++b) {
+            const float* base = part + ((long long)b * dim + d) * per;
+            for (long long f = (long long)blockIdx.y * stride + t; f < per; f += (long long)gridDim.y * stride) acc += base[f];
         }
-        __syncthreads();
+    }
+    s[t] = acc;
+    __syncthreads();
+    if (t < NPP) {
+        float tot = 0.0f;
+        for (int q = t; q < stride; q += NPP) tot += s[q];
+        const int NP = NPP - kPartPad;
+        if (t < N) atomicAdd(dA + (long long)d * N + t, tot);          // outputs are zeroed by the launcher
+        else if (t == NP && dD) atomicAdd(dD + d, tot);
+        else if (t == NP + 1 && dbias) atomicAdd(dbias + d, tot);
     }
 }
 

@@ -402,8 +402,12 @@ static int bwd_launch(const ScanBwdArgs& a, const BwdPlan& pl, float* seg, float
         launch_carry(a.wsPr, a.wsG, seg, pl.chains, pl.nchunks, st);
     }
     hipLaunchKernelGGL((selscan_bwd_chunk_kernel<NP, VEC>), grid, block, 0, st, a);
-    hipLaunchKernelGGL(selscan_bwd_finish_kernel, dim3((unsigned)a.dim), dim3(256), 0, st, (const float*)a.part, dA, dD,
-                       dbias, a.batch, a.dim, a.N, NP + kPartPad, pl.nchunks);
+    hipMemsetAsync(dA, 0, (size_t)a.dim * a.N * sizeof(float), st);
+    if (dD) hipMemsetAsync(dD, 0, (size_t)a.dim * sizeof(float), st);
+    if (dbias) hipMemsetAsync(dbias, 0, (size_t)a.dim * sizeof(float), st);
+    const int ysplit = pl.nchunks >= 2048 ? 16 : (pl.nchunks >= 256 ? 4 : 1);
+    hipLaunchKernelGGL(selscan_bwd_finish_kernel, dim3((unsigned)a.dim, (unsigned)ysplit), dim3(256), 0, st,
+                       (const float*)a.part, dA, dD, dbias, a.batch, a.dim, a.N, NP + kPartPad, pl.nchunks);
     return launch_status();
 }
 
