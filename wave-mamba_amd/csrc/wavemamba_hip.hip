@@ -197,7 +197,9 @@ static int ss2d_plan(Ss2dPlan& pl, int B, int D, int H, int W, int N, int R) {
     pl.row_nchunks = (int)((L + cl - 1) / cl);
     // column directions: one 16-wave workgroup per (64-column tile, segment, batch, 32-channel group)
     const int coltiles = (W + 63) / 64, cgroups = (D + kColCH * kColWaves - 1) / (kColCH * kColWaves);
-    long long nseg = (WM_COL_WGS + (long long)coltiles * B * cgroups - 1) / ((long long)coltiles * B * cgroups);
+    // workgroups wanted: fewer, longer segments on small maps (per-workgroup prologue dominates there)
+    const long long want_wgs = L >= (1LL << 20) ? WM_COL_WGS : WM_COL_WGS / 2;
+    long long nseg = (want_wgs + (long long)coltiles * B * cgroups - 1) / ((long long)coltiles * B * cgroups);
     if (nseg < 1) nseg = 1;
     long long sl = (H + nseg - 1) / nseg;
     sl = ((sl + kColT - 1) / kColT) * kColT;
