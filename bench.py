@@ -277,7 +277,11 @@ def main():
         roof = {
             "kernel": dom, "bound": "hbm", "achieved": table[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": table[dom]["frac"],
-            "traffic": (pmc or {}).get(dom, {}).get("hbm_bytes_per_launch"),
+            # PMC FETCH_SIZE + WRITE_SIZE measured on the UHD level-1 launch of this kernel, scaled by the ratio
+            # (measured / algorithmic) to the average launch of the timed region (launches differ by pyramid level)
+            "traffic": ((pmc or {}).get(dom, {}).get("traffic_over_algorithmic") or 0) *
+                       1e9 * table[dom]["algorithmic_GB_per_step"] / table[dom]["launches_per_step"] or None,
+            "traffic_over_algorithmic": (pmc or {}).get(dom, {}).get("traffic_over_algorithmic"),
             "launches_per_step": table[dom]["launches_per_step"],
             "avg_launch_ms": table[dom]["ms_per_step"] / table[dom]["launches_per_step"],
             "algorithmic_bytes_per_launch_avg": 1e9 * table[dom]["algorithmic_GB_per_step"] / table[dom]["launches_per_step"],
