@@ -6,7 +6,7 @@ The directory name carries a hyphen (it is the project's name); import it as `wa
     ops.dwt_init / ops.iwt_init / ops.selective_scan_fn   hand-written HIP behind a C ABI
     archs.wavemamba_arch.WaveMamba                        the reference's registry entry, re-built
 """
-from . import _lib, ops, registry, trainer   # noqa: F401
+from . import _lib, ops, registry, trainer, inference   # noqa: F401
 from .registry import ARCH_REGISTRY, build_network   # noqa: F401
 from .archs import wavemamba_arch           # noqa: F401  (registers 'WaveMamba')
 from .archs.wavemamba_arch import WaveMamba  # noqa: F401
