@@ -175,6 +175,10 @@ int wm_layernorm2d_fwd(const float* x, const float* weight, const float* bias, f
 int wm_gram_fwd(const float* X, const float* Y, float* G, float* nx, float* ny, int B, int C, int64_t L,
                 void* stream);
 
+/* Pixel-attention gate of PAConv (HFE branch): out = a * sigmoid(b), n fp32 elements (n % 4 == 0),
+ * wavemamba_arch.py:694-697 (`torch.mul(self.k3(x), self.sigmoid(self.k2(x)))`).  Forward only. */
+int wm_mul_sigmoid_fwd(const float* a, const float* b, float* out, int64_t n, void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * Profiling hooks used by bench.py (HIP events recorded on the launch stream around each kernel
  * class).  Disabled by default; when disabled the library records nothing.

@@ -346,7 +346,12 @@ class PAConv(nn.Module):
         self.k4 = nn.Conv2d(nf, nf // 2, kernel_size=k_size, padding=(k_size - 1) // 2, bias=False)
 
     def forward(self, x):
-        return self.k4(self.k3(x) * self.sigmoid(self.k2(x)))
+        ops = _OpsBackend.impl
+        a, g = self.k3(x), self.k2(x)
+        if (hasattr(ops, "mul_sigmoid") and a.is_cuda and a.dtype == torch.float32 and a.numel() % 4 == 0
+                and not (torch.is_grad_enabled() and a.requires_grad)):
+            return self.k4(ops.mul_sigmoid(a, g))
+        return self.k4(a * self.sigmoid(g))
 
 
 class Matching_transformation(nn.Module):

@@ -599,6 +599,20 @@ int wm_gram_fwd(const float* X, const float* Y, float* G, float* nx, float* ny, 
     return launch_status();
 }
 
+int wm_mul_sigmoid_fwd(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    if (n < 0) return WM_EINVAL;
+    if (n == 0) return WM_OK;
+    if (!a || !b || !out) return WM_ENULL;
+    if (n % 4 != 0) return WM_EUNSUPPORTED;
+    if (!aligned16(a) || !aligned16(b) || !aligned16(out)) return WM_EALIGN;
+    const long long n4 = n / 4;
+    long long blocks = (n4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(mul_sigmoid_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)a,
+                       (const float4*)b, (float4*)out, n4);
+    return launch_status();
+}
+
 void wm_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     g_prof.on = on != 0;
