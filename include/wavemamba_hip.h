@@ -175,6 +175,15 @@ int wm_layernorm2d_fwd(const float* x, const float* weight, const float* bias, f
 int wm_gram_fwd(const float* X, const float* Y, float* G, float* nx, float* ny, int B, int C, int64_t L,
                 void* stream);
 
+/* Training-side gradients of the two streaming helpers above.
+ *   wm_dwconv3x3_wgrad: dW (C,1,3,3) and db (C, may be NULL) of the depth-wise conv from x and gy (B,C,H,W);
+ *     the input gradient is wm_dwconv3x3_fwd(gy, flipped weight, NULL).
+ *   wm_layernorm2d_bwd: reference LayerNormFunction.backward (wavemamba_arch.py:545-557): gx, dweight, dbias. */
+int wm_dwconv3x3_wgrad(const float* x, const float* gy, float* dW, float* db, int B, int C, int H, int W,
+                       void* stream);
+int wm_layernorm2d_bwd(const float* x, const float* weight, const float* gy, float eps, float* gx,
+                       float* dweight, float* dbias, int B, int64_t L, int C, void* stream);
+
 /* Pixel-attention gate of PAConv (HFE branch): out = a * sigmoid(b), n fp32 elements (n % 4 == 0),
  * wavemamba_arch.py:694-697 (`torch.mul(self.k3(x), self.sigmoid(self.k2(x)))`).  Forward only. */
 int wm_mul_sigmoid_fwd(const float* a, const float* b, float* out, int64_t n, void* stream);

@@ -416,6 +416,42 @@ def test_layernorm2d_vs_torch(C, H, W):
     assert_close(got, want.detach(), 1e-5, "LayerNorm2d")
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 40, 72), (1, 5, 7, 9), (2, 96, 33, 260)])
+def test_dwconv3x3_gradients_vs_torch_autograd(shape):
+    import torch.nn.functional as F
+    B, C, H, W = shape
+    gg = gen(H * W)
+    x = torch.randn(*shape, generator=gg)
+    w = torch.randn(C, 1, 3, 3, generator=gg) * 0.3
+    b = torch.randn(C, generator=gg)
+    gy = torch.randn(*shape, generator=gg)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    want = torch.autograd.grad(F.conv2d(xr, wr, br, padding=1, groups=C), (xr, wr, br), gy)
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    got = torch.autograd.grad(wm.ops.dwconv3x3_train(xg, wg, bg), (xg, wg, bg), gy.to(DEV))
+    for name, a, r in zip(("dx", "dW", "db"), got, want):
+        assert_close(a, r, 2e-5, f"dwconv {name}")
+
+
+@pytest.mark.parametrize("C,H,W", [(32, 33, 47), (16, 8, 8), (8, 5, 130)])
+def test_layernorm2d_gradients_vs_torch_autograd(C, H, W):
+    x = torch.randn(2, C, H, W, generator=gen(1)) * 2 + 0.5
+    w = torch.randn(C, generator=gen(2))
+    b = torch.randn(C, generator=gen(3))
+    gy = torch.randn(2, C, H, W, generator=gen(4))
+
+    def ref(x_, w_, b_):
+        mu = x_.mean(1, keepdim=True)
+        var = (x_ - mu).pow(2).mean(1, keepdim=True)
+        return w_.view(1, -1, 1, 1) * ((x_ - mu) / (var + 1e-6).sqrt()) + b_.view(1, -1, 1, 1)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    want = torch.autograd.grad(ref(xr, wr, br), (xr, wr, br), gy)
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    got = torch.autograd.grad(wm.ops.layernorm2d_train(xg, wg, bg, 1e-6), (xg, wg, bg), gy.to(DEV))
+    for name, a, r in zip(("gx", "dw", "db"), got, want):
+        assert_close(a, r, 5e-5, f"LayerNorm2d {name}")
+
+
 @pytest.mark.parametrize("B,C,L", [(1, 32, 70000), (2, 32, 4099), (1, 16, 257), (3, 8, 64), (1, 32, 5)])
 def test_gram_vs_torch(B, C, L):
     x = torch.randn(B, C, L, generator=gen(L)) + 0.3

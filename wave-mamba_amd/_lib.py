@@ -36,6 +36,8 @@ SIGNATURES = {
     "wm_layernorm2d_fwd": (_i, [_p, _p, _p, _c.c_float, _p, _i, _i64, _i, _p]),
     "wm_gram_fwd": (_i, [_p] * 5 + [_i, _i, _i64, _p]),
     "wm_mul_sigmoid_fwd": (_i, [_p, _p, _p, _i64, _p]),
+    "wm_dwconv3x3_wgrad": (_i, [_p] * 4 + [_i] * 4 + [_p]),
+    "wm_layernorm2d_bwd": (_i, [_p, _p, _p, _c.c_float, _p, _p, _p, _i, _i64, _i, _p]),
     "wm_dwconv3x3_fwd": (_i, [_p] * 4 + [_i] * 5 + [_p]),
     "wm_prof_enable": (None, [_i]),
     "wm_prof_collect": (_i, [_c.POINTER(_i), _c.POINTER(_c.c_double)]),

@@ -55,9 +55,11 @@ def _dwconv(conv, x, act="none"):
     """Depth-wise 3x3 nn.Conv2d (+ optional SiLU).  Inference on the HIP backend goes to the
     streaming HIP kernel; training (autograd) and the test backends use the PyTorch conv."""
     ops = _OpsBackend.impl
-    if (hasattr(ops, "dwconv3x3") and x.is_cuda and x.dtype == torch.float32
-            and not (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad))):
-        return ops.dwconv3x3(x, conv.weight, conv.bias, act)
+    if hasattr(ops, "dwconv3x3") and x.is_cuda and x.dtype == torch.float32:
+        if not (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)):
+            return ops.dwconv3x3(x, conv.weight, conv.bias, act)
+        y = ops.dwconv3x3_train(x, conv.weight, conv.bias)          # HIP forward + backward (autograd)
+        return F.silu(y) if act == "silu" else y
     y = conv(x)
     return F.silu(y) if act == "silu" else y
 
@@ -286,9 +288,10 @@ class LayerNorm2d(nn.Module):
 
     def forward(self, x):
         ops = _OpsBackend.impl
-        if (hasattr(ops, "layernorm2d") and x.is_cuda and x.dtype == torch.float32 and x.shape[1] in (8, 16, 32)
-                and not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad))):
-            return ops.layernorm2d(x, self.weight, self.bias, self.eps)
+        if hasattr(ops, "layernorm2d") and x.is_cuda and x.dtype == torch.float32 and x.shape[1] in (8, 16, 32):
+            if not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
+                return ops.layernorm2d(x, self.weight, self.bias, self.eps)
+            return ops.layernorm2d_train(x, self.weight, self.bias, self.eps)
         mu = x.mean(1, keepdim=True)
         var = (x - mu).pow(2).mean(1, keepdim=True)
         y = (x - mu) / (var + self.eps).sqrt()

@@ -94,3 +94,85 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
 }
 
 }  // namespace wm
+
+namespace wm {
+
+// ---- weight / bias gradient of the depth-wise 3x3 convolution ------------------------------------------
+// dW[c][i][j] = sum_{b,h,w} gy[b,c,h,w] * x[b,c,h+i-1,w+j-1]   (zero padding),   db[c] = sum gy[b,c,h,w]
+// Same strip walk as the forward (3-row register window of x, 4 columns per thread); 10 per-thread partial
+// sums are reduced over the wave by shuffles and leave through one atomicAdd per wave and value.
+template <bool VEC>
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                              float* __restrict__ dW, float* __restrict__ db, int C,
+                                                              int H, int W, long long planes) {
+    const int lane = threadIdx.x;
+    const int cg = blockIdx.x * 64 + lane;
+    const int h0 = (blockIdx.y * 4 + threadIdx.y) * kDwRows;
+    for (long long plane = blockIdx.z; plane < planes; plane += gridDim.z) {
+        const int c = (int)(plane % C);
+        const float* xp = x + plane * (long long)H * W;
+        const float* gp = gy + plane * (long long)H * W;
+        const int w0 = cg * 4;
+        const bool colok = w0 < W;
+        auto load_row = [&](int r, float (&v)[6]) {
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool rowok = r >= 0 && r < H;
+            if (rowok && colok) {
+                if constexpr (VEC) q = *reinterpret_cast<const float4*>(xp + (long long)r * W + w0);
+                else {
+                    const float* p = xp + (long long)r * W + w0;
+                    q.x = p[0];
+                    if (w0 + 1 < W) q.y = p[1];
+                    if (w0 + 2 < W) q.z = p[2];
+                    if (w0 + 3 < W) q.w = p[3];
+                }
+            }
+            float left = __shfl_up(q.w, 1), right = __shfl_down(q.x, 1);
+            if (lane == 0) left = (rowok && w0 - 1 >= 0 && w0 - 1 < W) ? xp[(long long)r * W + w0 - 1] : 0.0f;
+            if (lane == 63) right = (rowok && w0 + 4 < W) ? xp[(long long)r * W + w0 + 4] : 0.0f;
+            v[0] = left; v[1] = q.x; v[2] = q.y; v[3] = q.z; v[4] = q.w; v[5] = right;
+        };
+        float acc[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) acc[i] = 0.0f;
+        if (h0 < H) {
+            float r0[6], r1[6], r2[6];
+            load_row(h0 - 1, r0);
+            load_row(h0, r1);
+            const int hend = min(H, h0 + kDwRows);
+            for (int h = h0; h < hend; ++h) {
+                load_row(h + 1, r2);
+                float g[4] = {0.f, 0.f, 0.f, 0.f};
+                if (colok) {
+                    const float* p = gp + (long long)h * W + w0;
+                    if constexpr (VEC) { const float4 q = *reinterpret_cast<const float4*>(p); g[0] = q.x; g[1] = q.y; g[2] = q.z; g[3] = q.w; }
+                    else { g[0] = p[0]; if (w0 + 1 < W) g[1] = p[1]; if (w0 + 2 < W) g[2] = p[2]; if (w0 + 3 < W) g[3] = p[3]; }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        acc[j] = fmaf(g[q], r0[q + j], acc[j]);
+                        acc[3 + j] = fmaf(g[q], r1[q + j], acc[3 + j]);
+                        acc[6 + j] = fmaf(g[q], r2[q + j], acc[6 + j]);
+                    }
+                    acc[9] += g[q];
+                }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            float v = acc[i];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0 && v != 0.0f) {
+                if (i < 9) atomicAdd(dW + c * 9 + i, v);
+                else if (db) atomicAdd(db + c, v);
+            }
+        }
+    }
+}
+
+}  // namespace wm

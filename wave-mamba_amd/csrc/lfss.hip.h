@@ -196,3 +196,56 @@ __global__ __launch_bounds__(256) void mul_sigmoid_kernel(const float4* __restri
 }
 
 }  // namespace wm
+
+namespace wm {
+
+// ---- LayerNorm2d backward (reference LayerNormFunction.backward, :545-557) --------------------------------
+//   g = gy * w ;  gx = rstd * (g - yhat * mean_c(g * yhat) - mean_c(g)) ;  dw[c] = sum gy*yhat ;  db[c] = sum gy
+// one thread = one pixel (mean / rstd / yhat recomputed from x); dw / db partials live in registers over a
+// grid-stride loop and leave through a wave shuffle reduction + one atomicAdd per wave and channel.
+template <int C>
+__global__ __launch_bounds__(256) void layernorm2d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ gy, float eps,
+                                                              float* __restrict__ gx, float* __restrict__ dw,
+                                                              float* __restrict__ db, int B, long long L) {
+    float pw[C], pb[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { pw[c] = 0.0f; pb[c] = 0.0f; }
+    const long long total = (long long)B * L;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long bb = idx / L, p = idx - bb * L;
+        float v[C], g[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { v[c] = x[(bb * C + c) * L + p]; g[c] = gy[(bb * C + c) * L + p]; }
+        float mean = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) mean += v[c];
+        mean *= (1.0f / C);
+        float var = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { const float d = v[c] - mean; var = fmaf(d, d, var); }
+        const float rstd = 1.0f / sqrtf(var * (1.0f / C) + eps);
+        float mg = 0.0f, mgy = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            v[c] = (v[c] - mean) * rstd;                          // yhat
+            pw[c] = fmaf(g[c], v[c], pw[c]);
+            pb[c] += g[c];
+            g[c] *= w[c];
+            mg += g[c];
+            mgy = fmaf(g[c], v[c], mgy);
+        }
+        mg *= (1.0f / C); mgy *= (1.0f / C);
+#pragma unroll
+        for (int c = 0; c < C; ++c) gx[(bb * C + c) * L + p] = rstd * (g[c] - v[c] * mgy - mg);
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        float a = pw[c], bsum = pb[c];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off); bsum += __shfl_xor(bsum, off); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(dw + c, a); atomicAdd(db + c, bsum); }
+    }
+}
+
+}  // namespace wm

@@ -613,6 +613,48 @@ int wm_mul_sigmoid_fwd(const float* a, const float* b, float* out, int64_t n, vo
     return launch_status();
 }
 
+int wm_dwconv3x3_wgrad(const float* x, const float* gy, float* dW, float* db, int B, int C, int H, int W,
+                       void* stream) {
+    if (B < 0 || C < 0 || H < 0 || W < 0) return WM_EINVAL;
+    if (C == 0) return WM_OK;
+    if (!dW) return WM_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(dW, 0, (size_t)C * 9 * sizeof(float), st);
+    if (e == hipSuccess && db) e = hipMemsetAsync(db, 0, (size_t)C * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    const long long planes = (long long)B * C;
+    if (planes == 0 || H == 0 || W == 0) return WM_OK;
+    if (!x || !gy) return WM_ENULL;
+    const bool vec = (W % 4 == 0) && aligned16(x) && aligned16(gy);
+    const dim3 block(64, 4);
+    const dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 4 * kDwRows - 1) / (4 * kDwRows)),
+                    (unsigned)(planes < 65535 ? planes : 65535));
+    if (vec) hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<true>), grid, block, 0, st, x, gy, dW, db, C, H, W, planes);
+    else hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<false>), grid, block, 0, st, x, gy, dW, db, C, H, W, planes);
+    return launch_status();
+}
+
+int wm_layernorm2d_bwd(const float* x, const float* weight, const float* gy, float eps, float* gx, float* dweight,
+                       float* dbias, int B, int64_t L, int C, void* stream) {
+    if (B < 0 || L < 0) return WM_EINVAL;
+    if (C != 8 && C != 16 && C != 32) return WM_EUNSUPPORTED;
+    if (!dweight || !dbias) return WM_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(dweight, 0, (size_t)C * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(dbias, 0, (size_t)C * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    const long long total = (long long)B * L;
+    if (total == 0) return WM_OK;
+    if (!x || !weight || !gy || !gx) return WM_ENULL;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    const dim3 grid((unsigned)blocks), block(256);
+    if (C == 32) hipLaunchKernelGGL((layernorm2d_bwd_kernel<32>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
+    else if (C == 16) hipLaunchKernelGGL((layernorm2d_bwd_kernel<16>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
+    else hipLaunchKernelGGL((layernorm2d_bwd_kernel<8>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
+    return launch_status();
+}
+
 void wm_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     g_prof.on = on != 0;

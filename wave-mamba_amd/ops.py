@@ -392,6 +392,66 @@ def gram(x, y):
     return G, nx, ny
 
 
+class _DWConvTrain(torch.autograd.Function):
+    """Depth-wise 3x3 conv (+bias) with HIP forward, input gradient (the same kernel on the flipped weight) and
+    weight / bias gradient (strip reduction).  Training-side replacement of MIOpen's naive depth-wise kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return dwconv3x3(x, weight, bias, "none")
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous().float()
+        B, C, H, W = x.shape
+        gx = dwconv3x3(gy, weight.detach().flip(2, 3).contiguous(), None, "none")
+        dW = torch.empty_like(weight, dtype=torch.float32)
+        db = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        with torch.cuda.device(x.device):
+            check(lib.wm_dwconv3x3_wgrad(_ptr(x.contiguous()), _ptr(gy), _ptr(dW), _ptr(db), B, C, H, W, _stream()),
+                  "wm_dwconv3x3_wgrad")
+        return gx, dW, db
+
+
+def dwconv3x3_train(x, weight, bias=None):
+    """Differentiable depth-wise 3x3 conv (stride 1, padding 1) on the HIP path (fp32 NCHW)."""
+    _require_cuda("dwconv3x3_train", x, weight, bias)
+    return _DWConvTrain.apply(x.contiguous().float(), weight, bias)
+
+
+class _LayerNorm2dTrain(torch.autograd.Function):
+    """LayerNorm2d with HIP forward and backward (reference LayerNormFunction, wavemamba_arch.py:532-557)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        ctx.save_for_backward(x, weight)
+        ctx.eps = float(eps)
+        return layernorm2d(x, weight, bias, eps)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, weight = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gy = gy.contiguous().float()
+        gx = torch.empty_like(x)
+        dw = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib.wm_layernorm2d_bwd(_ptr(x), _ptr(_w(weight)), _ptr(gy), ctx.eps, _ptr(gx), _ptr(dw), _ptr(db),
+                                         B, H * W, C, _stream()), "wm_layernorm2d_bwd")
+        return gx, dw, db, None
+
+
+def layernorm2d_train(x, weight, bias, eps):
+    _require_cuda("layernorm2d_train", x, weight, bias)
+    return _LayerNorm2dTrain.apply(x.contiguous().float(), weight, bias, eps)
+
+
 def mul_sigmoid(a, b):
     """a * sigmoid(b) in one pass (PAConv gate, reference :694-697); fp32, same shape, forward only."""
     lib = _lib.load()
