@@ -239,12 +239,18 @@ __global__ __launch_bounds__(256) void layernorm2d_bwd_kernel(const float* __res
 #pragma unroll
         for (int c = 0; c < C; ++c) gx[(bb * C + c) * L + p] = rstd * (g[c] - v[c] * mgy - mg);
     }
+    __shared__ float s_red[4][2 * C];                  // per-wave sums -> one atomic per block and channel
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         float a = pw[c], bsum = pb[c];
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off); bsum += __shfl_xor(bsum, off); }
-        if ((threadIdx.x & 63) == 0) { atomicAdd(dw + c, a); atomicAdd(db + c, bsum); }
+        if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6][c] = a; s_red[threadIdx.x >> 6][C + c] = bsum; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * C) {
+        const float t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+        atomicAdd((threadIdx.x < C ? dw : db) + (threadIdx.x % C), t);
     }
 }
 

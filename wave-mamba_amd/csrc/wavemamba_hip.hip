@@ -647,7 +647,7 @@ int wm_layernorm2d_bwd(const float* x, const float* weight, const float* gy, flo
     if (total == 0) return WM_OK;
     if (!x || !weight || !gy || !gx) return WM_ENULL;
     long long blocks = (total + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;                      // grid-stride: few blocks -> few atomics per channel
     const dim3 grid((unsigned)blocks), block(256);
     if (C == 32) hipLaunchKernelGGL((layernorm2d_bwd_kernel<32>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
     else if (C == 16) hipLaunchKernelGGL((layernorm2d_bwd_kernel<16>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
