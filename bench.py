@@ -33,6 +33,8 @@ from wave_mamba_amd.archs import wavemamba_arch as arch        # noqa: E402
 SHIPPED = dict(in_chn=3, wf=32, n_l_blocks=[1, 2, 4], n_h_blocks=[1, 1, 2], ffn_scale=2.0)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 SCAN_BYTES_PER_POS = {16: 3584, 32: 4096}   # 4*(3*KD + 2*K*N), KD = 256, K = 4
+# kernel classes whose HIP events are recorded inside the timed region (the candidates for `roofline`)
+TIMED_PROF = ("ss2d_row_scan", "ss2d_col_scan")
 
 
 def pad_to(x, mult=128):
@@ -220,7 +222,10 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    wm.ops.prof_enable(True)
+    # HIP events cost ~10 us of stream time per instrumented launch (353 wm:: launches per step = 3 ms,
+    # profiles/r01/README.md), so the timed region records only the scan kernel classes - the dominant
+    # kernel `roofline` reports - and the other classes are measured in an extra untimed pass below.
+    wm.ops.prof_enable(TIMED_PROF)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -229,7 +234,17 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    prof = wm.ops.prof_collect()
+    prof_timed = wm.ops.prof_collect()
+    prof_steps = {k: args.steps for k in TIMED_PROF}
+    prof = {k: prof_timed[k] for k in TIMED_PROF}
+    if rank == 0:
+        extra = max(2, min(args.steps, 5))
+        wm.ops.prof_enable(True)
+        for _ in range(extra):
+            step()
+        for k, v in wm.ops.prof_collect().items():
+            if k not in prof:
+                prof[k], prof_steps[k] = v, extra
     wm.ops.prof_enable(False)
     op_boundary = scan_op_boundary(device, hp, wp) if rank == 0 else None
     hip_graph = graph_replay(step, args.steps, device) if rank == 0 and world == 1 and args.graph else None
@@ -257,9 +272,11 @@ def main():
         for name, (n, ms) in prof.items():
             if not n:
                 continue
-            ent = {"launches_per_step": n / args.steps, "ms_per_step": ms / args.steps}
+            ks = prof_steps[name]
+            ent = {"launches_per_step": n / ks, "ms_per_step": ms / ks,
+                   "measured_in": "timed region" if name in TIMED_PROF else "untimed pass after it"}
             if algo.get(name):
-                gbs = algo[name] * args.steps / (ms * 1e-3) / 1e9
+                gbs = algo[name] * ks / (ms * 1e-3) / 1e9
                 ent.update({"algorithmic_GB_per_step": algo[name] / 1e9, "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS})
             table[name] = ent
         hot = [k for k in table if k != "dwconv3x3" and "frac" in table[k]]

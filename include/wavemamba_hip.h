@@ -191,15 +191,18 @@ int wm_mul_sigmoid_fwd(const float* a, const float* b, float* out, int64_t n, vo
 /* --------------------------------------------------------------------------------------------
  * Profiling hooks used by bench.py (HIP events recorded on the launch stream around each kernel
  * class).  Disabled by default; when disabled the library records nothing.
- *   kernel ids: 0 dwt/analysis, 1 iwt/synthesis, 2 scan chunk-reduce, 3 scan carry,
- *               4 scan chunk-scan (the dominant kernel), 5 scan bwd, 6 ss2d projection,
- *               7 depth-wise conv, 8 ss2d row chunk-scan, 9 ss2d col chunk-scan,
+ *   kernel ids: 0 haar analysis (dwt fwd / iwt bwd), 1 haar synthesis (iwt fwd / dwt bwd),
+ *               2 scan chunk-reduce, 3 scan carry, 4 scan chunk-scan (drop-in op), 5 lfss glue (in/mid/out),
+ *               6 ss2d projection, 7 depth-wise conv, 8 ss2d row chunk-scan, 9 ss2d col chunk-scan,
  *               10 ss2d row chunk-reduce, 11 ss2d col chunk-reduce, 12 selective-scan backward (all phases)
+ * wm_prof_enable(mask): bit k of `mask` switches recording for kernel id k (0 = off, ~0u = every class);
+ * a non-zero mask also clears what was recorded before.  Two hipEventRecord calls cost ~10 us of stream
+ * time per launch, so a caller timing a whole step enables only the classes it needs.
  * wm_prof_collect synchronises the recorded events (host-blocking) and returns, per kernel id,
- * the number of launches and their summed duration in milliseconds since wm_prof_enable(1).
+ * the number of launches and their summed duration in milliseconds since the last wm_prof_enable(mask != 0).
  * -------------------------------------------------------------------------------------------- */
 #define WM_PROF_NKERNELS 13
-void wm_prof_enable(int on);
+void wm_prof_enable(unsigned mask);
 int wm_prof_collect(int* launches /*[WM_PROF_NKERNELS]*/, double* total_ms /*[WM_PROF_NKERNELS]*/);
 
 #ifdef __cplusplus

@@ -22,7 +22,7 @@ namespace wm {
 // ------------------------------------------------------------------------------------------------
 struct Prof {
     std::mutex mu;
-    bool on = false;
+    unsigned mask = 0;                                          // bit k: record kernel class k
     std::vector<hipEvent_t> pool;                               // recycled events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> rec[WM_PROF_NKERNELS];
     hipEvent_t get() {
@@ -34,7 +34,7 @@ static Prof g_prof;
 
 struct ProfScope {
     int id; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr; bool active;
-    ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), active(g_prof.on) {
+    ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), active((g_prof.mask >> id_) & 1u) {
         if (!active) return;
         std::lock_guard<std::mutex> lk(g_prof.mu);
         e0 = g_prof.get(); e1 = g_prof.get();
@@ -254,7 +254,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 1; }
+int wm_abi_version(void) { return 2; }
 
 const char* wm_strerror(int code) {
     switch (code) {
@@ -655,10 +655,10 @@ int wm_layernorm2d_bwd(const float* x, const float* weight, const float* gy, flo
     return launch_status();
 }
 
-void wm_prof_enable(int on) {
+void wm_prof_enable(unsigned mask) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
-    g_prof.on = on != 0;
-    if (on)
+    g_prof.mask = mask;
+    if (mask)
         for (auto& v : g_prof.rec) {
             for (auto& pr : v) { g_prof.pool.push_back(pr.first); g_prof.pool.push_back(pr.second); }
             v.clear();

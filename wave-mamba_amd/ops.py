@@ -496,7 +496,16 @@ PROF_KERNELS = ("haar_analysis", "haar_synthesis", "selscan_chunk_reduce", "sels
 
 
 def prof_enable(on=True):
-    _lib.load().wm_prof_enable(int(bool(on)))
+    """on: False/True (every kernel class) or an iterable of PROF_KERNELS names (only those classes)."""
+    if on is True:
+        mask = 0xFFFFFFFF
+    elif not on:
+        mask = 0
+    else:
+        mask = 0
+        for name in on:
+            mask |= 1 << PROF_KERNELS.index(name)
+    _lib.load().wm_prof_enable(mask)
 
 
 def prof_collect():
