@@ -533,3 +533,41 @@ def test_dwconv3x3_vs_torch(shape, act):
     assert_close(got, ref, 1e-5, f"dwconv {shape} {act}")
     got_nb = wm.ops.dwconv3x3(x.to(DEV), w.to(DEV), None, "none")
     assert_close(got_nb, F.conv2d(x, w, None, padding=1, groups=C), 1e-5, "dwconv no bias")
+
+
+# ------------------------------------------------------------------------------------------------
+# dense 3x3 conv on the bf16 matrix cores with a two-term operand split: PAConv.k3/.k4, l_conv on
+# cat([LL, x_d]), h_out_conv, conv_01, last (reference :690-697, :966/:975, :993/:1006, :1021/:1037).
+# Floating-point kernel of a standard op -> the fp64 PyTorch CPU conv is the reference; bar: 2e-5 relative
+# (three bf16 products per term: <= 3 * 2^-18 per product; measured ~4e-6)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,Ca,Cb,Cout,H,W,bias", [
+    (1, 64, 0, 64, 70, 50, True), (2, 64, 0, 32, 33, 65, False), (1, 32, 32, 32, 40, 96, True),
+    (1, 32, 0, 96, 16, 32, True), (1, 3, 0, 32, 40, 64, True), (2, 32, 0, 3, 64, 96, True),
+    (1, 16, 8, 40, 5, 7, False), (1, 64, 0, 64, 1, 1, True), (1, 48, 0, 64, 31, 33, False),
+    (1, 64, 0, 64, 160, 256, False)])
+def test_conv3x3_vs_torch(B, Ca, Cb, Cout, H, W, bias):
+    import torch.nn.functional as F
+    gg = gen(Ca * 100 + Cout + H)
+    xa = torch.randn(B, Ca, H, W, generator=gg)
+    xb = torch.randn(B, Cb, H, W, generator=gg) if Cb else None
+    w = torch.randn(Cout, Ca + Cb, 3, 3, generator=gg) / (3.0 * (Ca + Cb) ** 0.5)
+    b = torch.randn(Cout, generator=gg) if bias else None
+    xin = xa if xb is None else torch.cat([xa, xb], 1)
+    ref = F.conv2d(xin.double(), w.double(), None if b is None else b.double(), padding=1).float()
+    got = wm.ops.conv3x3(*cu(xa, w, b, xb))
+    assert_close(got, ref, 2e-5, f"conv3x3 {(B, Ca, Cb, Cout, H, W)}")
+
+
+def test_conv3x3_weight_update_invalidates_prepared_copy():
+    import torch.nn.functional as F
+    gg = gen(5)
+    x = torch.randn(1, 32, 24, 40, generator=gg).to(DEV)
+    conv = torch.nn.Conv2d(32, 32, 3, 1, 1).to(DEV)
+    y0 = wm.ops.conv3x3(x, conv.weight, conv.bias)
+    with torch.no_grad():
+        conv.weight.mul_(2.0)                                   # in-place update, as an optimizer step does
+    y1 = wm.ops.conv3x3(x, conv.weight, conv.bias)
+    ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1).float()
+    assert_close(y1, ref.cpu(), 2e-5, "conv3x3 after in-place weight update")
+    assert not torch.allclose(y0, y1)

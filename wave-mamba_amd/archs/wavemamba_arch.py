@@ -64,6 +64,18 @@ def _dwconv(conv, x, act="none"):
     return F.silu(y) if act == "silu" else y
 
 
+def _conv3x3(conv, x, x2=None):
+    """Dense 3x3 nn.Conv2d (stride 1, padding 1) of `cat([x, x2], 1)` (or of `x`).  Inference on the HIP
+    backend goes to the matrix-core kernel (the concatenation is never materialised); training (autograd)
+    and the test backends use the PyTorch conv."""
+    ops = _OpsBackend.impl
+    if (hasattr(ops, "conv3x3") and ops.conv3x3_supported(x, conv.weight, x2)
+            and not (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad
+                                                  or (x2 is not None and x2.requires_grad)))):
+        return ops.conv3x3(x, conv.weight, conv.bias, x2)
+    return conv(x if x2 is None else torch.cat([x, x2], dim=1))
+
+
 # ================================================================================================
 # Low-frequency branch: SS2D / LFSSBlock
 # ================================================================================================
@@ -350,11 +362,11 @@ class PAConv(nn.Module):
 
     def forward(self, x):
         ops = _OpsBackend.impl
-        a, g = self.k3(x), self.k2(x)
+        a, g = _conv3x3(self.k3, x), self.k2(x)
         if (hasattr(ops, "mul_sigmoid") and a.is_cuda and a.dtype == torch.float32 and a.numel() % 4 == 0
                 and not (torch.is_grad_enabled() and a.requires_grad)):
-            return self.k4(ops.mul_sigmoid(a, g))
-        return self.k4(a * self.sigmoid(g))
+            return _conv3x3(self.k4, ops.mul_sigmoid(a, g))
+        return _conv3x3(self.k4, a * self.sigmoid(g))
 
 
 class Matching_transformation(nn.Module):
@@ -524,7 +536,7 @@ class DownFRG(nn.Module):
 
     def forward(self, x, x_d):
         ll, hl, lh, hh = self.dwt(x)
-        low = _run_lfss_stack(self.l_blk, self.l_conv(torch.cat([ll, x_d], dim=1)))
+        low = _run_lfss_stack(self.l_blk, _conv3x3(self.l_conv, ll, x_d))
         high = self.h_fusion([hl, lh, hh])
         for blk in self.h_blk:
             high = blk(high, low)
@@ -547,7 +559,7 @@ class upFRG(nn.Module):
         for blk in self.h_blk:
             x_h = blk(x_h, low)
         # reference: iwt(cat([x_l, h_out_conv(x_h)], 1)); the pair form skips the concatenation
-        return self.iwt(low, self.h_out_conv(x_h))
+        return self.iwt(low, _conv3x3(self.h_out_conv, x_h))
 
 
 class UNet(nn.Module):
@@ -570,13 +582,13 @@ class UNet(nn.Module):
     def forward(self, x):
         img = x
         d1, d2, d3 = self.ps_down1(img), self.ps_down2(img), self.ps_down3(img)
-        low, high1 = self.down_group1(self.conv_01(img), d1)
+        low, high1 = self.down_group1(_conv3x3(self.conv_01, img), d1)
         low, high2 = self.down_group2(low, d2)
         low, high3 = self.down_group3(low, d3)
         low = self.up_group3(low, high3)
         low = self.up_group2(low, high2)
         low = self.up_group1(low, high1)
-        return self.last(low) + img
+        return _conv3x3(self.last, low) + img
 
 
 @ARCH_REGISTRY.register()

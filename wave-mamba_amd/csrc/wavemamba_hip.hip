@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <mutex>
 #include <vector>
 
@@ -14,6 +15,7 @@
 #include "ss2d.hip.h"
 #include "lfss.hip.h"
 #include "gram.hip.h"
+#include "conv3x3.hip.h"
 
 namespace wm {
 
@@ -254,7 +256,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 2; }
+int wm_abi_version(void) { return 3; }
 
 const char* wm_strerror(int code) {
     switch (code) {
@@ -653,6 +655,77 @@ int wm_layernorm2d_bwd(const float* x, const float* weight, const float* gy, flo
     else if (C == 16) hipLaunchKernelGGL((layernorm2d_bwd_kernel<16>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
     else hipLaunchKernelGGL((layernorm2d_bwd_kernel<8>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
     return launch_status();
+}
+
+size_t wm_conv3x3_wfrag_bytes(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0) return 0;
+    return (size_t)((Cin + 15) / 16) * 9 * ((Cout + 31) / 32) * 2 * 64 * 16;
+}
+
+int wm_conv3x3_prep(const float* weight, void* wfrag, int Cout, int Cin, void* stream) {
+    if (Cout <= 0 || Cin <= 0) return WM_EINVAL;
+    if (!weight || !wfrag) return WM_ENULL;
+    if (!aligned16(wfrag)) return WM_EALIGN;
+    const int nch = (Cin + 15) / 16, mtot = (Cout + 31) / 32;
+    const long long total = (long long)nch * 9 * mtot * 128;
+    hipLaunchKernelGGL(conv3x3_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       weight, (uint4*)wfrag, Cout, Cin, nch, mtot);
+    return launch_status();
+}
+
+}  // extern "C"
+
+template <int RW, int MT>
+static int conv3x3_launch(const wm::Conv3x3Args& a, int B, hipStream_t st) {
+    constexpr int smem = ((4 * RW + 2) * wm::kCvPW * 4 + 2 * 9 * MT * 2 * 64) * 16;   // input planes + 2 weight buffers
+    static bool configured = false;                      // > 64 KB of LDS needs the opt-in, once per instantiation
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)wm::conv3x3_mfma_kernel<RW, MT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    const dim3 grid((unsigned)((a.W + wm::kCvTW - 1) / wm::kCvTW), (unsigned)((a.H + 4 * RW - 1) / (4 * RW)), (unsigned)B);
+    hipLaunchKernelGGL((wm::conv3x3_mfma_kernel<RW, MT>), grid, dim3(256), smem, st, a);
+    return launch_status();
+}
+
+extern "C" {
+
+int wm_conv3x3_fwd(const float* xa, const float* xb, const void* wfrag, const float* bias, float* y, int B, int Ca,
+                   int Cb, int Cout, int H, int W, void* stream) {
+    if (B < 0 || Ca <= 0 || Cb < 0 || Cout <= 0 || H < 0 || W < 0) return WM_EINVAL;
+    if (B == 0 || H == 0 || W == 0) return WM_OK;
+    if (!xa || !wfrag || !y || (Cb > 0 && !xb)) return WM_ENULL;
+    if (Cb > 0 && Ca % 8 != 0) return WM_EUNSUPPORTED;   // an 8-channel fragment never straddles the two sources
+    if (B > 65535) return WM_EUNSUPPORTED;
+    if (!aligned16(wfrag)) return WM_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    Conv3x3Args a;
+    a.xa = xa; a.xb = Cb > 0 ? xb : nullptr; a.wfrag = (const uint4*)wfrag; a.bias = bias; a.y = y;
+    a.Ca = Ca; a.Cb = Cb; a.Cout = Cout; a.H = H; a.W = W;
+    a.nch = (Ca + Cb + 15) / 16; a.mtot = (Cout + 31) / 32;
+    static const int rw_env = [] { const char* e = getenv("WM_CONV_RW"); return e ? atoi(e) : 0; }();
+    // 8 rows per wave (32 x 32 tile) halves the weight re-staging per pixel; the 16 x 32 tile keeps small maps on
+    // more compute units
+    const long long tiles8 = (long long)B * ((H + 31) / 32) * ((W + wm::kCvTW - 1) / wm::kCvTW);
+    const bool rw8 = rw_env ? rw_env == 8 : tiles8 >= 512;
+    ProfScope ps(13, st);
+    for (int mb = 0; mb < a.mtot;) {
+        a.mbase = mb;
+        const int left = a.mtot - mb;
+        int rc;
+        if (rw8) {
+            if (left >= 2) { rc = conv3x3_launch<8, 2>(a, B, st); mb += 2; }
+            else { rc = conv3x3_launch<8, 1>(a, B, st); mb += 1; }
+        } else {
+            if (left >= 3) { rc = conv3x3_launch<4, 3>(a, B, st); mb += 3; }
+            else if (left == 2) { rc = conv3x3_launch<4, 2>(a, B, st); mb += 2; }
+            else { rc = conv3x3_launch<4, 1>(a, B, st); mb += 1; }
+        }
+        if (rc) return rc;
+    }
+    return WM_OK;
 }
 
 void wm_prof_enable(unsigned mask) {

@@ -487,12 +487,66 @@ def dwconv3x3(x, weight, bias=None, act="none"):
     return y
 
 
+_WFRAG_CACHE = {}      # id(weight) -> (weakref, data_ptr, version, wfrag tensor)
+
+
+def _conv3x3_wfrag(weight):
+    """The prepared (bf16-split, fragment-ordered) copy of a (Cout, Cin, 3, 3) weight; rebuilt when the
+    parameter is updated in place (`_version`) or re-allocated."""
+    import weakref
+    key = id(weight)
+    ent = _WFRAG_CACHE.get(key)
+    if ent is not None and ent[0]() is weight and ent[1] == weight.data_ptr() and ent[2] == weight._version:
+        return ent[3]
+    lib = _lib.load()
+    cout, cin = weight.shape[:2]
+    frag = torch.empty(lib.wm_conv3x3_wfrag_bytes(cout, cin), dtype=torch.uint8, device=weight.device)
+    with torch.cuda.device(weight.device):
+        check(lib.wm_conv3x3_prep(_ptr(weight.detach().contiguous()), _ptr(frag), cout, cin, _stream()),
+              "wm_conv3x3_prep")
+    _WFRAG_CACHE[key] = (weakref.ref(weight, lambda _r, k=key: _WFRAG_CACHE.pop(k, None)), weight.data_ptr(),
+                         weight._version, frag)
+    return frag
+
+
+def conv3x3(x, weight, bias=None, x2=None):
+    """F.conv2d(cat([x, x2], 1) if x2 is not None else x, weight, bias, stride=1, padding=1) for a dense
+    (Cout, Cin, 3, 3) weight, NCHW fp32, forward only (no autograd graph is recorded).  bf16 matrix cores with
+    a two-term split of both operands: ~1e-6 relative to the fp32 result."""
+    lib = _lib.load()
+    _require_cuda("conv3x3", x, weight, bias, x2)
+    B, Ca, H, W = x.shape
+    Cb = 0 if x2 is None else x2.shape[1]
+    if x2 is not None and (x2.shape[0], x2.shape[2], x2.shape[3]) != (B, H, W):
+        raise RuntimeError(f"conv3x3: x2 {tuple(x2.shape)} does not match x {tuple(x.shape)}")
+    cout = weight.shape[0]
+    if tuple(weight.shape) != (cout, Ca + Cb, 3, 3):
+        raise RuntimeError(f"conv3x3: weight must be (Cout, {Ca + Cb}, 3, 3), got {tuple(weight.shape)}")
+    if x.dtype != torch.float32 or weight.dtype != torch.float32 or (x2 is not None and x2.dtype != torch.float32):
+        raise RuntimeError("conv3x3: float32 only")
+    x = x.contiguous()
+    x2 = None if x2 is None else x2.contiguous()
+    frag = _conv3x3_wfrag(weight)
+    y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.wm_conv3x3_fwd(_ptr(x), _ptr(x2), _ptr(frag), _ptr(None if bias is None else bias.detach().contiguous()),
+                                 _ptr(y), B, Ca, Cb, cout, H, W, _stream()), "wm_conv3x3_fwd")
+    return y
+
+
+def conv3x3_supported(x, weight, x2=None):
+    ca = x.shape[1]
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
+            and tuple(weight.shape[2:]) == (3, 3) and (x2 is None or (ca % 8 == 0 and x2.dtype == torch.float32)))
+
+
 # ------------------------------------------------------------------------------------------------
 # profiling hooks (bench.py)
 # ------------------------------------------------------------------------------------------------
 PROF_KERNELS = ("haar_analysis", "haar_synthesis", "selscan_chunk_reduce", "selscan_carry",
                 "selscan_chunk_scan", "lfss_glue", "ss2d_proj", "dwconv3x3",
-                "ss2d_row_scan", "ss2d_col_scan", "ss2d_row_reduce", "ss2d_col_reduce", "selscan_bwd")
+                "ss2d_row_scan", "ss2d_col_scan", "ss2d_row_reduce", "ss2d_col_reduce", "selscan_bwd",
+                "conv3x3")
 
 
 def prof_enable(on=True):
