@@ -188,21 +188,27 @@ int wm_layernorm2d_bwd(const float* x, const float* weight, const float* gy, flo
  * wavemamba_arch.py:694-697 (`torch.mul(self.k3(x), self.sigmoid(self.k2(x)))`).  Forward only. */
 int wm_mul_sigmoid_fwd(const float* a, const float* b, float* out, int64_t n, void* stream);
 
-/* Dense 3x3 convolution, stride 1, zero padding 1, NCHW fp32 (PAConv.k3/.k4
- * wavemamba_arch.py:690-697, DownFRG.l_conv :966/:975, upFRG.h_out_conv :993/:1006, UNet.conv_01/.last
- * :1021/:1037 - `nn.Conv2d(cin, cout, 3, 1, 1)`).  Forward only.  Runs on the bf16 matrix cores with a two-term
- * split of both operands (three products per term pair, fp32 accumulation): ~1e-6 relative, see
- * csrc/conv3x3.hip.h.
- *   wm_conv3x3_prep   weight (Cout, Cin, 3, 3) -> `wfrag` (wm_conv3x3_wfrag_bytes(Cout, Cin) bytes, 16-byte
- *                     aligned, caller-owned): split, zero-padded to 16 | Cin and 32 | Cout, MFMA fragment order.
- *                     Redo whenever the weight changes.
- *   wm_conv3x3_fwd    y (B, Cout, H, W) = conv(cat([xa (B, Ca, H, W), xb (B, Cb, H, W)], 1)) + bias; Cb may be 0
- *                     (xb ignored); Ca % 8 == 0 when Cb > 0; bias may be NULL; `wfrag` prepared for
- *                     Cin = Ca + Cb. */
-size_t wm_conv3x3_wfrag_bytes(int Cout, int Cin);
-int wm_conv3x3_prep(const float* weight, void* wfrag, int Cout, int Cin, void* stream);
-int wm_conv3x3_fwd(const float* xa, const float* xb, const void* wfrag, const float* bias, float* y, int B, int Ca,
-                   int Cb, int Cout, int H, int W, void* stream);
+/* Dense 3x3 (stride 1, zero padding 1) and 1x1 convolutions, NCHW fp32, with the element-wise neighbours they
+ * have in the HFE branch fused (wavemamba_arch.py: PAConv k2/k3/k4 :690-697 on
+ * cat([x, gather(candidates, idx)]) :666/:713, CMTAttention.qkv/.project_out :768-797, FeedForward 1x1s :733-742,
+ * DownFRG.l_conv on cat([x_LL, x_d]) :966/:975, upFRG.h_out_conv :993/:1006, UNet.conv_01/.last/ps_down*
+ * :1015-1037).  Forward only.  Runs on the bf16 matrix cores with a two-term split of both operands (three
+ * products, fp32 accumulation): 3-4e-6 relative to an fp64 convolution, see csrc/conv2d.hip.h.
+ *   wm_conv2d_prep    weight (Cout, Cin, ks, ks), ks in {1, 3} -> `wfrag` (wm_conv2d_wfrag_bytes(Cout, Cin, ks) bytes,
+ *                     16-byte aligned, caller-owned): split, zero-padded to 16 | Cin and 32 | Cout, MFMA fragment
+ *                     order.  Redo whenever the weight changes.
+ *   wm_conv2d_fwd     x = cat([xa (B, Ca, H, W), xb' (B, Cb, H, W)], 1) where xb' = xb (Cb_src == Cb, xb_index NULL)
+ *                     or xb'[b, c] = xb[b, xb_index[b, c]] for xb (B, Cb_src, H, W), xb_index (B, Cb) int32
+ *                     (torch.gather over channels, never materialised); Cb may be 0 (xb, xb_index ignored);
+ *                     Ca % 8 == 0 when Cb > 0.
+ *                     y (B, Cout, H, W) = conv(x) + bias;  y *= sigmoid(gate) if gate;  y += residual if residual
+ *                     (gate, residual: (B, Cout, H, W), may be NULL; bias may be NULL).  `wfrag` prepared for
+ *                     Cin = Ca + Cb and the same ks.  H * W < 2^31. */
+size_t wm_conv2d_wfrag_bytes(int Cout, int Cin, int ks);
+int wm_conv2d_prep(const float* weight, void* wfrag, int Cout, int Cin, int ks, void* stream);
+int wm_conv2d_fwd(const float* xa, const float* xb, const int* xb_index, const void* wfrag, const float* bias,
+                  const float* gate, const float* residual, float* y, int B, int Ca, int Cb, int Cb_src, int Cout,
+                  int H, int W, int ks, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * Profiling hooks used by bench.py (HIP events recorded on the launch stream around each kernel
@@ -211,14 +217,14 @@ int wm_conv3x3_fwd(const float* xa, const float* xb, const void* wfrag, const fl
  *               2 scan chunk-reduce, 3 scan carry, 4 scan chunk-scan (drop-in op), 5 lfss glue (in/mid/out),
  *               6 ss2d projection, 7 depth-wise conv, 8 ss2d row chunk-scan, 9 ss2d col chunk-scan,
  *               10 ss2d row chunk-reduce, 11 ss2d col chunk-reduce, 12 selective-scan backward (all phases),
- *               13 dense 3x3 convolution
+ *               13 dense 3x3 convolution, 14 1x1 convolution
  * wm_prof_enable(mask): bit k of `mask` switches recording for kernel id k (0 = off, ~0u = every class);
  * a non-zero mask also clears what was recorded before.  Two hipEventRecord calls cost ~10 us of stream
  * time per launch, so a caller timing a whole step enables only the classes it needs.
  * wm_prof_collect synchronises the recorded events (host-blocking) and returns, per kernel id,
  * the number of launches and their summed duration in milliseconds since the last wm_prof_enable(mask != 0).
  * -------------------------------------------------------------------------------------------- */
-#define WM_PROF_NKERNELS 14
+#define WM_PROF_NKERNELS 15
 void wm_prof_enable(unsigned mask);
 int wm_prof_collect(int* launches /*[WM_PROF_NKERNELS]*/, double* total_ms /*[WM_PROF_NKERNELS]*/);
 

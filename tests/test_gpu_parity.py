@@ -536,38 +536,68 @@ def test_dwconv3x3_vs_torch(shape, act):
 
 
 # ------------------------------------------------------------------------------------------------
-# dense 3x3 conv on the bf16 matrix cores with a two-term operand split: PAConv.k3/.k4, l_conv on
-# cat([LL, x_d]), h_out_conv, conv_01, last (reference :690-697, :966/:975, :993/:1006, :1021/:1037).
-# Floating-point kernel of a standard op -> the fp64 PyTorch CPU conv is the reference; bar: 2e-5 relative
-# (three bf16 products per term: <= 3 * 2^-18 per product; measured ~4e-6)
+# dense 3x3 / 1x1 conv on the bf16 matrix cores with a two-term operand split, fused with its element-wise
+# neighbours: PAConv.k2/.k3/.k4 on cat([x, gather(p, idx)]), qkv / project_in / project_out (+ residual), l_conv on
+# cat([LL, x_d]), h_out_conv, conv_01, last (+ img), ps_down* (reference :690-697, :666/:713, :733-797, :966/:975,
+# :993/:1006, :1015-1037).  Floating-point kernel of standard ops -> the fp64 PyTorch CPU composition is the
+# reference; bar: 2e-5 relative (three bf16 products per term: <= 3 * 2^-18 per product; measured ~4e-6)
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ks", [3, 1])
 @pytest.mark.parametrize("B,Ca,Cb,Cout,H,W,bias", [
     (1, 64, 0, 64, 70, 50, True), (2, 64, 0, 32, 33, 65, False), (1, 32, 32, 32, 40, 96, True),
     (1, 32, 0, 96, 16, 32, True), (1, 3, 0, 32, 40, 64, True), (2, 32, 0, 3, 64, 96, True),
     (1, 16, 8, 40, 5, 7, False), (1, 64, 0, 64, 1, 1, True), (1, 48, 0, 64, 31, 33, False),
-    (1, 64, 0, 64, 160, 256, False)])
-def test_conv3x3_vs_torch(B, Ca, Cb, Cout, H, W, bias):
+    (1, 64, 0, 64, 160, 256, False), (1, 12, 0, 32, 24, 40, True), (1, 192, 0, 32, 9, 17, True)])
+def test_conv2d_vs_torch(ks, B, Ca, Cb, Cout, H, W, bias):
     import torch.nn.functional as F
-    gg = gen(Ca * 100 + Cout + H)
+    gg = gen(Ca * 100 + Cout + H + ks)
     xa = torch.randn(B, Ca, H, W, generator=gg)
     xb = torch.randn(B, Cb, H, W, generator=gg) if Cb else None
-    w = torch.randn(Cout, Ca + Cb, 3, 3, generator=gg) / (3.0 * (Ca + Cb) ** 0.5)
+    w = torch.randn(Cout, Ca + Cb, ks, ks, generator=gg) / (ks * (Ca + Cb) ** 0.5)
     b = torch.randn(Cout, generator=gg) if bias else None
     xin = xa if xb is None else torch.cat([xa, xb], 1)
-    ref = F.conv2d(xin.double(), w.double(), None if b is None else b.double(), padding=1).float()
-    got = wm.ops.conv3x3(*cu(xa, w, b, xb))
-    assert_close(got, ref, 2e-5, f"conv3x3 {(B, Ca, Cb, Cout, H, W)}")
+    ref = F.conv2d(xin.double(), w.double(), None if b is None else b.double(), padding=ks // 2).float()
+    got = wm.ops.conv2d(*cu(xa, w, b, xb))
+    assert_close(got, ref, 2e-5, f"conv2d ks={ks} {(B, Ca, Cb, Cout, H, W)}")
 
 
-def test_conv3x3_weight_update_invalidates_prepared_copy():
+@pytest.mark.parametrize("ks", [3, 1])
+@pytest.mark.parametrize("B,Ca,Csrc,Cb,Cout,H,W", [(1, 32, 32, 32, 64, 24, 40), (2, 32, 32, 32, 64, 9, 33),
+                                                  (2, 16, 24, 8, 32, 17, 31)])
+def test_conv2d_gather_gate_residual(ks, B, Ca, Csrc, Cb, Cout, H, W):
+    """cat([x, gather(p, idx)]) as operand, `* sigmoid(gate)` and `+ residual` in the epilogue: the PAConv /
+    HFEBlock composition of the reference (:666, :694-697, :713, :849-853)."""
+    import torch.nn.functional as F
+    gg = gen(B * 31 + Cb + ks)
+    x = torch.randn(B, Ca, H, W, generator=gg)
+    p = torch.randn(B, Csrc, H, W, generator=gg)
+    idx = torch.randint(0, Csrc, (B, Cb), generator=gg)
+    w = torch.randn(Cout, Ca + Cb, ks, ks, generator=gg) / (ks * (Ca + Cb) ** 0.5)
+    b = torch.randn(Cout, generator=gg)
+    gate = torch.randn(B, Cout, H, W, generator=gg)
+    res = torch.randn(B, Cout, H, W, generator=gg)
+    xin = torch.cat([x, torch.gather(p, 1, idx[:, :, None, None].expand(-1, -1, H, W))], 1)
+    conv = F.conv2d(xin.double(), w.double(), b.double(), padding=ks // 2)
+    xd, wd, bd, pd, idxd, gd, rd = cu(x, w, b, p, idx, gate, res)
+    assert_close(wm.ops.conv2d(xd, wd, bd, pd, idxd), conv.float(), 2e-5, "conv2d gather")
+    assert_close(wm.ops.conv2d(xd, wd, bd, pd, idxd, gate=gd), (conv * torch.sigmoid(gate.double())).float(), 2e-5,
+                 "conv2d gather + gate")
+    assert_close(wm.ops.conv2d(xd, wd, bd, pd, idxd, gate=gd, residual=rd),
+                 (conv * torch.sigmoid(gate.double()) + res.double()).float(), 2e-5, "conv2d gather + gate + residual")
+    assert_close(wm.ops.conv2d(xd, wd, None, pd, idxd, residual=rd),
+                 (F.conv2d(xin.double(), w.double(), None, padding=ks // 2) + res.double()).float(), 2e-5,
+                 "conv2d gather + residual, no bias")
+
+
+def test_conv2d_weight_update_invalidates_prepared_copy():
     import torch.nn.functional as F
     gg = gen(5)
     x = torch.randn(1, 32, 24, 40, generator=gg).to(DEV)
     conv = torch.nn.Conv2d(32, 32, 3, 1, 1).to(DEV)
-    y0 = wm.ops.conv3x3(x, conv.weight, conv.bias)
+    y0 = wm.ops.conv2d(x, conv.weight, conv.bias)
     with torch.no_grad():
         conv.weight.mul_(2.0)                                   # in-place update, as an optimizer step does
-    y1 = wm.ops.conv3x3(x, conv.weight, conv.bias)
+    y1 = wm.ops.conv2d(x, conv.weight, conv.bias)
     ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1).float()
-    assert_close(y1, ref.cpu(), 2e-5, "conv3x3 after in-place weight update")
+    assert_close(y1, ref.cpu(), 2e-5, "conv2d after in-place weight update")
     assert not torch.allclose(y0, y1)

@@ -1,0 +1,13 @@
+#!/bin/bash
+# PMC passes (separate runs per counter group, MI355X_MICROARCH.md) over the dense 3x3 convolution at UHD level 1.
+# Usage: tools/pmc_conv.sh <outdir>
+set -u
+R=$PWD; OUT=$R/$1
+mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
+run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python $R/tools/bench_conv.py one > $OUT/$name.log 2>&1; }
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU
+run sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS
+run sq3 SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_LDS_ADDR_CONFLICT
+cd $R

@@ -64,16 +64,26 @@ def _dwconv(conv, x, act="none"):
     return F.silu(y) if act == "silu" else y
 
 
-def _conv3x3(conv, x, x2=None):
-    """Dense 3x3 nn.Conv2d (stride 1, padding 1) of `cat([x, x2], 1)` (or of `x`).  Inference on the HIP
-    backend goes to the matrix-core kernel (the concatenation is never materialised); training (autograd)
-    and the test backends use the PyTorch conv."""
+def _conv(conv, x, x2=None, x2_index=None, gate=None, residual=None):
+    """Dense 3x3 / 1x1 nn.Conv2d (stride 1, 'same' padding) of X = x | cat([x, x2], 1) |
+    cat([x, gather(x2, 1, x2_index)], 1), then `* sigmoid(gate)` and `+ residual` when given.  Inference on the
+    HIP backend is one matrix-core kernel (no concatenation, gather, bias, gate or residual kernels); training
+    (autograd) and the test backends compose the PyTorch ops."""
     ops = _OpsBackend.impl
-    if (hasattr(ops, "conv3x3") and ops.conv3x3_supported(x, conv.weight, x2)
-            and not (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad
-                                                  or (x2 is not None and x2.requires_grad)))):
-        return ops.conv3x3(x, conv.weight, conv.bias, x2)
-    return conv(x if x2 is None else torch.cat([x, x2], dim=1))
+    if (hasattr(ops, "conv2d") and ops.conv2d_supported(x, conv.weight, x2)
+            and not (torch.is_grad_enabled() and any(t is not None and t.requires_grad
+                                                     for t in (x, x2, gate, residual, conv.weight)))):
+        return ops.conv2d(x, conv.weight, conv.bias, x2, x2_index, gate, residual)
+    if x2 is not None:
+        if x2_index is not None:
+            x2 = torch.gather(x2, 1, x2_index.long()[:, :, None, None].expand(-1, -1, x2.shape[2], x2.shape[3]))
+        x = torch.cat([x, x2], dim=1)
+    y = conv(x)
+    if gate is not None:
+        y = y * torch.sigmoid(gate)
+    if residual is not None:
+        y = y + residual
+    return y
 
 
 # ================================================================================================
@@ -317,10 +327,10 @@ def _gram_ok(a, b):
             and not (torch.is_grad_enabled() and (a.requires_grad or b.requires_grad)))
 
 
-def nearest_candidate_maps(maps, candidates, num_matches):
-    """Channel matching (reference :618-666): for every channel of `maps` (B, C, HW) find its
-    L2-nearest channel of `candidates`; keep the `num_matches` channels whose nearest distance is
-    smallest (original channel order) and return the matched candidate maps (B, num_matches, HW)."""
+def nearest_candidate_index(maps, candidates, num_matches):
+    """Channel matching (reference :618-666): for every channel of `maps` (B, C, HW) the index of its L2-nearest
+    channel of `candidates`; keeps the `num_matches` channels whose nearest distance is smallest (original
+    channel order).  -> (B, num_matches) int64 channel indices into `candidates`."""
     ops = _OpsBackend.impl
     if _gram_ok(maps, candidates):
         # d^2 = |x|^2 + |y|^2 - 2 x.y, the same expansion torch.cdist uses for C > 25 (mm mode)
@@ -335,6 +345,12 @@ def nearest_candidate_maps(maps, candidates, num_matches):
     if num_matches < maps.size(1):
         rank = best_val.argsort(dim=1).argsort(dim=1)               # rank of each channel's distance
         best_idx = best_idx.masked_select(rank < num_matches).reshape(maps.size(0), num_matches)
+    return best_idx
+
+
+def nearest_candidate_maps(maps, candidates, num_matches):
+    """The matched candidate maps themselves: gather(candidates, nearest_candidate_index) -> (B, num_matches, HW)."""
+    best_idx = nearest_candidate_index(maps, candidates, num_matches)
     gather_idx = best_idx.unsqueeze(-1).expand(-1, -1, candidates.size(2))
     return torch.gather(candidates, 1, gather_idx)
 
@@ -351,7 +367,8 @@ class Matching(nn.Module):
 
 
 class PAConv(nn.Module):
-    """Pixel-attention conv: k4(k3(x) * sigmoid(k2(x))) (reference :683-700)."""
+    """Pixel-attention conv: k4(k3(x) * sigmoid(k2(x))) (reference :683-700).  `x` may be given as the pair
+    (x, x2[, x2_index]) standing for cat([x, gather(x2, x2_index)], 1)."""
 
     def __init__(self, nf, k_size=3):
         super().__init__()
@@ -360,13 +377,9 @@ class PAConv(nn.Module):
         self.k3 = nn.Conv2d(nf, nf, kernel_size=k_size, padding=(k_size - 1) // 2, bias=False)
         self.k4 = nn.Conv2d(nf, nf // 2, kernel_size=k_size, padding=(k_size - 1) // 2, bias=False)
 
-    def forward(self, x):
-        ops = _OpsBackend.impl
-        a, g = _conv3x3(self.k3, x), self.k2(x)
-        if (hasattr(ops, "mul_sigmoid") and a.is_cuda and a.dtype == torch.float32 and a.numel() % 4 == 0
-                and not (torch.is_grad_enabled() and a.requires_grad)):
-            return _conv3x3(self.k4, ops.mul_sigmoid(a, g))
-        return _conv3x3(self.k4, a * self.sigmoid(g))
+    def forward(self, x, x2=None, x2_index=None):
+        gate = _conv(self.k2, x, x2, x2_index)
+        return _conv(self.k4, _conv(self.k3, x, x2, x2_index, gate=gate))
 
 
 class Matching_transformation(nn.Module):
@@ -378,7 +391,10 @@ class Matching_transformation(nn.Module):
         self.paconv = PAConv(dim * 2)
 
     def forward(self, x, perception):
-        return self.paconv(torch.cat([x, self.matching(x, perception)], dim=1))
+        # reference :713: paconv(cat([x, matching(x, perception)], 1)); the matched maps are a channel gather of
+        # `perception`, handed to the convolutions as (perception, index)
+        idx = nearest_candidate_index(x.flatten(2), perception.flatten(2), self.num_matching)
+        return self.paconv(x, perception, idx)
 
 
 class FeedForward(nn.Module):
@@ -401,11 +417,11 @@ class FeedForward(nn.Module):
             nn.GELU(),
             nn.Conv2d(hidden, dim, 1, bias=bias))
 
-    def forward(self, x, perception):
-        y = _dwconv(self.project_in[1], self.project_in[0](x))
+    def forward(self, x, perception, residual=None):
+        y = _dwconv(self.project_in[1], _conv(self.project_in[0], x))
         if perception is not None:
             y = self.matching_transformation(y, perception)
-        return self.project_out[2](self.project_out[1](_dwconv(self.project_out[0], y)))
+        return _conv(self.project_out[2], self.project_out[1](_dwconv(self.project_out[0], y)), residual=residual)
 
 
 class CMTAttention(nn.Module):
@@ -425,9 +441,9 @@ class CMTAttention(nn.Module):
             self.matching_transformation = Matching_transformation(
                 dim=dim, match_factor=match_factor, ffn_expansion_factor=ffn_expansion_factor, bias=bias)
 
-    def forward(self, x, perception):
+    def forward(self, x, perception, residual=None):
         b, c, h, w = x.shape
-        q, k, v = _dwconv(self.qkv_dwconv, self.qkv(x)).chunk(3, dim=1)
+        q, k, v = _dwconv(self.qkv_dwconv, _conv(self.qkv, x)).chunk(3, dim=1)
         if self.matching is True:
             q = self.matching_transformation(q, perception)
         heads = self.num_heads
@@ -444,7 +460,7 @@ class CMTAttention(nn.Module):
             kn = F.normalize(k.reshape(b, heads, c // heads, h * w), dim=-1)
             attn = qn @ kn.transpose(-2, -1)
         attn = (attn * self.temperature).softmax(dim=-1)
-        return self.project_out((attn @ v).reshape(b, c, h, w))
+        return _conv(self.project_out, (attn @ v).reshape(b, c, h, w), residual=residual)
 
 
 class HFEBlock(nn.Module):
@@ -468,8 +484,8 @@ class HFEBlock(nn.Module):
 
     def forward(self, x, perception):
         p = self.LayerNorm(perception)
-        x = x + self.attn(self.norm1(x), p)
-        return x + self.ffn(self.norm2(x), p)
+        x = self.attn(self.norm1(x), p, residual=x)              # x + attn(...): the add rides in the 1x1 epilogue
+        return self.ffn(self.norm2(x), p, residual=x)
 
 
 class SKFF(nn.Module):
@@ -536,7 +552,7 @@ class DownFRG(nn.Module):
 
     def forward(self, x, x_d):
         ll, hl, lh, hh = self.dwt(x)
-        low = _run_lfss_stack(self.l_blk, _conv3x3(self.l_conv, ll, x_d))
+        low = _run_lfss_stack(self.l_blk, _conv(self.l_conv, ll, x_d))
         high = self.h_fusion([hl, lh, hh])
         for blk in self.h_blk:
             high = blk(high, low)
@@ -559,7 +575,7 @@ class upFRG(nn.Module):
         for blk in self.h_blk:
             x_h = blk(x_h, low)
         # reference: iwt(cat([x_l, h_out_conv(x_h)], 1)); the pair form skips the concatenation
-        return self.iwt(low, _conv3x3(self.h_out_conv, x_h))
+        return self.iwt(low, _conv(self.h_out_conv, x_h))
 
 
 class UNet(nn.Module):
@@ -581,14 +597,14 @@ class UNet(nn.Module):
 
     def forward(self, x):
         img = x
-        d1, d2, d3 = self.ps_down1(img), self.ps_down2(img), self.ps_down3(img)
-        low, high1 = self.down_group1(_conv3x3(self.conv_01, img), d1)
+        d1, d2, d3 = (_conv(ps[1], ps[0](img)) for ps in (self.ps_down1, self.ps_down2, self.ps_down3))
+        low, high1 = self.down_group1(_conv(self.conv_01, img), d1)
         low, high2 = self.down_group2(low, d2)
         low, high3 = self.down_group3(low, d3)
         low = self.up_group3(low, high3)
         low = self.up_group2(low, high2)
         low = self.up_group1(low, high1)
-        return _conv3x3(self.last, low) + img
+        return _conv(self.last, low, residual=img)
 
 
 @ARCH_REGISTRY.register()

@@ -1,0 +1,282 @@
+// conv2d.hip.h - dense 3x3 (stride 1, zero padding 1) and 1x1 convolutions over NCHW fp32 on the bf16 matrix
+// cores of gfx950, with fp32-class accuracy from a two-term bf16 split of both operands, and the element-wise
+// neighbours of those convolutions in the HFE branch fused into the operand fetch and the epilogue.
+//
+// Reference call sites (the HFE branch and the U-Net plumbing;
+// /root/reference/basicsr/archs/wavemamba_arch.py): PAConv k2 (1x1) / k3 / k4 (:690-697) on
+// cat([x, gather(candidates, idx)]) (:666, :713), CMTAttention.qkv / .project_out (:768-771, :797),
+// FeedForward.project_in[0] / .project_out[2] (:733-742), DownFRG.l_conv on cat([x_LL, x_d]) (:966, :975),
+// upFRG.h_out_conv (:993, :1006), UNet.conv_01 / .last / ps_down* (:1015-1021, :1037).  MIOpen served the 3x3 ones
+// with fp32 Winograd kernels (20 ms of the 70 ms UHD step), hipBLASLt the 1x1 ones, each followed by separate
+// bias / gate / residual / concatenation kernels (profiles/r01/bench_per_step_kernel_breakdown.txt).
+//
+// Arithmetic.  x = x_hi + x_lo + r with x_hi = bf16(x), x_lo = bf16(x - x_hi), |r| <= 2^-18 |x|.  The product
+// w*x is accumulated in fp32 as w_hi*x_hi + w_hi*x_lo + w_lo*x_hi (three `v_mfma_f32_32x32x16_bf16`); the
+// dropped terms are <= 3 * 2^-18 |w*x| per product (measured: 3-4e-6 relative on the output against an fp64
+// convolution, tests/test_gpu_parity.py).  The fp32-input MFMA is exact but runs at 1/16 of the bf16 rate:
+// 0.98 ms for the UHD level-1 64->64 3x3 convolution at 100 % of peak against 0.19 ms for three bf16 MFMAs.
+//
+// Implicit GEMM, M = output channels (32 per MFMA row tile), N = 32 pixels of one image row, K = (tap,
+// 16 input channels).  D[cout][pixel] puts 32 consecutive pixels of one channel in lanes 0-31 of every
+// accumulator register, so NCHW stores are 128-byte runs.  A workgroup (4 waves) owns a (4*RW) x 32 pixel tile
+// and 32*MT output channels: wave w owns RW rows.  Per 16-channel chunk the halo tile is fetched from NCHW with
+// lanes along W, split into bf16 hi/lo in registers and laid out in LDS as four planes [split][k-half][pixel] of
+// 16-byte fragments (a wave's B-operand read is one conflict-free contiguous KiB); the chunk's weights arrive
+// pre-split and fragment-ordered (conv2d_prep_kernel) by LDS-DMA.  Every staged row feeds the KS kernel rows
+// that touch it (B fragments are read once per kx, not once per tap).  Two workgroups share a compute unit
+// (<= 256 registers per wave, <= 80 KB of LDS each): one's fetch / convert / store phases run under the other's
+// MFMA phase.  Measured bound (s_memtime phase stamps): the L1 miss path, ~12 B/clk per compute unit - the
+// 3 cache lines a 34-pixel halo row touches are what a follow-up should cut (sliding window along W).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wm {
+
+using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
+using f32x16_t = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kCvTW = 32;             // tile width in pixels = one MFMA column tile
+
+struct Conv2dArgs {
+    const float* xa;                  // input channels [0, Ca)      (B, Ca, H, W)
+    const float* xb;                  // input channels [Ca, Ca+Cb): (B, Cbsrc, H, W) or null - cat([xa, xb'], 1) fused
+    const int* xb_idx;                // (B, Cb) or null: channel Ca + c is xb[b, xb_idx[b, c]] (torch.gather fused)
+    const uint4* wfrag;               // conv2d_prep_kernel output
+    const float* bias;                // (Cout) or null
+    const float* gate;                // (B, Cout, H, W) or null: out *= sigmoid(gate)
+    const float* res;                 // (B, Cout, H, W) or null: out += res
+    float* y;                         // (B, Cout, H, W)
+    int Ca, Cb, Cbsrc, Cout, H, W;
+    int nch;                          // ceil((Ca + Cb) / 16) input-channel chunks
+    int mtot;                         // ceil(Cout / 32) row tiles in wfrag
+    int mbase;                        // first row tile of this launch
+};
+
+union Frag16 {
+    bf16x8_t v;
+    uint4 u;
+};
+
+// w (Cout, Cin, KS, KS) fp32 -> wfrag[chunk][tap][m][split][lane] x 8 bf16: lane l of fragment (chunk, tap, m)
+// holds w[32 m + (l & 31)][16 chunk + 8 (l >> 5) + j][tap], j = 0..7 (the A-operand layout of
+// v_mfma_f32_32x32x16_bf16); channels beyond Cout / Cin are zero.
+__global__ __launch_bounds__(256) void conv2d_prep_kernel(const float* __restrict__ w, uint4* __restrict__ wfrag,
+                                                          int Cout, int Cin, int taps, int nch, int mtot) {
+    const long long total = (long long)nch * taps * mtot * 2 * 64;
+    for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int lane = (int)(idx & 63), split = (int)((idx >> 6) & 1);
+        long long rest = idx >> 7;
+        const int m = (int)(rest % mtot); rest /= mtot;
+        const int tap = (int)(rest % taps);
+        const int cc = (int)(rest / taps);
+        const int co = m * 32 + (lane & 31), ci0 = cc * 16 + (lane >> 5) * 8;
+        Frag16 f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ci = ci0 + j;
+            const float v = (co < Cout && ci < Cin) ? w[((long long)co * Cin + ci) * taps + tap] : 0.0f;
+            const __bf16 hi = (__bf16)v;
+            f.v[j] = split ? (__bf16)(v - (float)hi) : hi;
+        }
+        wfrag[idx] = f.u;
+    }
+}
+
+template <int KS /*1 or 3*/, int RW /*rows per wave*/, int MT /*32-channel row tiles per launch*/>
+__global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cv_smem[];
+    constexpr int PAD = KS / 2, TAPS = KS * KS;
+    constexpr int PW = kCvTW + 2 * PAD;              // staged row pitch in pixels
+    constexpr int TH = 4 * RW;                       // tile rows per workgroup
+    constexpr int NPIX = (TH + 2 * PAD) * PW;        // staged pixels per chunk
+    constexpr int PIT = (NPIX + 255) / 256;          // staged pixels per thread (x 2 k-halves x 8 channels)
+    constexpr int W_ITEMS = TAPS * MT * 2 * 64;      // 16-byte weight fragments per chunk (a multiple of 64)
+    constexpr int W_IT = (W_ITEMS + 255) / 256;
+    uint4* s_in = reinterpret_cast<uint4*>(cv_smem);                 // [split * 2 + khalf][NPIX]
+    uint4* s_w = reinterpret_cast<uint4*>(cv_smem) + 4 * NPIX;       // [tap][m][split][lane]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // workgroup q runs on XCD q mod 8 (each with a private L2): every XCD gets a contiguous band of row-major tiles
+    const int tiles_x = (a.W + kCvTW - 1) / kCvTW, tiles_y = (a.H + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y, nper = (ntiles + 7) / 8;
+    const int tile = (blockIdx.x & 7) * nper + (blockIdx.x >> 3);
+    if (tile >= ntiles) return;                       // uniform
+    const int w0 = (tile % tiles_x) * kCvTW, h0 = (tile / tiles_x) * TH, b = blockIdx.y;
+    const int H = a.H, W = a.W;
+    const long long HW = (long long)H * W;
+    const float* xa = a.xa + (long long)b * a.Ca * HW;
+    const float* xb = a.xb ? a.xb + (long long)b * a.Cbsrc * HW : a.xa;
+    const int* xb_idx = a.xb_idx ? a.xb_idx + (long long)b * a.Cb : nullptr;
+
+    // the thread's staged pixels: offset inside a channel plane (0 when outside the image: zero padding) - the
+    // same for every chunk, so all per-load address arithmetic is one uniform base plus this 32-bit offset
+    unsigned poff[PIT];
+    bool pok[PIT];
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+        const int p = tid + it * 256;
+        const int pr = p / PW, pc = p - pr * PW;
+        const int h = h0 - PAD + pr, w = w0 - PAD + pc;
+        pok[it] = p < NPIX && h >= 0 && h < H && w >= 0 && w < W;
+        poff[it] = pok[it] ? (unsigned)(h * W + w) : 0u;
+    }
+    float pin[2][PIT][8];
+
+    auto fetch = [&](int cc) {
+        // source plane of each of the chunk's 16 channels first (scalar loads of the gather indices, batched), then
+        // the vector loads.  Padded channels read plane 0 of xa and are zeroed in stage() (masking here would make
+        // the compiler branch around the loads and wait for each one)
+        const float* bj[2][8];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int c0 = cc * 16 + half * 8;                       // first of the 8 channels (wave-uniform)
+            const bool from_a = c0 < a.Ca;
+            const int cl = from_a ? c0 : c0 - a.Ca;                  // channel inside its source
+            const int cn = (from_a ? a.Ca : a.Cb) - cl;              // channels left in that source (may be <= 0)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool cok = j < cn;
+                const int ch = (cok && !from_a && xb_idx) ? xb_idx[cl + j] : cl + j;
+                bj[half][j] = cok ? (from_a ? xa : xb) + (long long)ch * HW : xa;
+            }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int it = 0; it < PIT; ++it) pin[half][it][j] = bj[half][j][poff[it]];
+        // weights: straight to LDS (LDS-DMA, 1 KiB per wave instruction, no staging registers); destination =
+        // wave-uniform base + lane * 16, which is exactly the [tap][m][split][lane] fragment order
+        const uint4* wsrc = a.wfrag + ((long long)cc * TAPS * a.mtot) * 128;
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int item0 = it * 256 + wave * 64;                  // wave-uniform
+            if (W_ITEMS % 256 == 0 || item0 < W_ITEMS) {
+                const int tm = item0 >> 7, tap = tm / MT, m = tm - tap * MT;
+                const uint4* g = wsrc + (tap * a.mtot + a.mbase + m) * 128 + (item0 & 64) + lane;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(s_w + item0), 16, 0, 0);
+            }
+        }
+    };
+
+    auto stage = [&](int cc) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int c0 = cc * 16 + half * 8;
+            const int cn = c0 < a.Ca ? a.Ca - c0 : a.Ca + a.Cb - c0;   // valid channels of this 8-group (uniform)
+#pragma unroll
+            for (int it = 0; it < PIT; ++it) {
+                const int p = tid + it * 256;
+                if (NPIX % 256 == 0 || p < NPIX) {
+                    Frag16 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = (j < cn && pok[it]) ? pin[half][it][j] : 0.0f;
+                        const __bf16 hv = (__bf16)v;
+                        hi.v[j] = hv;
+                        lo.v[j] = (__bf16)(v - (float)hv);
+                    }
+                    s_in[half * NPIX + p] = hi.u;
+                    s_in[(2 + half) * NPIX + p] = lo.u;
+                }
+            }
+        }
+    };
+
+    f32x16_t acc[MT][RW];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.0f;
+
+    const int khalf = lane >> 5, px = lane & 31;
+    for (int cc = 0; cc < a.nch; ++cc) {
+        fetch(cc);
+        stage(cc);
+        __syncthreads();
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            Frag16 Ah[KS][MT], Al[KS][MT];
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    Ah[ky][m].u = s_w[(((ky * KS + kx) * MT + m) * 2 + 0) * 64 + lane];
+                    Al[ky][m].u = s_w[(((ky * KS + kx) * MT + m) * 2 + 1) * 64 + lane];
+                }
+#pragma unroll
+            for (int j = 0; j < RW + 2 * PAD; ++j) {
+                const int pidx = (wave * RW + j) * PW + px + kx;
+                Frag16 Bh, Bl;
+                Bh.u = s_in[khalf * NPIX + pidx];
+                Bl.u = s_in[(2 + khalf) * NPIX + pidx];
+                // the staged row j feeds output row r = j - ky of kernel row ky; one pass per product term so
+                // consecutive MFMAs land on different accumulators
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int ky = 0; ky < KS; ++ky) {
+                        const int r = j - ky;
+                        if (r < 0 || r >= RW) continue;
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                term == 2 ? Al[ky][m].v : Ah[ky][m].v, term == 1 ? Bl.v : Bh.v, acc[m][r], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+
+    // D layout of v_mfma_f32_32x32x*: column = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const int w = w0 + px;
+    const bool full = (a.mbase + MT) * 32 <= a.Cout;                 // uniform: no channel guard on the stores
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int chb = (a.mbase + m) * 32 + 4 * khalf;
+        float bv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ch = chb + (i & 3) + 8 * (i >> 2);
+            bv[i] = (a.bias && ch < a.Cout) ? a.bias[ch] : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int h = h0 + wave * RW + r;
+            if (h >= H || w >= W) continue;
+            const long long o = (((long long)b * a.Cout + chb) * H + h) * W + w;
+            // all gate / residual loads of the 16 channels first, then the stores: y may alias neither, but the
+            // compiler cannot know and would wait for every load before the store that follows it
+            float gv[16], rv[16];
+            if (a.gate) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int dc = (i & 3) + 8 * (i >> 2);
+                    gv[i] = (full || chb + dc < a.Cout) ? a.gate[o + dc * HW] : 0.0f;
+                }
+            }
+            if (a.res) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int dc = (i & 3) + 8 * (i >> 2);
+                    rv[i] = (full || chb + dc < a.Cout) ? a.res[o + dc * HW] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int dc = (i & 3) + 8 * (i >> 2);
+                float v = acc[m][r][i] + bv[i];
+                if (a.gate) v = v / (1.0f + __expf(-gv[i]));
+                if (a.res) v += rv[i];
+                if (full || chb + dc < a.Cout) a.y[o + dc * HW] = v;
+            }
+        }
+    }
+}
+
+}  // namespace wm

@@ -15,7 +15,7 @@
 #include "ss2d.hip.h"
 #include "lfss.hip.h"
 #include "gram.hip.h"
-#include "conv3x3.hip.h"
+#include "conv2d.hip.h"
 
 namespace wm {
 
@@ -256,7 +256,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 3; }
+int wm_abi_version(void) { return 4; }
 
 const char* wm_strerror(int code) {
     switch (code) {
@@ -657,71 +657,74 @@ int wm_layernorm2d_bwd(const float* x, const float* weight, const float* gy, flo
     return launch_status();
 }
 
-size_t wm_conv3x3_wfrag_bytes(int Cout, int Cin) {
-    if (Cout <= 0 || Cin <= 0) return 0;
-    return (size_t)((Cin + 15) / 16) * 9 * ((Cout + 31) / 32) * 2 * 64 * 16;
+size_t wm_conv2d_wfrag_bytes(int Cout, int Cin, int ks) {
+    if (Cout <= 0 || Cin <= 0 || (ks != 1 && ks != 3)) return 0;
+    return (size_t)((Cin + 15) / 16) * ks * ks * ((Cout + 31) / 32) * 2 * 64 * 16;
 }
 
-int wm_conv3x3_prep(const float* weight, void* wfrag, int Cout, int Cin, void* stream) {
+int wm_conv2d_prep(const float* weight, void* wfrag, int Cout, int Cin, int ks, void* stream) {
     if (Cout <= 0 || Cin <= 0) return WM_EINVAL;
+    if (ks != 1 && ks != 3) return WM_EUNSUPPORTED;
     if (!weight || !wfrag) return WM_ENULL;
     if (!aligned16(wfrag)) return WM_EALIGN;
     const int nch = (Cin + 15) / 16, mtot = (Cout + 31) / 32;
-    const long long total = (long long)nch * 9 * mtot * 128;
-    hipLaunchKernelGGL(conv3x3_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       weight, (uint4*)wfrag, Cout, Cin, nch, mtot);
+    const long long total = (long long)nch * ks * ks * mtot * 128;
+    hipLaunchKernelGGL(conv2d_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       weight, (uint4*)wfrag, Cout, Cin, ks * ks, nch, mtot);
     return launch_status();
 }
 
 }  // extern "C"
 
-template <int RW, int MT>
-static int conv3x3_launch(const wm::Conv3x3Args& a, int B, hipStream_t st) {
-    constexpr int smem = ((4 * RW + 2) * wm::kCvPW * 4 + 2 * 9 * MT * 2 * 64) * 16;   // input planes + 2 weight buffers
+template <int KS, int RW, int MT>
+static int conv2d_launch(const wm::Conv2dArgs& a, int B, hipStream_t st) {
+    constexpr int PAD = KS / 2;
+    constexpr int smem = ((4 * RW + 2 * PAD) * (wm::kCvTW + 2 * PAD) * 4 + KS * KS * MT * 2 * 64) * 16;   // input planes + weights
     static bool configured = false;                      // > 64 KB of LDS needs the opt-in, once per instantiation
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)wm::conv3x3_mfma_kernel<RW, MT>,
+    if (!configured && smem > 65536) {
+        hipError_t e = hipFuncSetAttribute((const void*)wm::conv2d_mfma_kernel<KS, RW, MT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    const dim3 grid((unsigned)((a.W + wm::kCvTW - 1) / wm::kCvTW), (unsigned)((a.H + 4 * RW - 1) / (4 * RW)), (unsigned)B);
-    hipLaunchKernelGGL((wm::conv3x3_mfma_kernel<RW, MT>), grid, dim3(256), smem, st, a);
+    const int ntiles = ((a.W + wm::kCvTW - 1) / wm::kCvTW) * ((a.H + 4 * RW - 1) / (4 * RW));
+    const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8), (unsigned)B);
+    hipLaunchKernelGGL((wm::conv2d_mfma_kernel<KS, RW, MT>), grid, dim3(256), smem, st, a);
     return launch_status();
 }
 
 extern "C" {
 
-int wm_conv3x3_fwd(const float* xa, const float* xb, const void* wfrag, const float* bias, float* y, int B, int Ca,
-                   int Cb, int Cout, int H, int W, void* stream) {
-    if (B < 0 || Ca <= 0 || Cb < 0 || Cout <= 0 || H < 0 || W < 0) return WM_EINVAL;
+int wm_conv2d_fwd(const float* xa, const float* xb, const int* xb_index, const void* wfrag, const float* bias,
+                  const float* gate, const float* residual, float* y, int B, int Ca, int Cb, int Cb_src, int Cout,
+                  int H, int W, int ks, void* stream) {
+    if (B < 0 || Ca <= 0 || Cb < 0 || Cout <= 0 || H < 0 || W < 0 || Cb_src < 0) return WM_EINVAL;
+    if (ks != 1 && ks != 3) return WM_EUNSUPPORTED;
     if (B == 0 || H == 0 || W == 0) return WM_OK;
     if (!xa || !wfrag || !y || (Cb > 0 && !xb)) return WM_ENULL;
     if (Cb > 0 && Ca % 8 != 0) return WM_EUNSUPPORTED;   // an 8-channel fragment never straddles the two sources
-    if (B > 65535) return WM_EUNSUPPORTED;
+    if (Cb > 0 && !xb_index && Cb_src != Cb) return WM_EINVAL;
+    if (B > 65535 || (long long)H * W >= (1ll << 31)) return WM_EUNSUPPORTED;
     if (!aligned16(wfrag)) return WM_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    Conv3x3Args a;
-    a.xa = xa; a.xb = Cb > 0 ? xb : nullptr; a.wfrag = (const uint4*)wfrag; a.bias = bias; a.y = y;
-    a.Ca = Ca; a.Cb = Cb; a.Cout = Cout; a.H = H; a.W = W;
+    Conv2dArgs a;
+    a.xa = xa; a.xb = Cb > 0 ? xb : nullptr; a.xb_idx = Cb > 0 ? xb_index : nullptr; a.wfrag = (const uint4*)wfrag;
+    a.bias = bias; a.gate = gate; a.res = residual; a.y = y;
+    a.Ca = Ca; a.Cb = Cb; a.Cbsrc = Cb_src; a.Cout = Cout; a.H = H; a.W = W;
     a.nch = (Ca + Cb + 15) / 16; a.mtot = (Cout + 31) / 32;
-    static const int rw_env = [] { const char* e = getenv("WM_CONV_RW"); return e ? atoi(e) : 0; }();
-    // 8 rows per wave (32 x 32 tile) halves the weight re-staging per pixel; the 16 x 32 tile keeps small maps on
-    // more compute units
-    const long long tiles8 = (long long)B * ((H + 31) / 32) * ((W + wm::kCvTW - 1) / wm::kCvTW);
-    const bool rw8 = rw_env ? rw_env == 8 : tiles8 >= 512;
-    ProfScope ps(13, st);
+    ProfScope ps(ks == 3 ? 13 : 14, st);
     for (int mb = 0; mb < a.mtot;) {
         a.mbase = mb;
         const int left = a.mtot - mb;
         int rc;
-        if (rw8) {
-            if (left >= 2) { rc = conv3x3_launch<8, 2>(a, B, st); mb += 2; }
-            else { rc = conv3x3_launch<8, 1>(a, B, st); mb += 1; }
+        if (ks == 3) {
+            if (left >= 2) { rc = conv2d_launch<3, 4, 2>(a, B, st); mb += 2; }
+            else { rc = conv2d_launch<3, 4, 1>(a, B, st); mb += 1; }
         } else {
-            if (left >= 3) { rc = conv3x3_launch<4, 3>(a, B, st); mb += 3; }
-            else if (left == 2) { rc = conv3x3_launch<4, 2>(a, B, st); mb += 2; }
-            else { rc = conv3x3_launch<4, 1>(a, B, st); mb += 1; }
+            // 1x1 is bandwidth-bound: never read the input twice (3 row tiles in one launch on an 8-row tile)
+            if (left >= 3) { rc = conv2d_launch<1, 2, 3>(a, B, st); mb += 3; }
+            else if (left == 2) { rc = conv2d_launch<1, 4, 2>(a, B, st); mb += 2; }
+            else { rc = conv2d_launch<1, 4, 1>(a, B, st); mb += 1; }
         }
         if (rc) return rc;
     }

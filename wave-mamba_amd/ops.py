@@ -490,8 +490,8 @@ def dwconv3x3(x, weight, bias=None, act="none"):
 _WFRAG_CACHE = {}      # id(weight) -> (weakref, data_ptr, version, wfrag tensor)
 
 
-def _conv3x3_wfrag(weight):
-    """The prepared (bf16-split, fragment-ordered) copy of a (Cout, Cin, 3, 3) weight; rebuilt when the
+def _conv2d_wfrag(weight):
+    """The prepared (bf16-split, fragment-ordered) copy of a (Cout, Cin, ks, ks) weight; rebuilt when the
     parameter is updated in place (`_version`) or re-allocated."""
     import weakref
     key = id(weight)
@@ -499,45 +499,62 @@ def _conv3x3_wfrag(weight):
     if ent is not None and ent[0]() is weight and ent[1] == weight.data_ptr() and ent[2] == weight._version:
         return ent[3]
     lib = _lib.load()
-    cout, cin = weight.shape[:2]
-    frag = torch.empty(lib.wm_conv3x3_wfrag_bytes(cout, cin), dtype=torch.uint8, device=weight.device)
+    cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
+    frag = torch.empty(lib.wm_conv2d_wfrag_bytes(cout, cin, ks), dtype=torch.uint8, device=weight.device)
     with torch.cuda.device(weight.device):
-        check(lib.wm_conv3x3_prep(_ptr(weight.detach().contiguous()), _ptr(frag), cout, cin, _stream()),
-              "wm_conv3x3_prep")
+        check(lib.wm_conv2d_prep(_ptr(weight.detach().contiguous()), _ptr(frag), cout, cin, ks, _stream()),
+              "wm_conv2d_prep")
     _WFRAG_CACHE[key] = (weakref.ref(weight, lambda _r, k=key: _WFRAG_CACHE.pop(k, None)), weight.data_ptr(),
                          weight._version, frag)
     return frag
 
 
-def conv3x3(x, weight, bias=None, x2=None):
-    """F.conv2d(cat([x, x2], 1) if x2 is not None else x, weight, bias, stride=1, padding=1) for a dense
-    (Cout, Cin, 3, 3) weight, NCHW fp32, forward only (no autograd graph is recorded).  bf16 matrix cores with
-    a two-term split of both operands: ~1e-6 relative to the fp32 result."""
+def conv2d(x, weight, bias=None, x2=None, x2_index=None, gate=None, residual=None):
+    """y = F.conv2d(X, weight, bias, stride=1, padding=ks // 2) for a dense (Cout, Cin, ks, ks) weight, ks in
+    {1, 3}, NCHW fp32, where X = x, or cat([x, x2], 1), or cat([x, gather(x2, 1, x2_index)], 1) with x2_index
+    (B, Cb) channel indices into x2; then y *= sigmoid(gate) and y += residual when given.  Forward only (no
+    autograd graph is recorded).  bf16 matrix cores with a two-term split of both operands: 3-4e-6 relative to
+    the fp64 result."""
     lib = _lib.load()
-    _require_cuda("conv3x3", x, weight, bias, x2)
+    _require_cuda("conv2d", x, weight, bias, x2, x2_index, gate, residual)
     B, Ca, H, W = x.shape
-    Cb = 0 if x2 is None else x2.shape[1]
-    if x2 is not None and (x2.shape[0], x2.shape[2], x2.shape[3]) != (B, H, W):
-        raise RuntimeError(f"conv3x3: x2 {tuple(x2.shape)} does not match x {tuple(x.shape)}")
-    cout = weight.shape[0]
-    if tuple(weight.shape) != (cout, Ca + Cb, 3, 3):
-        raise RuntimeError(f"conv3x3: weight must be (Cout, {Ca + Cb}, 3, 3), got {tuple(weight.shape)}")
-    if x.dtype != torch.float32 or weight.dtype != torch.float32 or (x2 is not None and x2.dtype != torch.float32):
-        raise RuntimeError("conv3x3: float32 only")
+    cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
+    if weight.dim() != 4 or weight.shape[3] != ks or ks not in (1, 3):
+        raise RuntimeError(f"conv2d: weight must be (Cout, Cin, ks, ks) with ks in (1, 3), got {tuple(weight.shape)}")
+    cb = cb_src = 0
+    if x2 is not None:
+        if (x2.shape[0], x2.shape[2], x2.shape[3]) != (B, H, W):
+            raise RuntimeError(f"conv2d: x2 {tuple(x2.shape)} does not match x {tuple(x.shape)}")
+        cb_src = x2.shape[1]
+        cb = cb_src if x2_index is None else x2_index.shape[1]
+        if x2_index is not None and (x2_index.shape[0] != B or x2_index.dim() != 2):
+            raise RuntimeError(f"conv2d: x2_index must be (B, Cb), got {tuple(x2_index.shape)}")
+    if cin != Ca + cb:
+        raise RuntimeError(f"conv2d: weight expects {cin} input channels, got {Ca} + {cb}")
+    for t in (x, weight, x2, gate, residual):
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError("conv2d: float32 only")
+    for t, name in ((gate, "gate"), (residual, "residual")):
+        if t is not None and tuple(t.shape) != (B, cout, H, W):
+            raise RuntimeError(f"conv2d: {name} must be {(B, cout, H, W)}, got {tuple(t.shape)}")
     x = x.contiguous()
     x2 = None if x2 is None else x2.contiguous()
-    frag = _conv3x3_wfrag(weight)
+    idx = None if x2_index is None else x2_index.to(torch.int32).contiguous()
+    gate = None if gate is None else gate.contiguous()
+    residual = None if residual is None else residual.contiguous()
+    frag = _conv2d_wfrag(weight)
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        check(lib.wm_conv3x3_fwd(_ptr(x), _ptr(x2), _ptr(frag), _ptr(None if bias is None else bias.detach().contiguous()),
-                                 _ptr(y), B, Ca, Cb, cout, H, W, _stream()), "wm_conv3x3_fwd")
+        check(lib.wm_conv2d_fwd(_ptr(x), _ptr(x2), _ptr(idx), _ptr(frag),
+                                _ptr(None if bias is None else bias.detach().contiguous()), _ptr(gate), _ptr(residual),
+                                _ptr(y), B, Ca, cb, cb_src, cout, H, W, ks, _stream()), "wm_conv2d_fwd")
     return y
 
 
-def conv3x3_supported(x, weight, x2=None):
-    ca = x.shape[1]
+def conv2d_supported(x, weight, x2=None):
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
-            and tuple(weight.shape[2:]) == (3, 3) and (x2 is None or (ca % 8 == 0 and x2.dtype == torch.float32)))
+            and weight.dim() == 4 and tuple(weight.shape[2:]) in ((3, 3), (1, 1)) and x.shape[2] * x.shape[3] < 2 ** 31
+            and (x2 is None or (x.shape[1] % 8 == 0 and x2.dtype == torch.float32)))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -546,7 +563,7 @@ def conv3x3_supported(x, weight, x2=None):
 PROF_KERNELS = ("haar_analysis", "haar_synthesis", "selscan_chunk_reduce", "selscan_carry",
                 "selscan_chunk_scan", "lfss_glue", "ss2d_proj", "dwconv3x3",
                 "ss2d_row_scan", "ss2d_col_scan", "ss2d_row_reduce", "ss2d_col_reduce", "selscan_bwd",
-                "conv3x3")
+                "conv3x3", "conv1x1")
 
 
 def prof_enable(on=True):
