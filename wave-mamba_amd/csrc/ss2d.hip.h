@@ -391,8 +391,8 @@ __global__ __launch_bounds__(64) void ss2d_row_kernel(Ss2dArgs p) {
 #ifndef WM_COL_LB
 #define WM_COL_LB 1
 #endif
-#ifndef WM_COL_WGS
-#define WM_COL_WGS 1024
+#ifndef WM_COL_SLOTS
+#define WM_COL_SLOTS 512     // resident column-scan workgroups: 256 compute units x 2
 #endif
 constexpr int kColT = WM_COLT;  // record rows per LDS batch
 constexpr int kColCH = 2;       // channels per wave
@@ -477,29 +477,49 @@ __global__ __launch_bounds__(64 * kColWaves, WM_COL_LB) void ss2d_col_kernel(Ss2
     float yr[kColCH][kColT];        // previous directions' y (accumulate mode), fetched with u
 
     auto row_of = [&](int tau) { return REV ? H - 1 - tau : tau; };
+    // Loads are unconditional with clamped addresses (a lane outside the map re-reads column W-1, a row past the
+    // segment re-reads its last row; neither is ever used or stored): all 64-bit address arithmetic is done once
+    // here, a fetch is one 32-bit row offset (scalar) added to per-lane bases.  Predicated loads cost 25 instructions
+    // each - 3.1 k cycles per 4-row batch, 30 % of the kernel (s_memtime stamps).
+    const int wcl = min(w, W - 1);
+    const float* xbase[kColCH];
+    const float* ybase[kColCH];
+#pragma unroll
+    for (int c = 0; c < kColCH; ++c) {
+        const long long plane = ((long long)b * p.D + min(d0 + c, p.D - 1)) * H * (long long)W + wcl;
+        xbase[c] = p.x + plane;
+        ybase[c] = p.y + plane;
+    }
+    const float* rbase[NR4];       // the thread's float4 slots of a batch: record row 0 of the tile, clamped column
+    int rrow[NR4];                 // batch row of slot j
+    bool rused[NR4];
+#pragma unroll
+    for (int j = 0; j < NR4; ++j) {
+        const int f = min((int)threadIdx.x + NTH * j, kColT * 64 * kRS / 4 - 1);
+        const int i = f / (64 * kRS / 4);
+        const int fr = f - i * (64 * kRS / 4);
+        const int col = (4 * fr) / kRS, within = 4 * fr - col * kRS;
+        rrow[j] = i;
+        // the reduce phase never reads C: skip the last 64 B of every 144-B record
+        rused[j] = (PHASE == 3 || within < kRecPad + NP) && w0 + col < W;
+        rbase[j] = recb + (long long)(w0 + min(col, W - 1 - w0)) * kRS + within;
+    }
     auto fetch = [&](int tau0) {
 #pragma unroll
         for (int j = 0; j < NR4; ++j) {
-            const int f = threadIdx.x + NTH * j;                     // float4 index in the batch
-            const int i = f / (64 * kRS / 4);                         // batch row
-            const int fr = f - i * (64 * kRS / 4);
-            const int col = (4 * fr) / kRS;
-            rr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            // the reduce phase never reads C: skip the last 64 B of every 144-B record
-            const bool used = PHASE == 3 || (4 * fr - col * kRS) < kRecPad + NP;
-            if (i < kColT && tau0 + i < tau_end && w0 + col < W && used)
-                rr[j] = *reinterpret_cast<const float4*>(recb + ((long long)row_of(tau0 + i) * W + w0) * kRS + 4 * fr);
+            const int row = row_of(min(tau0 + rrow[j], tau_end - 1));
+            const float4 v = *reinterpret_cast<const float4*>(rbase[j] + (long long)row * W * kRS);
+            rr[j] = rused[j] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int c = 0; c < kColCH; ++c)
+        for (int i = 0; i < kColT; ++i) {
+            const long long roff = (long long)row_of(min(tau0 + i, tau_end - 1)) * W;      // wave-uniform
 #pragma unroll
-            for (int i = 0; i < kColT; ++i)
-            {
-                const bool ok = colok && chok[c] && tau0 + i < tau_end;
-                const long long off = (((long long)b * p.D + d0 + c) * H + row_of(tau0 + i)) * W + w;
-                ur[c][i] = ok ? p.x[off] : 0.0f;
-                yr[c][i] = (PHASE == 3 && ok && p.accumulate) ? p.y[off] : 0.0f;
+            for (int c = 0; c < kColCH; ++c) {
+                ur[c][i] = xbase[c][roff];
+                yr[c][i] = (PHASE == 3 && p.accumulate) ? ybase[c][roff] : 0.0f;
             }
+        }
     };
 
     fetch(tau_begin);

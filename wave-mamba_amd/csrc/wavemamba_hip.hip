@@ -199,13 +199,24 @@ static int ss2d_plan(Ss2dPlan& pl, int B, int D, int H, int W, int N, int R) {
     pl.row_nchunks = (int)((L + cl - 1) / cl);
     // column directions: one 16-wave workgroup per (64-column tile, segment, batch, 32-channel group)
     const int coltiles = (W + 63) / 64, cgroups = (D + kColCH * kColWaves - 1) / (kColCH * kColWaves);
-    // workgroups wanted: fewer, longer segments on small maps (per-workgroup prologue dominates there)
-    const long long want_wgs = L >= (1LL << 20) ? WM_COL_WGS : WM_COL_WGS / 2;
-    long long nseg = (want_wgs + (long long)coltiles * B * cgroups - 1) / ((long long)coltiles * B * cgroups);
-    if (nseg < 1) nseg = 1;
-    long long sl = (H + nseg - 1) / nseg;
-    sl = ((sl + kColT - 1) / kColT) * kColT;
-    if (sl < 16) sl = 16;
+    // segments per column: all workgroups do the same work and WM_COL_SLOTS of them are resident at once (two per
+    // compute unit: 240 registers, 36 KB of LDS), so the launch takes ceil(workgroups / slots) rounds of one
+    // segment each - pick the count that minimises rounds x (segment rows + a per-workgroup prologue / epilogue
+    // worth ~24 rows).  A fixed target count left the last round of the UHD level-1 / level-2 launches 34 % / 17 % full.
+    long long sl = H;
+    {
+        double best = 1e30;
+        for (int n = 1; n <= 64; ++n) {
+            long long s_rows = (H + n - 1) / n;
+            s_rows = ((s_rows + kColT - 1) / kColT) * kColT;
+            if (s_rows < 16) s_rows = 16;
+            const long long nn = (H + s_rows - 1) / s_rows;
+            const long long wgs = (((long long)coltiles * nn * B + 7) / 8) * 8 * cgroups;
+            const long long rounds = (wgs + WM_COL_SLOTS - 1) / WM_COL_SLOTS;
+            const double cost = (double)rounds * (double)(s_rows + 24);
+            if (cost < best * 0.999) { best = cost; sl = s_rows; }
+        }
+    }
     pl.col_seg = (int)sl;
     pl.col_nseg = (int)((H + sl - 1) / sl);
     pl.col_nchunks = (long long)W * pl.col_nseg;
