@@ -130,7 +130,7 @@ int wm_ss2d_core_fwd(const float* x, const float* x_proj_weight, const float* dt
  * Depth-wise 3x3 convolution, stride 1, zero padding 1, + bias, + optional SiLU.
  * Replaces nn.Conv2d(groups=channels) + nn.SiLU of SS2D (wavemamba_arch.py:346-355, :487) and the
  * ffn's conv2 (:220, :226) in LFSSBlock.  x, y (B, C, H, W) fp32; weight (C, 1, 3, 3); bias (C) or
- * NULL; act: 0 = none, 1 = SiLU.  Forward only (training keeps the autograd conv).
+ * NULL; act: 0 = none, 1 = SiLU, 2 = GELU (exact erf form).  Forward only (training keeps the autograd conv).
  * -------------------------------------------------------------------------------------------- */
 int wm_dwconv3x3_fwd(const float* x, const float* weight, const float* bias, float* y,
                      int B, int C, int H, int W, int act, void* stream);
@@ -210,6 +210,24 @@ int wm_conv2d_fwd(const float* xa, const float* xb, const int* xb_index, const v
                   const float* gate, const float* residual, float* y, int B, int Ca, int Cb, int Cb_src, int Cout,
                   int H, int W, int ks, void* stream);
 
+/* Small-tensor steps of the HFE branch as single kernels (csrc/hfe.hip.h).  Forward only.
+ *   wm_match_index   channel matching with every channel kept (wavemamba_arch.py:659-666, match_factor = 1):
+ *                    index[b, c] = argmin_j (nx[b, c] + ny[b, j] - 2 G[b, c, j]) from wm_gram_fwd's outputs; (B, C) int32.
+ *   wm_attn_fold     transposed attention folded into its output projection (:787-797): Wout[b] (C, C) =
+ *                    Wpo (C, C) @ blockdiag_h softmax_j(G[b, h] / (max(|q_i|, 1e-12) max(|k_j|, 1e-12)) * temperature[h]);
+ *                    G (B * heads, C / heads, C / heads), nq / nk (B * heads, C / heads) squared norms.  C <= 64.
+ *                    project_out(attn @ v) is then the 1x1 convolution of v with Wout[b] (+ project_out's bias).
+ *   wm_skff_fwd      SKFF of three sub-bands (:937-959): out = sum_i softmax_i(Wfc[i] prelu(Wdu mean(x0 + x1 + x2))) x_i.
+ *                    x_i, out (B, C, H, W); Wdu (d, C); prelu (1); Wfc (3, C, d); C <= 64, d <= 16; workspace
+ *                    wm_skff_workspace_bytes(B, C) bytes. */
+int wm_match_index(const float* G, const float* nx, const float* ny, int* index, int B, int C, void* stream);
+int wm_attn_fold(const float* G, const float* nq, const float* nk, const float* temperature, const float* Wpo,
+                 float* Wout, int B, int C, int heads, void* stream);
+size_t wm_skff_workspace_bytes(int B, int C);
+int wm_skff_fwd(const float* x0, const float* x1, const float* x2, const float* Wdu, const float* prelu,
+                const float* Wfc, float* out, void* workspace, size_t workspace_bytes, int B, int C, int d, int H, int W,
+                void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * Profiling hooks used by bench.py (HIP events recorded on the launch stream around each kernel
  * class).  Disabled by default; when disabled the library records nothing.
@@ -217,14 +235,14 @@ int wm_conv2d_fwd(const float* xa, const float* xb, const int* xb_index, const v
  *               2 scan chunk-reduce, 3 scan carry, 4 scan chunk-scan (drop-in op), 5 lfss glue (in/mid/out),
  *               6 ss2d projection, 7 depth-wise conv, 8 ss2d row chunk-scan, 9 ss2d col chunk-scan,
  *               10 ss2d row chunk-reduce, 11 ss2d col chunk-reduce, 12 selective-scan backward (all phases),
- *               13 dense 3x3 convolution, 14 1x1 convolution
+ *               13 dense 3x3 convolution, 14 1x1 convolution, 15 SKFF (all three kernels)
  * wm_prof_enable(mask): bit k of `mask` switches recording for kernel id k (0 = off, ~0u = every class);
  * a non-zero mask also clears what was recorded before.  Two hipEventRecord calls cost ~10 us of stream
  * time per launch, so a caller timing a whole step enables only the classes it needs.
  * wm_prof_collect synchronises the recorded events (host-blocking) and returns, per kernel id,
  * the number of launches and their summed duration in milliseconds since the last wm_prof_enable(mask != 0).
  * -------------------------------------------------------------------------------------------- */
-#define WM_PROF_NKERNELS 15
+#define WM_PROF_NKERNELS 16
 void wm_prof_enable(unsigned mask);
 int wm_prof_collect(int* launches /*[WM_PROF_NKERNELS]*/, double* total_ms /*[WM_PROF_NKERNELS]*/);
 

@@ -601,3 +601,66 @@ def test_conv2d_weight_update_invalidates_prepared_copy():
     ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1).float()
     assert_close(y1, ref.cpu(), 2e-5, "conv2d after in-place weight update")
     assert not torch.allclose(y0, y1)
+
+
+# ------------------------------------------------------------------------------------------------
+# small-tensor HFE kernels (csrc/hfe.hip.h) against the PyTorch composition of the reference
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,C,L", [(1, 32, 4096), (2, 32, 777), (3, 8, 64)])
+def test_match_index_vs_cdist_topk(B, C, L):
+    """reference :659-666 with every channel kept: nearest candidate channel under the L2 distance."""
+    gg = gen(B * 7 + C)
+    x = torch.randn(B, C, L, generator=gg)
+    p = torch.randn(B, C, L, generator=gg)
+    p[:, 3] = x[:, 5] + 1e-3 * torch.randn(B, L, generator=gg)      # an unambiguous nearest pair
+    ref = torch.cdist(x.double(), p.double()).topk(k=1, largest=False)[1].squeeze(-1)
+    G, nx, ny = wm.ops.gram(*cu(x, p))
+    got = wm.ops.match_index(G, nx, ny).cpu().long()
+    assert torch.equal(got, ref)
+    assert got[0, 5] == 3
+
+
+@pytest.mark.parametrize("B,C,heads,L", [(1, 32, 1, 2000), (2, 32, 2, 640), (1, 64, 4, 333)])
+def test_attn_fold_vs_reference_composition(B, C, heads, L):
+    """project_out(softmax(normalize(q) @ normalize(k)^T * temperature) @ v), reference :787-797."""
+    import torch.nn.functional as F
+    gg = gen(C + heads)
+    ch = C // heads
+    q = torch.randn(B * heads, ch, L, generator=gg)
+    k = torch.randn(B * heads, ch, L, generator=gg)
+    v = torch.randn(B, C, L, generator=gg)
+    temp = torch.rand(heads, generator=gg) + 0.5
+    wpo = torch.randn(C, C, 1, 1, generator=gg) / C ** 0.5
+    qn = F.normalize(q.double().reshape(B, heads, ch, L), dim=-1)
+    kn = F.normalize(k.double().reshape(B, heads, ch, L), dim=-1)
+    attn = ((qn @ kn.transpose(-2, -1)) * temp.double().view(1, heads, 1, 1)).softmax(dim=-1)
+    ref = torch.einsum("oc,bcl->bol", wpo.double().view(C, C), (attn @ v.double().reshape(B, heads, ch, L)).reshape(B, C, L))
+    G, nq, nk = wm.ops.gram(*cu(q, k))
+    wf = wm.ops.attn_fold(G, nq, nk, temp.to(DEV), wpo.to(DEV), B, heads)
+    got = torch.einsum("boc,bcl->bol", wf.double().cpu(), v.double())
+    assert_close(got.float(), ref.float(), 2e-5, "attention folded into project_out")
+
+
+@pytest.mark.parametrize("B,C,H,W", [(1, 32, 40, 72), (2, 32, 17, 23), (1, 16, 8, 8)])
+def test_skff_vs_module_path(B, C, H, W):
+    torch.manual_seed(11)
+    m = arch.SKFF(C, height=3, reduction=8).eval()
+    with torch.no_grad():
+        m.conv_du[1].weight.fill_(0.2)
+    feats = [torch.randn(B, C, H, W, generator=gen(i + 3)) for i in range(3)]
+    with torch.no_grad():
+        ref = m.double()([f.double() for f in feats]).float()      # CPU: no ops backend kernel applies -> PyTorch path
+        got = m.float().to(DEV)([f.to(DEV) for f in feats])
+    assert_close(got, ref, 1e-5, "SKFF")
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 33, 47), (2, 5, 7, 9)])
+def test_dwconv3x3_gelu(shape):
+    import torch.nn.functional as F
+    B, C, H, W = shape
+    gg = gen(W)
+    x = torch.randn(*shape, generator=gg)
+    w = torch.randn(C, 1, 3, 3, generator=gg) * 0.3
+    b = torch.randn(C, generator=gg)
+    ref = F.gelu(F.conv2d(x.double(), w.double(), b.double(), padding=1, groups=C)).float()
+    assert_close(wm.ops.dwconv3x3(*cu(x, w, b), "gelu"), ref, 1e-5, "dwconv + gelu")

@@ -9,8 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WAVEMAMBA_HIP_LIB") or os.path.join(HERE, "libwavemamba_hip.so")  # env: A/B builds
 
 WM_F32, WM_BF16 = 0, 1
-WM_PROF_NKERNELS = 15
-ABI_VERSION = 4
+WM_PROF_NKERNELS = 16
+ABI_VERSION = 5
 
 _c = ctypes
 _p, _i, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
@@ -39,6 +39,10 @@ SIGNATURES = {
     "wm_dwconv3x3_wgrad": (_i, [_p] * 4 + [_i] * 4 + [_p]),
     "wm_layernorm2d_bwd": (_i, [_p, _p, _p, _c.c_float, _p, _p, _p, _i, _i64, _i, _p]),
     "wm_dwconv3x3_fwd": (_i, [_p] * 4 + [_i] * 5 + [_p]),
+    "wm_match_index": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "wm_attn_fold": (_i, [_p] * 6 + [_i, _i, _i, _p]),
+    "wm_skff_workspace_bytes": (_sz, [_i, _i]),
+    "wm_skff_fwd": (_i, [_p] * 7 + [_p, _sz] + [_i] * 5 + [_p]),
     "wm_conv2d_wfrag_bytes": (_sz, [_i, _i, _i]),
     "wm_conv2d_prep": (_i, [_p, _p, _i, _i, _i, _p]),
     "wm_conv2d_fwd": (_i, [_p] * 8 + [_i] * 8 + [_p]),

@@ -52,16 +52,16 @@ def get_ops_backend():
 
 
 def _dwconv(conv, x, act="none"):
-    """Depth-wise 3x3 nn.Conv2d (+ optional SiLU).  Inference on the HIP backend goes to the
+    """Depth-wise 3x3 nn.Conv2d (+ optional SiLU / exact GELU).  Inference on the HIP backend goes to the
     streaming HIP kernel; training (autograd) and the test backends use the PyTorch conv."""
     ops = _OpsBackend.impl
     if hasattr(ops, "dwconv3x3") and x.is_cuda and x.dtype == torch.float32:
         if not (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)):
             return ops.dwconv3x3(x, conv.weight, conv.bias, act)
         y = ops.dwconv3x3_train(x, conv.weight, conv.bias)          # HIP forward + backward (autograd)
-        return F.silu(y) if act == "silu" else y
-    y = conv(x)
-    return F.silu(y) if act == "silu" else y
+    else:
+        y = conv(x)
+    return F.silu(y) if act == "silu" else F.gelu(y) if act == "gelu" else y
 
 
 def _conv(conv, x, x2=None, x2_index=None, gate=None, residual=None):
@@ -335,6 +335,8 @@ def nearest_candidate_index(maps, candidates, num_matches):
     if _gram_ok(maps, candidates):
         # d^2 = |x|^2 + |y|^2 - 2 x.y, the same expansion torch.cdist uses for C > 25 (mm mode)
         G, nx, ny = ops.gram(maps, candidates)
+        if hasattr(ops, "match_index") and (num_matches is None or num_matches == -1 or num_matches >= maps.size(1)):
+            return ops.match_index(G, nx, ny)                       # every channel kept: one argmin kernel
         dist = (nx.unsqueeze(2) + ny.unsqueeze(1) - 2.0 * G).clamp_min(1e-30).sqrt()
     else:
         dist = torch.cdist(maps, candidates)                        # (B, C, C)
@@ -351,7 +353,7 @@ def nearest_candidate_index(maps, candidates, num_matches):
 def nearest_candidate_maps(maps, candidates, num_matches):
     """The matched candidate maps themselves: gather(candidates, nearest_candidate_index) -> (B, num_matches, HW)."""
     best_idx = nearest_candidate_index(maps, candidates, num_matches)
-    gather_idx = best_idx.unsqueeze(-1).expand(-1, -1, candidates.size(2))
+    gather_idx = best_idx.long().unsqueeze(-1).expand(-1, -1, candidates.size(2))
     return torch.gather(candidates, 1, gather_idx)
 
 
@@ -421,7 +423,8 @@ class FeedForward(nn.Module):
         y = _dwconv(self.project_in[1], _conv(self.project_in[0], x))
         if perception is not None:
             y = self.matching_transformation(y, perception)
-        return _conv(self.project_out[2], self.project_out[1](_dwconv(self.project_out[0], y)), residual=residual)
+        # project_out = [depth-wise 3x3, GELU, 1x1]: the GELU rides in the depth-wise kernel
+        return _conv(self.project_out[2], _dwconv(self.project_out[0], y, act="gelu"), residual=residual)
 
 
 class CMTAttention(nn.Module):
@@ -450,9 +453,20 @@ class CMTAttention(nn.Module):
         q = q.reshape(b * heads, c // heads, h * w)
         k = k.reshape(b * heads, c // heads, h * w)
         v = v.reshape(b, heads, c // heads, h * w)
+        ops = _OpsBackend.impl
         if _gram_ok(q, k):
             # normalize(q) @ normalize(k)^T == (q @ k^T) / (max(|q|, eps) max(|k|, eps)): one pass over q, k
-            G, nq, nk = _OpsBackend.impl.gram(q.contiguous(), k.contiguous())
+            G, nq, nk = ops.gram(q.contiguous(), k.contiguous())
+            if (hasattr(ops, "attn_fold") and c <= 64 and ops.conv2d_supported(x, self.project_out.weight)
+                    and not (torch.is_grad_enabled() and any(t.requires_grad for t in self.parameters()))):
+                # project_out(softmax(...) @ v) = (W_po @ blockdiag(attn)) @ v: a tiny kernel folds the (c/heads)^2
+                # attention into the 1x1 weight, the 1x1 convolution kernel applies it (+ bias, + residual)
+                wf = ops.attn_fold(G, nq, nk, self.temperature.reshape(heads), self.project_out.weight, b, heads)
+                vv = v.reshape(b, c, h, w)
+                outs = [ops.conv2d(vv[i:i + 1], wf[i].view(c, c, 1, 1), self.project_out.bias,
+                                   residual=None if residual is None else residual[i:i + 1], dynamic_weight=True)
+                        for i in range(b)]
+                return outs[0] if b == 1 else torch.cat(outs, 0)
             scale = nq.sqrt().clamp_min(1e-12).unsqueeze(2) * nk.sqrt().clamp_min(1e-12).unsqueeze(1)
             attn = (G / scale).reshape(b, heads, c // heads, c // heads)
         else:
@@ -503,6 +517,14 @@ class SKFF(nn.Module):
 
     def forward(self, inp_feats):
         b, c = inp_feats[0].shape[:2]
+        ops = _OpsBackend.impl
+        x0 = inp_feats[0]
+        if (hasattr(ops, "skff") and self.height == 3 and len(inp_feats) == 3 and x0.is_cuda and x0.dtype == torch.float32
+                and c <= 64 and self.conv_du[0].weight.shape[0] <= 16 and self.conv_du[1].weight.numel() == 1
+                and not (torch.is_grad_enabled() and (any(t.requires_grad for t in inp_feats)
+                                                      or any(p.requires_grad for p in self.parameters())))):
+            w_fc = torch.stack([fc.weight.reshape(c, -1) for fc in self.fcs], 0)      # (3, C, d)
+            return ops.skff(inp_feats[0], inp_feats[1], inp_feats[2], self.conv_du[0].weight, self.conv_du[1].weight, w_fc)
         stack = torch.stack(list(inp_feats), dim=1)                    # (B, height, C, H, W)
         squeeze = self.conv_du(self.avg_pool(stack.sum(dim=1)))
         weights = torch.cat([fc(squeeze) for fc in self.fcs], dim=1).view(b, self.height, c, 1, 1)

@@ -18,7 +18,10 @@ constexpr int kDwRows = 16;     // output rows per thread strip
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
 
-template <int ACT /*0 none, 1 silu*/, bool VEC>
+// exact (erf) GELU, nn.GELU() default: FeedForward.project_out[1] after its depth-wise conv (reference :739-741)
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+template <int ACT /*0 none, 1 silu, 2 gelu*/, bool VEC>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ wgt,
                                                         const float* __restrict__ bias,
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
                     acc = fmaf(k[0], r0[j], acc); acc = fmaf(k[1], r0[j + 1], acc); acc = fmaf(k[2], r0[j + 2], acc);
                     acc = fmaf(k[3], r1[j], acc); acc = fmaf(k[4], r1[j + 1], acc); acc = fmaf(k[5], r1[j + 2], acc);
                     acc = fmaf(k[6], r2[j], acc); acc = fmaf(k[7], r2[j + 1], acc); acc = fmaf(k[8], r2[j + 2], acc);
-                    o[j] = ACT == 1 ? silu_f(acc) : acc;
+                    o[j] = ACT == 1 ? silu_f(acc) : ACT == 2 ? gelu_f(acc) : acc;
                 }
                 if (colok) {
                     if constexpr (VEC) {

@@ -16,6 +16,7 @@
 #include "lfss.hip.h"
 #include "gram.hip.h"
 #include "conv2d.hip.h"
+#include "hfe.hip.h"
 
 namespace wm {
 
@@ -267,7 +268,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 4; }
+int wm_abi_version(void) { return 5; }
 
 const char* wm_strerror(int code) {
     switch (code) {
@@ -474,7 +475,7 @@ int wm_selscan_bwd(const float* u, const float* delta, const float* A, const flo
 int wm_dwconv3x3_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int C,
                      int H, int W, int act, void* stream) {
     if (B < 0 || C < 0 || H < 0 || W < 0) return WM_EINVAL;
-    if (act != 0 && act != 1) return WM_EUNSUPPORTED;
+    if (act < 0 || act > 2) return WM_EUNSUPPORTED;
     const long long planes = (long long)B * C;
     if (planes == 0 || H == 0 || W == 0) return WM_OK;
     if (!x || !weight || !y) return WM_ENULL;
@@ -486,6 +487,7 @@ int wm_dwconv3x3_fwd(const float* x, const float* weight, const float* bias, flo
     ProfScope ps(7, st);
 #define WM_DW(ACT, VEC) hipLaunchKernelGGL((dwconv3x3_kernel<ACT, VEC>), grid, block, 0, st, x, weight, bias, y, C, H, W, planes)
     if (act == 1) { if (vec) WM_DW(1, true); else WM_DW(1, false); }
+    else if (act == 2) { if (vec) WM_DW(2, true); else WM_DW(2, false); }
     else          { if (vec) WM_DW(0, true); else WM_DW(0, false); }
 #undef WM_DW
     return launch_status();
@@ -597,9 +599,14 @@ int wm_gram_fwd(const float* X, const float* Y, float* G, float* nx, float* ny, 
     if (!X || !Y || !G || !nx || !ny) return WM_ENULL;
     if (!aligned16(X) || !aligned16(Y)) return WM_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(G, 0, (size_t)B * C * C * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(nx, 0, (size_t)B * C * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(ny, 0, (size_t)B * C * sizeof(float), st);
+    hipError_t e;
+    if (nx == G + (size_t)B * C * C && ny == nx + (size_t)B * C) {          // one allocation: one fill
+        e = hipMemsetAsync(G, 0, (size_t)B * C * (C + 2) * sizeof(float), st);
+    } else {
+        e = hipMemsetAsync(G, 0, (size_t)B * C * C * sizeof(float), st);
+        if (e == hipSuccess) e = hipMemsetAsync(nx, 0, (size_t)B * C * sizeof(float), st);
+        if (e == hipSuccess) e = hipMemsetAsync(ny, 0, (size_t)B * C * sizeof(float), st);
+    }
     if (e != hipSuccess) return (int)e;
     if (L == 0) return WM_OK;
     long long waves = (L + 511) / 512;                         // >= 512 positions per wave
@@ -665,6 +672,56 @@ int wm_layernorm2d_bwd(const float* x, const float* weight, const float* gy, flo
     if (C == 32) hipLaunchKernelGGL((layernorm2d_bwd_kernel<32>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
     else if (C == 16) hipLaunchKernelGGL((layernorm2d_bwd_kernel<16>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
     else hipLaunchKernelGGL((layernorm2d_bwd_kernel<8>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
+    return launch_status();
+}
+
+int wm_match_index(const float* G, const float* nx, const float* ny, int* index, int B, int C, void* stream) {
+    if (B < 0 || C < 0) return WM_EINVAL;
+    if (B == 0 || C == 0) return WM_OK;
+    if (!G || !nx || !ny || !index) return WM_ENULL;
+    hipLaunchKernelGGL(match_argmin_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, G, nx, ny, index, C);
+    return launch_status();
+}
+
+int wm_attn_fold(const float* G, const float* nq, const float* nk, const float* temperature, const float* Wpo,
+                 float* Wout, int B, int C, int heads, void* stream) {
+    if (B < 0 || C <= 0 || heads <= 0 || C % heads != 0) return WM_EINVAL;
+    if (C > 64) return WM_EUNSUPPORTED;
+    if (B == 0) return WM_OK;
+    if (!G || !nq || !nk || !temperature || !Wpo || !Wout) return WM_ENULL;
+    hipLaunchKernelGGL(attn_fold_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, G, nq, nk, temperature,
+                       Wpo, Wout, C, heads);
+    return launch_status();
+}
+
+size_t wm_skff_workspace_bytes(int B, int C) { return (B <= 0 || C <= 0) ? 0 : (size_t)B * C * 4 * sizeof(float); }
+
+int wm_skff_fwd(const float* x0, const float* x1, const float* x2, const float* Wdu, const float* prelu,
+                const float* Wfc, float* out, void* workspace, size_t workspace_bytes, int B, int C, int d, int H, int W,
+                void* stream) {
+    if (B < 0 || C <= 0 || d <= 0 || H < 0 || W < 0) return WM_EINVAL;
+    if (C > 64 || d > 16) return WM_EUNSUPPORTED;
+    if (B == 0 || H == 0 || W == 0) return WM_OK;
+    if (!x0 || !x1 || !x2 || !Wdu || !prelu || !Wfc || !out || !workspace) return WM_ENULL;
+    if (workspace_bytes < wm_skff_workspace_bytes(B, C)) return WM_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* sums = (float*)workspace;                     // (B, C)
+    float* wts = sums + (size_t)B * C;                   // (B, 3, C)
+    hipError_t e = hipMemsetAsync(sums, 0, (size_t)B * C * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    const long long HW = (long long)H * W, planes = (long long)B * C;
+    if (planes > 65535) return WM_EUNSUPPORTED;
+    const bool vec = (HW % 4 == 0) && aligned16(x0) && aligned16(x1) && aligned16(x2) && aligned16(out);
+    long long bpp = (HW / 4 + 256 * 8 - 1) / (256 * 8);              // >= 8 float4 per thread
+    const long long cap = (256 * 16 + planes - 1) / planes;          // ~16 blocks per compute unit in flight
+    if (bpp > cap) bpp = cap;
+    if (bpp < 1) bpp = 1;
+    const dim3 grid((unsigned)bpp, (unsigned)planes), block(256);
+    ProfScope ps(15, st);
+    hipLaunchKernelGGL(chansum3_kernel, grid, block, 0, st, x0, x1, x2, sums, HW, vec);
+    hipLaunchKernelGGL(skff_weights_kernel, dim3((unsigned)B), dim3(64), 0, st, sums, Wdu, prelu, Wfc, wts, C, d,
+                       (float)(1.0 / (double)HW));
+    hipLaunchKernelGGL(skff_apply_kernel, grid, block, 0, st, x0, x1, x2, wts, out, C, HW, vec);
     return launch_status();
 }
 

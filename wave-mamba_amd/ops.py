@@ -384,9 +384,10 @@ def gram(x, y):
     if y.shape != x.shape or C > 32 or x.dtype != torch.float32 or y.dtype != torch.float32:
         raise NotImplementedError("gram: two fp32 (B, C<=32, L) tensors of equal shape")
     x, y = x.contiguous(), y.contiguous()
-    G = torch.empty((B, C, C), dtype=torch.float32, device=x.device)
-    nx = torch.empty((B, C), dtype=torch.float32, device=x.device)
-    ny = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    buf = torch.empty(B * C * (C + 2), dtype=torch.float32, device=x.device)      # one allocation: one fill in the library
+    G = buf[:B * C * C].view(B, C, C)
+    nx = buf[B * C * C:B * C * (C + 1)].view(B, C)
+    ny = buf[B * C * (C + 1):].view(B, C)
     with torch.cuda.device(x.device):
         check(lib.wm_gram_fwd(_ptr(x), _ptr(y), _ptr(G), _ptr(nx), _ptr(ny), B, C, L, _stream()), "wm_gram_fwd")
     return G, nx, ny
@@ -469,7 +470,7 @@ def mul_sigmoid(a, b):
 # depth-wise 3x3 convolution (+ bias, + SiLU) - inference path of SS2D.conv2d / ffn.conv2
 # ------------------------------------------------------------------------------------------------
 def dwconv3x3(x, weight, bias=None, act="none"):
-    """F.conv2d(x, weight, bias, stride=1, padding=1, groups=C) [+ SiLU when act == 'silu'] for a
+    """F.conv2d(x, weight, bias, stride=1, padding=1, groups=C) [+ SiLU / exact GELU when act == 'silu' / 'gelu'] for a
     (C, 1, 3, 3) weight, NCHW fp32, forward only (no autograd graph is recorded)."""
     lib = _lib.load()
     _require_cuda("dwconv3x3", x, weight, bias)
@@ -483,19 +484,65 @@ def dwconv3x3(x, weight, bias=None, act="none"):
     with torch.cuda.device(x.device):
         check(lib.wm_dwconv3x3_fwd(_ptr(x), _ptr(weight.detach().contiguous()),
                                    _ptr(None if bias is None else bias.detach().contiguous()), _ptr(y),
-                                   B, C, H, W, {"none": 0, "silu": 1}[act], _stream()), "wm_dwconv3x3_fwd")
+                                   B, C, H, W, {"none": 0, "silu": 1, "gelu": 2}[act], _stream()), "wm_dwconv3x3_fwd")
     return y
+
+
+def match_index(G, nx, ny):
+    """Channel matching with every channel kept: (B, C) int32 index of the L2-nearest candidate channel from the
+    Gram outputs of `gram(maps, candidates)` (argmin_j |x_c|^2 + |y_j|^2 - 2 x_c . y_j)."""
+    lib = _lib.load()
+    _require_cuda("match_index", G, nx, ny)
+    B, C = nx.shape
+    idx = torch.empty((B, C), dtype=torch.int32, device=G.device)
+    with torch.cuda.device(G.device):
+        check(lib.wm_match_index(_ptr(G.contiguous()), _ptr(nx.contiguous()), _ptr(ny.contiguous()), _ptr(idx), B, C,
+                                 _stream()), "wm_match_index")
+    return idx
+
+
+def attn_fold(G, nq, nk, temperature, w_po, batch, heads):
+    """(batch, C, C) = w_po @ blockdiag_h softmax(G / (|q||k|) * temperature): the transposed attention folded into its
+    1x1 output projection.  G (batch * heads, ch, ch), nq / nk (batch * heads, ch) squared norms."""
+    lib = _lib.load()
+    _require_cuda("attn_fold", G, nq, nk, temperature, w_po)
+    C = w_po.shape[0]
+    out = torch.empty((batch, C, C), dtype=torch.float32, device=G.device)
+    with torch.cuda.device(G.device):
+        check(lib.wm_attn_fold(_ptr(G.contiguous()), _ptr(nq.contiguous()), _ptr(nk.contiguous()),
+                               _ptr(temperature.detach().contiguous()), _ptr(w_po.detach().reshape(C, C).contiguous()),
+                               _ptr(out), batch, C, heads, _stream()), "wm_attn_fold")
+    return out
+
+
+def skff(x0, x1, x2, w_du, prelu, w_fc):
+    """SKFF of three (B, C, H, W) sub-bands: w_du (d, C[, 1, 1]), prelu (1,), w_fc (3, C, d) -> (B, C, H, W)."""
+    lib = _lib.load()
+    _require_cuda("skff", x0, x1, x2, w_du, prelu, w_fc)
+    B, C, H, W = x0.shape
+    d = w_du.shape[0]
+    if x1.shape != x0.shape or x2.shape != x0.shape or x0.dtype != torch.float32:
+        raise RuntimeError("skff: three fp32 tensors of equal shape")
+    x0, x1, x2 = x0.contiguous(), x1.contiguous(), x2.contiguous()
+    out = torch.empty_like(x0)
+    ws = torch.empty(lib.wm_skff_workspace_bytes(B, C), dtype=torch.uint8, device=x0.device)
+    with torch.cuda.device(x0.device):
+        check(lib.wm_skff_fwd(_ptr(x0), _ptr(x1), _ptr(x2), _ptr(w_du.detach().reshape(d, C).contiguous()),
+                              _ptr(prelu.detach().contiguous()), _ptr(w_fc.detach().reshape(3, C, d).contiguous()),
+                              _ptr(out), _ptr(ws), ws.numel(), B, C, d, H, W, _stream()), "wm_skff_fwd")
+    return out
 
 
 _WFRAG_CACHE = {}      # id(weight) -> (weakref, data_ptr, version, wfrag tensor)
 
 
-def _conv2d_wfrag(weight):
+def _conv2d_wfrag(weight, cache=True):
     """The prepared (bf16-split, fragment-ordered) copy of a (Cout, Cin, ks, ks) weight; rebuilt when the
-    parameter is updated in place (`_version`) or re-allocated."""
+    parameter is updated in place (`_version`) or re-allocated.  cache=False: a weight computed on the fly
+    (the folded attention), prepared every time."""
     import weakref
     key = id(weight)
-    ent = _WFRAG_CACHE.get(key)
+    ent = _WFRAG_CACHE.get(key) if cache else None
     if ent is not None and ent[0]() is weight and ent[1] == weight.data_ptr() and ent[2] == weight._version:
         return ent[3]
     lib = _lib.load()
@@ -504,17 +551,18 @@ def _conv2d_wfrag(weight):
     with torch.cuda.device(weight.device):
         check(lib.wm_conv2d_prep(_ptr(weight.detach().contiguous()), _ptr(frag), cout, cin, ks, _stream()),
               "wm_conv2d_prep")
-    _WFRAG_CACHE[key] = (weakref.ref(weight, lambda _r, k=key: _WFRAG_CACHE.pop(k, None)), weight.data_ptr(),
-                         weight._version, frag)
+    if cache:
+        _WFRAG_CACHE[key] = (weakref.ref(weight, lambda _r, k=key: _WFRAG_CACHE.pop(k, None)), weight.data_ptr(),
+                             weight._version, frag)
     return frag
 
 
-def conv2d(x, weight, bias=None, x2=None, x2_index=None, gate=None, residual=None):
+def conv2d(x, weight, bias=None, x2=None, x2_index=None, gate=None, residual=None, dynamic_weight=False):
     """y = F.conv2d(X, weight, bias, stride=1, padding=ks // 2) for a dense (Cout, Cin, ks, ks) weight, ks in
     {1, 3}, NCHW fp32, where X = x, or cat([x, x2], 1), or cat([x, gather(x2, 1, x2_index)], 1) with x2_index
     (B, Cb) channel indices into x2; then y *= sigmoid(gate) and y += residual when given.  Forward only (no
     autograd graph is recorded).  bf16 matrix cores with a two-term split of both operands: 3-4e-6 relative to
-    the fp64 result."""
+    the fp64 result.  dynamic_weight: `weight` is a freshly computed tensor (no prepared-copy cache)."""
     lib = _lib.load()
     _require_cuda("conv2d", x, weight, bias, x2, x2_index, gate, residual)
     B, Ca, H, W = x.shape
@@ -542,7 +590,7 @@ def conv2d(x, weight, bias=None, x2=None, x2_index=None, gate=None, residual=Non
     idx = None if x2_index is None else x2_index.to(torch.int32).contiguous()
     gate = None if gate is None else gate.contiguous()
     residual = None if residual is None else residual.contiguous()
-    frag = _conv2d_wfrag(weight)
+    frag = _conv2d_wfrag(weight, cache=not dynamic_weight)
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         check(lib.wm_conv2d_fwd(_ptr(x), _ptr(x2), _ptr(idx), _ptr(frag),
@@ -563,7 +611,7 @@ def conv2d_supported(x, weight, x2=None):
 PROF_KERNELS = ("haar_analysis", "haar_synthesis", "selscan_chunk_reduce", "selscan_carry",
                 "selscan_chunk_scan", "lfss_glue", "ss2d_proj", "dwconv3x3",
                 "ss2d_row_scan", "ss2d_col_scan", "ss2d_row_reduce", "ss2d_col_reduce", "selscan_bwd",
-                "conv3x3", "conv1x1")
+                "conv3x3", "conv1x1", "skff")
 
 
 def prof_enable(on=True):
