@@ -279,9 +279,11 @@ def main():
                 gbs = algo[name] * ks / (ms * 1e-3) / 1e9
                 ent.update({"algorithmic_GB_per_step": algo[name] / 1e9, "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS})
             table[name] = ent
+        hfe_only = ("conv3x3", "conv1x1", "skff")        # HFE-branch / plumbing kernels, not the hot path
         hot = [k for k in table if k != "dwconv3x3" and "frac" in table[k]]
         dom = max(hot, key=lambda k: table[k]["ms_per_step"])
-        hot_ms = sum(table[k]["ms_per_step"] for k in table if k != "dwconv3x3")
+        hot_ms = sum(table[k]["ms_per_step"] for k in table if k != "dwconv3x3" and k not in hfe_only)
+        hfe_ms = sum(table[k]["ms_per_step"] for k in table if k in hfe_only)
         # transcendental ceiling of the scan kernels: KD*N = 4096 exp per block-position per pass
         exp_peak = 18.5e12                                  # v_exp_f32 lane-ops/s, tools/microbench.hip on MI355X
         scan_ms = sum(table[k]["ms_per_step"] for k in table if k.endswith(("_scan", "_reduce")))
@@ -305,7 +307,7 @@ def main():
             "note": "scan kernels are bound by v_exp_f32 issue (KD*N exp per position per pass), not by HBM: "
                     "see exp_frac; HBM fractions are reported for every hot-path kernel in roofline_table",
             "exp_frac_scan_kernels": (2 * 4096 * pos / (scan_ms * 1e-3) / exp_peak) if scan_ms else None,
-            "hot_path_ms_per_step": hot_ms,
+            "hot_path_ms_per_step": hot_ms, "hfe_conv_skff_ms_per_step": hfe_ms,
         }
         line = {
             "metric": "UHD (3840x2160) images/sec fwd", "value": world * args.steps / elapsed,

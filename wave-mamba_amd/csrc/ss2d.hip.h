@@ -398,10 +398,19 @@ constexpr int kColT = WM_COLT;  // record rows per LDS batch
 constexpr int kColCH = 2;       // channels per wave
 constexpr int kColWaves = WM_COLWAVES;   // waves per workgroup -> 2 * kColWaves channels per workgroup
 
+// LDS image of a record row batch: kColT rows x 64 columns x RSL floats.  The chunk-scan phase keeps whole records
+// (36 floats); the chunk-reduce phase never reads C and keeps only [dt_r | B] (20 floats).  Both strides are
+// conflict-free for the 16-byte B/C reads (every 16-lane group of ds_read_b128 lands on 64 distinct banks).
+template <int PHASE> struct ColRec { static constexpr int RSL = PHASE == 3 ? kRS : kRecPad + 16; };
+template <int PHASE> constexpr int col_lds_bytes() { return 2 * kColT * 64 * ColRec<PHASE>::RSL * 4; }
+
 template <int PHASE, bool REV>
 __global__ __launch_bounds__(64 * kColWaves, WM_COL_LB) void ss2d_col_kernel(Ss2dArgs p) {
     constexpr int NP = 16;
-    __shared__ __attribute__((aligned(16))) float s_rec[kColT * 64 * kRS];     // 36,864 B
+    constexpr int RSL = ColRec<PHASE>::RSL;          // floats per record in LDS
+    constexpr int CH4 = RSL / 4;                     // 16-byte pieces per record (9 or 5)
+    constexpr int BUF = kColT * 64 * RSL;            // floats per buffer
+    extern __shared__ __attribute__((aligned(16))) float s_col[];           // 2 buffers
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -470,17 +479,13 @@ __global__ __launch_bounds__(64 * kColWaves, WM_COL_LB) void ss2d_col_kernel(Ss2
     }
 
     const float* recb = p.rec + ((long long)b * 4 + k) * L * kRS;
-    constexpr int NTH = 64 * kColWaves;
-    constexpr int NR4 = (kColT * 64 * kRS / 4 + NTH - 1) / NTH;        // float4 per thread per batch (3)
-    float4 rr[NR4];
     float ur[kColCH][kColT];
     float yr[kColCH][kColT];        // previous directions' y (accumulate mode), fetched with u
 
     auto row_of = [&](int tau) { return REV ? H - 1 - tau : tau; };
-    // Loads are unconditional with clamped addresses (a lane outside the map re-reads column W-1, a row past the
+    // u / y: unconditional loads with clamped addresses (a lane outside the map re-reads column W-1, a row past the
     // segment re-reads its last row; neither is ever used or stored): all 64-bit address arithmetic is done once
-    // here, a fetch is one 32-bit row offset (scalar) added to per-lane bases.  Predicated loads cost 25 instructions
-    // each - 3.1 k cycles per 4-row batch, 30 % of the kernel (s_memtime stamps).
+    // here, a fetch adds one wave-uniform row offset to per-lane bases.
     const int wcl = min(w, W - 1);
     const float* xbase[kColCH];
     const float* ybase[kColCH];
@@ -490,26 +495,30 @@ __global__ __launch_bounds__(64 * kColWaves, WM_COL_LB) void ss2d_col_kernel(Ss2
         xbase[c] = p.x + plane;
         ybase[c] = p.y + plane;
     }
-    const float* rbase[NR4];       // the thread's float4 slots of a batch: record row 0 of the tile, clamped column
-    int rrow[NR4];                 // batch row of slot j
-    bool rused[NR4];
+    // records: LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write; the destination is wave-uniform
+    // base + lane * 16, i.e. the batch image is filled in 1-KiB runs).  A batch is kColT * CH4 runs, run r = row
+    // r / CH4, pieces [64 (r % CH4), +64) of that row's 64 * CH4; the wave takes runs wv, wv + kColWaves, ...
+    // Piece e of a row is bytes [16 (e % CH4), +16) of the record of column e / CH4 (clamped into the map).
+    constexpr int NRUN = kColT * CH4;
+    constexpr int RPW = (NRUN + kColWaves - 1) / kColWaves;          // runs per wave
+    unsigned pofs[RPW];                                              // the lane's source offset inside a record row (floats)
 #pragma unroll
-    for (int j = 0; j < NR4; ++j) {
-        const int f = min((int)threadIdx.x + NTH * j, kColT * 64 * kRS / 4 - 1);
-        const int i = f / (64 * kRS / 4);
-        const int fr = f - i * (64 * kRS / 4);
-        const int col = (4 * fr) / kRS, within = 4 * fr - col * kRS;
-        rrow[j] = i;
-        // the reduce phase never reads C: skip the last 64 B of every 144-B record
-        rused[j] = (PHASE == 3 || within < kRecPad + NP) && w0 + col < W;
-        rbase[j] = recb + (long long)(w0 + min(col, W - 1 - w0)) * kRS + within;
+    for (int j = 0; j < RPW; ++j) {
+        const int r = min(wv + kColWaves * j, NRUN - 1);
+        const int e = (r % CH4) * 64 + lane;
+        pofs[j] = (unsigned)(min(e / CH4, W - 1 - w0) * kRS + (e % CH4) * 4);
     }
-    auto fetch = [&](int tau0) {
+    auto fetch = [&](int tau0, int buf) {
 #pragma unroll
-        for (int j = 0; j < NR4; ++j) {
-            const int row = row_of(min(tau0 + rrow[j], tau_end - 1));
-            const float4 v = *reinterpret_cast<const float4*>(rbase[j] + (long long)row * W * kRS);
-            rr[j] = rused[j] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < RPW; ++j) {
+            const int r = wv + kColWaves * j;                        // wave-uniform
+            if (NRUN % kColWaves == 0 || r < NRUN) {
+                const int row = row_of(min(tau0 + r / CH4, tau_end - 1));
+                const float* g = recb + ((long long)row * W + w0) * kRS + pofs[j];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(s_col + buf * BUF + r * 256),
+                                                 16, 0, 0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < kColT; ++i) {
@@ -522,25 +531,24 @@ __global__ __launch_bounds__(64 * kColWaves, WM_COL_LB) void ss2d_col_kernel(Ss2
         }
     };
 
-    fetch(tau_begin);
-    for (int tau0 = tau_begin; tau0 < tau_end; tau0 += kColT) {
-#pragma unroll
-        for (int j = 0; j < NR4; ++j) {
-            const int f = threadIdx.x + NTH * j;
-            if (f < kColT * 64 * kRS / 4) *reinterpret_cast<float4*>(&s_rec[4 * f]) = rr[j];
-        }
+    fetch(tau_begin, 0);
+    int buf = 0;
+    for (int tau0 = tau_begin; tau0 < tau_end; tau0 += kColT, buf ^= 1) {
         float uc[kColCH][kColT], yc[kColCH][kColT];
 #pragma unroll
         for (int c = 0; c < kColCH; ++c)
 #pragma unroll
             for (int i = 0; i < kColT; ++i) { uc[c][i] = ur[c][i]; yc[c][i] = yr[c][i]; }
+        // one barrier per batch: it publishes this batch's image (every wave waited for its own DMA runs) and
+        // retires the other buffer (all waves finished the previous batch), which the next fetch overwrites
         __syncthreads();
-        if (tau0 + kColT < tau_end) fetch(tau0 + kColT);
+        if (tau0 + kColT < tau_end) fetch(tau0 + kColT, buf ^ 1);
+        const float* s_rec = s_col + buf * BUF;
 
 #pragma unroll
         for (int i = 0; i < kColT; ++i) {
             if (tau0 + i < tau_end) {                                  // uniform
-                const float* rc = &s_rec[(i * 64 + lane) * kRS];
+                const float* rc = &s_rec[(i * 64 + lane) * RSL];
                 const float4 dr = *reinterpret_cast<const float4*>(rc);
                 float4 bq[NP / 4], cq[NP / 4];
 #pragma unroll
@@ -580,7 +588,6 @@ __global__ __launch_bounds__(64 * kColWaves, WM_COL_LB) void ss2d_col_kernel(Ss2
                 }
             }
         }
-        __syncthreads();
     }
 
     if (PHASE == 1 && colok) {

@@ -251,12 +251,18 @@ static void ss2d_launch_col(Ss2dArgs a, const Ss2dPlan& pl, float* seg, hipStrea
     const int cgroups = (a.D + kColCH * kColWaves - 1) / (kColCH * kColWaves);
     const long long ntiles = (long long)((a.W + 63) / 64) * pl.col_nseg * a.B;
     const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8 * cgroups)), block(64 * kColWaves);    // XCD-aware order, see kernel
+    static bool configured = false;                      // the chunk-scan image is 72 KB of dynamic LDS: opt in once
+    if (!configured) {
+        hipFuncSetAttribute((const void*)ss2d_col_kernel<3, REV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            col_lds_bytes<3>());
+        configured = true;
+    }
     if (pl.col_nchunks > 1) {
-        { ProfScope ps(11, st); hipLaunchKernelGGL((ss2d_col_kernel<1, REV>), grid, block, 0, st, a); }
+        { ProfScope ps(11, st); hipLaunchKernelGGL((ss2d_col_kernel<1, REV>), grid, block, col_lds_bytes<1>(), st, a); }
         launch_carry(a.wsP, a.wsH, seg, (long long)a.B * a.D * 16, (int)pl.col_nchunks, st);
     }
     ProfScope ps(9, st);
-    hipLaunchKernelGGL((ss2d_col_kernel<3, REV>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((ss2d_col_kernel<3, REV>), grid, block, col_lds_bytes<3>(), st, a);
 }
 
 }  // namespace wm
