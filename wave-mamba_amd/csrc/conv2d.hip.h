@@ -25,8 +25,13 @@
 // pre-split and fragment-ordered (conv2d_prep_kernel) by LDS-DMA.  Every staged row feeds the KS kernel rows
 // that touch it (B fragments are read once per kx, not once per tap).  Two workgroups share a compute unit
 // (<= 256 registers per wave, <= 80 KB of LDS each): one's fetch / convert / store phases run under the other's
-// MFMA phase.  Measured bound (s_memtime phase stamps): the L1 miss path, ~12 B/clk per compute unit - the
-// 3 cache lines a 34-pixel halo row touches are what a follow-up should cut (sliding window along W).
+// MFMA phase.  Measured bound (s_memtime phase stamps): the L2 -> L1 fill path, 13-19 B/clk per compute unit for
+// this access pattern - a 34-pixel halo row touches 3 cache lines (110 KB of lines per 16-channel chunk for 39 KB of
+// pixels) and each workgroup re-fetches the weights.  Tried: a persistent wave-specialised variant (4 loader + 4 MFMA
+// waves per compute unit, double-buffered LDS, 16-byte loads): correct, 0.65 ms against 0.62 ms - the loaders stall
+// on the same fill path (8.5 k of 11.5 k cycles per chunk in load issue; 0.8 k with the loads stubbed out), so the
+// lever is lines per pixel, not overlap: an output tile shifted by one pixel needs exactly one line per row (two
+// carried pixels + the aligned line).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
