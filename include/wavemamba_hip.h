@@ -210,6 +210,20 @@ int wm_conv2d_fwd(const float* xa, const float* xb, const int* xb_index, const v
                   const float* gate, const float* residual, float* y, int B, int Ca, int Cb, int Cb_src, int Cout,
                   int H, int W, int ks, void* stream);
 
+/* Backward of wm_ss2d_core_fwd: autograd of SS2D.forward_core (wavemamba_arch.py:446-478) - the four directional
+ * flattenings, the x_proj / dt_proj einsums and the selective scan - without materialising xs / dts / Bs / Cs.
+ *   dy_*            gradients of the four outputs in wm_ss2d_core_fwd's order, each (B, D, L) row-major positions; for
+ *                   the merged forward pass the same pointer four times.
+ *   dx (B, D, H, W), dx_proj_weight (4, R + 2N, D), ddt_projs_weight (4, D, R), ddt_projs_bias (4, D),
+ *   dA_logs (4 D, N), dDs (4 D): overwritten.
+ * Same limits as the forward (N <= 16, R <= 4, D <= 64); workspace wm_ss2d_core_bwd_workspace_bytes(...), 16-byte aligned. */
+size_t wm_ss2d_core_bwd_workspace_bytes(int B, int D, int H, int W, int N, int R);
+int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt_projs_weight,
+                     const float* dt_projs_bias, const float* A_logs, const float* Ds, const float* dy_row_fwd,
+                     const float* dy_row_rev, const float* dy_col_fwd, const float* dy_col_rev, float* dx,
+                     float* dx_proj_weight, float* ddt_projs_weight, float* ddt_projs_bias, float* dA_logs, float* dDs,
+                     void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int N, int R, void* stream);
+
 /* Small-tensor steps of the HFE branch as single kernels (csrc/hfe.hip.h).  Forward only.
  *   wm_match_index   channel matching with every channel kept (wavemamba_arch.py:659-666, match_factor = 1):
  *                    index[b, c] = argmin_j (nx[b, c] + ny[b, j] - 2 G[b, c, j]) from wm_gram_fwd's outputs; (B, C) int32.

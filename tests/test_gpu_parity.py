@@ -664,3 +664,56 @@ def test_dwconv3x3_gelu(shape):
     b = torch.randn(C, generator=gg)
     ref = F.gelu(F.conv2d(x.double(), w.double(), b.double(), padding=1, groups=C)).float()
     assert_close(wm.ops.dwconv3x3(*cu(x, w, b), "gelu"), ref, 1e-5, "dwconv + gelu")
+
+
+# ------------------------------------------------------------------------------------------------
+# fused SS2D core backward (wm_ss2d_core_bwd) against the reference's autograd of forward_core
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["s16", "sq16", "d8"])
+def test_ss2d_core_backward_golden(golden, tag):
+    """Gradients of the reference's real SS2D.forward_core (tests/golden/make_golden.py) for four random dys."""
+    g = golden("scan")
+    names = ("core_x", "x_proj_weight", "dt_projs_weight", "dt_projs_bias", "A_logs", "Ds")
+    args = [t.clone().requires_grad_(True) for t in cu(*[g[f"{tag}_{n}"] for n in names])]
+    ys = wm.ops.ss2d_core(*args)
+    dys = cu(*[g[f"{tag}_core_dy{i}"] for i in range(4)])
+    grads = torch.autograd.grad(ys, args, dys)
+    refs = ("core_dx", "core_dx_proj_weight", "core_ddt_projs_weight", "core_ddt_projs_bias", "core_dA_logs", "core_dDs")
+    for got, rn in zip(grads, refs):
+        assert_close(got, g[f"{tag}_{rn}"], 2e-4, f"{tag} {rn}")
+
+
+@pytest.mark.parametrize("B,D,H,W,N,R", [(1, 64, 12, 20, 16, 2), (2, 32, 7, 9, 16, 2), (1, 16, 33, 5, 8, 1),
+                                         (1, 64, 40, 48, 16, 4)])
+@pytest.mark.parametrize("merged", [True, False])
+def test_ss2d_core_backward_vs_unfused_autograd(B, D, H, W, N, R, merged):
+    """Fused backward against PyTorch autograd through the direction glue + the HIP op-boundary scan (itself checked
+    against the reference goldens and the oracle above)."""
+    x, Wx, Wdt, bias, A_logs, Ds = [t.to(DEV).requires_grad_(True) for t in random_core_case(B, D, H, W, N, R, seed=H + W)]
+    L = H * W
+
+    def unfused():
+        xs = torch.stack([x.view(B, -1, L), x.transpose(2, 3).contiguous().view(B, -1, L)], dim=1).view(B, 2, -1, L)
+        xs = torch.cat([xs, torch.flip(xs, dims=[-1])], dim=1)
+        x_dbl = torch.einsum("b k d l, k c d -> b k c l", xs, Wx)
+        dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
+        dts = torch.einsum("b k r l, k d r -> b k d l", dts, Wdt)
+        out = wm.ops.selective_scan_fn(xs.reshape(B, -1, L), dts.reshape(B, -1, L), -torch.exp(A_logs), Bs.contiguous(),
+                                       Cs.contiguous(), Ds, None, bias.reshape(-1), True).view(B, 4, -1, L)
+        inv = torch.flip(out[:, 2:4], dims=[-1]).view(B, 2, -1, L)
+        wh = out[:, 1].view(B, -1, W, H).transpose(2, 3).contiguous().view(B, -1, L)
+        invwh = inv[:, 1].view(B, -1, W, H).transpose(2, 3).contiguous().view(B, -1, L)
+        return out[:, 0], inv[:, 0], wh, invwh
+
+    params = [x, Wx, Wdt, bias, A_logs, Ds]
+    gg = torch.Generator(device=DEV).manual_seed(5)
+    if merged:
+        dy = torch.randn(B, D, L, device=DEV, generator=gg)
+        ref = torch.autograd.grad(sum(unfused()), params, dy)
+        got = torch.autograd.grad(wm.ops.ss2d_core(*params, merged=True), params, dy)
+    else:
+        dys = [torch.randn(B, D, L, device=DEV, generator=gg) for _ in range(4)]
+        ref = torch.autograd.grad(unfused(), params, dys)
+        got = torch.autograd.grad(wm.ops.ss2d_core(*params), params, dys)
+    for a, b, nm in zip(got, ref, ("dx", "dWx", "dWdt", "dbias", "dA_logs", "dDs")):
+        assert_close(a, b, 2e-4, f"fused core bwd {nm} {(B, D, H, W, N, R)} merged={merged}")

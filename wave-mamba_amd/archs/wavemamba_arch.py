@@ -230,12 +230,11 @@ class SS2D(nn.Module):
         return out[:, 0], back[:, 0], y_col, y_col_back
 
     def _fused_ok(self, x):
-        """The fused HIP core serves inference on the HIP backend; training (autograd) and
-        out-of-range shapes take the direction glue + selective_scan_fn path below."""
+        """The fused HIP core (forward wm_ss2d_core_fwd, backward wm_ss2d_core_bwd) serves inference and training
+        on the HIP backend; out-of-range shapes and the test backends take the direction glue +
+        selective_scan_fn path below."""
         ops = _OpsBackend.impl
         if not (hasattr(ops, "ss2d_core") and x.is_cuda and x.dtype == torch.float32):
-            return False
-        if torch.is_grad_enabled() and (x.requires_grad or self.x_proj_weight.requires_grad):
             return False
         return ops.ss2d_core_supported(self.d_inner, self.d_state, self.dt_rank)
 

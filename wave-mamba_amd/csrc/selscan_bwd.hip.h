@@ -40,7 +40,15 @@ struct ScanBwdArgs {
     float *wsPr, *wsG;             // adjoint summaries   [nchunks-1-chunk][chain]
     float *part;                   // [chunk][batch*dim][NP + kPartPad]
     int batch, dim, L, N, G, dpg, wpg, nchunks, softplus, atomic_bc;
+    // fused SS2D-core backward (MODE 1 forward time, MODE 2 reversed time; ss2d_bwd.hip.h): u = x and dy are
+    // (batch, dim, L) planes of the scan layout, `A` holds A_logs, delta / B / C come from the record tile
+    const float* rec;              // records of this direction, batch stride rec_bstride floats
+    const float* Wdt;              // (dim, R) dt projection of this direction
+    float* dplanes;                // (R + 2N, L) gradient planes [d dt_r | dB | dC] of this direction, batch stride dpl_bstride
+    long long rec_bstride, dpl_bstride;
+    int R;
 };
+constexpr int kPartPadFused = 8;   // fused partial record: NP (dA) + [dD, dbias, dWdt[0..3], 0, 0]
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -125,32 +133,118 @@ __device__ __forceinline__ void bwd_load_bc(const float* __restrict__ base, long
     }
 }
 
+// ---- fused SS2D-core operand tiles -----------------------------------------------------------------------
+// tile of chunk t0 covers positions plo .. plo + 15; LDS column tt is scan time t0 + tt: position plo + tt forward,
+// plo + 15 - tt reversed.  Valid position columns are [c_lo, c_hi).
+template <bool REV> struct FusedTile {
+    long long plo; int c_lo, c_hi;
+    __device__ __forceinline__ FusedTile(long long L, int t0, int tl) {
+        plo = REV ? (L - kBT - t0) : (long long)t0;
+        c_lo = REV ? kBT - tl : 0; c_hi = REV ? kBT : tl;
+    }
+};
+template <bool REV, bool VEC>
+__device__ __forceinline__ void fused_load_rows(const float* __restrict__ base, long long L, const FusedTile<REV>& ft,
+                                                int nch, int lane, float* __restrict__ s) {
+    const int trow = lane >> 2, tq = lane & 3, c = 4 * tq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 16 * i + trow;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < nch) {
+            const float* q = base + (long long)r * L + ft.plo + c;
+            if constexpr (VEC) { if (c >= ft.c_lo && c < ft.c_hi) v = *reinterpret_cast<const float4*>(q); }
+            else {
+                if (c + 0 >= ft.c_lo && c + 0 < ft.c_hi) v.x = q[0];
+                if (c + 1 >= ft.c_lo && c + 1 < ft.c_hi) v.y = q[1];
+                if (c + 2 >= ft.c_lo && c + 2 < ft.c_hi) v.z = q[2];
+                if (c + 3 >= ft.c_lo && c + 3 < ft.c_hi) v.w = q[3];
+            }
+        }
+        if (REV) *reinterpret_cast<float4*>(&s[r * kBRow + 4 * (3 - tq)]) = make_float4(v.w, v.z, v.y, v.x);
+        else *reinterpret_cast<float4*>(&s[r * kBRow + 4 * tq]) = v;
+    }
+}
+// record tile (16 positions x [dt_r(4) | B(16) | C(16)]) -> s_dtr [tt][4], s_B [tt][16], s_C [tt][16]
+template <bool REV>
+__device__ __forceinline__ void fused_load_rec(const float* __restrict__ rec, const FusedTile<REV>& ft, int lane,
+                                               float* __restrict__ s_dtr, float* __restrict__ s_B, float* __restrict__ s_C) {
+    constexpr int RS = 36;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int f = lane + 64 * j;                              // float4 index inside the 16 x 36 tile
+        if (f < kBT * RS / 4) {
+            const int col = (4 * f) / RS, within = 4 * f - col * RS;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col >= ft.c_lo && col < ft.c_hi) v = *reinterpret_cast<const float4*>(rec + ft.plo * RS + 4 * f);
+            const int tt = REV ? kBT - 1 - col : col;
+            float* dst = within == 0 ? s_dtr + tt * 4 : (within < 20 ? s_B + tt * 16 + (within - 4) : s_C + tt * 16 + (within - 20));
+            *reinterpret_cast<float4*>(dst) = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // bwd-reduce: forward (P, H) and adjoint (G) chunk summaries in one pass
 // ------------------------------------------------------------------------------------------------
-template <int NP, bool VEC>
+// the per-channel decay rates: A (op boundary) or -exp(A_logs) (fused core), pre-multiplied by log2(e)
+template <int NP, int MODE>
+__device__ __forceinline__ void bwd_load_A(const ScanBwdArgs& p, int d, v2f (&A2)[NP / 2]) {
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        float a = 0.0f;
+        if (n < p.N) {
+            const float raw = p.A[(long long)d * p.N + n];
+            a = (MODE == 0 ? raw : -expf(raw)) * 1.4426950408889634f;
+        }
+        if (n & 1) A2[n / 2].y = a; else A2[n / 2].x = a;
+    }
+}
+// fused core: every operand tile of one chunk into LDS (s_d = raw delta = Wdt . dt_r, bias added by the caller)
+template <int NP, bool VEC, bool REV>
+__device__ __forceinline__ void fused_load_all(const ScanBwdArgs& p, const BwdTileIdx& ix, int t0, int tl, int lane,
+                                               float* s_u, float* s_d, float* s_dy, float* s_B, float* s_C, float* s_dtr) {
+    static_assert(NP == 16, "fused core: N <= 16");
+    const FusedTile<REV> ft(p.L, t0, tl);
+    const long long rowbase = ((long long)ix.b * p.dim + ix.ch0) * p.L;
+    fused_load_rows<REV, VEC>(p.u + rowbase, p.L, ft, ix.nch, lane, s_u);
+    fused_load_rows<REV, VEC>(p.dy + rowbase, p.L, ft, ix.nch, lane, s_dy);
+    fused_load_rec<REV>(p.rec + ix.b * p.rec_bstride, ft, lane, s_dtr, s_B, s_C);
+    __syncthreads();
+    float wdt[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wdt[r] = (r < p.R && ix.live) ? p.Wdt[(long long)ix.d * p.R + r] : 0.0f;
+#pragma unroll
+    for (int tt = 0; tt < kBT; ++tt) {
+        const float4 dr = *reinterpret_cast<const float4*>(&s_dtr[tt * 4]);
+        s_d[lane * kBRow + tt] = fmaf(wdt[3], dr.w, fmaf(wdt[2], dr.z, fmaf(wdt[1], dr.y, wdt[0] * dr.x)));
+    }
+}
+
+template <int NP, bool VEC, int MODE>
 __global__ __launch_bounds__(64) void selscan_bwd_reduce_kernel(ScanBwdArgs p) {
     __shared__ __attribute__((aligned(16))) float s_u[64 * kBRow], s_d[64 * kBRow], s_dy[64 * kBRow];
     __shared__ __attribute__((aligned(16))) float s_B[kBT * NP], s_C[kBT * NP];
+    __shared__ __attribute__((aligned(16))) float s_dtr[MODE == 0 ? 4 : kBT * 4];
     const int lane = threadIdx.x, chunk = blockIdx.x;
     const BwdTileIdx ix = bwd_decode(p, blockIdx.y, lane);
     const long long L = p.L;
     const int t0 = chunk * kBT, t_end = min(p.L, t0 + kBT), tl = t_end - t0;
 
     v2f A2[NP / 2];
-#pragma unroll
-    for (int n = 0; n < NP; ++n) {
-        const float a = (n < p.N) ? p.A[(long long)ix.d * p.N + n] * 1.4426950408889634f : 0.0f;
-        if (n & 1) A2[n / 2].y = a; else A2[n / 2].x = a;
-    }
+    bwd_load_A<NP, MODE>(p, ix.d, A2);
     const float bias = p.bias ? p.bias[ix.d] : 0.0f;
-    const long long rowbase = ((long long)ix.b * p.dim + ix.ch0) * L;
-    const long long bcbase = ((long long)ix.b * p.G + ix.g) * p.N * L;
-    bwd_load_rows<VEC>(p.u + rowbase, L, t0, t_end, ix.nch, lane, s_u);
-    bwd_load_rows<VEC>(p.delta + rowbase, L, t0, t_end, ix.nch, lane, s_d);
-    bwd_load_rows<VEC>(p.dy + rowbase, L, t0, t_end, ix.nch, lane, s_dy);
-    bwd_load_bc<NP, VEC>(p.Bm + bcbase, L, t0, t_end, p.N, lane, s_B);
-    bwd_load_bc<NP, VEC>(p.Cm + bcbase, L, t0, t_end, p.N, lane, s_C);
+    if constexpr (MODE == 0) {
+        const long long rowbase = ((long long)ix.b * p.dim + ix.ch0) * L;
+        const long long bcbase = ((long long)ix.b * p.G + ix.g) * p.N * L;
+        bwd_load_rows<VEC>(p.u + rowbase, L, t0, t_end, ix.nch, lane, s_u);
+        bwd_load_rows<VEC>(p.delta + rowbase, L, t0, t_end, ix.nch, lane, s_d);
+        bwd_load_rows<VEC>(p.dy + rowbase, L, t0, t_end, ix.nch, lane, s_dy);
+        bwd_load_bc<NP, VEC>(p.Bm + bcbase, L, t0, t_end, p.N, lane, s_B);
+        bwd_load_bc<NP, VEC>(p.Cm + bcbase, L, t0, t_end, p.N, lane, s_C);
+    } else if constexpr (NP == 16) {
+        fused_load_all<NP, VEC, MODE == 2>(p, ix, t0, tl, lane, s_u, s_d, s_dy, s_B, s_C, s_dtr);
+    }
     __syncthreads();
 
     v2f h[NP / 2], pf[NP / 2], gl[NP / 2];
@@ -204,33 +298,34 @@ __global__ __launch_bounds__(64) void selscan_bwd_reduce_kernel(ScanBwdArgs p) {
 // ------------------------------------------------------------------------------------------------
 // bwd-chunk: the gradients of one 16-step chunk
 // ------------------------------------------------------------------------------------------------
-template <int NP, bool VEC>
+template <int NP, bool VEC, int MODE>
 __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
     constexpr int NSUB = kBT / kBS;
     __shared__ __attribute__((aligned(16))) float s_u[64 * kBRow], s_d[64 * kBRow], s_dy[64 * kBRow];
     __shared__ __attribute__((aligned(16))) float s_B[kBT * NP], s_C[kBT * NP];
     __shared__ __attribute__((aligned(16))) float s_hs[NSUB * NP * 64];       // state at the start of each sub-tile
-    __shared__ __attribute__((aligned(16))) float s_red[2 * NP * kBRow];      // dB rows then dC rows, [value][step]
+    __shared__ __attribute__((aligned(16))) float s_red[(2 * NP + (MODE == 0 ? 0 : 4)) * kBRow];   // dB, dC (, d dt_r) rows, [value][step]
+    __shared__ __attribute__((aligned(16))) float s_dtr[MODE == 0 ? 4 : kBT * 4];
     const int lane = threadIdx.x, chunk = blockIdx.x;
     const BwdTileIdx ix = bwd_decode(p, blockIdx.y, lane);
     const long long L = p.L;
     const int t0 = chunk * kBT, t_end = min(p.L, t0 + kBT), tl = t_end - t0;
 
     v2f A2[NP / 2];
-#pragma unroll
-    for (int n = 0; n < NP; ++n) {
-        const float a = (n < p.N) ? p.A[(long long)ix.d * p.N + n] * 1.4426950408889634f : 0.0f;
-        if (n & 1) A2[n / 2].y = a; else A2[n / 2].x = a;
-    }
+    bwd_load_A<NP, MODE>(p, ix.d, A2);
     const float bias = p.bias ? p.bias[ix.d] : 0.0f;
     const float Dd = p.D ? p.D[ix.d] : 0.0f;
     const long long rowbase = ((long long)ix.b * p.dim + ix.ch0) * L;
     const long long bcbase = ((long long)ix.b * p.G + ix.g) * p.N * L;
-    bwd_load_rows<VEC>(p.u + rowbase, L, t0, t_end, ix.nch, lane, s_u);
-    bwd_load_rows<VEC>(p.delta + rowbase, L, t0, t_end, ix.nch, lane, s_d);
-    bwd_load_rows<VEC>(p.dy + rowbase, L, t0, t_end, ix.nch, lane, s_dy);
-    bwd_load_bc<NP, VEC>(p.Bm + bcbase, L, t0, t_end, p.N, lane, s_B);
-    bwd_load_bc<NP, VEC>(p.Cm + bcbase, L, t0, t_end, p.N, lane, s_C);
+    if constexpr (MODE == 0) {
+        bwd_load_rows<VEC>(p.u + rowbase, L, t0, t_end, ix.nch, lane, s_u);
+        bwd_load_rows<VEC>(p.delta + rowbase, L, t0, t_end, ix.nch, lane, s_d);
+        bwd_load_rows<VEC>(p.dy + rowbase, L, t0, t_end, ix.nch, lane, s_dy);
+        bwd_load_bc<NP, VEC>(p.Bm + bcbase, L, t0, t_end, p.N, lane, s_B);
+        bwd_load_bc<NP, VEC>(p.Cm + bcbase, L, t0, t_end, p.N, lane, s_C);
+    } else if constexpr (NP == 16) {
+        fused_load_all<NP, VEC, MODE == 2>(p, ix, t0, tl, lane, s_u, s_d, s_dy, s_B, s_C, s_dtr);
+    }
 
     const long long chains = (long long)p.batch * p.dim * NP;
     const long long row = ((long long)ix.b * p.dim + ix.d) * NP;
@@ -370,6 +465,7 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
     }
     __syncthreads();
 
+    if constexpr (MODE == 0) {
     // ---- write back: du, ddelta rows; dB, dC rows; per-chunk partials --------------------------------
     {
         const int trow = lane >> 2, tq = lane & 3, t = t0 + 4 * tq;
@@ -417,14 +513,106 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
             *reinterpret_cast<float4*>(pr + 4 * q) = make_float4(dA[2 * q].x, dA[2 * q].y, dA[2 * q + 1].x, dA[2 * q + 1].y);
         *reinterpret_cast<float4*>(pr + NP) = make_float4(dDp, dbp, 0.f, 0.f);
     }
+    } else {
+    // ---- fused core: dx += du; d dt_r = Wdt^T ddelta (channel sum), dWdt partial; gradient planes ------------
+    constexpr bool REV = MODE == 2;
+    const FusedTile<REV> ft(L, t0, tl);
+    float wdt[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wdt[r] = (r < p.R && ix.live) ? p.Wdt[(long long)ix.d * p.R + r] : 0.0f;
+    float dwp[4] = {0.f, 0.f, 0.f, 0.f};
+    float ddl[kBT];
+#pragma unroll
+    for (int tt = 0; tt < kBT; ++tt) {
+        ddl[tt] = tt < tl ? s_d[lane * kBRow + tt] : 0.0f;             // ddelta_t of this lane's channel
+        const float4 dr = *reinterpret_cast<const float4*>(&s_dtr[tt * 4]);
+        dwp[0] = fmaf(ddl[tt], dr.x, dwp[0]); dwp[1] = fmaf(ddl[tt], dr.y, dwp[1]);
+        dwp[2] = fmaf(ddl[tt], dr.z, dwp[2]); dwp[3] = fmaf(ddl[tt], dr.w, dwp[3]);
+    }
+    // d dt_r[r][tt] = sum over channels of ddelta[d][tt] * Wdt[d][r]: 16 steps x 2 ranks = one 32-value reduction
+#pragma unroll
+    for (int pair = 0; pair < 2; ++pair) {
+        if (2 * pair < p.R) {                                           // uniform
+            float v[32], o[8];
+#pragma unroll
+            for (int tt = 0; tt < kBT; ++tt) { v[2 * tt] = ddl[tt] * wdt[2 * pair]; v[2 * tt + 1] = ddl[tt] * wdt[2 * pair + 1]; }
+            wave_reduce32(v, o);
+            if ((lane & 15) == 0) {
+                const int rowg = lane >> 4;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int val = 8 * rowg + i;                       // = 2 tt + e
+                    s_red[(2 * NP + 2 * pair + (val & 1)) * kBRow + (val >> 1)] = o[i];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int trow = lane >> 2, tq = lane & 3, c = 4 * tq;
+        const bool cok = c >= ft.c_lo && c < ft.c_hi;                   // VEC: the whole quad is valid or not
+        // dx += du (du sits in s_dy, LDS column = scan time)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 16 * i + trow;
+            if (r < ix.nch) {
+                float4 a = *reinterpret_cast<const float4*>(&s_dy[r * kBRow + (REV ? 4 * (3 - tq) : 4 * tq)]);
+                if (REV) a = make_float4(a.w, a.z, a.y, a.x);
+                float* o = p.du + rowbase + (long long)r * L + ft.plo + c;
+                if constexpr (VEC) {
+                    if (cok) {
+                        const float4 e = *reinterpret_cast<const float4*>(o);
+                        *reinterpret_cast<float4*>(o) = make_float4(e.x + a.x, e.y + a.y, e.z + a.z, e.w + a.w);
+                    }
+                } else {
+                    const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (c + j >= ft.c_lo && c + j < ft.c_hi) o[j] += av[j];
+                }
+            }
+        }
+        // gradient planes in x_proj row order: [0, R) d dt_r, [R, R+N) dB, [R+N, R+2N) dC
+        float* dpl = p.dplanes + ix.b * p.dpl_bstride;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int rr = 16 * i + trow;                              // s_red row: 0..15 dB, 16..31 dC, 32..35 d dt_r
+            int plane = -1;
+            if (rr < NP) { if (rr < p.N) plane = p.R + rr; }
+            else if (rr < 2 * NP) { if (rr - NP < p.N) plane = p.R + p.N + (rr - NP); }
+            else if (rr < 2 * NP + 4) { if (rr - 2 * NP < p.R) plane = rr - 2 * NP; }
+            if (plane >= 0) {
+                float4 v = *reinterpret_cast<const float4*>(&s_red[rr * kBRow + (REV ? 4 * (3 - tq) : 4 * tq)]);
+                if (REV) v = make_float4(v.w, v.z, v.y, v.x);
+                float* o = dpl + (long long)plane * L + ft.plo + c;
+                if constexpr (VEC) { if (cok) *reinterpret_cast<float4*>(o) = v; }
+                else {
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (c + j >= ft.c_lo && c + j < ft.c_hi) o[j] = vv[j];
+                }
+            }
+        }
+    }
+    if (ix.live) {
+        float* pr = p.part + (((long long)ix.b * p.dim + ix.d) * p.nchunks + chunk) * (NP + kPartPadFused);
+#pragma unroll
+        for (int q = 0; q < NP / 4; ++q)
+            *reinterpret_cast<float4*>(pr + 4 * q) = make_float4(dA[2 * q].x, dA[2 * q].y, dA[2 * q + 1].x, dA[2 * q + 1].y);
+        *reinterpret_cast<float4*>(pr + NP) = make_float4(dDp, dbp, dwp[0], dwp[1]);
+        *reinterpret_cast<float4*>(pr + NP + 4) = make_float4(dwp[2], dwp[3], 0.f, 0.f);
+    }
+    }
 }
 
 // dA (dim, N), dD (dim), dbias (dim) = sums of the per-chunk partials over chunks and batch.
 // One block per channel streams its [batch][chunk][NPP] partials (contiguous per batch item); a thread
 // keeps a fixed column j = f mod NPP by striding in multiples of NPP, then an LDS tree over the threads.
+// Fused core (A_logs != null): dA_logs = dA * A with A = -exp(A_logs), and dWdt (dim, R) from record slots NP + 2 ...
 __global__ __launch_bounds__(256) void selscan_bwd_finish_kernel(const float* __restrict__ part, float* __restrict__ dA,
                                                                  float* __restrict__ dD, float* __restrict__ dbias,
-                                                                 int batch, int dim, int N, int NPP, int nchunks) {
+                                                                 int batch, int dim, int N, int NPP, int nchunks,
+                                                                 const float* __restrict__ A_logs, float* __restrict__ dWdt,
+                                                                 int R, int NP) {
     __shared__ float s[256];
     const int d = blockIdx.x;
     const int stride = (256 / NPP) * NPP;                   // active threads: a multiple of the record length
@@ -443,10 +631,10 @@ __global__ __launch_bounds__(256) void selscan_bwd_finish_kernel(const float* __
     if (t < NPP) {
         float tot = 0.0f;
         for (int q = t; q < stride; q += NPP) tot += s[q];
-        const int NP = NPP - kPartPad;
-        if (t < N) atomicAdd(dA + (long long)d * N + t, tot);          // outputs are zeroed by the launcher
+        if (t < N) atomicAdd(dA + (long long)d * N + t, A_logs ? -expf(A_logs[(long long)d * N + t]) * tot : tot);   // outputs are zeroed by the launcher
         else if (t == NP && dD) atomicAdd(dD + d, tot);
         else if (t == NP + 1 && dbias) atomicAdd(dbias + d, tot);
+        else if (dWdt && t >= NP + 2 && t < NP + 2 + R) atomicAdd(dWdt + (long long)d * R + (t - NP - 2), tot);
     }
 }
 

@@ -1,0 +1,155 @@
+// ss2d_bwd.hip.h - backward of the fused SS2D core (wm_ss2d_core_bwd): the pieces around the chunked scan backward.
+//
+// Reference: autograd of SS2D.forward_core (/root/reference/basicsr/archs/wavemamba_arch.py:446-478) - the four
+// directional flattenings, the x_proj / dt_proj einsums (:453-455) and the selective scan (:465-471).
+//
+// Structure (host side in wavemamba_hip.hip):
+//   row directions (k = 0, 2) scan the map in its own layout; column directions (k = 1, 3) are the row directions of
+//   the TRANSPOSED map, so x and dy are transposed once (transpose_planes_kernel) and everything else is shared:
+//   1. ss2d_proj_kernel (forward kernel, re-run) -> records [dt_r | B | C] per position of the layout
+//   2. selscan_bwd_{reduce,chunk}_kernel<16, VEC, MODE 1 / 2> (selscan_bwd.hip.h): the chunked adjoint scan with its
+//      operand tiles taken from x, dy and the records; dx += du, gradient planes [d dt_r | dB | dC] in x_proj row order,
+//      per-chunk partials of dA, dD, dbias, dWdt
+//   3. projbwd_dx_kernel: dx[d][p] += sum_k sum_c Wx[k][c][d] g_k[c][p]         (the x_proj einsum, transposed)
+//      projgrad_kernel:   dWx[k][c][d] = sum_{b,p} g_k[c][p] x[d][p]             (fp32 MFMA 16x16x4, K = positions)
+//   4. selscan_bwd_finish_kernel: dA_logs = dA * A, dDs, d dt_projs_bias, d dt_projs_weight
+//   then dx += transpose(dx^T).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace wm {
+
+// out[plane][w][h] = in[plane][h][w]; grid (ceil(W/32), ceil(H/32), planes), block (32, 8)
+__global__ __launch_bounds__(256) void transpose_planes_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                               int H, int W, int accumulate) {
+    __shared__ float tile[32][33];
+    const long long plane = blockIdx.z;
+    const float* ip = in + plane * (long long)H * W;
+    float* op = out + plane * (long long)H * W;
+    const int w0 = blockIdx.x * 32, h0 = blockIdx.y * 32;
+#pragma unroll
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int h = h0 + j, w = w0 + threadIdx.x;
+        tile[j][threadIdx.x] = (h < H && w < W) ? ip[(long long)h * W + w] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int w = w0 + j, h = h0 + threadIdx.x;                 // output row = w, column = h
+        if (w < W && h < H) {
+            float* o = op + (long long)w * H + h;
+            *o = accumulate ? *o + tile[threadIdx.x][j] : tile[threadIdx.x][j];
+        }
+    }
+}
+
+struct ProjBwdArgs {
+    const float* g;            // gradient planes [b][kk][CP][L], kk = 0, 1: the two directions of this layout
+    const float* x;            // (B, D, L) planes of this layout
+    const float* Wx0;          // x_proj_weight of direction kk = 0: (CP, D)
+    const float* Wx1;          // ... kk = 1
+    float* dx;                 // (B, D, L), accumulated into
+    float* dWx0;               // (CP, D), accumulated into by atomics (zeroed by the caller)
+    float* dWx1;
+    int B, D, CP;
+    long long L;
+};
+
+// dx[b][d][p] += sum_kk sum_c Wx_kk[c][d] g[b][kk][c][p].  One thread = one position; the gradient rows sit in
+// registers, the weights are wave-uniform scalar operands.  grid (ceil(L / 256), B), block (256).  D <= 64, CP <= 36.
+__global__ __launch_bounds__(256) void projbwd_dx_kernel(const ProjBwdArgs a) {
+    const long long p = blockIdx.x * 256ll + threadIdx.x;
+    const int b = blockIdx.y;
+    if (p >= a.L) return;
+    float acc[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) acc[d] = 0.0f;
+    for (int kk = 0; kk < 2; ++kk) {
+        const float* gp = a.g + (((long long)b * 2 + kk) * a.CP) * a.L + p;
+        const float* W = kk ? a.Wx1 : a.Wx0;
+        for (int c = 0; c < a.CP; ++c) {
+            const float gv = gp[(long long)c * a.L];
+            const float* wr = W + (long long)c * a.D;               // uniform
+#pragma unroll
+            for (int d = 0; d < 64; ++d)
+                if (d < a.D) acc[d] = fmaf(wr[d], gv, acc[d]);
+        }
+    }
+    float* o = a.dx + (long long)b * a.D * a.L + p;
+#pragma unroll
+    for (int d = 0; d < 64; ++d)
+        if (d < a.D) o[(long long)d * a.L] += acc[d];
+}
+
+typedef float pg_f4 __attribute__((ext_vector_type(4)));
+constexpr int kPgWaves = 4;
+
+// dWx_kk[c][d] += sum_p g[b][kk][c][p] x[b][d][p] for a slice of p per wave: fp32 MFMA 16x16x4 with both operands read
+// as 16-byte runs of 4 consecutive positions (rows = planes), 3 x 4 output tiles (48 x 64), block-level LDS sum, then
+// one atomic per element per block.  grid (blocks, B, 2), block (64 * kPgWaves).
+__global__ __launch_bounds__(64 * kPgWaves) void projgrad_kernel(const ProjBwdArgs a, long long slice) {
+    __shared__ float s_part[kPgWaves][48 * 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y, kk = blockIdx.z;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const long long wave = (long long)blockIdx.x * kPgWaves + wv;
+    const long long l_begin = wave * slice, l_end = min(a.L, l_begin + slice);
+    const float* gb = a.g + (((long long)b * 2 + kk) * a.CP) * a.L;
+    const float* xb = a.x + (long long)b * a.D * a.L;
+    const bool vec = (a.L & 3) == 0;
+    pg_f4 acc[3][4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (pg_f4){0.f, 0.f, 0.f, 0.f};
+    auto load4 = [&](const float* base, int row, int nrows, long long l) -> float4 {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < nrows) {
+            const float* q = base + (long long)row * a.L + l;
+            if (vec) { if (l < l_end) v = *reinterpret_cast<const float4*>(q); }
+            else {
+                if (l + 0 < l_end) v.x = q[0];
+                if (l + 1 < l_end) v.y = q[1];
+                if (l + 2 < l_end) v.z = q[2];
+                if (l + 3 < l_end) v.w = q[3];
+            }
+        }
+        return v;
+    };
+    for (long long l0 = l_begin; l0 < l_end; l0 += 16) {
+        const long long l = l0 + 4 * kq;
+        float4 ga[3], xa[4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ga[i] = load4(gb, i16 + 16 * i, a.CP, l);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xa[j] = load4(xb, i16 + 16 * j, a.D, l);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gv = c == 0 ? ga[i].x : c == 1 ? ga[i].y : c == 2 ? ga[i].z : ga[i].w;
+                    const float xv = c == 0 ? xa[j].x : c == 1 ? xa[j].y : c == 2 ? xa[j].z : xa[j].w;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv, xv, acc[i][j], 0, 0, 0);
+                }
+    }
+    // D layout: lane holds rows 4 kq .. 4 kq + 3 of column i16
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_part[wv][(16 * i + 4 * kq + r) * 64 + 16 * j + i16] = acc[i][j][r];
+    __syncthreads();
+    float* dW = kk ? a.dWx1 : a.dWx0;
+    for (int e = threadIdx.x; e < 48 * 64; e += 64 * kPgWaves) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w4 = 0; w4 < kPgWaves; ++w4) t += s_part[w4][e];
+        const int c = e >> 6, d = e & 63;
+        if (c < a.CP && d < a.D) atomicAdd(dW + (long long)c * a.D + d, t);
+    }
+}
+
+}  // namespace wm

@@ -17,6 +17,7 @@
 #include "gram.hip.h"
 #include "conv2d.hip.h"
 #include "hfe.hip.h"
+#include "ss2d_bwd.hip.h"
 
 namespace wm {
 
@@ -274,7 +275,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 5; }
+int wm_abi_version(void) { return 6; }
 
 const char* wm_strerror(int code) {
     switch (code) {
@@ -419,17 +420,18 @@ static int bwd_launch(const ScanBwdArgs& a, const BwdPlan& pl, float* seg, float
     const dim3 grid((unsigned)pl.nchunks, (unsigned)pl.rows), block(64);
     ProfScope ps(12, st);
     if (pl.nchunks > 1) {
-        hipLaunchKernelGGL((selscan_bwd_reduce_kernel<NP, VEC>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((selscan_bwd_reduce_kernel<NP, VEC, 0>), grid, block, 0, st, a);
         launch_carry(a.wsP, a.wsH, seg, pl.chains, pl.nchunks, st);
         launch_carry(a.wsPr, a.wsG, seg, pl.chains, pl.nchunks, st);
     }
-    hipLaunchKernelGGL((selscan_bwd_chunk_kernel<NP, VEC>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((selscan_bwd_chunk_kernel<NP, VEC, 0>), grid, block, 0, st, a);
     hipMemsetAsync(dA, 0, (size_t)a.dim * a.N * sizeof(float), st);
     if (dD) hipMemsetAsync(dD, 0, (size_t)a.dim * sizeof(float), st);
     if (dbias) hipMemsetAsync(dbias, 0, (size_t)a.dim * sizeof(float), st);
     const int ysplit = pl.nchunks >= 2048 ? 16 : (pl.nchunks >= 256 ? 4 : 1);
     hipLaunchKernelGGL(selscan_bwd_finish_kernel, dim3((unsigned)a.dim, (unsigned)ysplit), dim3(256), 0, st,
-                       (const float*)a.part, dA, dD, dbias, a.batch, a.dim, a.N, NP + kPartPad, pl.nchunks);
+                       (const float*)a.part, dA, dD, dbias, a.batch, a.dim, a.N, NP + kPartPad, pl.nchunks,
+                       (const float*)nullptr, (float*)nullptr, 0, NP);
     return launch_status();
 }
 
@@ -544,6 +546,159 @@ int wm_ss2d_core_fwd(const float* x, const float* x_proj_weight, const float* dt
     ss2d_launch_col<false>(a, pl, seg, st);
     a.k = 3; a.y = merged ? y_row_fwd : y_col_rev; a.accumulate = merged;
     ss2d_launch_col<true>(a, pl, seg, st);
+    return launch_status();
+}
+
+}  // extern "C"
+namespace wm {
+struct CoreBwdPlan {
+    BwdPlan scan; long long L; int CP;
+    size_t rec_bytes, gpl_bytes, map_bytes, part_bytes, scan_bytes, total;
+};
+static int core_bwd_plan(CoreBwdPlan& pl, int B, int D, int H, int W, int N, int R) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || N <= 0 || R <= 0) return WM_EINVAL;
+    if (N > 16 || R > kRecPad || D > 64) return WM_EUNSUPPORTED;
+    pl.L = (long long)H * W;
+    if (pl.L > 0x7fffffffLL) return WM_EUNSUPPORTED;
+    int rc = bwd_plan(pl.scan, B, D, (int)pl.L, N, 1);
+    if (rc) return rc;
+    pl.CP = R + 2 * N;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    pl.rec_bytes = up((size_t)B * 4 * pl.L * kRS * sizeof(float));
+    pl.gpl_bytes = up((size_t)B * 2 * pl.CP * pl.L * sizeof(float));
+    pl.map_bytes = up((size_t)B * D * pl.L * sizeof(float));
+    pl.part_bytes = up((size_t)pl.scan.nchunks * B * D * (16 + kPartPadFused) * sizeof(float));
+    pl.scan_bytes = up(4 * pl.scan.arr_bytes + pl.scan.seg_bytes);
+    pl.total = pl.rec_bytes + pl.gpl_bytes + 4 * pl.map_bytes + pl.scan_bytes + pl.part_bytes;
+    return WM_OK;
+}
+
+// one direction of one layout: chunked adjoint scan with fused operands, then the parameter-gradient reduction
+template <bool VEC, int MODE>
+static void core_bwd_dir(ScanBwdArgs a, const CoreBwdPlan& pl, float* seg, const float* A_logs_k, float* dA_logs_k,
+                         float* dD_k, float* dbias_k, float* dWdt_k, hipStream_t st) {
+    const dim3 grid((unsigned)pl.scan.nchunks, (unsigned)pl.scan.rows), block(64);
+    if (pl.scan.nchunks > 1) {
+        hipLaunchKernelGGL((selscan_bwd_reduce_kernel<16, VEC, MODE>), grid, block, 0, st, a);
+        launch_carry(a.wsP, a.wsH, seg, pl.scan.chains, pl.scan.nchunks, st);
+        launch_carry(a.wsPr, a.wsG, seg, pl.scan.chains, pl.scan.nchunks, st);
+    }
+    hipLaunchKernelGGL((selscan_bwd_chunk_kernel<16, VEC, MODE>), grid, block, 0, st, a);
+    const int ysplit = pl.scan.nchunks >= 2048 ? 16 : (pl.scan.nchunks >= 256 ? 4 : 1);
+    hipLaunchKernelGGL(selscan_bwd_finish_kernel, dim3((unsigned)a.dim, (unsigned)ysplit), dim3(256), 0, st,
+                       (const float*)a.part, dA_logs_k, dD_k, dbias_k, a.batch, a.dim, a.N, 16 + kPartPadFused,
+                       pl.scan.nchunks, A_logs_k, dWdt_k, a.R, 16);
+}
+}  // namespace wm
+extern "C" {
+
+size_t wm_ss2d_core_bwd_workspace_bytes(int B, int D, int H, int W, int N, int R) {
+    CoreBwdPlan pl;
+    if (core_bwd_plan(pl, B, D, H, W, N, R) != WM_OK) return 0;
+    return pl.total;
+}
+
+int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt_projs_weight,
+                     const float* dt_projs_bias, const float* A_logs, const float* Ds, const float* dy_row_fwd,
+                     const float* dy_row_rev, const float* dy_col_fwd, const float* dy_col_rev, float* dx,
+                     float* dx_proj_weight, float* ddt_projs_weight, float* ddt_projs_bias, float* dA_logs, float* dDs,
+                     void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int N, int R, void* stream) {
+    if (B == 0 || D == 0 || H == 0 || W == 0) return (B < 0 || D < 0 || H < 0 || W < 0) ? WM_EINVAL : WM_OK;
+    CoreBwdPlan pl;
+    int rc = core_bwd_plan(pl, B, D, H, W, N, R);
+    if (rc) return rc;
+    if (!x || !x_proj_weight || !dt_projs_weight || !dt_projs_bias || !A_logs || !Ds || !dy_row_fwd || !dy_row_rev ||
+        !dy_col_fwd || !dy_col_rev || !dx || !dx_proj_weight || !ddt_projs_weight || !ddt_projs_bias || !dA_logs || !dDs ||
+        !workspace) return WM_ENULL;
+    if (workspace_bytes < pl.total) return WM_EWORKSPACE;
+    if (!aligned16(workspace)) return WM_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const long long L = pl.L;
+    const int CP = pl.CP;
+    char* w = (char*)workspace;
+    float* rec = (float*)w; w += pl.rec_bytes;
+    float* gpl = (float*)w; w += pl.gpl_bytes;
+    float* xT = (float*)w; w += pl.map_bytes;
+    float* dyTa = (float*)w; w += pl.map_bytes;
+    float* dyTb = (float*)w; w += pl.map_bytes;
+    float* dxT = (float*)w; w += pl.map_bytes;
+    float* wsP = (float*)w; float* wsH = (float*)(w + pl.scan.arr_bytes); float* wsPr = (float*)(w + 2 * pl.scan.arr_bytes);
+    float* wsG = (float*)(w + 3 * pl.scan.arr_bytes); float* seg = (float*)(w + 4 * pl.scan.arr_bytes);
+    w += pl.scan_bytes;
+    float* part = (float*)w;
+
+    hipError_t e = hipMemsetAsync(dx, 0, (size_t)B * D * L * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(dx_proj_weight, 0, (size_t)4 * CP * D * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(ddt_projs_weight, 0, (size_t)4 * D * R * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(ddt_projs_bias, 0, (size_t)4 * D * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(dA_logs, 0, (size_t)4 * D * N * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(dDs, 0, (size_t)4 * D * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+
+    ProfScope ps(12, st);
+    for (int layout = 0; layout < 2; ++layout) {
+        const int Hl = layout ? W : H, Wl = layout ? H : W;                 // the column directions see the transposed map
+        const float* xl = x; float* dxl = dx;
+        const float* dyl[2] = {dy_row_fwd, dy_row_rev};
+        if (layout) {
+            const dim3 tg((unsigned)((W + 31) / 32), (unsigned)((H + 31) / 32), (unsigned)(B * D)), tb(32, 8);
+            hipLaunchKernelGGL(transpose_planes_kernel, tg, tb, 0, st, x, xT, H, W, 0);
+            hipLaunchKernelGGL(transpose_planes_kernel, tg, tb, 0, st, dy_col_fwd, dyTa, H, W, 0);
+            if (dy_col_rev != dy_col_fwd) hipLaunchKernelGGL(transpose_planes_kernel, tg, tb, 0, st, dy_col_rev, dyTb, H, W, 0);
+            e = hipMemsetAsync(dxT, 0, (size_t)B * D * L * sizeof(float), st);
+            if (e != hipSuccess) return (int)e;
+            xl = xT; dxl = dxT; dyl[0] = dyTa; dyl[1] = dy_col_rev != dy_col_fwd ? dyTb : dyTa;
+        }
+        {   // records of this layout (all four directions' projections; the two of this layout are used)
+            Ss2dArgs pa;
+            pa.x = xl; pa.rec = rec; pa.Wx = x_proj_weight; pa.Wdt = dt_projs_weight; pa.dtb = dt_projs_bias;
+            pa.A_logs = A_logs; pa.Ds = Ds; pa.y = nullptr; pa.wsP = nullptr; pa.wsH = nullptr;
+            pa.B = B; pa.D = D; pa.H = Hl; pa.W = Wl; pa.L = (int)L; pa.N = N; pa.R = R; pa.k = 0;
+            pa.chunk_len = 0; pa.nchunks = 0; pa.nseg = 0; pa.accumulate = 0;
+            const int groups = (int)((L + 31) / 32);
+            long long waves = (long long)B * groups;
+            int blocks = (int)((waves + 1) / 2);
+            if (blocks > 256 * 4) blocks = 256 * 4;
+            hipLaunchKernelGGL(ss2d_proj_kernel, dim3((unsigned)blocks), dim3(128), 0, st, pa, groups);
+        }
+        for (int kk = 0; kk < 2; ++kk) {
+            const int k = layout ? (kk ? 3 : 1) : (kk ? 2 : 0);
+            ScanBwdArgs a;
+            a.u = xl; a.delta = nullptr; a.A = A_logs + (size_t)k * D * N; a.Bm = nullptr; a.Cm = nullptr;
+            a.D = Ds + (size_t)k * D; a.bias = dt_projs_bias + (size_t)k * D; a.dy = dyl[kk];
+            a.du = dxl; a.ddelta = nullptr; a.dB = nullptr; a.dC = nullptr;
+            a.wsP = wsP; a.wsH = wsH; a.wsPr = wsPr; a.wsG = wsG; a.part = part;
+            a.batch = B; a.dim = D; a.L = (int)L; a.N = N; a.G = 1; a.dpg = D; a.wpg = 1; a.nchunks = pl.scan.nchunks;
+            a.softplus = 1; a.atomic_bc = 0;
+            a.rec = rec + (size_t)k * L * kRS; a.rec_bstride = 4 * L * kRS;
+            a.Wdt = dt_projs_weight + (size_t)k * D * R; a.R = R;
+            a.dplanes = gpl + (size_t)kk * CP * L; a.dpl_bstride = 2LL * CP * L;
+            const bool vec = (L % 4 == 0) && aligned16(xl) && aligned16(dyl[kk]) && aligned16(dxl) && aligned16(gpl);
+            float* dA_k = dA_logs + (size_t)k * D * N; float* dD_k = dDs + (size_t)k * D;
+            float* db_k = ddt_projs_bias + (size_t)k * D; float* dW_k = ddt_projs_weight + (size_t)k * D * R;
+            if (kk == 0) { if (vec) core_bwd_dir<true, 1>(a, pl, seg, a.A, dA_k, dD_k, db_k, dW_k, st);
+                           else core_bwd_dir<false, 1>(a, pl, seg, a.A, dA_k, dD_k, db_k, dW_k, st); }
+            else         { if (vec) core_bwd_dir<true, 2>(a, pl, seg, a.A, dA_k, dD_k, db_k, dW_k, st);
+                           else core_bwd_dir<false, 2>(a, pl, seg, a.A, dA_k, dD_k, db_k, dW_k, st); }
+        }
+        ProjBwdArgs g;
+        g.g = gpl; g.x = xl; g.dx = dxl; g.B = B; g.D = D; g.CP = CP; g.L = L;
+        const int k0 = layout ? 1 : 0, k1 = layout ? 3 : 2;
+        g.Wx0 = x_proj_weight + (size_t)k0 * CP * D; g.Wx1 = x_proj_weight + (size_t)k1 * CP * D;
+        g.dWx0 = dx_proj_weight + (size_t)k0 * CP * D; g.dWx1 = dx_proj_weight + (size_t)k1 * CP * D;
+        hipLaunchKernelGGL(projbwd_dx_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)B), dim3(256), 0, st, g);
+        long long waves = (L + 1023) / 1024;
+        if (waves > 2048) waves = 2048;
+        waves = ((waves + kPgWaves - 1) / kPgWaves) * kPgWaves;
+        long long slice = (L + waves - 1) / waves;
+        slice = ((slice + 15) / 16) * 16;
+        hipLaunchKernelGGL(projgrad_kernel, dim3((unsigned)(waves / kPgWaves), (unsigned)B, 2), dim3(64 * kPgWaves), 0, st,
+                           g, slice);
+        if (layout) {
+            const dim3 tg((unsigned)((H + 31) / 32), (unsigned)((W + 31) / 32), (unsigned)(B * D)), tb(32, 8);
+            hipLaunchKernelGGL(transpose_planes_kernel, tg, tb, 0, st, (const float*)dxT, dx, W, H, 1);   // dx += (dx^T)^T
+        }
+    }
     return launch_status();
 }
 

@@ -278,13 +278,7 @@ def ss2d_core_supported(d_inner, d_state, dt_rank):
     return d_inner <= 64 and d_state <= 16 and dt_rank <= 4
 
 
-def ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, merged=False):
-    """SS2D.forward_core (reference wavemamba_arch.py:446-478) in one call.
-    x (B, D, H, W) fp32 -> (y_row_fwd, y_row_rev, y_col_fwd, y_col_rev), each (B, D, H*W) in
-    row-major l - the reference's return order; merged=True returns their sum (what :490 computes).
-    Forward only (no autograd graph)."""
-    lib = _lib.load()
-    _require_cuda("ss2d_core", x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
+def _ss2d_core_shapes(x, x_proj_weight, dt_projs_weight, A_logs):
     B, D, H, W = x.shape
     K, C, D2 = x_proj_weight.shape
     R, N = dt_projs_weight.shape[2], A_logs.shape[1]
@@ -292,7 +286,13 @@ def ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, merg
         raise RuntimeError("ss2d_core: inconsistent parameter shapes")
     if not ss2d_core_supported(D, N, R):
         raise NotImplementedError(f"ss2d_core: d_inner={D}, d_state={N}, dt_rank={R} outside the fused kernel's range")
-    f = [t.detach().contiguous().float() for t in (x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)]
+    return B, D, H, W, N, R
+
+
+def _ss2d_core_fwd(f, merged):
+    lib = _lib.load()
+    x = f[0]
+    B, D, H, W, N, R = _ss2d_core_shapes(x, f[1], f[2], f[4])
     L = H * W
     outs = [torch.empty((B, D, L), dtype=torch.float32, device=x.device) for _ in range(1 if merged else 4)]
     ws_bytes = lib.wm_ss2d_core_fwd_workspace_bytes(B, D, H, W, N, R)
@@ -301,6 +301,55 @@ def ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, merg
     with torch.cuda.device(x.device):
         check(lib.wm_ss2d_core_fwd(*[_ptr(t) for t in f], *ptrs, int(bool(merged)), _ptr(ws), ws_bytes,
                                    B, D, H, W, N, R, _stream()), "wm_ss2d_core_fwd")
+    return outs
+
+
+class _SS2DCoreFn(torch.autograd.Function):
+    """SS2D.forward_core with HIP forward (wm_ss2d_core_fwd) and HIP backward (wm_ss2d_core_bwd).  Nothing but x and
+    the parameters is saved: the backward re-runs the projection and the chunked scan from them."""
+
+    @staticmethod
+    def forward(ctx, merged, x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds):
+        f = [t.detach().contiguous().float() for t in (x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)]
+        ctx.save_for_backward(*f)
+        ctx.merged = merged
+        outs = _ss2d_core_fwd(f, merged)
+        return outs[0] if merged else tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        lib = _lib.load()
+        f = ctx.saved_tensors
+        x = f[0]
+        B, D, H, W, N, R = _ss2d_core_shapes(x, f[1], f[2], f[4])
+        if ctx.merged:
+            g = dys[0].contiguous().float()
+            dy = [g, g, g, g]
+        else:
+            dy = [(torch.zeros((B, D, H * W), dtype=torch.float32, device=x.device) if g is None else g.contiguous().float())
+                  for g in dys]
+        outs = [torch.empty_like(x), torch.empty_like(f[1]), torch.empty_like(f[2]), torch.empty_like(f[3]),
+                torch.empty_like(f[4]), torch.empty_like(f[5])]
+        ws_bytes = lib.wm_ss2d_core_bwd_workspace_bytes(B, D, H, W, N, R)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib.wm_ss2d_core_bwd(*[_ptr(t) for t in f], *[_ptr(t) for t in dy], *[_ptr(t) for t in outs],
+                                       _ptr(ws), ws_bytes, B, D, H, W, N, R, _stream()), "wm_ss2d_core_bwd")
+        return (None, *outs)
+
+
+def ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, merged=False):
+    """SS2D.forward_core (reference wavemamba_arch.py:446-478) in one call.
+    x (B, D, H, W) fp32 -> (y_row_fwd, y_row_rev, y_col_fwd, y_col_rev), each (B, D, H*W) in
+    row-major l - the reference's return order; merged=True returns their sum (what :490 computes).
+    Differentiable w.r.t. x and the five parameters (HIP backward, wm_ss2d_core_bwd)."""
+    _lib.load()
+    _require_cuda("ss2d_core", x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
+    _ss2d_core_shapes(x, x_proj_weight, dt_projs_weight, A_logs)
+    args = (x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
+    if torch.is_grad_enabled() and any(t.requires_grad for t in args):
+        return _SS2DCoreFn.apply(bool(merged), *args)
+    outs = _ss2d_core_fwd([t.detach().contiguous().float() for t in args], merged)
     return outs[0] if merged else tuple(outs)
 
 
