@@ -55,30 +55,39 @@ struct ProjBwdArgs {
     long long L;
 };
 
-// dx[b][d][p] += sum_kk sum_c Wx_kk[c][d] g[b][kk][c][p].  One thread = one position; the gradient rows sit in
-// registers, the weights are wave-uniform scalar operands.  grid (ceil(L / 256), B), block (256).  D <= 64, CP <= 36.
+// dx[b][d][p] += sum_kk sum_c Wx_kk[c][d] g[b][kk][c][p].  One thread = one position with its 2 CP gradient values in
+// registers; the two weight matrices sit in LDS transposed ([d][kk * CP + c], 16-byte broadcast reads).
+// grid (ceil(L / 256), B), block (256).  D <= 64, CP <= 36.
 __global__ __launch_bounds__(256) void projbwd_dx_kernel(const ProjBwdArgs a) {
+    constexpr int KP = 72;                                           // padded row: 2 * 36
+    __shared__ __attribute__((aligned(16))) float s_w[64 * KP];
+    for (int e = threadIdx.x; e < 64 * KP; e += 256) {
+        const int d = e / KP, q = e - d * KP, kk = q / 36, c = q - kk * 36;
+        s_w[e] = (d < a.D && c < a.CP) ? (kk ? a.Wx1 : a.Wx0)[(long long)c * a.D + d] : 0.0f;
+    }
+    __syncthreads();
     const long long p = blockIdx.x * 256ll + threadIdx.x;
     const int b = blockIdx.y;
     if (p >= a.L) return;
-    float acc[64];
+    float g[KP];
 #pragma unroll
-    for (int d = 0; d < 64; ++d) acc[d] = 0.0f;
     for (int kk = 0; kk < 2; ++kk) {
         const float* gp = a.g + (((long long)b * 2 + kk) * a.CP) * a.L + p;
-        const float* W = kk ? a.Wx1 : a.Wx0;
-        for (int c = 0; c < a.CP; ++c) {
-            const float gv = gp[(long long)c * a.L];
-            const float* wr = W + (long long)c * a.D;               // uniform
 #pragma unroll
-            for (int d = 0; d < 64; ++d)
-                if (d < a.D) acc[d] = fmaf(wr[d], gv, acc[d]);
-        }
+        for (int c = 0; c < 36; ++c) g[kk * 36 + c] = c < a.CP ? gp[(long long)c * a.L] : 0.0f;
     }
     float* o = a.dx + (long long)b * a.D * a.L + p;
+    for (int d = 0; d < a.D; ++d) {
+        const float4* wr = reinterpret_cast<const float4*>(&s_w[d * KP]);
+        float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
-    for (int d = 0; d < 64; ++d)
-        if (d < a.D) o[(long long)d * a.L] += acc[d];
+        for (int q = 0; q < KP / 4; ++q) {
+            const float4 w4 = wr[q];
+            acc0 = fmaf(w4.x, g[4 * q], acc0); acc1 = fmaf(w4.y, g[4 * q + 1], acc1);
+            acc0 = fmaf(w4.z, g[4 * q + 2], acc0); acc1 = fmaf(w4.w, g[4 * q + 3], acc1);
+        }
+        o[(long long)d * a.L] += acc0 + acc1;
+    }
 }
 
 typedef float pg_f4 __attribute__((ext_vector_type(4)));
