@@ -717,3 +717,15 @@ def test_ss2d_core_backward_vs_unfused_autograd(B, D, H, W, N, R, merged):
         got = torch.autograd.grad(wm.ops.ss2d_core(*params), params, dys)
     for a, b, nm in zip(got, ref, ("dx", "dWx", "dWdt", "dbias", "dA_logs", "dDs")):
         assert_close(a, b, 2e-4, f"fused core bwd {nm} {(B, D, H, W, N, R)} merged={merged}")
+
+
+def test_batched_forward_equals_per_image_forward():
+    """Batch strides of every fused path (gathered conv operands, per-image folded attention weights, SKFF, merged
+    scans): a 2-image batch must reproduce the two single-image forwards."""
+    torch.manual_seed(0)
+    net = wm.WaveMamba(in_chn=3, wf=32, n_l_blocks=[1, 2, 4], n_h_blocks=[1, 1, 2], ffn_scale=2.0).eval().to(DEV)
+    x = torch.rand(2, 3, 64, 96, generator=gen(9)).to(DEV)
+    with torch.no_grad():
+        both = net.restoration_network(x)
+        one = torch.cat([net.restoration_network(x[i:i + 1]) for i in range(2)], 0)
+    assert_close(both, one.cpu(), 1e-5, "batch of 2 vs two single images")
