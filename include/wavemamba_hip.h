@@ -203,12 +203,18 @@ int wm_mul_sigmoid_fwd(const float* a, const float* b, float* out, int64_t n, vo
  *                     Ca % 8 == 0 when Cb > 0.
  *                     y (B, Cout, H, W) = conv(x) + bias;  y *= sigmoid(gate) if gate;  y += residual if residual
  *                     (gate, residual: (B, Cout, H, W), may be NULL; bias may be NULL).  `wfrag` prepared for
- *                     Cin = Ca + Cb and the same ks.  H * W < 2^31. */
+ *                     Cin = Ca + Cb and the same ks.  H * W < 2^31.
+ *   wm_conv2d_gated_fwd  y = conv3x3(x; wfrag3) * sigmoid(conv1x1(x; wfrag1) + bias1) over the same (concatenated /
+ *                     gathered) input: PAConv's k3(x) * sigmoid(k2(x)) (:694-697) in one kernel - the 1x1 shares the
+ *                     3x3's centre-tap operand fragments.  wfrag3 / wfrag1 prepared with ks = 3 / 1 for (Cout, Ca + Cb). */
 size_t wm_conv2d_wfrag_bytes(int Cout, int Cin, int ks);
 int wm_conv2d_prep(const float* weight, void* wfrag, int Cout, int Cin, int ks, void* stream);
 int wm_conv2d_fwd(const float* xa, const float* xb, const int* xb_index, const void* wfrag, const float* bias,
                   const float* gate, const float* residual, float* y, int B, int Ca, int Cb, int Cb_src, int Cout,
                   int H, int W, int ks, void* stream);
+int wm_conv2d_gated_fwd(const float* xa, const float* xb, const int* xb_index, const void* wfrag3, const void* wfrag1,
+                        const float* bias1, float* y, int B, int Ca, int Cb, int Cb_src, int Cout, int H, int W,
+                        void* stream);
 
 /* Backward of wm_ss2d_core_fwd: autograd of SS2D.forward_core (wavemamba_arch.py:446-478) - the four directional
  * flattenings, the x_proj / dt_proj einsums and the selective scan - without materialising xs / dts / Bs / Cs.

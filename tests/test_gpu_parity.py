@@ -729,3 +729,25 @@ def test_batched_forward_equals_per_image_forward():
         both = net.restoration_network(x)
         one = torch.cat([net.restoration_network(x[i:i + 1]) for i in range(2)], 0)
     assert_close(both, one.cpu(), 1e-5, "batch of 2 vs two single images")
+
+
+@pytest.mark.parametrize("B,Ca,Csrc,Cb,Cout,H,W", [(1, 32, 32, 32, 64, 24, 40), (2, 32, 32, 32, 64, 9, 33),
+                                                  (1, 64, 0, 0, 64, 31, 17), (2, 16, 24, 8, 40, 17, 31)])
+def test_conv2d_gated_vs_torch(B, Ca, Csrc, Cb, Cout, H, W):
+    """PAConv's k3(x) * sigmoid(k2(x)) (reference :694-697) in one kernel, on cat([x, gather(p, idx)])."""
+    import torch.nn.functional as F
+    gg = gen(B * 17 + Cout)
+    x = torch.randn(B, Ca, H, W, generator=gg)
+    w3 = torch.randn(Cout, Ca + Cb, 3, 3, generator=gg) / (3 * (Ca + Cb) ** 0.5)
+    w1 = torch.randn(Cout, Ca + Cb, 1, 1, generator=gg) / (Ca + Cb) ** 0.5
+    b1 = torch.randn(Cout, generator=gg)
+    if Cb:
+        p = torch.randn(B, Csrc, H, W, generator=gg)
+        idx = torch.randint(0, Csrc, (B, Cb), generator=gg)
+        xin = torch.cat([x, torch.gather(p, 1, idx[:, :, None, None].expand(-1, -1, H, W))], 1)
+        got = wm.ops.conv2d_gated(*cu(x, w3, w1, b1, p, idx))
+    else:
+        xin = x
+        got = wm.ops.conv2d_gated(*cu(x, w3, w1, b1))
+    ref = F.conv2d(xin.double(), w3.double(), None, padding=1) * torch.sigmoid(F.conv2d(xin.double(), w1.double(), b1.double()))
+    assert_close(got, ref.float(), 2e-5, f"conv2d_gated {(B, Ca, Cb, Cout, H, W)}")

@@ -379,6 +379,13 @@ class PAConv(nn.Module):
         self.k4 = nn.Conv2d(nf, nf // 2, kernel_size=k_size, padding=(k_size - 1) // 2, bias=False)
 
     def forward(self, x, x2=None, x2_index=None):
+        ops = _OpsBackend.impl
+        if (hasattr(ops, "conv2d_gated") and self.k3.bias is None and tuple(self.k3.weight.shape[2:]) == (3, 3)
+                and ops.conv2d_supported(x, self.k3.weight, x2)
+                and not (torch.is_grad_enabled() and any(t is not None and t.requires_grad
+                                                         for t in (x, x2, self.k3.weight, self.k2.weight)))):
+            # k3(x) * sigmoid(k2(x)): the 1x1 rides on the 3x3's centre tap, the gate never exists as a tensor
+            return _conv(self.k4, ops.conv2d_gated(x, self.k3.weight, self.k2.weight, self.k2.bias, x2, x2_index))
         gate = _conv(self.k2, x, x2, x2_index)
         return _conv(self.k4, _conv(self.k3, x, x2, x2_index, gate=gate))
 

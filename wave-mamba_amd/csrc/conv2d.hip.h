@@ -51,6 +51,8 @@ struct Conv2dArgs {
     const float* bias;                // (Cout) or null
     const float* gate;                // (B, Cout, H, W) or null: out *= sigmoid(gate)
     const float* res;                 // (B, Cout, H, W) or null: out += res
+    const uint4* wfrag1;              // G1X1 kernels: prepared 1x1 weights over the same input (PAConv.k2), else unused
+    const float* bias1;               // G1X1: bias of that 1x1 (or null)
     float* y;                         // (B, Cout, H, W)
     int Ca, Cb, Cbsrc, Cout, H, W;
     int nch;                          // ceil((Ca + Cb) / 16) input-channel chunks
@@ -88,7 +90,10 @@ __global__ __launch_bounds__(256) void conv2d_prep_kernel(const float* __restric
     }
 }
 
-template <int KS /*1 or 3*/, int RW /*rows per wave*/, int MT /*32-channel row tiles per launch*/>
+// G1X1 (3x3 only): a second, 1x1 convolution of the same input (its own prepared weights a.wfrag1 / a.bias1) rides on
+// the centre tap's B fragments into a second accumulator set and gates the output: y = conv3x3(X) * sigmoid(conv1x1(X) +
+// b1) - PAConv's k3(x) * sigmoid(k2(x)) (reference :694-697) without the gate tensor ever existing.
+template <int KS /*1 or 3*/, int RW /*rows per wave*/, int MT /*32-channel row tiles per launch*/, bool G1X1 = false>
 __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cv_smem[];
     constexpr int PAD = KS / 2, TAPS = KS * KS;
@@ -98,8 +103,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
     constexpr int PIT = (NPIX + 255) / 256;          // staged pixels per thread (x 2 k-halves x 8 channels)
     constexpr int W_ITEMS = TAPS * MT * 2 * 64;      // 16-byte weight fragments per chunk (a multiple of 64)
     constexpr int W_IT = (W_ITEMS + 255) / 256;
+    constexpr int W1_ITEMS = G1X1 ? MT * 2 * 64 : 0; // the 1x1's fragments per chunk
+    static_assert(!G1X1 || KS == 3, "the gating 1x1 rides on a 3x3");
     uint4* s_in = reinterpret_cast<uint4*>(cv_smem);                 // [split * 2 + khalf][NPIX]
     uint4* s_w = reinterpret_cast<uint4*>(cv_smem) + 4 * NPIX;       // [tap][m][split][lane]
+    uint4* s_w1 = s_w + W_ITEMS;                                     // [m][split][lane]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // workgroup q runs on XCD q mod 8 (each with a private L2): every XCD gets a contiguous band of row-major tiles
@@ -165,6 +173,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
                                                  (__attribute__((address_space(3))) void*)(s_w + item0), 16, 0, 0);
             }
         }
+        if constexpr (G1X1) {
+            const uint4* w1src = a.wfrag1 + ((long long)cc * a.mtot) * 128;
+            const int item0 = wave * 64;                             // MT * 128 fragments: waves 0 .. 2 MT - 1
+            if (item0 < W1_ITEMS) {
+                const uint4* g = w1src + (a.mbase + (item0 >> 7)) * 128 + (item0 & 64) + lane;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(s_w1 + item0), 16, 0, 0);
+            }
+        }
     };
 
     auto stage = [&](int cc) {
@@ -192,12 +209,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
     };
 
     f32x16_t acc[MT][RW];
+    f32x16_t acc1[G1X1 ? MT : 1][G1X1 ? RW : 1];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < RW; ++r)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.0f;
+            for (int i = 0; i < 16; ++i) { acc[m][r][i] = 0.0f; if (G1X1) acc1[m][r][i] = 0.0f; }
 
     const int khalf = lane >> 5, px = lane & 31;
     for (int cc = 0; cc < a.nch; ++cc) {
@@ -233,6 +251,21 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
                             acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                                 term == 2 ? Al[ky][m].v : Ah[ky][m].v, term == 1 ? Bl.v : Bh.v, acc[m][r], 0, 0, 0);
                     }
+                if constexpr (G1X1) {
+                    if (kx == PAD && j >= PAD && j < RW + PAD) {       // centre tap: staged row j is output row j - PAD
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            Frag16 Wh, Wl;
+                            Wh.u = s_w1[(m * 2 + 0) * 64 + lane];
+                            Wl.u = s_w1[(m * 2 + 1) * 64 + lane];
+                            f32x16_t c1 = acc1[m][j - PAD];
+                            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wh.v, Bh.v, c1, 0, 0, 0);
+                            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wh.v, Bl.v, c1, 0, 0, 0);
+                            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wl.v, Bh.v, c1, 0, 0, 0);
+                            acc1[m][j - PAD] = c1;
+                        }
+                    }
+                }
             }
         }
         __syncthreads();
@@ -244,11 +277,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int chb = (a.mbase + m) * 32 + 4 * khalf;
-        float bv[16];
+        float bv[16], b1v[G1X1 ? 16 : 1];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int ch = chb + (i & 3) + 8 * (i >> 2);
             bv[i] = (a.bias && ch < a.Cout) ? a.bias[ch] : 0.0f;
+            if (G1X1) b1v[i] = (a.bias1 && ch < a.Cout) ? a.bias1[ch] : 0.0f;
         }
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
@@ -276,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
             for (int i = 0; i < 16; ++i) {
                 const int dc = (i & 3) + 8 * (i >> 2);
                 float v = acc[m][r][i] + bv[i];
+                if constexpr (G1X1) v = v / (1.0f + __expf(-(acc1[m][r][i] + b1v[i])));
                 if (a.gate) v = v / (1.0f + __expf(-gv[i]));
                 if (a.res) v += rv[i];
                 if (full || chb + dc < a.Cout) a.y[o + dc * HW] = v;

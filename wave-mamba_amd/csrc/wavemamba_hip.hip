@@ -275,7 +275,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 6; }
+int wm_abi_version(void) { return 7; }
 
 const char* wm_strerror(int code) {
     switch (code) {
@@ -905,20 +905,20 @@ int wm_conv2d_prep(const float* weight, void* wfrag, int Cout, int Cin, int ks, 
 
 }  // extern "C"
 
-template <int KS, int RW, int MT>
+template <int KS, int RW, int MT, bool G1X1 = false>
 static int conv2d_launch(const wm::Conv2dArgs& a, int B, hipStream_t st) {
     constexpr int PAD = KS / 2;
-    constexpr int smem = ((4 * RW + 2 * PAD) * (wm::kCvTW + 2 * PAD) * 4 + KS * KS * MT * 2 * 64) * 16;   // input planes + weights
+    constexpr int smem = ((4 * RW + 2 * PAD) * (wm::kCvTW + 2 * PAD) * 4 + (KS * KS + (G1X1 ? 1 : 0)) * MT * 2 * 64) * 16;   // input planes + weights
     static bool configured = false;                      // > 64 KB of LDS needs the opt-in, once per instantiation
     if (!configured && smem > 65536) {
-        hipError_t e = hipFuncSetAttribute((const void*)wm::conv2d_mfma_kernel<KS, RW, MT>,
+        hipError_t e = hipFuncSetAttribute((const void*)wm::conv2d_mfma_kernel<KS, RW, MT, G1X1>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
     const int ntiles = ((a.W + wm::kCvTW - 1) / wm::kCvTW) * ((a.H + 4 * RW - 1) / (4 * RW));
     const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8), (unsigned)B);
-    hipLaunchKernelGGL((wm::conv2d_mfma_kernel<KS, RW, MT>), grid, dim3(256), smem, st, a);
+    hipLaunchKernelGGL((wm::conv2d_mfma_kernel<KS, RW, MT, G1X1>), grid, dim3(256), smem, st, a);
     return launch_status();
 }
 
@@ -938,7 +938,7 @@ int wm_conv2d_fwd(const float* xa, const float* xb, const int* xb_index, const v
     hipStream_t st = (hipStream_t)stream;
     Conv2dArgs a;
     a.xa = xa; a.xb = Cb > 0 ? xb : nullptr; a.xb_idx = Cb > 0 ? xb_index : nullptr; a.wfrag = (const uint4*)wfrag;
-    a.bias = bias; a.gate = gate; a.res = residual; a.y = y;
+    a.bias = bias; a.gate = gate; a.res = residual; a.y = y; a.wfrag1 = nullptr; a.bias1 = nullptr;
     a.Ca = Ca; a.Cb = Cb; a.Cbsrc = Cb_src; a.Cout = Cout; a.H = H; a.W = W;
     a.nch = (Ca + Cb + 15) / 16; a.mtot = (Cout + 31) / 32;
     ProfScope ps(ks == 3 ? 13 : 14, st);
@@ -955,6 +955,31 @@ int wm_conv2d_fwd(const float* xa, const float* xb, const int* xb_index, const v
             else if (left == 2) { rc = conv2d_launch<1, 4, 2>(a, B, st); mb += 2; }
             else { rc = conv2d_launch<1, 4, 1>(a, B, st); mb += 1; }
         }
+        if (rc) return rc;
+    }
+    return WM_OK;
+}
+
+int wm_conv2d_gated_fwd(const float* xa, const float* xb, const int* xb_index, const void* wfrag3, const void* wfrag1,
+                        const float* bias1, float* y, int B, int Ca, int Cb, int Cb_src, int Cout, int H, int W,
+                        void* stream) {
+    if (B < 0 || Ca <= 0 || Cb < 0 || Cout <= 0 || H < 0 || W < 0 || Cb_src < 0) return WM_EINVAL;
+    if (B == 0 || H == 0 || W == 0) return WM_OK;
+    if (!xa || !wfrag3 || !wfrag1 || !y || (Cb > 0 && !xb)) return WM_ENULL;
+    if (Cb > 0 && Ca % 8 != 0) return WM_EUNSUPPORTED;
+    if (Cb > 0 && !xb_index && Cb_src != Cb) return WM_EINVAL;
+    if (B > 65535 || (long long)H * W >= (1ll << 31)) return WM_EUNSUPPORTED;
+    if (!aligned16(wfrag3) || !aligned16(wfrag1)) return WM_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    Conv2dArgs a;
+    a.xa = xa; a.xb = Cb > 0 ? xb : nullptr; a.xb_idx = Cb > 0 ? xb_index : nullptr; a.wfrag = (const uint4*)wfrag3;
+    a.bias = nullptr; a.gate = nullptr; a.res = nullptr; a.y = y; a.wfrag1 = (const uint4*)wfrag1; a.bias1 = bias1;
+    a.Ca = Ca; a.Cb = Cb; a.Cbsrc = Cb_src; a.Cout = Cout; a.H = H; a.W = W;
+    a.nch = (Ca + Cb + 15) / 16; a.mtot = (Cout + 31) / 32;
+    ProfScope ps(13, st);
+    for (int mb = 0; mb < a.mtot; ++mb) {                // one 32-channel row tile per launch: two accumulator sets
+        a.mbase = mb;
+        const int rc = conv2d_launch<3, 4, 1, true>(a, B, st);
         if (rc) return rc;
     }
     return WM_OK;

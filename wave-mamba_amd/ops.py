@@ -648,6 +648,40 @@ def conv2d(x, weight, bias=None, x2=None, x2_index=None, gate=None, residual=Non
     return y
 
 
+def conv2d_gated(x, weight3, weight1, bias1=None, x2=None, x2_index=None):
+    """conv3x3(X; weight3) * sigmoid(conv1x1(X; weight1) + bias1) with X as in `conv2d` - PAConv's k3(x) * sigmoid(k2(x))
+    (reference wavemamba_arch.py:694-697) in one kernel.  weight3 (Cout, Cin, 3, 3) without bias, weight1
+    (Cout, Cin, 1, 1).  Forward only."""
+    lib = _lib.load()
+    _require_cuda("conv2d_gated", x, weight3, weight1, bias1, x2, x2_index)
+    B, Ca, H, W = x.shape
+    cout, cin = weight3.shape[0], weight3.shape[1]
+    if tuple(weight3.shape) != (cout, cin, 3, 3) or tuple(weight1.shape) != (cout, cin, 1, 1):
+        raise RuntimeError(f"conv2d_gated: weights must be (Cout, Cin, 3, 3) and (Cout, Cin, 1, 1), got "
+                           f"{tuple(weight3.shape)} and {tuple(weight1.shape)}")
+    cb = cb_src = 0
+    if x2 is not None:
+        if (x2.shape[0], x2.shape[2], x2.shape[3]) != (B, H, W):
+            raise RuntimeError(f"conv2d_gated: x2 {tuple(x2.shape)} does not match x {tuple(x.shape)}")
+        cb_src = x2.shape[1]
+        cb = cb_src if x2_index is None else x2_index.shape[1]
+    if cin != Ca + cb:
+        raise RuntimeError(f"conv2d_gated: weights expect {cin} input channels, got {Ca} + {cb}")
+    for t in (x, weight3, weight1, x2):
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError("conv2d_gated: float32 only")
+    x = x.contiguous()
+    x2 = None if x2 is None else x2.contiguous()
+    idx = None if x2_index is None else x2_index.to(torch.int32).contiguous()
+    f3, f1 = _conv2d_wfrag(weight3), _conv2d_wfrag(weight1)
+    y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.wm_conv2d_gated_fwd(_ptr(x), _ptr(x2), _ptr(idx), _ptr(f3), _ptr(f1),
+                                      _ptr(None if bias1 is None else bias1.detach().contiguous()), _ptr(y),
+                                      B, Ca, cb, cb_src, cout, H, W, _stream()), "wm_conv2d_gated_fwd")
+    return y
+
+
 def conv2d_supported(x, weight, x2=None):
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
             and weight.dim() == 4 and tuple(weight.shape[2:]) in ((3, 3), (1, 1)) and x.shape[2] * x.shape[3] < 2 ** 31
