@@ -977,9 +977,13 @@ int wm_conv2d_gated_fwd(const float* xa, const float* xb, const int* xb_index, c
     a.Ca = Ca; a.Cb = Cb; a.Cbsrc = Cb_src; a.Cout = Cout; a.H = H; a.W = W;
     a.nch = (Ca + Cb + 15) / 16; a.mtot = (Cout + 31) / 32;
     ProfScope ps(13, st);
-    for (int mb = 0; mb < a.mtot; ++mb) {                // one 32-channel row tile per launch: two accumulator sets
+    for (int mb = 0; mb < a.mtot;) {
+        // two accumulator sets per wave: 64 channels x 8-row tiles read the input once (0.79 ms against 0.90 ms for
+        // two 32-channel x 16-row launches at UHD level 1, 64 -> 64); a last odd row tile takes the 16-row form
         a.mbase = mb;
-        const int rc = conv2d_launch<3, 4, 1, true>(a, B, st);
+        int rc;
+        if (a.mtot - mb >= 2) { rc = conv2d_launch<3, 2, 2, true>(a, B, st); mb += 2; }
+        else { rc = conv2d_launch<3, 4, 1, true>(a, B, st); mb += 1; }
         if (rc) return rc;
     }
     return WM_OK;
