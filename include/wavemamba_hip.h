@@ -230,6 +230,14 @@ int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt
                      float* dx_proj_weight, float* ddt_projs_weight, float* ddt_projs_bias, float* dA_logs, float* dDs,
                      void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int N, int R, void* stream);
 
+/* nn.LayerNorm(C) over the last axis of contiguous token tensors (T, C): LFSSBlock.ln_1 / ln_2, SS2D.out_norm
+ * (wavemamba_arch.py:385, :493, :507-526), forward and backward (training).  C in {8, 16, 32, 64}; biased variance,
+ * eps inside the square root; dweight / dbias (C) are overwritten.  16-byte aligned pointers. */
+int wm_layernorm_tok_fwd(const float* x, const float* weight, const float* bias, float eps, float* y, int64_t T, int C,
+                         void* stream);
+int wm_layernorm_tok_bwd(const float* x, const float* weight, const float* gy, float eps, float* gx, float* dweight,
+                         float* dbias, int64_t T, int C, void* stream);
+
 /* Small-tensor steps of the HFE branch as single kernels (csrc/hfe.hip.h).  Forward only.
  *   wm_match_index   channel matching with every channel kept (wavemamba_arch.py:659-666, match_factor = 1):
  *                    index[b, c] = argmin_j (nx[b, c] + ny[b, j] - 2 G[b, c, j]) from wm_gram_fwd's outputs; (B, C) int32.

@@ -751,3 +751,24 @@ def test_conv2d_gated_vs_torch(B, Ca, Csrc, Cb, Cout, H, W):
         got = wm.ops.conv2d_gated(*cu(x, w3, w1, b1))
     ref = F.conv2d(xin.double(), w3.double(), None, padding=1) * torch.sigmoid(F.conv2d(xin.double(), w1.double(), b1.double()))
     assert_close(got, ref.float(), 2e-5, f"conv2d_gated {(B, Ca, Cb, Cout, H, W)}")
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 56, 32), (1, 7, 9, 64), (3, 130, 16), (5, 8)])
+def test_layernorm_tok_forward_backward_vs_torch(shape):
+    """nn.LayerNorm over the last axis of token tensors (ln_1 / ln_2 / out_norm), forward and gradients."""
+    import torch.nn.functional as F
+    C = shape[-1]
+    gg = gen(C + len(shape))
+    x = torch.randn(*shape, generator=gg) * 2.0 + 0.5
+    w = torch.randn(C, generator=gg) * 0.5 + 1.0
+    b = torch.randn(C, generator=gg)
+    gy = torch.randn(*shape, generator=gg)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    ref = F.layer_norm(xr, (C,), wr, br, 1e-5)
+    gref = torch.autograd.grad(ref, (xr, wr, br), gy.double())
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    got = wm.ops.layernorm_tok(xd, wd, bd, 1e-5)
+    ggot = torch.autograd.grad(got, (xd, wd, bd), gy.to(DEV))
+    assert_close(got.detach(), ref.detach().float(), 1e-5, f"layernorm_tok {shape}")
+    for a, r, nm in zip(ggot, gref, ("gx", "dweight", "dbias")):
+        assert_close(a, r.float(), 2e-5, f"layernorm_tok {nm} {shape}")

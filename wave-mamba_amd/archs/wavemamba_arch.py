@@ -64,6 +64,17 @@ def _dwconv(conv, x, act="none"):
     return F.silu(y) if act == "silu" else F.gelu(y) if act == "gelu" else y
 
 
+def _ln_tok(norm, x):
+    """nn.LayerNorm over the last axis of token tensors: the HIP kernel pair (forward + backward) on the HIP backend,
+    the module elsewhere."""
+    ops = _OpsBackend.impl
+    if (hasattr(ops, "layernorm_tok") and isinstance(norm, nn.LayerNorm) and norm.elementwise_affine
+            and norm.bias is not None and len(norm.normalized_shape) == 1
+            and ops.layernorm_tok_supported(x, norm.normalized_shape[0])):
+        return ops.layernorm_tok(x, norm.weight, norm.bias, norm.eps)
+    return norm(x)
+
+
 def _conv(conv, x, x2=None, x2_index=None, gate=None, residual=None):
     """Dense 3x3 / 1x1 nn.Conv2d (stride 1, 'same' padding) of X = x | cat([x, x2], 1) |
     cat([x, gather(x2, 1, x2_index)], 1), then `* sigmoid(gate)` and `+ residual` when given.  Inference on the
@@ -250,7 +261,7 @@ class SS2D(nn.Module):
             assert y1.dtype == torch.float32
             y = y1 + y2 + y3 + y4
         y = y.transpose(1, 2).contiguous().view(B, H, W, -1)
-        y = self.out_norm(y) * F.silu(z)
+        y = _ln_tok(self.out_norm, y) * F.silu(z)
         y = self.out_proj(y)
         return self.dropout(y) if self.dropout is not None else y
 
@@ -289,8 +300,8 @@ class LFSSBlock(nn.Module):
         if self._fused_ok(input):
             return _OpsBackend.impl.lfss_block_forward(input, x_size, self)
         tok = input.view(B, x_size[0], x_size[1], C)
-        tok = tok * self.skip_scale + self.drop_path(self.self_attention(self.ln_1(tok)))
-        mix = self.conv_blk(self.ln_2(tok).permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1)
+        tok = tok * self.skip_scale + self.drop_path(self.self_attention(_ln_tok(self.ln_1, tok)))
+        mix = self.conv_blk(_ln_tok(self.ln_2, tok).permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1)
         tok = tok * self.skip_scale2 + mix
         return tok.reshape(B, L, C)
 

@@ -254,4 +254,76 @@ __global__ __launch_bounds__(256) void layernorm2d_bwd_kernel(const float* __res
     }
 }
 
+// ---- LayerNorm over the last (contiguous) axis of token tensors (..., C): nn.LayerNorm(C) of LFSSBlock.ln_1 / ln_2
+// and SS2D.out_norm (reference :345-386, :493, :522-526), forward and backward for training --------------------------
+// C / 4 lanes per token, 4 channels per lane: a wave instruction moves 64 x 16 contiguous bytes; the channel sums run over
+// the token's lanes by shuffles.  Backward: dgamma / dbeta partials stay in the lane's 4 registers over a grid-stride loop,
+// then lanes with the same channel quad meet by shuffles, waves through LDS, blocks through one atomic per channel.
+template <int C>
+__device__ __forceinline__ float tok_sum(float v) {
+#pragma unroll
+    for (int off = 1; off < C / 4; off <<= 1) v += __shfl_xor(v, off);
+    return v;
+}
+template <int C>
+__global__ __launch_bounds__(256) void layernorm_tok_kernel(const float4* __restrict__ x, const float4* __restrict__ w,
+                                                            const float4* __restrict__ b, float eps,
+                                                            float4* __restrict__ y, long long T) {
+    constexpr int LPT = C / 4;
+    const int q = threadIdx.x % LPT;                                 // channel quad of this lane
+    const float4 wv = w[q], bv = b[q];
+    const long long stride = (long long)gridDim.x * (256 / LPT);
+    for (long long t = (long long)blockIdx.x * (256 / LPT) + threadIdx.x / LPT; t < T; t += stride) {
+        const float4 v = x[t * LPT + q];
+        const float mean = tok_sum<C>((v.x + v.y) + (v.z + v.w)) * (1.0f / C);
+        const float4 d = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+        const float var = tok_sum<C>(fmaf(d.x, d.x, fmaf(d.y, d.y, fmaf(d.z, d.z, d.w * d.w)))) * (1.0f / C);
+        const float rstd = 1.0f / sqrtf(var + eps);
+        y[t * LPT + q] = make_float4(fmaf(d.x * rstd, wv.x, bv.x), fmaf(d.y * rstd, wv.y, bv.y),
+                                     fmaf(d.z * rstd, wv.z, bv.z), fmaf(d.w * rstd, wv.w, bv.w));
+    }
+}
+template <int C>
+__global__ __launch_bounds__(256) void layernorm_tok_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w,
+                                                                const float4* __restrict__ gy, float eps,
+                                                                float4* __restrict__ gx, float* __restrict__ dw,
+                                                                float* __restrict__ db, long long T) {
+    constexpr int LPT = C / 4;
+    const int q = threadIdx.x % LPT;
+    const float4 wv = w[q];
+    float4 pw = make_float4(0.f, 0.f, 0.f, 0.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long stride = (long long)gridDim.x * (256 / LPT);
+    for (long long t = (long long)blockIdx.x * (256 / LPT) + threadIdx.x / LPT; t < T; t += stride) {
+        const float4 v = x[t * LPT + q], g0 = gy[t * LPT + q];
+        const float mean = tok_sum<C>((v.x + v.y) + (v.z + v.w)) * (1.0f / C);
+        float4 d = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+        const float var = tok_sum<C>(fmaf(d.x, d.x, fmaf(d.y, d.y, fmaf(d.z, d.z, d.w * d.w)))) * (1.0f / C);
+        const float rstd = 1.0f / sqrtf(var + eps);
+        d = make_float4(d.x * rstd, d.y * rstd, d.z * rstd, d.w * rstd);                    // yhat
+        pw = make_float4(fmaf(g0.x, d.x, pw.x), fmaf(g0.y, d.y, pw.y), fmaf(g0.z, d.z, pw.z), fmaf(g0.w, d.w, pw.w));
+        pb = make_float4(pb.x + g0.x, pb.y + g0.y, pb.z + g0.z, pb.w + g0.w);
+        const float4 g = make_float4(g0.x * wv.x, g0.y * wv.y, g0.z * wv.z, g0.w * wv.w);
+        const float mg = tok_sum<C>((g.x + g.y) + (g.z + g.w)) * (1.0f / C);
+        const float mgy = tok_sum<C>(fmaf(g.x, d.x, fmaf(g.y, d.y, fmaf(g.z, d.z, g.w * d.w)))) * (1.0f / C);
+        gx[t * LPT + q] = make_float4(rstd * (g.x - d.x * mgy - mg), rstd * (g.y - d.y * mgy - mg),
+                                      rstd * (g.z - d.z * mgy - mg), rstd * (g.w - d.w * mgy - mg));
+    }
+    float acc[8] = {pw.x, pw.y, pw.z, pw.w, pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int off = LPT; off < 64; off <<= 1) acc[i] += __shfl_xor(acc[i], off);     // lanes with the same quad
+    __shared__ float s_red[4][2 * C];
+    const int lane = threadIdx.x & 63;
+    if (lane < LPT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s_red[threadIdx.x >> 6][4 * lane + i] = acc[i]; s_red[threadIdx.x >> 6][C + 4 * lane + i] = acc[4 + i]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * C) {
+        const float t = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+        atomicAdd((threadIdx.x < C ? dw : db) + (threadIdx.x % C), t);
+    }
+}
+
 }  // namespace wm

@@ -275,7 +275,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 7; }
+int wm_abi_version(void) { return 8; }
 
 const char* wm_strerror(int code) {
     switch (code) {
@@ -833,6 +833,48 @@ int wm_layernorm2d_bwd(const float* x, const float* weight, const float* gy, flo
     if (C == 32) hipLaunchKernelGGL((layernorm2d_bwd_kernel<32>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
     else if (C == 16) hipLaunchKernelGGL((layernorm2d_bwd_kernel<16>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
     else hipLaunchKernelGGL((layernorm2d_bwd_kernel<8>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
+    return launch_status();
+}
+
+int wm_layernorm_tok_fwd(const float* x, const float* weight, const float* bias, float eps, float* y, int64_t T, int C,
+                         void* stream) {
+    if (T < 0) return WM_EINVAL;
+    if (C != 8 && C != 16 && C != 32 && C != 64) return WM_EUNSUPPORTED;
+    if (T == 0) return WM_OK;
+    if (!x || !weight || !bias || !y) return WM_ENULL;
+    if (!aligned16(x) || !aligned16(y) || !aligned16(weight) || !aligned16(bias)) return WM_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const int tpb = 256 / (C / 4);
+    long long blocks = (T + tpb - 1) / tpb;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    const dim3 grid((unsigned)blocks), block(256);
+#define WM_LNT(CC) hipLaunchKernelGGL((layernorm_tok_kernel<CC>), grid, block, 0, st, (const float4*)x, (const float4*)weight, \
+                                      (const float4*)bias, eps, (float4*)y, (long long)T)
+    if (C == 64) WM_LNT(64); else if (C == 32) WM_LNT(32); else if (C == 16) WM_LNT(16); else WM_LNT(8);
+#undef WM_LNT
+    return launch_status();
+}
+
+int wm_layernorm_tok_bwd(const float* x, const float* weight, const float* gy, float eps, float* gx, float* dweight,
+                         float* dbias, int64_t T, int C, void* stream) {
+    if (T < 0) return WM_EINVAL;
+    if (C != 8 && C != 16 && C != 32 && C != 64) return WM_EUNSUPPORTED;
+    if (!dweight || !dbias) return WM_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(dweight, 0, (size_t)C * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(dbias, 0, (size_t)C * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    if (T == 0) return WM_OK;
+    if (!x || !weight || !gy || !gx) return WM_ENULL;
+    if (!aligned16(x) || !aligned16(gy) || !aligned16(gx) || !aligned16(weight)) return WM_EALIGN;
+    const int tpb = 256 / (C / 4);
+    long long blocks = (T + tpb - 1) / tpb;
+    if (blocks > 1024) blocks = 1024;                    // grid-stride: few blocks -> few atomics per channel
+    const dim3 grid((unsigned)blocks), block(256);
+#define WM_LNTB(CC) hipLaunchKernelGGL((layernorm_tok_bwd_kernel<CC>), grid, block, 0, st, (const float4*)x, (const float4*)weight, \
+                                       (const float4*)gy, eps, (float4*)gx, dweight, dbias, (long long)T)
+    if (C == 64) WM_LNTB(64); else if (C == 32) WM_LNTB(32); else if (C == 16) WM_LNTB(16); else WM_LNTB(8);
+#undef WM_LNTB
     return launch_status();
 }
 

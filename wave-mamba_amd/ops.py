@@ -502,6 +502,56 @@ def layernorm2d_train(x, weight, bias, eps):
     return _LayerNorm2dTrain.apply(x.contiguous().float(), weight, bias, eps)
 
 
+class _LayerNormTok(torch.autograd.Function):
+    """nn.LayerNorm(C) over the last axis of a contiguous (..., C) fp32 tensor: HIP forward and backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        lib = _lib.load()
+        C = x.shape[-1]
+        w, b = weight.detach().contiguous().float(), bias.detach().contiguous().float()
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            check(lib.wm_layernorm_tok_fwd(_ptr(x), _ptr(w), _ptr(b), float(eps), _ptr(y), x.numel() // C, C, _stream()),
+                  "wm_layernorm_tok_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        C = x.shape[-1]
+        gy = gy.contiguous().float()
+        gx = torch.empty_like(x)
+        dw = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib.wm_layernorm_tok_bwd(_ptr(x), _ptr(w), _ptr(gy), ctx.eps, _ptr(gx), _ptr(dw), _ptr(db),
+                                           x.numel() // C, C, _stream()), "wm_layernorm_tok_bwd")
+        return gx, dw, db, None
+
+
+def layernorm_tok_supported(x, C):
+    return x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == C and C in (8, 16, 32, 64)
+
+
+def layernorm_tok(x, weight, bias, eps):
+    """F.layer_norm(x, (C,), weight, bias, eps) for a (..., C) fp32 tensor, C in {8, 16, 32, 64}; differentiable
+    (HIP backward: input gradient + weight / bias gradients in one pass)."""
+    _require_cuda("layernorm_tok", x, weight, bias)
+    x = x.contiguous().float()
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or bias.requires_grad):
+        return _LayerNormTok.apply(x, weight, bias, eps)
+    return _LayerNormTok.forward(_NoCtx(), x, weight, bias, eps)
+
+
+class _NoCtx:
+    def save_for_backward(self, *a):
+        pass
+
+
 def mul_sigmoid(a, b):
     """a * sigmoid(b) in one pass (PAConv gate, reference :694-697); fp32, same shape, forward only."""
     lib = _lib.load()
