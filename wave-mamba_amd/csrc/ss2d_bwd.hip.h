@@ -91,13 +91,16 @@ __global__ __launch_bounds__(256) void projbwd_dx_kernel(const ProjBwdArgs a) {
 }
 
 typedef float pg_f4 __attribute__((ext_vector_type(4)));
-constexpr int kPgWaves = 4;
+constexpr int kPgWaves = 16;
 
 // dWx_kk[c][d] += sum_p g[b][kk][c][p] x[b][d][p] for a slice of p per wave: fp32 MFMA 16x16x4 with both operands read
-// as 16-byte runs of 4 consecutive positions (rows = planes), 3 x 4 output tiles (48 x 64), block-level LDS sum, then
-// one atomic per element per block.  grid (blocks, B, 2), block (64 * kPgWaves).
+// as 16-byte runs of 4 consecutive positions (rows = planes), 3 x 4 output tiles (48 x 64), block-level sum by LDS
+// atomics (16 waves per block: 4 resident waves per SIMD hide the load latency), then one global atomic per element
+// per block.  grid (blocks, B, 2), block (64 * kPgWaves).
 __global__ __launch_bounds__(64 * kPgWaves) void projgrad_kernel(const ProjBwdArgs a, long long slice) {
-    __shared__ float s_part[kPgWaves][48 * 64];
+    __shared__ float s_part[48 * 64];                               // the block's waves meet here by LDS atomics
+    for (int e = threadIdx.x; e < 48 * 64; e += 64 * kPgWaves) s_part[e] = 0.0f;
+    __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.y, kk = blockIdx.z;
     const int i16 = lane & 15, kq = lane >> 4;
@@ -149,13 +152,11 @@ __global__ __launch_bounds__(64 * kPgWaves) void projgrad_kernel(const ProjBwdAr
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s_part[wv][(16 * i + 4 * kq + r) * 64 + 16 * j + i16] = acc[i][j][r];
+            for (int r = 0; r < 4; ++r) atomicAdd(&s_part[(16 * i + 4 * kq + r) * 64 + 16 * j + i16], acc[i][j][r]);
     __syncthreads();
     float* dW = kk ? a.dWx1 : a.dWx0;
     for (int e = threadIdx.x; e < 48 * 64; e += 64 * kPgWaves) {
-        float t = 0.0f;
-#pragma unroll
-        for (int w4 = 0; w4 < kPgWaves; ++w4) t += s_part[w4][e];
+        const float t = s_part[e];
         const int c = e >> 6, d = e & 63;
         if (c < a.CP && d < a.D) atomicAdd(dW + (long long)c * a.D + d, t);
     }

@@ -687,8 +687,8 @@ int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt
         g.Wx0 = x_proj_weight + (size_t)k0 * CP * D; g.Wx1 = x_proj_weight + (size_t)k1 * CP * D;
         g.dWx0 = dx_proj_weight + (size_t)k0 * CP * D; g.dWx1 = dx_proj_weight + (size_t)k1 * CP * D;
         hipLaunchKernelGGL(projbwd_dx_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)B), dim3(256), 0, st, g);
-        long long waves = (L + 1023) / 1024;
-        if (waves > 2048) waves = 2048;
+        long long waves = (L + 255) / 256;                                  // >= 256 positions per wave
+        if (waves > 4096) waves = 4096;
         waves = ((waves + kPgWaves - 1) / kPgWaves) * kPgWaves;
         long long slice = (L + waves - 1) / waves;
         slice = ((slice + 15) / 16) * 16;
