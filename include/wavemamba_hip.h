@@ -238,6 +238,14 @@ int wm_layernorm_tok_fwd(const float* x, const float* weight, const float* bias,
 int wm_layernorm_tok_bwd(const float* x, const float* weight, const float* gy, float eps, float* gx, float* dweight,
                          float* dbias, int64_t T, int C, void* stream);
 
+/* The caller's I/O step (inference_wavemamba.py:99-113, basicsr/utils/img_util.py:9-98).
+ *   wm_image_pre_u8   image (h, w, 3) uint8 on the device -> out (3, Hp, Wp) fp32 = channel-major, / 255, reflect-padded
+ *                     bottom / right (Hp >= h, Wp >= w, pads smaller than the image); swap_rb: BGR -> RGB.
+ *   wm_image_post_u8  in (3, Hp, Wp) fp32 -> image (h, w, 3) uint8 = round_half_even(clamp(in[:, :h, :w], 0, 1) * 255);
+ *                     swap_rb: RGB -> BGR. */
+int wm_image_pre_u8(const uint8_t* image, float* out, int h, int w, int Hp, int Wp, int swap_rb, void* stream);
+int wm_image_post_u8(const float* in, uint8_t* image, int h, int w, int Hp, int Wp, int swap_rb, void* stream);
+
 /* Small-tensor steps of the HFE branch as single kernels (csrc/hfe.hip.h).  Forward only.
  *   wm_match_index   channel matching with every channel kept (wavemamba_arch.py:659-666, match_factor = 1):
  *                    index[b, c] = argmin_j (nx[b, c] + ny[b, j] - 2 G[b, c, j]) from wm_gram_fwd's outputs; (B, C) int32.

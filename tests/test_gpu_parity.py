@@ -772,3 +772,44 @@ def test_layernorm_tok_forward_backward_vs_torch(shape):
     assert_close(got.detach(), ref.detach().float(), 1e-5, f"layernorm_tok {shape}")
     for a, r, nm in zip(ggot, gref, ("gx", "dweight", "dbias")):
         assert_close(a, r.float(), 2e-5, f"layernorm_tok {nm} {shape}")
+
+
+# ------------------------------------------------------------------------------------------------
+# the caller's I/O step: uint8 <-> padded fp32 tensors, bit-exact against the PyTorch spelling
+# of inference_wavemamba.py:99-113 / img_util.py
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("h,w", [(70, 130), (128, 256), (130, 200), (257, 129)])
+@pytest.mark.parametrize("swap", [True, False])
+def test_image_pre_post_u8_bit_exact(h, w, swap):
+    from wave_mamba_amd import inference
+    gg = gen(h + w)
+    img = torch.randint(0, 256, (h, w, 3), generator=gg, dtype=torch.uint8)
+    t = img.permute(2, 0, 1).float()
+    if swap:
+        t = t[[2, 1, 0]]
+    ref = inference.check_image_size((t / 255.0).unsqueeze(0))
+    got = wm.ops.image_pre_u8(img.to(DEV), 128, swap)
+    assert torch.equal(got.cpu(), ref)
+    y = torch.randn(1, 3, ref.shape[2], ref.shape[3], generator=gg) * 0.7 + 0.5
+    y[0, 0, 0, :4] = torch.tensor([0.5 / 255, 1.5 / 255, 2.5 / 255, 254.5 / 255])      # ties: half to even
+    q = (y[:, :, :h, :w].clamp(0, 1) * 255.0).round().to(torch.uint8)[0]
+    if swap:
+        q = q[[2, 1, 0]]
+    assert torch.equal(wm.ops.image_post_u8(y.to(DEV), h, w, swap).cpu(), q.permute(1, 2, 0).contiguous())
+
+
+def test_uint8_pipeline_matches_sequential(golden):
+    from wave_mamba_amd import inference
+    import numpy as np
+    torch.manual_seed(0)
+    net = wm.WaveMamba(in_chn=3, wf=8, n_l_blocks=[1, 1, 1], n_h_blocks=[1, 1, 1], ffn_scale=2.0).eval().to(DEV)
+    rng = np.random.default_rng(0)
+    imgs = [rng.integers(0, 256, size=(90 + 7 * i, 150 - 5 * i, 3), dtype=np.uint8) for i in range(5)]
+    pipe = inference.UInt8Pipeline(net, DEV)
+    outs = list(pipe.run(imgs))
+    assert len(outs) == len(imgs)
+    for im, o in zip(imgs, outs):
+        t = torch.from_numpy(im).to(DEV)
+        with torch.no_grad():
+            ref = wm.ops.image_post_u8(net.restoration_network(wm.ops.image_pre_u8(t)), im.shape[0], im.shape[1])
+        assert o.shape == im.shape and np.array_equal(o, ref.cpu().numpy())

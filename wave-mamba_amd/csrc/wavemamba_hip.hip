@@ -18,6 +18,7 @@
 #include "conv2d.hip.h"
 #include "hfe.hip.h"
 #include "ss2d_bwd.hip.h"
+#include "imageio.hip.h"
 
 namespace wm {
 
@@ -275,7 +276,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 8; }
+int wm_abi_version(void) { return 9; }
 
 const char* wm_strerror(int code) {
     switch (code) {
@@ -875,6 +876,28 @@ int wm_layernorm_tok_bwd(const float* x, const float* weight, const float* gy, f
                                        (const float4*)gy, eps, (float4*)gx, dweight, dbias, (long long)T)
     if (C == 64) WM_LNTB(64); else if (C == 32) WM_LNTB(32); else if (C == 16) WM_LNTB(16); else WM_LNTB(8);
 #undef WM_LNTB
+    return launch_status();
+}
+
+int wm_image_pre_u8(const uint8_t* image, float* out, int h, int w, int Hp, int Wp, int swap_rb, void* stream) {
+    if (h < 0 || w < 0 || Hp < h || Wp < w) return WM_EINVAL;
+    if (Hp == 0 || Wp == 0) return WM_OK;
+    if (h == 0 || w == 0) return WM_EINVAL;
+    if (Hp - h > h - 1 || Wp - w > w - 1) return WM_EINVAL;            // reflect padding needs pad < size
+    if (!image || !out) return WM_ENULL;
+    if (Hp > 65535) return WM_EUNSUPPORTED;
+    hipLaunchKernelGGL(image_pre_kernel, dim3((unsigned)((Wp + 255) / 256), (unsigned)Hp), dim3(256), 0, (hipStream_t)stream,
+                       image, out, h, w, Hp, Wp, swap_rb);
+    return launch_status();
+}
+
+int wm_image_post_u8(const float* in, uint8_t* image, int h, int w, int Hp, int Wp, int swap_rb, void* stream) {
+    if (h < 0 || w < 0 || Hp < h || Wp < w) return WM_EINVAL;
+    if (h == 0 || w == 0) return WM_OK;
+    if (!in || !image) return WM_ENULL;
+    if (h > 65535) return WM_EUNSUPPORTED;
+    hipLaunchKernelGGL(image_post_kernel, dim3((unsigned)((w + 255) / 256), (unsigned)h), dim3(256), 0, (hipStream_t)stream,
+                       in, image, h, w, Hp, Wp, swap_rb);
     return launch_status();
 }
 

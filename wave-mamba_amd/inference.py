@@ -37,3 +37,79 @@ def psnr_uint8(a, b):
     if float(mse) == 0.0:
         return float("inf")
     return float(20.0 * torch.log10(255.0 / mse.sqrt()))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# uint8 host images in, uint8 host images out (inference_wavemamba.py:99-113 end to end):
+# pinned double-buffered H2D / D2H on side streams under the previous / next image's forward.
+# ------------------------------------------------------------------------------------------------------------------
+class UInt8Pipeline:
+    """enhance host uint8 images (h, w, 3; BGR as cv2 reads them, or RGB with swap_rb=False) with the network on `device`.
+
+    Per image: pinned staging buffer -> H2D on the upload stream -> wm_image_pre_u8 (CHW, / 255, reflect pad) ->
+    restoration_network -> wm_image_post_u8 (crop, clamp, * 255, round, HWC) -> D2H on the download stream into a pinned
+    buffer.  Two buffers each way, events between the streams: the copies of images i + 1 / i - 1 run under the forward
+    of image i.  `run(images)` yields numpy uint8 results in order."""
+
+    def __init__(self, net, device, window_size=128, swap_rb=True):
+        from . import ops
+        self.net, self.device, self.window, self.swap_rb, self.ops = net, torch.device(device), window_size, swap_rb, ops
+        self.up, self.down = torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)
+        self._pin_in, self._pin_out, self._dev_in = [None, None], [None, None], [None, None]
+
+    def _buf(self, store, slot, shape, pinned):
+        t = store[slot]
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = (torch.empty(shape, dtype=torch.uint8, pin_memory=True) if pinned
+                 else torch.empty(shape, dtype=torch.uint8, device=self.device))
+            store[slot] = t
+        return t
+
+    @torch.no_grad()
+    def run(self, images):
+        import numpy as np
+        main = torch.cuda.current_stream(self.device)
+        pending = []                                   # (pinned output, download-done event, slot)
+        out_free = [None, None]                        # events: the pinned output slot was consumed
+        uploaded = None
+        it = iter(images)
+
+        def upload(img, slot):
+            a = torch.from_numpy(np.ascontiguousarray(img))
+            pin = self._buf(self._pin_in, slot, a.shape, True)
+            pin.copy_(a)
+            dev = self._buf(self._dev_in, slot, a.shape, False)
+            with torch.cuda.stream(self.up):
+                dev.copy_(pin, non_blocking=True)
+                ev = torch.cuda.Event(); ev.record(self.up)
+            return dev, ev
+
+        nxt = next(it, None)
+        slot = 0
+        if nxt is not None:
+            uploaded = upload(nxt, slot)
+        while uploaded is not None:
+            dev, ev = uploaded
+            nxt = next(it, None)
+            uploaded = upload(nxt, slot ^ 1) if nxt is not None else None     # overlaps with the forward below
+            main.wait_event(ev)
+            h, w = dev.shape[:2]
+            x = self.ops.image_pre_u8(dev, self.window, self.swap_rb)
+            y = self.net.restoration_network(x)
+            res = self.ops.image_post_u8(y, h, w, self.swap_rb)
+            done = torch.cuda.Event(); done.record(main)
+            pin_out = self._buf(self._pin_out, slot, res.shape, True)
+            with torch.cuda.stream(self.down):
+                self.down.wait_event(done)
+                pin_out.copy_(res, non_blocking=True)
+                res.record_stream(self.down)
+                dl = torch.cuda.Event(); dl.record(self.down)
+            pending.append((pin_out, dl))
+            if len(pending) == 2:                      # the slot about to be reused must have been handed out
+                p, e = pending.pop(0)
+                e.synchronize()
+                yield p.numpy().copy()
+            slot ^= 1
+        for p, e in pending:
+            e.synchronize()
+            yield p.numpy().copy()

@@ -587,6 +587,37 @@ def dwconv3x3(x, weight, bias=None, act="none"):
     return y
 
 
+def image_pre_u8(img, window_size=128, swap_rb=True):
+    """(h, w, 3) uint8 device image -> (1, 3, Hp, Wp) fp32 in [0, 1], channel-major, reflect-padded to multiples of
+    `window_size` (inference_wavemamba.py:99-105 + :28-36); swap_rb: BGR (cv2) -> RGB."""
+    lib = _lib.load()
+    _require_cuda("image_pre_u8", img)
+    if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
+        raise RuntimeError(f"image_pre_u8: expected (h, w, 3) uint8, got {tuple(img.shape)} {img.dtype}")
+    h, w = img.shape[:2]
+    Hp, Wp = h + (window_size - h % window_size) % window_size, w + (window_size - w % window_size) % window_size
+    out = torch.empty((1, 3, Hp, Wp), dtype=torch.float32, device=img.device)
+    with torch.cuda.device(img.device):
+        check(lib.wm_image_pre_u8(_ptr(img.contiguous()), _ptr(out), h, w, Hp, Wp, int(bool(swap_rb)), _stream()),
+              "wm_image_pre_u8")
+    return out
+
+
+def image_post_u8(t, h, w, swap_rb=True):
+    """(1, 3, Hp, Wp) fp32 -> (h, w, 3) uint8: crop, clamp [0, 1], * 255, round half to even, channel-last
+    (inference_wavemamba.py:112-113 + tensor2img, img_util.py:67-94); swap_rb: RGB -> BGR."""
+    lib = _lib.load()
+    _require_cuda("image_post_u8", t)
+    if t.dtype != torch.float32 or t.dim() != 4 or t.shape[0] != 1 or t.shape[1] != 3:
+        raise RuntimeError(f"image_post_u8: expected (1, 3, Hp, Wp) float32, got {tuple(t.shape)} {t.dtype}")
+    Hp, Wp = t.shape[2:]
+    out = torch.empty((h, w, 3), dtype=torch.uint8, device=t.device)
+    with torch.cuda.device(t.device):
+        check(lib.wm_image_post_u8(_ptr(t.contiguous()), _ptr(out), h, w, Hp, Wp, int(bool(swap_rb)), _stream()),
+              "wm_image_post_u8")
+    return out
+
+
 def match_index(G, nx, ny):
     """Channel matching with every channel kept: (B, C) int32 index of the L2-nearest candidate channel from the
     Gram outputs of `gram(maps, candidates)` (argmin_j |x_c|^2 + |y_j|^2 - 2 x_c . y_j)."""
