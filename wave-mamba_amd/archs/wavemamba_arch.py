@@ -11,9 +11,12 @@ Boundary contract (citations into /root/reference/basicsr/archs/wavemamba_arch.p
     the reference's initial weights bit for bit (checked by tests against committed fingerprints).
 
 Hot path (the part that is NOT PyTorch): the three Haar DWTs and three IWTs per forward
-(DownFRG / upFRG) and the 14 selective scans (one per LFSSBlock) go to hand-written gfx950 kernels
-through `wave_mamba_amd.ops`.  Everything else (HFEBlock branch, small convs, LayerNorms) stays on
-PyTorch-ROCm as SURVEY.md section 8 scopes it.
+(DownFRG / upFRG) and the 14 LFSSBlocks (SS2D four-direction core, its prologue / epilogue, the gated ffn) go to
+hand-written gfx950 kernels through `wave_mamba_amd.ops`; so does, as the first "next" row of SURVEY.md section 8f,
+every full-map operator of the HFE branch and the U-Net plumbing in inference (dense 3x3 / 1x1 convolutions with their
+concatenations, gathers, gates and residuals fused, Gram matrices, channel matching, the folded attention, SKFF,
+LayerNorm2d, depth-wise convolutions).  Training takes the HIP kernels that have a backward (DWT / IWT, the SS2D core,
+depth-wise conv, the LayerNorms) and PyTorch autograd for the rest.
 
 This file can be dropped into a `basicsr/archs/` folder: the auto-scan (`archs/__init__.py:12-16`)
 imports every `*_arch.py`, and the registry resolution in `registry.py` then binds to the real
@@ -307,7 +310,7 @@ class LFSSBlock(nn.Module):
 
 
 # ================================================================================================
-# High-frequency branch: HFEBlock family (PyTorch-ROCm; out of HIP scope)
+# High-frequency branch: HFEBlock family (HIP kernels in inference, PyTorch autograd in training)
 # ================================================================================================
 class LayerNorm2d(nn.Module):
     """Per-pixel LayerNorm over channels of an NCHW map, eps 1e-6 (reference :532-569)."""
