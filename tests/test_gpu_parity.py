@@ -813,3 +813,23 @@ def test_uint8_pipeline_matches_sequential(golden):
         with torch.no_grad():
             ref = wm.ops.image_post_u8(net.restoration_network(wm.ops.image_pre_u8(t)), im.shape[0], im.shape[1])
         assert o.shape == im.shape and np.array_equal(o, ref.cpu().numpy())
+
+
+@pytest.mark.parametrize("ks,B,Cin,Cout,H,W,bias", [(3, 2, 32, 64, 24, 40, True), (1, 1, 64, 32, 17, 33, True),
+                                                    (3, 1, 3, 32, 16, 32, False), (1, 2, 12, 32, 9, 20, True)])
+def test_conv2d_train_gradients_vs_torch_autograd(ks, B, Cin, Cout, H, W, bias):
+    import torch.nn.functional as F
+    gg = gen(ks * 10 + Cin)
+    x = torch.randn(B, Cin, H, W, generator=gg)
+    w = torch.randn(Cout, Cin, ks, ks, generator=gg) / (ks * Cin ** 0.5)
+    b = torch.randn(Cout, generator=gg) if bias else None
+    gy = torch.randn(B, Cout, H, W, generator=gg)
+    ps = [t.double().requires_grad_(True) for t in (x, w)] + ([b.double().requires_grad_(True)] if bias else [])
+    ref = F.conv2d(ps[0], ps[1], ps[2] if bias else None, padding=ks // 2)
+    gref = torch.autograd.grad(ref, ps, gy.double())
+    qs = [t.to(DEV).requires_grad_(True) for t in (x, w)] + ([b.to(DEV).requires_grad_(True)] if bias else [])
+    got = wm.ops.conv2d_train(qs[0], qs[1], qs[2] if bias else None)
+    ggot = torch.autograd.grad(got, qs, gy.to(DEV))
+    assert_close(got.detach(), ref.detach().float(), 2e-5, "conv2d_train forward")
+    for a, r, nm in zip(ggot, gref, ("gx", "gw", "gb")):
+        assert_close(a, r.float(), 5e-5, f"conv2d_train {nm} ks={ks}")

@@ -92,7 +92,10 @@ def _conv(conv, x, x2=None, x2_index=None, gate=None, residual=None):
         if x2_index is not None:
             x2 = torch.gather(x2, 1, x2_index.long()[:, :, None, None].expand(-1, -1, x2.shape[2], x2.shape[3]))
         x = torch.cat([x, x2], dim=1)
-    y = conv(x)
+    if hasattr(ops, "conv2d_train") and ops.conv2d_supported(x, conv.weight) and torch.is_grad_enabled():
+        y = ops.conv2d_train(x, conv.weight, conv.bias)             # HIP forward + input gradient (autograd)
+    else:
+        y = conv(x)
     if gate is not None:
         y = y * torch.sigmoid(gate)
     if residual is not None:

@@ -763,6 +763,39 @@ def conv2d_gated(x, weight3, weight1, bias1=None, x2=None, x2_index=None):
     return y
 
 
+class _Conv2dTrain(torch.autograd.Function):
+    """Dense 3x3 / 1x1 convolution (stride 1, 'same' padding) for training: forward and input gradient on the
+    matrix-core kernel (the input gradient is the same convolution with the weight transposed and flipped), weight and
+    bias gradients from ATen's convolution_backward (MIOpen / hipBLASLt)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return conv2d(x.detach(), weight.detach(), None if bias is None else bias.detach())
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous().float()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.detach().transpose(0, 1).flip(2, 3).contiguous()          # (Cin, Cout, ks, ks)
+            gx = conv2d(gy, wt, None, dynamic_weight=True)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            ks = weight.shape[2]
+            _, gw, gb = torch.ops.aten.convolution_backward(
+                gy, x, weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1], [ks // 2, ks // 2], [1, 1], False,
+                [0, 0], 1, [False, True, ctx.has_bias])
+        return gx, gw, gb
+
+
+def conv2d_train(x, weight, bias=None):
+    """F.conv2d(x, weight, bias, stride=1, padding=ks // 2) with autograd (see _Conv2dTrain)."""
+    _require_cuda("conv2d_train", x, weight, bias)
+    return _Conv2dTrain.apply(x.contiguous().float(), weight, bias)
+
+
 def conv2d_supported(x, weight, x2=None):
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
             and weight.dim() == 4 and tuple(weight.shape[2:]) in ((3, 3), (1, 1)) and x.shape[2] * x.shape[3] < 2 ** 31
