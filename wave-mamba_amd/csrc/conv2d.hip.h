@@ -30,8 +30,9 @@
 // pixels) and each workgroup re-fetches the weights.  Tried: a persistent wave-specialised variant (4 loader + 4 MFMA
 // waves per compute unit, double-buffered LDS, 16-byte loads): correct, 0.65 ms against 0.62 ms - the loaders stall
 // on the same fill path (8.5 k of 11.5 k cycles per chunk in load issue; 0.8 k with the loads stubbed out), so the
-// lever is lines per pixel, not overlap: an output tile shifted by one pixel needs exactly one line per row (two
-// carried pixels + the aligned line).
+// lever is not overlap.  Also tried: output tiles shifted one pixel left so a staged row is one aligned line plus
+// two pixels of the previous one (a third fewer input lines, stores straddling two lines): 0.60 ms against 0.56 ms -
+// what the misaligned stores cost outweighs the saved fills.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
