@@ -303,7 +303,8 @@ __global__ __launch_bounds__(64) void ss2d_row_kernel(Ss2dArgs p) {
                 for (int j = 0; j < 4; ++j) {
                     const int col = REV ? 15 - (4 * q + j) : 4 * q + j;
                     const float4 dr = *reinterpret_cast<const float4*>(&s_rec[col * kRS]);
-                    dts[j] = fmaf(wdt[3], dr.w, fmaf(wdt[2], dr.z, fmaf(wdt[1], dr.y, fmaf(wdt[0], dr.x, bias))));
+                    dts[j] = fmaf(wdt[1], dr.y, fmaf(wdt[0], dr.x, bias));
+                    if (p.R > 2) dts[j] = fmaf(wdt[3], dr.w, fmaf(wdt[2], dr.z, dts[j]));               // uniform
                 }
                 const v2f sa = softplus2((v2f){dts[0], dts[1]}), sb = softplus2((v2f){dts[2], dts[3]});
                 dts[0] = sa.x; dts[1] = sa.y; dts[2] = sb.x; dts[3] = sb.y;
