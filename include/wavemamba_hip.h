@@ -246,6 +246,9 @@ int wm_layernorm_tok_bwd(const float* x, const float* weight, const float* gy, f
 int wm_image_pre_u8(const uint8_t* image, float* out, int h, int w, int Hp, int Wp, int swap_rb, void* stream);
 int wm_image_post_u8(const float* in, uint8_t* image, int h, int w, int Hp, int Wp, int swap_rb, void* stream);
 
+/* sums (C) = sum over batch and plane of x (B, C, H, W): the bias gradient of a convolution (training). */
+int wm_plane_sums(const float* x, float* sums, int B, int C, int H, int W, void* stream);
+
 /* Small-tensor steps of the HFE branch as single kernels (csrc/hfe.hip.h).  Forward only.
  *   wm_match_index   channel matching with every channel kept (wavemamba_arch.py:659-666, match_factor = 1):
  *                    index[b, c] = argmin_j (nx[b, c] + ny[b, j] - 2 G[b, c, j]) from wm_gram_fwd's outputs; (B, C) int32.

@@ -276,7 +276,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 9; }
+int wm_abi_version(void) { return 10; }
 
 const char* wm_strerror(int code) {
     switch (code) {
@@ -898,6 +898,26 @@ int wm_image_post_u8(const float* in, uint8_t* image, int h, int w, int Hp, int 
     if (h > 65535) return WM_EUNSUPPORTED;
     hipLaunchKernelGGL(image_post_kernel, dim3((unsigned)((w + 255) / 256), (unsigned)h), dim3(256), 0, (hipStream_t)stream,
                        in, image, h, w, Hp, Wp, swap_rb);
+    return launch_status();
+}
+
+int wm_plane_sums(const float* x, float* sums, int B, int C, int H, int W, void* stream) {
+    if (B < 0 || C < 0 || H < 0 || W < 0) return WM_EINVAL;
+    if (C == 0) return WM_OK;
+    if (!sums) return WM_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sums, 0, (size_t)C * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    const long long HW = (long long)H * W, planes = (long long)B * C;
+    if (planes == 0 || HW == 0) return WM_OK;
+    if (!x) return WM_ENULL;
+    if (planes > 65535) return WM_EUNSUPPORTED;
+    const bool vec = (HW % 4 == 0) && aligned16(x);
+    long long bpp = (HW / 4 + 256 * 8 - 1) / (256 * 8);
+    const long long cap = (256 * 16 + planes - 1) / planes;
+    if (bpp > cap) bpp = cap;
+    if (bpp < 1) bpp = 1;
+    hipLaunchKernelGGL(plane_sums_kernel, dim3((unsigned)bpp, (unsigned)planes), dim3(256), 0, st, x, sums, C, HW, vec);
     return launch_status();
 }
 

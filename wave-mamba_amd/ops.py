@@ -763,6 +763,18 @@ def conv2d_gated(x, weight3, weight1, bias1=None, x2=None, x2_index=None):
     return y
 
 
+def plane_sums(x):
+    """x (B, C, H, W) fp32 -> (C,) sums over batch and plane (bias gradient of a convolution)."""
+    lib = _lib.load()
+    _require_cuda("plane_sums", x)
+    B, C, H, W = x.shape
+    x = x.contiguous().float()
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.wm_plane_sums(_ptr(x), _ptr(out), B, C, H, W, _stream()), "wm_plane_sums")
+    return out
+
+
 class _Conv2dTrain(torch.autograd.Function):
     """Dense 3x3 / 1x1 convolution (stride 1, 'same' padding) for training: forward and input gradient on the
     matrix-core kernel (the input gradient is the same convolution with the weight transposed and flipped), weight and
@@ -782,11 +794,12 @@ class _Conv2dTrain(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = weight.detach().transpose(0, 1).flip(2, 3).contiguous()          # (Cin, Cout, ks, ks)
             gx = conv2d(gy, wt, None, dynamic_weight=True)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        if ctx.needs_input_grad[1]:
             ks = weight.shape[2]
-            _, gw, gb = torch.ops.aten.convolution_backward(
-                gy, x, weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1], [ks // 2, ks // 2], [1, 1], False,
-                [0, 0], 1, [False, True, ctx.has_bias])
+            _, gw, _ = torch.ops.aten.convolution_backward(
+                gy, x, weight, None, [1, 1], [ks // 2, ks // 2], [1, 1], False, [0, 0], 1, [False, True, False])
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = plane_sums(gy)
         return gx, gw, gb
 
 
