@@ -246,6 +246,11 @@ int wm_layernorm_tok_bwd(const float* x, const float* weight, const float* gy, f
 int wm_image_pre_u8(const uint8_t* image, float* out, int h, int w, int Hp, int Wp, int swap_rb, void* stream);
 int wm_image_post_u8(const float* in, uint8_t* image, int h, int w, int Hp, int Wp, int swap_rb, void* stream);
 
+/* dW (O, I) = gy^T x for token-major gy (T, O), x (T, I): weight gradient of nn.Linear (SS2D.in_proj / out_proj,
+ * wavemamba_arch.py:345 / :386) in training.  (O, I) in {(128,32), (32,64), (64,16), (16,32), (32,16), (16,16), (64,32),
+ * (32,32), (16,64)}: the in_proj / out_proj shapes of hidden_dim 32, 16, 8. */
+int wm_linear_wgrad(const float* gy, const float* x, float* dW, int64_t T, int O, int I, void* stream);
+
 /* sums (C) = sum over batch and plane of x (B, C, H, W): the bias gradient of a convolution (training). */
 int wm_plane_sums(const float* x, float* sums, int B, int C, int H, int W, void* stream);
 

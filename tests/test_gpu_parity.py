@@ -833,3 +833,18 @@ def test_conv2d_train_gradients_vs_torch_autograd(ks, B, Cin, Cout, H, W, bias):
     assert_close(got.detach(), ref.detach().float(), 2e-5, "conv2d_train forward")
     for a, r, nm in zip(ggot, gref, ("gx", "gw", "gb")):
         assert_close(a, r.float(), 5e-5, f"conv2d_train {nm} ks={ks}")
+
+
+@pytest.mark.parametrize("T,O,I", [(5000, 128, 32), (777, 32, 64), (64, 16, 16), (3, 64, 16), (100003, 32, 32)])
+def test_linear_wgrad_vs_torch(T, O, I):
+    """Weight gradient of SS2D.in_proj / out_proj (nn.Linear without bias) on the MFMA reduction kernel."""
+    gg = gen(T % 97 + O)
+    x = torch.randn(T, I, generator=gg)
+    w = torch.randn(O, I, generator=gg) / I ** 0.5
+    gy = torch.randn(T, O, generator=gg)
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    y = wm.ops.linear_nobias(xd, wd)
+    gx, gw = torch.autograd.grad(y, (xd, wd), gy.to(DEV))
+    assert_close(y.detach(), (x.double() @ w.double().t()).float(), 1e-5, "linear fwd")
+    assert_close(gx, (gy.double() @ w.double()).float(), 1e-5, "linear gx")
+    assert_close(gw, (gy.double().t() @ x.double()).float(), 2e-5, "linear gw")

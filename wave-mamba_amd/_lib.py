@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("WAVEMAMBA_HIP_LIB") or os.path.join(HERE, "libwavemam
 
 WM_F32, WM_BF16 = 0, 1
 WM_PROF_NKERNELS = 16
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _c = ctypes
 _p, _i, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
@@ -45,6 +45,7 @@ SIGNATURES = {
     "wm_layernorm_tok_bwd": (_i, [_p, _p, _p, _c.c_float, _p, _p, _p, _i64, _i, _p]),
     "wm_image_pre_u8": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "wm_image_post_u8": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "wm_linear_wgrad": (_i, [_p, _p, _p, _i64, _i, _i, _p]),
     "wm_plane_sums": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "wm_match_index": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "wm_attn_fold": (_i, [_p] * 6 + [_i, _i, _i, _p]),

@@ -78,6 +78,16 @@ def _ln_tok(norm, x):
     return norm(x)
 
 
+def _linear(lin, x):
+    """Bias-free nn.Linear on token tensors: in training on the HIP backend the weight gradient (a tiny matrix reduced
+    over ~5e5 tokens) runs on the MFMA reduction kernel instead of a 32 x 32-tile library GEMM."""
+    ops = _OpsBackend.impl
+    if (lin.bias is None and hasattr(ops, "linear_nobias") and torch.is_grad_enabled() and lin.weight.requires_grad
+            and ops.linear_nobias_supported(x, lin.weight)):
+        return ops.linear_nobias(x, lin.weight)
+    return lin(x)
+
+
 def _conv(conv, x, x2=None, x2_index=None, gate=None, residual=None):
     """Dense 3x3 / 1x1 nn.Conv2d (stride 1, 'same' padding) of X = x | cat([x, x2], 1) |
     cat([x, gather(x2, 1, x2_index)], 1), then `* sigmoid(gate)` and `+ residual` when given.  Inference on the
@@ -257,7 +267,7 @@ class SS2D(nn.Module):
 
     def forward(self, x, **kwargs):
         B, H, W, C = x.shape
-        x, z = self.in_proj(x).chunk(2, dim=-1)
+        x, z = _linear(self.in_proj, x).chunk(2, dim=-1)
         x = _dwconv(self.conv2d, x.permute(0, 3, 1, 2).contiguous(), act="silu")
         if self._fused_ok(x):                      # y1 + y2 + y3 + y4 accumulated inside the kernels
             y = _OpsBackend.impl.ss2d_core(x, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias,
@@ -268,7 +278,7 @@ class SS2D(nn.Module):
             y = y1 + y2 + y3 + y4
         y = y.transpose(1, 2).contiguous().view(B, H, W, -1)
         y = _ln_tok(self.out_norm, y) * F.silu(z)
-        y = self.out_proj(y)
+        y = _linear(self.out_proj, y)
         return self.dropout(y) if self.dropout is not None else y
 
 

@@ -162,4 +162,73 @@ __global__ __launch_bounds__(64 * kPgWaves) void projgrad_kernel(const ProjBwdAr
     }
 }
 
+// dW[o][i] += sum_t gy[t][o] x[t][i] for token-major operands gy (T, O), x (T, I): the weight gradient of nn.Linear
+// (SS2D.in_proj / out_proj, reference :345 / :386; hipBLASLt runs a 32 x 32 tile with K = T ~ 5e5 at 0.5 ms a call).
+// fp32 MFMA 16x16x4: lane (r = lane & 15, kq = lane >> 4) feeds gy[t0 + kq][16 a + r] and x[t0 + kq][16 b + r] (64-byte
+// runs per token and operand tile), OT x IT output tiles per wave, a slice of tokens per wave, LDS atomics per block, one
+// global atomic per element per block.  grid (blocks), block (64 * kLwWaves); O = 16 OT, I = 16 IT.
+constexpr int kLwWaves = 8;
+// One load of V = min(4, tiles) consecutive channels per lane feeds V row tiles: tile a, lane row r <-> channel
+// (a / V) * 16 V + V r + (a % V) - a fixed permutation of the channels inside each group of 16 V.
+template <int NT> struct LwVec { static constexpr int V = NT >= 4 ? 4 : (NT >= 2 ? 2 : 1); };
+template <int NT>
+__device__ __forceinline__ void lw_load(const float* __restrict__ row, int r, bool ok, float (&v)[NT]) {
+    constexpr int V = LwVec<NT>::V;
+#pragma unroll
+    for (int g = 0; g < NT / V; ++g) {
+        const float* q = row + g * 16 * V + V * r;
+        if constexpr (V == 4) {
+            const float4 t = ok ? *reinterpret_cast<const float4*>(q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[4 * g] = t.x; v[4 * g + 1] = t.y; v[4 * g + 2] = t.z; v[4 * g + 3] = t.w;
+        } else if constexpr (V == 2) {
+            const float2 t = ok ? *reinterpret_cast<const float2*>(q) : make_float2(0.f, 0.f);
+            v[2 * g] = t.x; v[2 * g + 1] = t.y;
+        } else {
+            v[g] = ok ? q[0] : 0.0f;
+        }
+    }
+}
+template <int NT> __device__ __forceinline__ int lw_channel(int a, int r) {
+    constexpr int V = LwVec<NT>::V;
+    return (a / V) * 16 * V + V * r + (a % V);
+}
+template <int OT, int IT>
+__global__ __launch_bounds__(64 * kLwWaves) void linear_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                     float* __restrict__ dW, long long T, long long slice) {
+    constexpr int O = 16 * OT, I = 16 * IT;
+    __shared__ float s_part[O * I];
+    for (int e = threadIdx.x; e < O * I; e += 64 * kLwWaves) s_part[e] = 0.0f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const long long wave = (long long)blockIdx.x * kLwWaves + wv;
+    const long long t_begin = wave * slice, t_end = min(T, t_begin + slice);
+    pg_f4 acc[OT][IT];
+#pragma unroll
+    for (int a = 0; a < OT; ++a)
+#pragma unroll
+        for (int b = 0; b < IT; ++b) acc[a][b] = (pg_f4){0.f, 0.f, 0.f, 0.f};
+    for (long long t0 = t_begin; t0 < t_end; t0 += 4) {
+        const long long t = t0 + kq;
+        const bool ok = t < t_end;
+        float ga[OT], xa[IT];
+        lw_load<OT>(gy + (ok ? t : 0) * O, r, ok, ga);
+        lw_load<IT>(x + (ok ? t : 0) * I, r, ok, xa);
+#pragma unroll
+        for (int a = 0; a < OT; ++a)
+#pragma unroll
+            for (int b = 0; b < IT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[a], xa[b], acc[a][b], 0, 0, 0);
+    }
+    // D layout: lane holds tile rows 4 kq .. 4 kq + 3 (o side) of tile column r (i side)
+#pragma unroll
+    for (int a = 0; a < OT; ++a)
+#pragma unroll
+        for (int b = 0; b < IT; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                atomicAdd(&s_part[lw_channel<OT>(a, 4 * kq + q) * I + lw_channel<IT>(b, r)], acc[a][b][q]);
+    __syncthreads();
+    for (int e = threadIdx.x; e < O * I; e += 64 * kLwWaves) atomicAdd(dW + e, s_part[e]);
+}
+
 }  // namespace wm

@@ -276,7 +276,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 10; }
+int wm_abi_version(void) { return 11; }
 
 const char* wm_strerror(int code) {
     switch (code) {
@@ -899,6 +899,34 @@ int wm_image_post_u8(const float* in, uint8_t* image, int h, int w, int Hp, int 
     hipLaunchKernelGGL(image_post_kernel, dim3((unsigned)((w + 255) / 256), (unsigned)h), dim3(256), 0, (hipStream_t)stream,
                        in, image, h, w, Hp, Wp, swap_rb);
     return launch_status();
+}
+
+}  // extern "C"
+template <int OT, int IT>
+static void linear_wgrad_launch(const float* gy, const float* x, float* dW, long long T, hipStream_t st) {
+    long long waves = (T + 511) / 512;                                  // >= 512 tokens per wave
+    if (waves > 4096) waves = 4096;
+    waves = ((waves + wm::kLwWaves - 1) / wm::kLwWaves) * wm::kLwWaves;
+    long long slice = (T + waves - 1) / waves;
+    slice = ((slice + 3) / 4) * 4;
+    hipLaunchKernelGGL((wm::linear_wgrad_kernel<OT, IT>), dim3((unsigned)(waves / wm::kLwWaves)), dim3(64 * wm::kLwWaves), 0,
+                       st, gy, x, dW, T, slice);
+}
+extern "C" {
+
+int wm_linear_wgrad(const float* gy, const float* x, float* dW, int64_t T, int O, int I, void* stream) {
+    if (T < 0 || O <= 0 || I <= 0) return WM_EINVAL;
+    if (!dW) return WM_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(dW, 0, (size_t)O * I * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    if (T == 0) return WM_OK;
+    if (!gy || !x) return WM_ENULL;
+    if (O % 16 != 0 || I % 16 != 0 || O * I > 8192) return WM_EUNSUPPORTED;
+#define WM_LW(OT, IT) if (O == 16 * OT && I == 16 * IT) { linear_wgrad_launch<OT, IT>(gy, x, dW, (long long)T, st); return launch_status(); }
+    WM_LW(8, 2) WM_LW(2, 4) WM_LW(4, 1) WM_LW(1, 2) WM_LW(2, 1) WM_LW(1, 1) WM_LW(4, 2) WM_LW(2, 2) WM_LW(1, 4)
+#undef WM_LW
+    return WM_EUNSUPPORTED;
 }
 
 int wm_plane_sums(const float* x, float* sums, int B, int C, int H, int W, void* stream) {

@@ -763,6 +763,45 @@ def conv2d_gated(x, weight3, weight1, bias1=None, x2=None, x2_index=None):
     return y
 
 
+_LINEAR_WGRAD_SHAPES = {(128, 32), (32, 64), (64, 16), (16, 32), (32, 16), (16, 16), (64, 32), (32, 32), (16, 64)}
+
+
+class _LinearNoBias(torch.autograd.Function):
+    """F.linear(x, weight) for token tensors (..., I): ATen GEMMs for the output and the input gradient, the HIP MFMA
+    reduction for the weight gradient (a (O, I) result with K = number of tokens)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return F.linear(x, weight)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, weight = ctx.saved_tensors
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = gy.matmul(weight)
+        if ctx.needs_input_grad[1]:
+            O, I = weight.shape
+            g2, x2 = gy.reshape(-1, O).contiguous().float(), x.reshape(-1, I).contiguous().float()
+            gw = torch.empty((O, I), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                check(lib.wm_linear_wgrad(_ptr(g2), _ptr(x2), _ptr(gw), g2.shape[0], O, I, _stream()), "wm_linear_wgrad")
+        return gx, gw
+
+
+def linear_nobias_supported(x, weight):
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and tuple(weight.shape) in _LINEAR_WGRAD_SHAPES)
+
+
+def linear_nobias(x, weight):
+    """F.linear(x, weight) with the weight gradient on the HIP reduction kernel (training)."""
+    _require_cuda("linear_nobias", x, weight)
+    return _LinearNoBias.apply(x, weight)
+
+
 def plane_sums(x):
     """x (B, C, H, W) fp32 -> (C,) sums over batch and plane (bias gradient of a convolution)."""
     lib = _lib.load()
