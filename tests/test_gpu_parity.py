@@ -848,3 +848,30 @@ def test_linear_wgrad_vs_torch(T, O, I):
     assert_close(y.detach(), (x.double() @ w.double().t()).float(), 1e-5, "linear fwd")
     assert_close(gx, (gy.double() @ w.double()).float(), 1e-5, "linear gx")
     assert_close(gw, (gy.double().t() @ x.double()).float(), 2e-5, "linear gw")
+
+
+def test_conv2d_uhd_level1_crop_and_linearity():
+    """BASELINE config 2 size (UHD level 1, 64 -> 64, 3x3 on cat([x, gather(p, idx)])): an interior + border crop against
+    the fp64 convolution of the same crop, and linearity in the input (size-independent property)."""
+    import torch.nn.functional as F
+    H, W = 1088, 1920
+    gg = torch.Generator(device=DEV).manual_seed(21)
+    x = torch.randn(1, 32, H, W, device=DEV, generator=gg)
+    p = torch.randn(1, 32, H, W, device=DEV, generator=gg)
+    idx = torch.randint(0, 32, (1, 32), device=DEV, generator=gg)
+    w = torch.randn(64, 64, 3, 3, device=DEV, generator=gg) / 24
+    y = wm.ops.conv2d(x, w, None, p, idx)
+    xin = torch.cat([x, torch.gather(p, 1, idx[:, :, None, None].expand(-1, -1, H, W))], 1)
+    for (h0, w0) in ((0, 0), (H - 66, W - 130), (500, 1000)):
+        hs, ws = slice(max(h0 - 1, 0), min(h0 + 65, H)), slice(max(w0 - 1, 0), min(w0 + 129, W))
+        ref = F.conv2d(xin[:, :, hs, ws].double(), w.double(), padding=1)
+        oh, ow = h0 - hs.start, w0 - ws.start
+        a = y[:, :, h0:h0 + 64, w0:w0 + 128]
+        b = ref[:, :, oh:oh + 64, ow:ow + 128]
+        # rows / columns at the crop border see zero padding instead of the neighbouring pixels: compare the interior,
+        # and the true image border where the padding is real
+        ih = slice(0 if h0 == 0 else 1, 64 if h0 + 64 >= H else 63)
+        iw = slice(0 if w0 == 0 else 1, 128 if w0 + 128 >= W else 127)
+        assert_close(a[:, :, ih, iw], b[:, :, ih, iw].float().cpu(), 2e-5, f"conv2d UHD crop at {(h0, w0)}")
+    y2 = wm.ops.conv2d(2.0 * x, w, None, 2.0 * p, idx)
+    assert_close(y2, (2.0 * y).cpu(), 1e-6, "conv2d linearity at UHD level 1")
