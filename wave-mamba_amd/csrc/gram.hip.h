@@ -53,25 +53,32 @@ __global__ __launch_bounds__(64 * kGramWaves) void gram32_kernel(const float* __
         return v;
     };
 
-    for (long long l0 = l_begin; l0 < l_end; l0 += 16) {
-        const long long l = l0 + 4 * kq;
-        float4 xa[2], ya[2];
+    // 32 positions per iteration: a lane reads two adjacent 16-byte pieces of a row, the four lanes of a row a whole
+    // 128-byte line (the contraction order is free, so positions l0 + 8 kq .. + 7 go to this lane)
+    for (long long l0 = l_begin; l0 < l_end; l0 += 32) {
+        const long long l = l0 + 8 * kq;
+        float4 xa[2][2], ya[2][2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) { xa[h] = load4(xb, i16 + 16 * h, l); ya[h] = load4(yb, i16 + 16 * h, l); }
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            sx[h] = fmaf(xa[h].x, xa[h].x, fmaf(xa[h].y, xa[h].y, fmaf(xa[h].z, xa[h].z, fmaf(xa[h].w, xa[h].w, sx[h]))));
-            sy[h] = fmaf(ya[h].x, ya[h].x, fmaf(ya[h].y, ya[h].y, fmaf(ya[h].z, ya[h].z, fmaf(ya[h].w, ya[h].w, sy[h]))));
+            for (int u = 0; u < 2; ++u) { xa[h][u] = load4(xb, i16 + 16 * h, l + 4 * u); ya[h][u] = load4(yb, i16 + 16 * h, l + 4 * u); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                sx[h] = fmaf(xa[h][u].x, xa[h][u].x, fmaf(xa[h][u].y, xa[h][u].y, fmaf(xa[h][u].z, xa[h][u].z, fmaf(xa[h][u].w, xa[h][u].w, sx[h]))));
+                sy[h] = fmaf(ya[h][u].x, ya[h][u].x, fmaf(ya[h][u].y, ya[h][u].y, fmaf(ya[h][u].z, ya[h][u].z, fmaf(ya[h][u].w, ya[h][u].w, sy[h]))));
+            }
+            const float xc[2][4] = {{xa[0][u].x, xa[0][u].y, xa[0][u].z, xa[0][u].w}, {xa[1][u].x, xa[1][u].y, xa[1][u].z, xa[1][u].w}};
+            const float yc[2][4] = {{ya[0][u].x, ya[0][u].y, ya[0][u].z, ya[0][u].w}, {ya[1][u].x, ya[1][u].y, ya[1][u].z, ya[1][u].w}};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb)
+                        acc[a][bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[a][c], yc[bb][c], acc[a][bb], 0, 0, 0);
         }
-        const float xc[2][4] = {{xa[0].x, xa[0].y, xa[0].z, xa[0].w}, {xa[1].x, xa[1].y, xa[1].z, xa[1].w}};
-        const float yc[2][4] = {{ya[0].x, ya[0].y, ya[0].z, ya[0].w}, {ya[1].x, ya[1].y, ya[1].z, ya[1].w}};
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int bb = 0; bb < 2; ++bb)
-                    acc[a][bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[a][c], yc[bb][c], acc[a][bb], 0, 0, 0);
     }
     // D layout: lane holds rows 4*kq .. 4*kq+3 (i) of column i16 (j).  Block-level sum in LDS first:
     // one atomic per output element per BLOCK instead of per wave.

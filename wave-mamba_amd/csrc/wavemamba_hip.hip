@@ -775,7 +775,7 @@ int wm_gram_fwd(const float* X, const float* Y, float* G, float* nx, float* ny, 
     if (waves > 4096) waves = 4096;
     waves = ((waves + kGramWaves - 1) / kGramWaves) * kGramWaves;
     long long slice = (L + waves - 1) / waves;
-    slice = ((slice + 15) / 16) * 16;
+    slice = ((slice + 31) / 32) * 32;
     const dim3 grid((unsigned)(waves / kGramWaves), (unsigned)B), block(64 * kGramWaves);
     hipLaunchKernelGGL(gram32_kernel, grid, block, 0, st, X, Y, G, nx, ny, C, (long long)L, slice);
     return launch_status();
