@@ -161,7 +161,7 @@ int wm_lfss_out_fwd(const float* fc, const float* tok1, const float* conv3_weigh
 /* --------------------------------------------------------------------------------------------
  * LayerNorm2d of the HFE branch (first "next" row): per-pixel LayerNorm over the C
  * channels of an NCHW map, eps inside the square root, biased variance (wavemamba_arch.py:532-569).
- * x, y (B, C, L) fp32; C in {8, 16, 32}.  Forward only.
+ * x, y (B, C, L) fp32; C in {8, 16, 32, 64}.  Forward only.
  * -------------------------------------------------------------------------------------------- */
 int wm_layernorm2d_fwd(const float* x, const float* weight, const float* bias, float eps, float* y,
                        int B, int64_t L, int C, void* stream);

@@ -143,8 +143,8 @@ class ffn(nn.Module):
         self.conv3 = nn.Conv2d(hidden // 2, num_feat, kernel_size=1)
 
     def forward(self, x):
-        gate, value = _dwconv(self.conv2, self.conv1(x)).chunk(2, dim=1)
-        return self.conv3(F.gelu(gate) * value)
+        gate, value = _dwconv(self.conv2, _conv(self.conv1, x)).chunk(2, dim=1)
+        return _conv(self.conv3, F.gelu(gate) * value)
 
 
 class SS2D(nn.Module):
@@ -310,6 +310,39 @@ class LFSSBlock(nn.Module):
         if ss.dropout is not None or ss.in_proj.bias is not None or ss.out_proj.bias is not None:
             return False
         return ops.lfss_block_supported(ss.d_model, ss.d_inner, ss.d_state, ss.dt_rank, self.conv_blk.conv1.out_channels)
+
+    def _nchw_train_ok(self, x):
+        """Training on the HIP backend: the block on NCHW planes, every operator but the gates / skips an autograd
+        Function over HIP kernels (LayerNorm2d, 1x1 convolutions, depth-wise conv, the SS2D core) - no token <-> map
+        permutes.  Same shape range as the fused inference path."""
+        ops = _OpsBackend.impl
+        ss = self.self_attention
+        if not (torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+            return False
+        if not all(hasattr(ops, n) for n in ("layernorm2d_train", "conv2d_train", "dwconv3x3_train", "ss2d_core")):
+            return False
+        if ss.dropout is not None or ss.in_proj.bias is not None or ss.out_proj.bias is not None:
+            return False
+        if not (isinstance(self.ln_1, nn.LayerNorm) and isinstance(self.ln_2, nn.LayerNorm)):
+            return False
+        return ops.lfss_block_supported(ss.d_model, ss.d_inner, ss.d_state, ss.dt_rank, self.conv_blk.conv1.out_channels)
+
+    def forward_nchw_train(self, x):
+        """(B, C, H, W) -> (B, C, H, W); the same arithmetic as forward() on the (B, HW, C) view (:520-528)."""
+        ops = _OpsBackend.impl
+        ss = self.self_attention
+        C, D = ss.d_model, ss.d_inner
+        a = ops.layernorm2d_train(x, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps)
+        w_in = ss.in_proj.weight.view(2 * D, C, 1, 1)
+        xs = ops.conv2d_train(a, w_in[:D])                                      # nn.Linear = 1x1 convolution
+        z = ops.conv2d_train(a, w_in[D:])
+        xs = F.silu(ops.dwconv3x3_train(xs, ss.conv2d.weight, ss.conv2d.bias))
+        y = ops.ss2d_core(xs, ss.x_proj_weight, ss.dt_projs_weight, ss.dt_projs_bias, ss.A_logs, ss.Ds, merged=True)
+        y = ops.layernorm2d_train(y.view_as(xs), ss.out_norm.weight, ss.out_norm.bias, ss.out_norm.eps)
+        o = ops.conv2d_train(y * F.silu(z), ss.out_proj.weight.view(C, D, 1, 1))
+        t = x * self.skip_scale.view(1, -1, 1, 1) + o
+        u = ops.layernorm2d_train(t, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
+        return t * self.skip_scale2.view(1, -1, 1, 1) + self.conv_blk(u)
 
     def forward(self, input, x_size):
         B, L, C = input.shape
@@ -579,6 +612,10 @@ def _run_lfss_stack(blocks, x):
         for i, blk in enumerate(blocks):
             t = ops.lfss_block_forward(t, (h, w), blk, tok_nchw=(i == 0), out_nchw=(i == len(blocks) - 1))
         return t
+    if blocks and all(blk._nchw_train_ok(x) for blk in blocks):
+        for blk in blocks:
+            x = blk.forward_nchw_train(x)
+        return x
     t = _tokens(x)
     for blk in blocks:
         t = blk(t, [h, w])

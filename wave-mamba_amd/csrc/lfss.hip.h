@@ -254,6 +254,64 @@ __global__ __launch_bounds__(256) void layernorm2d_bwd_kernel(const float* __res
     }
 }
 
+// ---- LayerNorm2d backward for wide maps (C = 64: SS2D.out_norm on (B, D, L) planes in the NCHW training path) ---------
+// The register-resident form above needs 4 C values per thread; here the channels are streamed three times (statistics,
+// the two means of the gradient, the input gradient - re-reads hit in cache) and only the 2 C parameter-gradient
+// partials stay in registers.
+template <int C>
+__global__ __launch_bounds__(256) void layernorm2d_bwd_stream_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                     const float* __restrict__ gy, float eps,
+                                                                     float* __restrict__ gx, float* __restrict__ dw,
+                                                                     float* __restrict__ db, int B, long long L) {
+    float pw[C], pb[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { pw[c] = 0.0f; pb[c] = 0.0f; }
+    const long long total = (long long)B * L;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long bb = idx / L, p = idx - bb * L;
+        const float* xp = x + bb * C * L + p;
+        const float* gp = gy + bb * C * L + p;
+        float* op = gx + bb * C * L + p;
+        float mean = 0.0f;
+#pragma unroll 16
+        for (int c = 0; c < C; ++c) mean += xp[(long long)c * L];
+        mean *= (1.0f / C);
+        float var = 0.0f;
+#pragma unroll 16
+        for (int c = 0; c < C; ++c) { const float d = xp[(long long)c * L] - mean; var = fmaf(d, d, var); }
+        const float rstd = 1.0f / sqrtf(var * (1.0f / C) + eps);
+        float mg = 0.0f, mgy = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float yh = (xp[(long long)c * L] - mean) * rstd, g0 = gp[(long long)c * L];
+            pw[c] = fmaf(g0, yh, pw[c]);
+            pb[c] += g0;
+            const float g = g0 * w[c];
+            mg += g;
+            mgy = fmaf(g, yh, mgy);
+        }
+        mg *= (1.0f / C); mgy *= (1.0f / C);
+#pragma unroll 16
+        for (int c = 0; c < C; ++c) {
+            const float yh = (xp[(long long)c * L] - mean) * rstd;
+            op[(long long)c * L] = rstd * (gp[(long long)c * L] * w[c] - yh * mgy - mg);
+        }
+    }
+    __shared__ float s_red[4][2 * C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        float a = pw[c], bsum = pb[c];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off); bsum += __shfl_xor(bsum, off); }
+        if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6][c] = a; s_red[threadIdx.x >> 6][C + c] = bsum; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * C) {
+        const float t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+        atomicAdd((threadIdx.x < C ? dw : db) + (threadIdx.x % C), t);
+    }
+}
+
 // ---- LayerNorm over the last (contiguous) axis of token tensors (..., C): nn.LayerNorm(C) of LFSSBlock.ln_1 / ln_2
 // and SS2D.out_norm (reference :345-386, :493, :522-526), forward and backward for training --------------------------
 // C / 4 lanes per token, 4 channels per lane: a wave instruction moves 64 x 16 contiguous bytes; the channel sums run over

@@ -750,6 +750,15 @@ int wm_layernorm2d_fwd(const float* x, const float* weight, const float* bias, f
                        int64_t L, int C, void* stream) {
     if (B < 0 || L < 0) return WM_EINVAL;
     if (B && L && (!x || !weight || !bias || !y)) return WM_ENULL;
+    if (C == 64) {                                       // SS2D.out_norm on (B, D, L) planes (NCHW training path)
+        const long long total = (long long)B * L;
+        if (total == 0) return WM_OK;
+        hipStream_t st = (hipStream_t)stream;
+        ProfScope ps(5, st);
+        hipLaunchKernelGGL((layernorm2d_kernel<64>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, weight, bias,
+                           eps, y, B, (long long)L);
+        return launch_status();
+    }
     WM_LFSS_DISPATCH(layernorm2d_kernel, x, weight, bias, eps, y, B, (long long)L);
 }
 
@@ -819,7 +828,7 @@ int wm_dwconv3x3_wgrad(const float* x, const float* gy, float* dW, float* db, in
 int wm_layernorm2d_bwd(const float* x, const float* weight, const float* gy, float eps, float* gx, float* dweight,
                        float* dbias, int B, int64_t L, int C, void* stream) {
     if (B < 0 || L < 0) return WM_EINVAL;
-    if (C != 8 && C != 16 && C != 32) return WM_EUNSUPPORTED;
+    if (C != 8 && C != 16 && C != 32 && C != 64) return WM_EUNSUPPORTED;
     if (!dweight || !dbias) return WM_ENULL;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(dweight, 0, (size_t)C * sizeof(float), st);
@@ -831,7 +840,8 @@ int wm_layernorm2d_bwd(const float* x, const float* weight, const float* gy, flo
     long long blocks = (total + 255) / 256;
     if (blocks > 512) blocks = 512;                      // grid-stride: few blocks -> few atomics per channel
     const dim3 grid((unsigned)blocks), block(256);
-    if (C == 32) hipLaunchKernelGGL((layernorm2d_bwd_kernel<32>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
+    if (C == 64) hipLaunchKernelGGL((layernorm2d_bwd_stream_kernel<64>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
+    else if (C == 32) hipLaunchKernelGGL((layernorm2d_bwd_kernel<32>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
     else if (C == 16) hipLaunchKernelGGL((layernorm2d_bwd_kernel<16>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
     else hipLaunchKernelGGL((layernorm2d_bwd_kernel<8>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
     return launch_status();

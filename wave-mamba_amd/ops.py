@@ -412,8 +412,8 @@ def layernorm2d(x, weight, bias, eps):
     lib = _lib.load()
     _require_cuda("layernorm2d", x, weight, bias)
     B, C, H, W = x.shape
-    if C not in (8, 16, 32) or x.dtype != torch.float32:
-        raise NotImplementedError("layernorm2d: fp32, C in {8, 16, 32}")
+    if C not in (8, 16, 32, 64) or x.dtype != torch.float32:
+        raise NotImplementedError("layernorm2d: fp32, C in {8, 16, 32, 64}")
     x = x.contiguous()
     y = torch.empty_like(x)
     with torch.cuda.device(x.device):
