@@ -12,9 +12,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "wavemamba_hip.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("haar.hip.h", "selscan.hip.h", "selscan_bwd.hip.h",
-                                                         "ss2d.hip.h")] + \
-       [os.path.join(HERE, "..", "include", "wavemamba_hip.h")]
+DEPS = [SRC] + sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))
+                      if f.endswith(".hip.h")) + [os.path.join(HERE, "..", "include", "wavemamba_hip.h")]
 LIB = os.path.join(HERE, "libwavemamba_hip.so")
 
 
