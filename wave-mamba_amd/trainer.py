@@ -61,3 +61,72 @@ def reduce_loss_dict(loss_dict):
     if dist.get_rank() == 0:
         vec /= dist.get_world_size()
     return {k: float(v) for k, v in zip(keys, vec)}
+
+
+# ---- reference-format checkpoints (basicsr/models/base_model.py:214-261, :299-326, :328-373) -----------------------
+def _bare(net):
+    return net.module if isinstance(net, (torch.nn.parallel.DistributedDataParallel, torch.nn.DataParallel)) else net
+
+
+def _atomic_save(obj, path):
+    """torch.save into a sibling temp file, then rename: a reader never sees a torn checkpoint (the reference retries
+    the write three times instead, :247-260)."""
+    import os
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    tmp = f"{path}.tmp{os.getpid()}"
+    torch.save(obj, tmp)
+    os.replace(tmp, path)
+
+
+def save_network(net, path, current_iter=-1, epoch=0, param_key="params"):
+    """`{param_key: state_dict on the CPU without 'module.' prefixes, 'iter': int | 'latest', 'epoch': int}` -
+    the file layout `inference_wavemamba.py:74` / `load_network` read.  Rank 0 only (`@master_only`, :214)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+        return None
+    state = {(k[7:] if k.startswith("module.") else k): v.detach().cpu() for k, v in _bare(net).state_dict().items()}
+    _atomic_save({param_key: state, "iter": "latest" if current_iter == -1 else current_iter, "epoch": epoch}, path)
+    return path
+
+
+def load_network(net, path, strict=True, param_key="params"):
+    """Counterpart of base_model.py:299-326: `param_key` falls back to 'params' when absent (None = the file is the
+    bare state dict), 'module.' prefixes are dropped, and with strict=False tensors whose shape differs are skipped
+    instead of raising.  Returns (missing_keys, unexpected_keys, skipped_for_shape)."""
+    blob = torch.load(path, map_location="cpu", weights_only=False)
+    if param_key is not None:
+        if param_key not in blob and "params" in blob:
+            param_key = "params"
+        blob = blob[param_key]
+    state = {(k[7:] if k.startswith("module.") else k): v for k, v in blob.items()}
+    target = _bare(net)
+    skipped = []
+    if not strict:
+        own = target.state_dict()
+        skipped = sorted(k for k, v in state.items() if k in own and own[k].shape != v.shape)
+        for k in skipped:
+            del state[k]
+    res = target.load_state_dict(state, strict=strict)
+    return list(res.missing_keys), list(res.unexpected_keys), skipped
+
+
+def save_training_state(path, epoch, current_iter, optimizers, schedulers=()):
+    """`{'epoch', 'iter', 'optimizers': [...], 'schedulers': [...]}` (base_model.py:328-357); nothing is written for
+    current_iter == -1, and only rank 0 writes."""
+    if current_iter == -1 or (dist.is_available() and dist.is_initialized() and dist.get_rank() != 0):
+        return None
+    _atomic_save({"epoch": epoch, "iter": current_iter, "optimizers": [o.state_dict() for o in optimizers],
+                  "schedulers": [s.state_dict() for s in schedulers]}, path)
+    return path
+
+
+def resume_training(path_or_state, optimizers, schedulers=()):
+    """base_model.py:359-373.  Returns (epoch, iter)."""
+    st = path_or_state if isinstance(path_or_state, dict) else torch.load(path_or_state, map_location="cpu",
+                                                                            weights_only=False)
+    if len(st["optimizers"]) != len(optimizers) or len(st["schedulers"]) != len(schedulers):
+        raise ValueError("resume_training: optimizer / scheduler count differs from the saved state")
+    for o, s in zip(optimizers, st["optimizers"]):
+        o.load_state_dict(s)
+    for o, s in zip(schedulers, st["schedulers"]):
+        o.load_state_dict(s)
+    return st["epoch"], st["iter"]
