@@ -359,7 +359,7 @@ def test_lfss_block_golden(golden):
     assert_close(y, g["y"], TOL, "LFSSBlock (fused HIP path)")
 
 
-@pytest.mark.parametrize("C,H,W", [(32, 40, 72), (16, 17, 23), (8, 64, 64)])
+@pytest.mark.parametrize("C,H,W", [(32, 40, 72), (32, 33, 31), (32, 5, 7), (16, 17, 23), (8, 64, 64)])
 def test_lfss_block_fused_vs_module_path(C, H, W):
     """fused block kernels vs the same block evaluated through the PyTorch modules + HIP scan."""
     torch.manual_seed(C)
@@ -376,6 +376,50 @@ def test_lfss_block_fused_vs_module_path(C, H, W):
         finally:
             arch.LFSSBlock._fused_ok = saved
     assert_close(fused, ref, TOL, f"LFSSBlock C={C}")
+
+
+@pytest.mark.parametrize("B,L", [(1, 64), (2, 1000), (3, 37), (1, 4097)])
+@pytest.mark.parametrize("nchw", [False, True])
+def test_lfss_glue_kernels_c32_vs_fp64(B, L, nchw):
+    """The three glue kernels at the shipped width (C = 32: projections on the fp32 matrix cores), called through the
+    C ABI with both token layouts and ragged group counts, against the fp64 composition of reference :483-494,
+    :524-526, :226-230."""
+    from wave_mamba_amd import _lib
+    from wave_mamba_amd.ops import _ptr, _stream, check
+    lib = _lib.load()
+    C, D = 32, 64
+    g = torch.Generator(device=DEV); g.manual_seed(B * 131 + L)
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    ln1w, ln1b, ln2w, ln2b = rn(C) * 0.2 + 1, rn(C) * 0.2, rn(C) * 0.2 + 1, rn(C) * 0.2
+    onw, onb = rn(D) * 0.2 + 1, rn(D) * 0.2
+    Win, Wout, W1, b1, W3, b3 = rn(2 * D, C) / 6, rn(C, D) / 8, rn(D, C) / 6, rn(D) * 0.2, rn(C, C) / 6, rn(C) * 0.2
+    sk1, sk2 = rn(C) * 0.2 + 1, rn(C) * 0.2 + 1
+    tokens = rn(B, L, C)                                                    # logical (B, L, C)
+    tok = tokens.transpose(1, 2).contiguous() if nchw else tokens           # as laid out for the kernels
+    ysum, zz, fc = rn(B, D, L) * 2, rn(B, D, L) * 2, rn(B, D, L)
+    F = torch.nn.functional
+    d = lambda t: t.double()
+    # lfss_in
+    x = torch.empty(B, D, L, device=DEV); z = torch.empty(B, D, L, device=DEV)
+    check(lib.wm_lfss_in_fwd(_ptr(tok), int(nchw), _ptr(ln1w), _ptr(ln1b), 1e-5, _ptr(Win), _ptr(x), _ptr(z), B, L, C,
+                             _stream()), "in")
+    xz = F.linear(F.layer_norm(d(tokens), (C,), d(ln1w), d(ln1b), 1e-5), d(Win)).transpose(1, 2)
+    assert_close(x, xz[:, :D], TOL, "lfss_in x"); assert_close(z, xz[:, D:], TOL, "lfss_in z")
+    # lfss_mid
+    tok1 = torch.empty(B, L, C, device=DEV); f = torch.empty(B, D, L, device=DEV)
+    check(lib.wm_lfss_mid_fwd(_ptr(ysum), _ptr(zz), _ptr(tok), int(nchw), _ptr(onw), _ptr(onb), 1e-5, _ptr(Wout), _ptr(sk1),
+                              _ptr(ln2w), _ptr(ln2b), 1e-5, _ptr(W1), _ptr(b1), _ptr(tok1), _ptr(f), B, L, C, _stream()), "mid")
+    yy = F.layer_norm(d(ysum).transpose(1, 2), (D,), d(onw), d(onb), 1e-5) * F.silu(d(zz).transpose(1, 2))
+    t1 = d(tokens) * d(sk1) + F.linear(yy, d(Wout))
+    ff = F.linear(F.layer_norm(t1, (C,), d(ln2w), d(ln2b), 1e-5), d(W1), d(b1)).transpose(1, 2)
+    assert_close(tok1, t1, TOL, "lfss_mid tok1"); assert_close(f, ff, TOL, "lfss_mid f")
+    # lfss_out
+    out = torch.empty((B, C, L) if nchw else (B, L, C), device=DEV)
+    check(lib.wm_lfss_out_fwd(_ptr(fc), _ptr(tok1), _ptr(W3), _ptr(b3), _ptr(sk2), _ptr(out), int(nchw), B, L, C, _stream()),
+          "out")
+    gg = (F.gelu(d(fc[:, :C])) * d(fc[:, C:])).transpose(1, 2)
+    o = d(tok1) * d(sk2) + F.linear(gg, d(W3), d(b3))
+    assert_close(out.transpose(1, 2) if nchw else out, o, TOL, "lfss_out")
 
 
 def test_lfss_block_d_state_32_uses_op_boundary_scan():

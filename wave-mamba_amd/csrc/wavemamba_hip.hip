@@ -14,6 +14,7 @@
 #include "dwconv.hip.h"
 #include "ss2d.hip.h"
 #include "lfss.hip.h"
+#include "lfss_mfma.hip.h"
 #include "gram.hip.h"
 #include "conv2d.hip.h"
 #include "hfe.hip.h"
@@ -722,6 +723,17 @@ int wm_lfss_in_fwd(const float* tok, int tok_nchw, const float* ln_w, const floa
     if (B < 0 || L < 0) return WM_EINVAL;
     if (B && L && (!tok || !ln_w || !ln_b || !in_proj_weight || !x || !z)) return WM_ENULL;
     if (!tok_nchw && !aligned16(tok)) return WM_EALIGN;
+    if (C == 32 && B && L) {
+        const int ngl = (int)((L + 63) / 64);
+        const long long ngroups = (long long)B * ngl;
+        const int gpw = lfss_groups_per_wave(ngroups);
+        const long long waves = (ngroups + gpw - 1) / gpw;
+        hipStream_t st = (hipStream_t)stream;
+        ProfScope ps(5, st);
+        hipLaunchKernelGGL(lfss_in_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, tok, tok_nchw, ln_w, ln_b,
+                           ln_eps, in_proj_weight, x, z, B, (long long)L, ngl, ngroups, gpw);
+        return launch_status();
+    }
     WM_LFSS_DISPATCH(lfss_in_kernel, tok, tok_nchw, ln_w, ln_b, ln_eps, in_proj_weight, x, z, B, (long long)L);
 }
 
@@ -734,6 +746,18 @@ int wm_lfss_mid_fwd(const float* ysum, const float* z, const float* tok, int tok
     if (B && L && (!ysum || !z || !tok || !out_norm_w || !out_norm_b || !out_proj_weight || !skip_scale || !ln2_w ||
                    !ln2_b || !conv1_weight || !conv1_bias || !tok1 || !f)) return WM_ENULL;
     if ((!tok_nchw && !aligned16(tok)) || !aligned16(tok1)) return WM_EALIGN;
+    if (C == 32 && B && L) {                                 // the shipped width: projections on the matrix cores
+        const int ngl = (int)((L + 63) / 64);
+        const long long ngroups = (long long)B * ngl;
+        const int gpw = lfss_groups_per_wave(ngroups);
+        const long long waves = (ngroups + gpw - 1) / gpw;
+        hipStream_t st = (hipStream_t)stream;
+        ProfScope ps(5, st);
+        hipLaunchKernelGGL(lfss_mid_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ysum, z, tok, tok_nchw,
+                           out_norm_w, out_norm_b, out_norm_eps, out_proj_weight, skip_scale, ln2_w, ln2_b, ln2_eps,
+                           conv1_weight, conv1_bias, tok1, f, B, (long long)L, ngl, ngroups, gpw);
+        return launch_status();
+    }
     WM_LFSS_DISPATCH(lfss_mid_kernel, ysum, z, tok, tok_nchw, out_norm_w, out_norm_b, out_norm_eps, out_proj_weight,
                      skip_scale, ln2_w, ln2_b, ln2_eps, conv1_weight, conv1_bias, tok1, f, B, (long long)L);
 }
@@ -743,6 +767,17 @@ int wm_lfss_out_fwd(const float* fc, const float* tok1, const float* conv3_weigh
     if (B < 0 || L < 0) return WM_EINVAL;
     if (B && L && (!fc || !tok1 || !conv3_weight || !conv3_bias || !skip_scale2 || !out)) return WM_ENULL;
     if (!aligned16(tok1) || (!out_nchw && !aligned16(out))) return WM_EALIGN;
+    if (C == 32 && B && L) {
+        const int ngl = (int)((L + 63) / 64);
+        const long long ngroups = (long long)B * ngl;
+        const int gpw = lfss_groups_per_wave(ngroups);
+        const long long waves = (ngroups + gpw - 1) / gpw;
+        hipStream_t st = (hipStream_t)stream;
+        ProfScope ps(5, st);
+        hipLaunchKernelGGL(lfss_out_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, fc, tok1, conv3_weight,
+                           conv3_bias, skip_scale2, out, out_nchw, B, (long long)L, ngl, ngroups, gpw);
+        return launch_status();
+    }
     WM_LFSS_DISPATCH(lfss_out_kernel, fc, tok1, conv3_weight, conv3_bias, skip_scale2, out, out_nchw, B, (long long)L);
 }
 
