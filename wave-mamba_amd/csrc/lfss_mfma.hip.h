@@ -27,146 +27,12 @@ __device__ __forceinline__ float silu_fast(float v) {
 }
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32); }
 
-constexpr int kLfssSlots = 2048;        // resident waves: 1024 SIMDs x 2
-
-// waves each take `gpw` consecutive groups of 64 positions; chosen so that the waves fill whole rounds of the slots
-inline int lfss_groups_per_wave(long long ngroups) {
-    const long long rounds = (ngroups + 8LL * kLfssSlots - 1) / (8LL * kLfssSlots);
-    long long gpw = (ngroups + rounds * kLfssSlots - 1) / (rounds * kLfssSlots);
+// waves each take `gpw` consecutive groups of 64 positions; chosen so that the waves fill whole rounds of the
+// `slots` resident waves (1024 SIMDs x the kernel's waves per SIMD), at most 8 groups per wave
+inline int lfss_groups_per_wave(long long ngroups, int slots) {
+    const long long rounds = (ngroups + 8LL * slots - 1) / (8LL * slots);
+    long long gpw = (ngroups + rounds * slots - 1) / (rounds * slots);
     return (int)(gpw < 1 ? 1 : gpw);
-}
-
-// ---- lfss_mid: ysum, z, tok -> tok1 (B, L, C), f (B, D, L) -------------------------------------------
-__global__ __launch_bounds__(256, 2) void lfss_mid_mfma_kernel(
-    const float* __restrict__ ysum, const float* __restrict__ z, const float* __restrict__ tok, int tok_nchw,
-    const float* __restrict__ on_w, const float* __restrict__ on_b, float on_eps,
-    const float* __restrict__ W_out /*(C, D)*/, const float* __restrict__ skip1,
-    const float* __restrict__ ln2_w, const float* __restrict__ ln2_b, float ln2_eps,
-    const float* __restrict__ W1 /*(D, C)*/, const float* __restrict__ b1,
-    float* __restrict__ tok1, float* __restrict__ f, int B, long long L, int ngl, long long ngroups, int gpw) {
-    constexpr int C = 32, D = 64;
-    __shared__ __attribute__((aligned(16))) float s_skip[C];
-    __shared__ __attribute__((aligned(16))) float s_b1[D];
-    const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x < C) s_skip[threadIdx.x] = skip1[threadIdx.x];
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + D) {
-        const int m = threadIdx.x - 64;
-        float acc = b1[m];
-        for (int k = 0; k < C; ++k) acc = fmaf(W1[m * C + k], ln2_b[k], acc);
-        s_b1[m] = acc;
-    }
-    // A operands: lane (m = n, k = h)
-    float Aout[D / 2], A1[2][C / 2];
-#pragma unroll
-    for (int j = 0; j < D / 2; ++j) Aout[j] = W_out[n * D + 2 * j + h];
-#pragma unroll
-    for (int j = 0; j < C / 2; ++j) {
-        const int k = (j & 3) + 8 * (j >> 2) + 4 * h;
-        const float g = ln2_w[k];
-        A1[0][j] = W1[n * C + k] * g;
-        A1[1][j] = W1[(32 + n) * C + k] * g;
-    }
-    __syncthreads();
-
-    const long long g0 = ((long long)blockIdx.x * 4 + wv) * gpw;
-    for (int gi = 0; gi < gpw; ++gi) {
-        const long long g = g0 + gi;
-        if (g >= ngroups) break;
-        const long long b = g / ngl;
-        const long long p0 = (g - b * ngl) * 64;
-        // ---- thread-per-position: out_norm, gate ----
-        const long long pc = min(p0 + lane, L - 1);
-        const float* yp = ysum + b * D * L + pc;
-        const float* zp = z + b * D * L + pc;
-        float y[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) y[d] = yp[(long long)d * L];
-        float mean = 0.0f;
-#pragma unroll
-        for (int d = 0; d < D; ++d) mean += y[d];
-        mean *= (1.0f / D);
-        float var = 0.0f;
-#pragma unroll
-        for (int d = 0; d < D; ++d) { const float q = y[d] - mean; var = fmaf(q, q, var); }
-        const float rstd = rsqrtf(var * (1.0f / D) + on_eps);
-#pragma unroll
-        for (int d = 0; d < D; ++d)
-            y[d] = fmaf((y[d] - mean) * rstd, on_w[d], on_b[d]) * silu_fast(zp[(long long)d * L]);
-        // ---- B operands of the two tiles ----
-#pragma unroll
-        for (int j = 0; j < D / 2; ++j) {
-            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(y[2 * j]), __float_as_uint(y[2 * j + 1]),
-                                                            false, false);
-            y[2 * j] = __uint_as_float(r[0]);           // tile 0: positions p0 + n,      channels 2j + h
-            y[2 * j + 1] = __uint_as_float(r[1]);       // tile 1: positions p0 + 32 + n, channels 2j + h
-        }
-        lfss_v16f acc[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-#pragma unroll
-        for (int j = 0; j < D / 2; ++j) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aout[j], y[2 * j], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aout[j], y[2 * j + 1], acc[1], 0, 0, 0);
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const long long pos = p0 + 32 * t + n;
-            const bool ok = pos < L;
-            const long long pq = min(pos, L - 1);
-            float tt[16];
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int row0 = 8 * gq + 4 * h;
-                float4 tk;
-                if (tok_nchw) {
-                    const float* tp = tok + (b * C + row0) * L + pq;
-                    tk = make_float4(tp[0], tp[L], tp[2 * L], tp[3 * L]);
-                } else {
-                    tk = *reinterpret_cast<const float4*>(tok + (b * L + pq) * C + row0);
-                }
-                const float4 sk = *reinterpret_cast<const float4*>(&s_skip[row0]);
-                tt[4 * gq] = fmaf(tk.x, sk.x, acc[t][4 * gq]);
-                tt[4 * gq + 1] = fmaf(tk.y, sk.y, acc[t][4 * gq + 1]);
-                tt[4 * gq + 2] = fmaf(tk.z, sk.z, acc[t][4 * gq + 2]);
-                tt[4 * gq + 3] = fmaf(tk.w, sk.w, acc[t][4 * gq + 3]);
-            }
-            if (ok) {
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq)
-                    *reinterpret_cast<float4*>(tok1 + (b * L + pos) * C + 8 * gq + 4 * h) =
-                        make_float4(tt[4 * gq], tt[4 * gq + 1], tt[4 * gq + 2], tt[4 * gq + 3]);
-            }
-            float s = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s += tt[i];
-            const float m2 = xhalf_sum(s) * (1.0f / C);
-            float v2 = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { tt[i] -= m2; v2 = fmaf(tt[i], tt[i], v2); }
-            const float r2 = rsqrtf(xhalf_sum(v2) * (1.0f / C) + ln2_eps);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) tt[i] *= r2;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                lfss_v16f a;
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const float4 bb = *reinterpret_cast<const float4*>(&s_b1[32 * mt + 8 * gq + 4 * h]);
-                    a[4 * gq] = bb.x; a[4 * gq + 1] = bb.y; a[4 * gq + 2] = bb.z; a[4 * gq + 3] = bb.w;
-                }
-#pragma unroll
-                for (int j = 0; j < C / 2; ++j) a = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[mt][j], tt[j], a, 0, 0, 0);
-                if (ok) {
-                    float* fp = f + (b * D + 32 * mt + 4 * h) * L + pos;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) fp[(long long)(8 * (i >> 2) + (i & 3)) * L] = a[i];
-                }
-            }
-        }
-    }
 }
 
 // A 32-position tile of a (B, L, 32) token array or a (B, 32, L) plane stack in accumulator layout: register 4g + i of
@@ -213,15 +79,165 @@ __device__ __forceinline__ void tile_normalise(float (&v)[16], float eps) {
     for (int i = 0; i < 16; ++i) v[i] *= r;
 }
 
+// A operands live in LDS in fetch order: operand j of lane l at s[((j >> 2) * 64 + l) * 4 + (j & 3)] - one
+// conflict-free ds_read_b128 per four MFMAs (256 B per MFMA against 64 cycles of matrix-core time).
+__device__ __forceinline__ int aop_slot(int j, int l) { return ((j >> 2) * 64 + l) * 4 + (j & 3); }
+// channel held by accumulator register j in lanes of half h
+__device__ __forceinline__ int acc_chan(int j, int h) { return (j & 3) + 8 * (j >> 2) + 4 * h; }
+
+#ifndef WM_LFSS_MID_WAVES
+#define WM_LFSS_MID_WAVES 4
+#endif
+#ifndef WM_LFSS_IN_WAVES
+#define WM_LFSS_IN_WAVES 4
+#endif
+
+// two tiles' accumulators of one output row block -> 256-byte runs: after the swap, register i of `lo` is channel
+// row(i) at positions p0 .. p0 + 63 and register i of `hi` is channel row(i) + 4
+__device__ __forceinline__ void store_rows64(float* __restrict__ plane0 /* channel 0 of the 32-row block, + p0 + lane */,
+                                             long long L, bool ok, lfss_v16f lo, lfss_v16f hi) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo[i]), __float_as_uint(hi[i]), false, false);
+        if (ok) {
+            const long long ro = (long long)(8 * (i >> 2) + (i & 3)) * L;
+            plane0[ro] = __uint_as_float(r[0]);
+            plane0[ro + 4 * L] = __uint_as_float(r[1]);
+        }
+    }
+}
+
+// ---- lfss_mid: ysum, z, tok -> tok1 (B, L, C), f (B, D, L) -------------------------------------------
+__global__ __launch_bounds__(256, WM_LFSS_MID_WAVES) void lfss_mid_mfma_kernel(
+    const float* __restrict__ ysum, const float* __restrict__ z, const float* __restrict__ tok, int tok_nchw,
+    const float* __restrict__ on_w, const float* __restrict__ on_b, float on_eps,
+    const float* __restrict__ W_out /*(C, D)*/, const float* __restrict__ skip1,
+    const float* __restrict__ ln2_w, const float* __restrict__ ln2_b, float ln2_eps,
+    const float* __restrict__ W1 /*(D, C)*/, const float* __restrict__ b1,
+    float* __restrict__ tok1, float* __restrict__ f, int B, long long L, int ngl, long long ngroups, int gpw) {
+    constexpr int C = 32, D = 64;
+    __shared__ __attribute__((aligned(16))) float s_skip[C];
+    __shared__ __attribute__((aligned(16))) float s_b1[D];
+    __shared__ __attribute__((aligned(16))) float s_Aout[(D / 2) * 64];          // 32 operands x 64 lanes
+    __shared__ __attribute__((aligned(16))) float s_A1[2 * (C / 2) * 64];        // 2 row blocks x 16 operands
+    const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x < C) s_skip[threadIdx.x] = skip1[threadIdx.x];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + D) {
+        const int m = threadIdx.x - 64;
+        float acc = b1[m];
+        for (int k = 0; k < C; ++k) acc = fmaf(W1[m * C + k], ln2_b[k], acc);
+        s_b1[m] = acc;
+    }
+    for (int e = threadIdx.x; e < (D / 2) * 64; e += 256) {
+        const int j = e >> 6, l = e & 63;
+        s_Aout[aop_slot(j, l)] = W_out[(l & 31) * D + 2 * j + (l >> 5)];
+    }
+    for (int e = threadIdx.x; e < 2 * (C / 2) * 64; e += 256) {
+        const int mt = e >> 10, j = (e >> 6) & 15, l = e & 63;
+        const int k = acc_chan(j, l >> 5);
+        s_A1[aop_slot(mt * 16 + j, l)] = W1[(32 * mt + (l & 31)) * C + k] * ln2_w[k];
+    }
+    __syncthreads();
+
+    const long long g0 = ((long long)blockIdx.x * 4 + wv) * gpw;
+    for (int gi = 0; gi < gpw; ++gi) {
+        const long long g = g0 + gi;
+        if (g >= ngroups) break;
+        const long long b = g / ngl;
+        const long long p0 = (g - b * ngl) * 64;
+        // ---- thread-per-position: out_norm, gate ----
+        const bool okl = p0 + lane < L;
+        const long long pc = min(p0 + lane, L - 1);
+        const float* yp = ysum + b * D * L + pc;
+        const float* zp = z + b * D * L + pc;
+        float y[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) y[d] = yp[(long long)d * L];
+        float mean = 0.0f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) mean += y[d];
+        mean *= (1.0f / D);
+        float var = 0.0f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { const float q = y[d] - mean; var = fmaf(q, q, var); }
+        const float rstd = rsqrtf(var * (1.0f / D) + on_eps);
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            y[d] = fmaf((y[d] - mean) * rstd, on_w[d], on_b[d]) * silu_fast(zp[(long long)d * L]);
+        // ---- B operands of the two tiles ----
+#pragma unroll
+        for (int j = 0; j < D / 2; ++j) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(y[2 * j]), __float_as_uint(y[2 * j + 1]),
+                                                            false, false);
+            y[2 * j] = __uint_as_float(r[0]);           // tile 0: positions p0 + n,      channels 2j + h
+            y[2 * j + 1] = __uint_as_float(r[1]);       // tile 1: positions p0 + 32 + n, channels 2j + h
+        }
+        lfss_v16f acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+#pragma unroll
+        for (int j4 = 0; j4 < D / 8; ++j4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&s_Aout[(j4 * 64 + lane) * 4]);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], y[2 * (4 * j4 + jj)], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], y[2 * (4 * j4 + jj) + 1], acc[1], 0, 0, 0);
+            }
+        }
+        float tt[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const long long pos = p0 + 32 * t + n;
+            const long long pq = min(pos, L - 1);
+            load_tile32(tok, tok_nchw != 0, b, pq, L, h, tt[t]);
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 sk = *reinterpret_cast<const float4*>(&s_skip[8 * gq + 4 * h]);
+                tt[t][4 * gq] = fmaf(tt[t][4 * gq], sk.x, acc[t][4 * gq]);
+                tt[t][4 * gq + 1] = fmaf(tt[t][4 * gq + 1], sk.y, acc[t][4 * gq + 1]);
+                tt[t][4 * gq + 2] = fmaf(tt[t][4 * gq + 2], sk.z, acc[t][4 * gq + 2]);
+                tt[t][4 * gq + 3] = fmaf(tt[t][4 * gq + 3], sk.w, acc[t][4 * gq + 3]);
+            }
+            if (pos < L) store_tile32(tok1, false, b, pos, L, h, tt[t]);
+            tile_normalise(tt[t], ln2_eps);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            lfss_v16f a[2];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 bb = *reinterpret_cast<const float4*>(&s_b1[32 * mt + 8 * gq + 4 * h]);
+                a[0][4 * gq] = bb.x; a[0][4 * gq + 1] = bb.y; a[0][4 * gq + 2] = bb.z; a[0][4 * gq + 3] = bb.w;
+            }
+            a[1] = a[0];
+#pragma unroll
+            for (int j4 = 0; j4 < C / 8; ++j4) {
+                const float4 a4 = *reinterpret_cast<const float4*>(&s_A1[((mt * 4 + j4) * 64 + lane) * 4]);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    a[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], tt[0][4 * j4 + jj], a[0], 0, 0, 0);
+                    a[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], tt[1][4 * j4 + jj], a[1], 0, 0, 0);
+                }
+            }
+            store_rows64(f + (b * D + 32 * mt) * L + p0 + lane, L, okl, a[0], a[1]);
+        }
+    }
+}
+
 // ---- lfss_in: tok -> x (B, D, L), z (B, D, L) ------------------------------------------------------
 // ln_1's affine is folded into in_proj (W' = W diag(w), bias' = W b).
-__global__ __launch_bounds__(256, 2) void lfss_in_mfma_kernel(const float* __restrict__ tok, int tok_nchw,
-                                                             const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-                                                             float eps, const float* __restrict__ W_in /*(2D, C)*/,
-                                                             float* __restrict__ x, float* __restrict__ z, int B, long long L,
-                                                             int ngl, long long ngroups, int gpw) {
+__global__ __launch_bounds__(256, WM_LFSS_IN_WAVES) void lfss_in_mfma_kernel(
+    const float* __restrict__ tok, int tok_nchw, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
+    const float* __restrict__ W_in /*(2D, C)*/, float* __restrict__ x, float* __restrict__ z, int B, long long L, int ngl,
+    long long ngroups, int gpw) {
     constexpr int C = 32, D = 64;
     __shared__ __attribute__((aligned(16))) float s_bias[2 * D];
+    __shared__ __attribute__((aligned(16))) float s_A[4 * (C / 2) * 64];         // 4 row blocks x 16 operands
     const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x < 2 * D) {
@@ -229,13 +245,10 @@ __global__ __launch_bounds__(256, 2) void lfss_in_mfma_kernel(const float* __res
         for (int k = 0; k < C; ++k) acc = fmaf(W_in[threadIdx.x * C + k], ln_b[k], acc);
         s_bias[threadIdx.x] = acc;
     }
-    float A[4][C / 2];
-#pragma unroll
-    for (int j = 0; j < C / 2; ++j) {
-        const int k = (j & 3) + 8 * (j >> 2) + 4 * h;
-        const float g = ln_w[k];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) A[mt][j] = W_in[(32 * mt + n) * C + k] * g;
+    for (int e = threadIdx.x; e < 4 * (C / 2) * 64; e += 256) {
+        const int mt = e >> 10, j = (e >> 6) & 15, l = e & 63;
+        const int k = acc_chan(j, l >> 5);
+        s_A[aop_slot(mt * 16 + j, l)] = W_in[(32 * mt + (l & 31)) * C + k] * ln_w[k];
     }
     __syncthreads();
     const long long g0 = ((long long)blockIdx.x * 4 + wv) * gpw;
@@ -244,30 +257,33 @@ __global__ __launch_bounds__(256, 2) void lfss_in_mfma_kernel(const float* __res
         if (g >= ngroups) break;
         const long long b = g / ngl;
         const long long p0 = (g - b * ngl) * 64;
+        const bool okl = p0 + lane < L;
         float a[2][16];
 #pragma unroll
         for (int t = 0; t < 2; ++t) load_tile32(tok, tok_nchw != 0, b, min(p0 + 32 * t + n, L - 1), L, h, a[t]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const long long pos = p0 + 32 * t + n;
-            const bool ok = pos < L;
-            tile_normalise(a[t], eps);
+        for (int t = 0; t < 2; ++t) tile_normalise(a[t], eps);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                lfss_v16f acc;
+        for (int mt = 0; mt < 4; ++mt) {
+            lfss_v16f acc[2];
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const float4 bb = *reinterpret_cast<const float4*>(&s_bias[32 * mt + 8 * gq + 4 * h]);
-                    acc[4 * gq] = bb.x; acc[4 * gq + 1] = bb.y; acc[4 * gq + 2] = bb.z; acc[4 * gq + 3] = bb.w;
-                }
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 bb = *reinterpret_cast<const float4*>(&s_bias[32 * mt + 8 * gq + 4 * h]);
+                acc[0][4 * gq] = bb.x; acc[0][4 * gq + 1] = bb.y; acc[0][4 * gq + 2] = bb.z; acc[0][4 * gq + 3] = bb.w;
+            }
+            acc[1] = acc[0];
 #pragma unroll
-                for (int j = 0; j < C / 2; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[mt][j], a[t][j], acc, 0, 0, 0);
-                if (ok) {
-                    float* dp = (mt < 2 ? x + (b * D + 32 * mt + 4 * h) * L : z + (b * D + 32 * (mt - 2) + 4 * h) * L) + pos;
+            for (int j4 = 0; j4 < C / 8; ++j4) {
+                const float4 a4 = *reinterpret_cast<const float4*>(&s_A[((mt * 4 + j4) * 64 + lane) * 4]);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) dp[(long long)(8 * (i >> 2) + (i & 3)) * L] = acc[i];
+                for (int jj = 0; jj < 4; ++jj) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], a[0][4 * j4 + jj], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], a[1][4 * j4 + jj], acc[1], 0, 0, 0);
                 }
             }
+            float* dp = (mt < 2 ? x + (b * D + 32 * mt) * L : z + (b * D + 32 * (mt - 2)) * L) + p0 + lane;
+            store_rows64(dp, L, okl, acc[0], acc[1]);
         }
     }
 }

@@ -726,7 +726,7 @@ int wm_lfss_in_fwd(const float* tok, int tok_nchw, const float* ln_w, const floa
     if (C == 32 && B && L) {
         const int ngl = (int)((L + 63) / 64);
         const long long ngroups = (long long)B * ngl;
-        const int gpw = lfss_groups_per_wave(ngroups);
+        const int gpw = lfss_groups_per_wave(ngroups, 1024 * WM_LFSS_IN_WAVES);
         const long long waves = (ngroups + gpw - 1) / gpw;
         hipStream_t st = (hipStream_t)stream;
         ProfScope ps(5, st);
@@ -749,7 +749,7 @@ int wm_lfss_mid_fwd(const float* ysum, const float* z, const float* tok, int tok
     if (C == 32 && B && L) {                                 // the shipped width: projections on the matrix cores
         const int ngl = (int)((L + 63) / 64);
         const long long ngroups = (long long)B * ngl;
-        const int gpw = lfss_groups_per_wave(ngroups);
+        const int gpw = lfss_groups_per_wave(ngroups, 1024 * WM_LFSS_MID_WAVES);
         const long long waves = (ngroups + gpw - 1) / gpw;
         hipStream_t st = (hipStream_t)stream;
         ProfScope ps(5, st);
@@ -770,7 +770,7 @@ int wm_lfss_out_fwd(const float* fc, const float* tok1, const float* conv3_weigh
     if (C == 32 && B && L) {
         const int ngl = (int)((L + 63) / 64);
         const long long ngroups = (long long)B * ngl;
-        const int gpw = lfss_groups_per_wave(ngroups);
+        const int gpw = lfss_groups_per_wave(ngroups, 2048);
         const long long waves = (ngroups + gpw - 1) / gpw;
         hipStream_t st = (hipStream_t)stream;
         ProfScope ps(5, st);
