@@ -34,6 +34,37 @@ __global__ __launch_bounds__(256) void copy_kernel(const float4* __restrict__ in
     for (; i < n; i += stride) out[i] = in[i];
 }
 
+// the access pattern of the NCHW streaming kernels: one thread = one position, NPL planes of L floats each
+template <int NPL>
+__global__ __launch_bounds__(256) void plane_copy_kernel(const float* __restrict__ in, float* __restrict__ out, long long L) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= L) return;
+    float v[NPL];
+#pragma unroll
+    for (int d = 0; d < NPL; ++d) v[d] = in[d * L + p];
+#pragma unroll
+    for (int d = 0; d < NPL; ++d) out[d * L + p] = v[d];
+}
+template <int NPL>
+__global__ __launch_bounds__(256) void plane_fill_kernel(float* __restrict__ out, long long L) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= L) return;
+#pragma unroll
+    for (int d = 0; d < NPL; ++d) out[d * L + p] = (float)d;
+}
+__global__ __launch_bounds__(256) void fill_kernel(float4* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+__global__ __launch_bounds__(256) void sum_kernel(const float4* __restrict__ in, float* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float s = 0.f;
+    for (; i < n; i += stride) { const float4 v = in[i]; s += v.x + v.y + v.z + v.w; }
+    if (s == 123.456f) out[0] = s;
+}
+
 template <int MODE>
 static double run_rate(float* d, int iters, const char* name, double ops_per_iter) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -65,6 +96,49 @@ int main() {
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("float4 copy, %6d blocks   %8.3f ms/iter  %8.1f GB/s (read+write)\n", blocks, ms / 5, 2.0 * bytes * 5 / ms * 1e-6);
+    }
+    {
+        const int blocks = 8192;
+        hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, 0, b, bytes / 16);
+        hipEventRecord(e0);
+        for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, 0, b, bytes / 16);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("float4 fill (write only)       %8.3f ms/iter  %8.1f GB/s\n", ms / 5, 1.0 * bytes * 5 / ms * 1e-6);
+        hipLaunchKernelGGL(sum_kernel, dim3(blocks), dim3(256), 0, 0, a, d, bytes / 16);
+        hipEventRecord(e0);
+        for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(sum_kernel, dim3(blocks), dim3(256), 0, 0, a, d, bytes / 16);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("float4 sum (read only)         %8.3f ms/iter  %8.1f GB/s\n", ms / 5, 1.0 * bytes * 5 / ms * 1e-6);
+    }
+    {   // 64 planes of 1088 x 1920 floats (UHD level 1, D = 64): 535 MB each way
+        const long long L = 1088LL * 1920;
+        const int blocks = (int)((L + 255) / 256);
+        hipLaunchKernelGGL(plane_copy_kernel<64>, dim3(blocks), dim3(256), 0, 0, (const float*)a, (float*)b, L);
+        hipEventRecord(e0);
+        for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(plane_copy_kernel<64>, dim3(blocks), dim3(256), 0, 0, (const float*)a, (float*)b, L);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("plane copy, 64 planes x 1 dword per lane   %8.3f ms/iter  %8.1f GB/s (read+write)\n", ms / 5, 2.0 * 64 * L * 4 * 5 / ms * 1e-6);
+        hipLaunchKernelGGL(plane_copy_kernel<128>, dim3(blocks), dim3(256), 0, 0, (const float*)a, (float*)b, L);
+        hipEventRecord(e0);
+        for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(plane_copy_kernel<128>, dim3(blocks), dim3(256), 0, 0, (const float*)a, (float*)b, L);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("plane copy, 128 planes x 1 dword per lane  %8.3f ms/iter  %8.1f GB/s (read+write)\n", ms / 5, 2.0 * 128 * L * 4 * 5 / ms * 1e-6);
+        hipLaunchKernelGGL(plane_fill_kernel<128>, dim3(blocks), dim3(256), 0, 0, (float*)b, L);
+        hipEventRecord(e0);
+        for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(plane_fill_kernel<128>, dim3(blocks), dim3(256), 0, 0, (float*)b, L);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("plane fill, 128 planes x 1 dword per lane  %8.3f ms/iter  %8.1f GB/s (write only)\n", ms / 5, 128.0 * L * 4 * 5 / ms * 1e-6);
+        hipLaunchKernelGGL(plane_copy_kernel<16>, dim3(blocks), dim3(256), 0, 0, (const float*)a, (float*)b, L);
+        hipEventRecord(e0);
+        for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(plane_copy_kernel<16>, dim3(blocks), dim3(256), 0, 0, (const float*)a, (float*)b, L);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("plane copy, 16 planes x 1 dword per lane   %8.3f ms/iter  %8.1f GB/s (read+write)\n", ms / 5, 2.0 * 16 * L * 4 * 5 / ms * 1e-6);
     }
     return 0;
 }

@@ -162,9 +162,23 @@ __global__ __launch_bounds__(256, WM_LFSS_MID_WAVES) void lfss_mid_mfma_kernel(
 #pragma unroll
         for (int d = 0; d < D; ++d) { const float q = y[d] - mean; var = fmaf(q, q, var); }
         const float rstd = rsqrtf(var * (1.0f / D) + on_eps);
+        // z in explicit double-buffered batches: left to itself the compiler issues the 64 loads one at a time, each
+        // followed by its wait (64 serialised round trips per group)
+        constexpr int ZB = 8;
+        float zb[2][ZB];
 #pragma unroll
-        for (int d = 0; d < D; ++d)
-            y[d] = fmaf((y[d] - mean) * rstd, on_w[d], on_b[d]) * silu_fast(zp[(long long)d * L]);
+        for (int i = 0; i < ZB; ++i) zb[0][i] = zp[(long long)i * L];
+#pragma unroll
+        for (int d0 = 0; d0 < D; d0 += ZB) {
+            const int cur = (d0 / ZB) & 1;
+            if (d0 + ZB < D) {
+#pragma unroll
+                for (int i = 0; i < ZB; ++i) zb[cur ^ 1][i] = zp[(long long)(d0 + ZB + i) * L];
+            }
+#pragma unroll
+            for (int i = 0; i < ZB; ++i)
+                y[d0 + i] = fmaf((y[d0 + i] - mean) * rstd, on_w[d0 + i], on_b[d0 + i]) * silu_fast(zb[cur][i]);
+        }
         // ---- B operands of the two tiles ----
 #pragma unroll
         for (int j = 0; j < D / 2; ++j) {
@@ -251,18 +265,29 @@ __global__ __launch_bounds__(256, WM_LFSS_IN_WAVES) void lfss_in_mfma_kernel(
         s_A[aop_slot(mt * 16 + j, l)] = W_in[(32 * mt + (l & 31)) * C + k] * ln_w[k];
     }
     __syncthreads();
-    const long long g0 = ((long long)blockIdx.x * 4 + wv) * gpw;
+    const long long g0 = (long long)blockIdx.x * 4 * gpw + wv;     // the block's waves walk adjacent groups together
+    float nx[2][16];
+    auto load_tok = [&](long long g) {
+        const long long b = g / ngl;
+        const long long p0 = (g - b * ngl) * 64;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) load_tile32(tok, tok_nchw != 0, b, min(p0 + 32 * t + n, L - 1), L, h, nx[t]);
+    };
+    if (g0 < ngroups) load_tok(g0);
     for (int gi = 0; gi < gpw; ++gi) {
-        const long long g = g0 + gi;
+        const long long g = g0 + 4 * gi;
         if (g >= ngroups) break;
         const long long b = g / ngl;
         const long long p0 = (g - b * ngl) * 64;
         const bool okl = p0 + lane < L;
         float a[2][16];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) load_tile32(tok, tok_nchw != 0, b, min(p0 + 32 * t + n, L - 1), L, h, a[t]);
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) tile_normalise(a[t], eps);
+            for (int i = 0; i < 16; ++i) a[t][i] = nx[t][i];
+            tile_normalise(a[t], eps);
+        }
+        if (gi + 1 < gpw && g + 4 < ngroups) load_tok(g + 4);       // ahead of this group's 128 stores
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             lfss_v16f acc[2];
@@ -310,9 +335,9 @@ __global__ __launch_bounds__(256, 2) void lfss_out_mfma_kernel(const float* __re
         const float4 s4 = *reinterpret_cast<const float4*>(&s_skip[8 * gq + 4 * h]);
         sk[4 * gq] = s4.x; sk[4 * gq + 1] = s4.y; sk[4 * gq + 2] = s4.z; sk[4 * gq + 3] = s4.w;
     }
-    const long long g0 = ((long long)blockIdx.x * 4 + wv) * gpw;
+    const long long g0 = (long long)blockIdx.x * 4 * gpw + wv;     // the block's waves walk adjacent groups together
     for (int gi = 0; gi < gpw; ++gi) {
-        const long long g = g0 + gi;
+        const long long g = g0 + 4 * gi;
         if (g >= ngroups) break;
         const long long b = g / ngl;
         const long long p0 = (g - b * ngl) * 64;

@@ -187,17 +187,22 @@ __global__ __launch_bounds__(64) void ss2d_row_kernel(Ss2dArgs p) {
     const int t_begin = chunk * p.chunk_len;
     const int t_end = min(p.L, t_begin + p.chunk_len);
 
+    // parameter loads first, unconditional with clamped indices (see the column kernel)
     v2f A2[NP / 2];
+    float araw[NP], wdt[kRecPad];
 #pragma unroll
-    for (int n = 0; n < NP; ++n) {
-        const float a = (n < p.N) ? -expf(p.A_logs[(long long)kd * p.N + n]) * 1.4426950408889634f : 0.0f;
-        if (n & 1) A2[n / 2].y = a; else A2[n / 2].x = a;
-    }
-    float wdt[kRecPad];
+    for (int n = 0; n < NP; ++n) araw[n] = p.A_logs[(long long)kd * p.N + min(n, p.N - 1)];
 #pragma unroll
-    for (int r = 0; r < kRecPad; ++r) wdt[r] = (r < p.R) ? p.Wdt[(long long)kd * p.R + r] : 0.0f;
+    for (int r = 0; r < kRecPad; ++r) wdt[r] = p.Wdt[(long long)kd * p.R + min(r, p.R - 1)];
     const float bias = p.dtb[kd];
     const float Dd = p.Ds[kd];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        const float a = (n < p.N) ? -expf(araw[n]) * 1.4426950408889634f : 0.0f;
+        if (n & 1) A2[n / 2].y = a; else A2[n / 2].x = a;
+    }
+#pragma unroll
+    for (int r = 0; r < kRecPad; ++r) wdt[r] = (r < p.R) ? wdt[r] : 0.0f;
 
     v2f h[NP / 2];
     const long long wsrow = ((long long)chunk * p.B * p.D + (long long)b * p.D + d) * NP;
@@ -440,23 +445,33 @@ __global__ __launch_bounds__(64 * kColWaves, WM_COL_LB) void ss2d_col_kernel(Ss2
     v2f A2[kColCH][NP / 2];
     float wdt[kColCH][kRecPad], bias[kColCH], Dd[kColCH];
     bool chok[kColCH];
+    // All parameter loads first, unconditional with clamped indices (a `n < N ? load : 0` select compiles to a branch
+    // around each load followed by its own wait: 32 serialised round trips before the first scan step).
+    float araw[kColCH][NP];
 #pragma unroll
     for (int c = 0; c < kColCH; ++c) {
         const int d = d0 + c;
         chok[c] = d < p.D;
         const int kd = k * p.D + (chok[c] ? d : 0);
 #pragma unroll
+        for (int n = 0; n < NP; ++n) araw[c][n] = p.A_logs[(long long)kd * p.N + min(n, p.N - 1)];
+#pragma unroll
+        for (int r = 0; r < kRecPad; ++r) wdt[c][r] = p.Wdt[(long long)kd * p.R + min(r, p.R - 1)];
+        bias[c] = p.dtb[kd];
+        Dd[c] = p.Ds[kd];
+    }
+#pragma unroll
+    for (int c = 0; c < kColCH; ++c) {
+#pragma unroll
         for (int n = 0; n < NP; ++n) {
-            float a = (n < p.N) ? -expf(p.A_logs[(long long)kd * p.N + n]) * 1.4426950408889634f : 0.0f;
+            float a = (n < p.N) ? -expf(araw[c][n]) * 1.4426950408889634f : 0.0f;
             // wave-uniform, but v_pk_mul_f32 cannot take an SGPR pair: pin the value in a VGPR once
             // (otherwise the compiler re-copies SGPR -> VGPR at every use, 16 v_mov per step)
             asm volatile("" : "+v"(a));
             if (n & 1) A2[c][n / 2].y = a; else A2[c][n / 2].x = a;
         }
 #pragma unroll
-        for (int r = 0; r < kRecPad; ++r) wdt[c][r] = (r < p.R) ? p.Wdt[(long long)kd * p.R + r] : 0.0f;
-        bias[c] = p.dtb[kd];
-        Dd[c] = p.Ds[kd];
+        for (int r = 0; r < kRecPad; ++r) wdt[c][r] = (r < p.R) ? wdt[c][r] : 0.0f;
     }
 
     const int omega = REV ? W - 1 - w : w;
