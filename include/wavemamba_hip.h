@@ -170,10 +170,13 @@ int wm_layernorm2d_fwd(const float* x, const float* weight, const float* bias, f
  * Channel Gram matrix over the pixel axis (HFE branch): G[b][i][j] = sum_l X[b][i][l] Y[b][j][l],
  * nx[b][i] = sum_l X^2, ny likewise.  X, Y (B, C, L) fp32, C <= 32; G (B, C, C), nx, ny (B, C) are
  * overwritten.  Replaces torch.cdist(x, perception) (wavemamba_arch.py:664) and
- * normalize(q) @ normalize(k)^T (:787-790), both contractions over H*W.
+ * normalize(q) @ normalize(k)^T (:787-790), both contractions over H*W.  `workspace`
+ * (wm_gram_workspace_bytes, 16-byte aligned) holds the per-block partial sums, which are added in a
+ * fixed order: the result is bit-reproducible run to run, as the reference's matmul is.
  * -------------------------------------------------------------------------------------------- */
-int wm_gram_fwd(const float* X, const float* Y, float* G, float* nx, float* ny, int B, int C, int64_t L,
-                void* stream);
+size_t wm_gram_workspace_bytes(int B, int C, int64_t L);
+int wm_gram_fwd(const float* X, const float* Y, float* G, float* nx, float* ny, void* workspace,
+                size_t workspace_bytes, int B, int C, int64_t L, void* stream);
 
 /* Training-side gradients of the two streaming helpers above.
  *   wm_dwconv3x3_wgrad: dW (C,1,3,3) and db (C, may be NULL) of the depth-wise conv from x and gy (B,C,H,W);

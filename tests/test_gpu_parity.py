@@ -919,3 +919,19 @@ def test_conv2d_uhd_level1_crop_and_linearity():
         assert_close(a[:, :, ih, iw], b[:, :, ih, iw].float().cpu(), 2e-5, f"conv2d UHD crop at {(h0, w0)}")
     y2 = wm.ops.conv2d(2.0 * x, w, None, 2.0 * p, idx)
     assert_close(y2, (2.0 * y).cpu(), 1e-6, "conv2d linearity at UHD level 1")
+
+
+def test_forward_is_bit_reproducible():
+    """No atomics on the inference path (Gram partials and SKFF plane sums are added in block order): two forwards of
+    the same input agree bit for bit, like the reference's deterministic ATen kernels."""
+    torch.manual_seed(3)
+    x = torch.randn(2, 32, 272 * 480, device=DEV)
+    y = torch.randn(2, 32, 272 * 480, device=DEV)
+    a, b = wm.ops.gram(x, y), wm.ops.gram(x, y)
+    assert all(torch.equal(p, q) for p, q in zip(a, b))
+    net = wm.WaveMamba(in_chn=3, wf=32, n_l_blocks=[1, 1, 1], n_h_blocks=[1, 1, 1], ffn_scale=2.0).eval().to(DEV)
+    img = torch.rand(1, 3, 256, 384, device=DEV)
+    with torch.no_grad():
+        o1 = net.restoration_network(img)
+        o2 = net.restoration_network(img)
+    assert torch.equal(o1, o2)

@@ -7,8 +7,9 @@
 // (normalize(q) @ normalize(k)^T, :787-790: G / (|q||k|)).  K = H*W is ~2 M at UHD with M = N = 32:
 // a library GEMM runs one tiny tile with a huge K; here every wave owns a slice of l, feeds
 // fp32 MFMA 16x16x4 straight from 16-byte row loads (both operands use the SAME lane->(row, l)
-// mapping, so no layout shuffling), and the 32x32 partials meet through atomics.  HBM-bound:
-// 2*C*L*4 bytes read once.
+// mapping, so no layout shuffling).  The blocks' 32x32 partials go to a workspace and a second small kernel adds
+// them in block order: bit-reproducible run to run (atomics were not, once more than two blocks met on an element).
+// HBM-bound: 2*C*L*4 bytes read once.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -16,10 +17,11 @@ namespace wm {
 
 typedef float gram_f4 __attribute__((ext_vector_type(4)));
 
-constexpr int kGramWaves = 8;          // waves per block: their 32x32 partials meet in LDS before the atomics
+constexpr int kGramWaves = 8;          // waves per block: their 32x32 partials meet in LDS
+constexpr int kGramPart = 32 * 32 + 64; // floats per block partial: G (32 x 32), nx (32), ny (32)
+// part: [B][gridDim.x][kGramPart]
 __global__ __launch_bounds__(64 * kGramWaves) void gram32_kernel(const float* __restrict__ X, const float* __restrict__ Y,
-                                                     float* __restrict__ G, float* __restrict__ nx,
-                                                     float* __restrict__ ny, int C, long long L, long long slice) {
+                                                     float* __restrict__ part, int C, long long L, long long slice) {
     const int lane = threadIdx.x & 63;
     __shared__ float s_part[kGramWaves][32 * 32 + 64];
     const int wv = threadIdx.x >> 6;
@@ -97,18 +99,43 @@ __global__ __launch_bounds__(64 * kGramWaves) void gram32_kernel(const float* __
         if (kq == 0) { s_part[wv][1024 + i16 + 16 * h] = vx; s_part[wv][1056 + i16 + 16 * h] = vy; }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 32 * 32 + 64; e += 64 * kGramWaves) {
+    float* dst = part + ((long long)b * gridDim.x + blockIdx.x) * kGramPart;
+    for (int e = threadIdx.x; e < kGramPart; e += 64 * kGramWaves) {
         float t = 0.0f;
 #pragma unroll
         for (int w8 = 0; w8 < kGramWaves; ++w8) t += s_part[w8][e];
-        if (e < 1024) {
-            const int i = e >> 5, j = e & 31;
-            if (i < C && j < C) atomicAdd(G + ((long long)b * C + i) * C + j, t);
-        } else if (e < 1056) {
-            if (e - 1024 < C) atomicAdd(nx + (long long)b * C + (e - 1024), t);
-        } else {
-            if (e - 1056 < C) atomicAdd(ny + (long long)b * C + (e - 1056), t);
-        }
+        dst[e] = t;
+    }
+}
+
+// G, nx, ny = sum over the nblk block partials, in block order.  One thread per (element, quarter of the blocks);
+// the four quarters meet in LDS in fixed order.
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ part, float* __restrict__ G,
+                                                          float* __restrict__ nx, float* __restrict__ ny, int C, int nblk) {
+    __shared__ float s_q[4][64];
+    const int b = blockIdx.y, el = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    const int per = (nblk + 3) / 4, k0 = min(nblk, q * per), k1 = min(nblk, k0 + per);
+    const float* src = part + (long long)b * nblk * kGramPart + e;
+    float t = 0.0f;
+    for (int k = k0; k < k1; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(long long)min(k + j, k1 - 1) * kGramPart];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += (k + j < k1) ? v[j] : 0.0f;
+    }
+    s_q[q][el] = t;
+    __syncthreads();
+    if (q != 0) return;
+    t = ((s_q[0][el] + s_q[1][el]) + s_q[2][el]) + s_q[3][el];
+    if (e < 1024) {
+        const int i = e >> 5, j = e & 31;
+        if (i < C && j < C) G[((long long)b * C + i) * C + j] = t;
+    } else if (e < 1056) {
+        if (e - 1024 < C) nx[(long long)b * C + (e - 1024)] = t;
+    } else {
+        if (e - 1056 < C) ny[(long long)b * C + (e - 1056)] = t;
     }
 }
 

@@ -69,9 +69,10 @@ __global__ __launch_bounds__(256) void attn_fold_kernel(const float* __restrict_
     }
 }
 
-// sums[b * C + c] += sum over the plane of (x0 + x1 + x2)[b, c]; grid (blocks per plane, B * C), block (256)
+// part[(b * C + c) * gridDim.x + block] = this block's share of the plane sum of (x0 + x1 + x2)[b, c]; the shares are
+// added in block order by skff_weights_kernel (bit-reproducible; atomics were not).  grid (blocks per plane, B * C)
 __global__ __launch_bounds__(256) void chansum3_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
-                                                       const float* __restrict__ x2, float* __restrict__ sums,
+                                                       const float* __restrict__ x2, float* __restrict__ part,
                                                        long long HW, bool vec) {
     const long long plane = blockIdx.y;
     const float* p0 = x0 + plane * HW; const float* p1 = x1 + plane * HW; const float* p2 = x2 + plane * HW;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void chansum3_kernel(const float* __restrict__
     __shared__ float s_w[4];
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(sums + plane, (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
+    if (threadIdx.x == 0) part[plane * gridDim.x + blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
 
 // sums[c] += sum over the batch and the plane of x[b, c]: bias gradients of the convolutions in training (ATen's
@@ -119,14 +120,26 @@ __global__ __launch_bounds__(256) void plane_sums_kernel(const float* __restrict
     if (threadIdx.x == 0) atomicAdd(sums + (plane % C), (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
 }
 
-// grid (B), block (64): sums (B, C) -> band weights w (B, 3, C).  Wdu (d, C), prelu (1), Wfc (3, C, d); no biases
+// grid (B), block (64): block partials of the plane sums (B, C, bpp) -> band weights w (B, 3, C).  Wdu (d, C), prelu (1), Wfc (3, C, d); no biases
 // (SKFF is built with bias=False, :943/:947).  C <= 64, d <= 16.
-__global__ __launch_bounds__(64) void skff_weights_kernel(const float* __restrict__ sums, const float* __restrict__ Wdu,
-                                                          const float* __restrict__ prelu, const float* __restrict__ Wfc,
-                                                          float* __restrict__ w, int C, int d, float inv_hw) {
+__global__ __launch_bounds__(64) void skff_weights_kernel(const float* __restrict__ part, int bpp,
+                                                          const float* __restrict__ Wdu, const float* __restrict__ prelu,
+                                                          const float* __restrict__ Wfc, float* __restrict__ w, int C, int d,
+                                                          float inv_hw) {
     __shared__ float s_mean[64], s_z[16];
     const int b = blockIdx.x, t = threadIdx.x;
-    if (t < C) s_mean[t] = sums[b * C + t] * inv_hw;
+    if (t < C) {
+        const float* pp = part + ((long long)b * C + t) * bpp;
+        float s = 0.0f;
+        for (int k = 0; k < bpp; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = pp[min(k + j, bpp - 1)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (k + j < bpp) ? v[j] : 0.0f;
+        }
+        s_mean[t] = s * inv_hw;
+    }
     __syncthreads();
     if (t < d) {
         float z = 0.0f;

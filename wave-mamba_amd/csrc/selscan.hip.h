@@ -319,9 +319,17 @@ __global__ __launch_bounds__(64, WM_LB_WAVES) void selscan_chunk_kernel(ScanArgs
 // dependent FMA chain never waits on memory), the 64 segment aggregates of a chain are combined
 // through LDS, then each thread re-walks its segment replacing the end state H[c] by the carry-in.
 constexpr int kCarrySeg = 64;
-__global__ __launch_bounds__(1024) void selscan_carry_kernel(const float* __restrict__ wsP,
-                                                             float* __restrict__ wsH,
-                                                             long long nchains, int nchunks) {
+// Up to four independent carry problems over the same chains in one launch (blockIdx.z): the fused SS2D core runs
+// its four directions' carries together - they are latency-bound launches of a few microseconds each.
+struct CarryDir { float* wsP; float* wsH; float* segP; float* segH; int nchunks; int nsegs; };
+struct CarryBatch { CarryDir d[4]; };
+
+template <bool SEGS>      // SEGS: scan the per-segment aggregates (segP, segH) instead of the chunk summaries
+__global__ __launch_bounds__(1024) void selscan_carry_kernel(CarryBatch cb, long long nchains) {
+    const CarryDir cd = cb.d[blockIdx.z];
+    const float* __restrict__ wsP = SEGS ? cd.segP : cd.wsP;
+    float* __restrict__ wsH = SEGS ? cd.segH : cd.wsH;
+    const int nchunks = SEGS ? cd.nsegs : cd.nchunks;
     __shared__ float sP[kCarrySeg][17];
     __shared__ float sH[kCarrySeg][17];
     const int cl = threadIdx.x & 15;                       // chain within the block
@@ -374,11 +382,13 @@ __global__ __launch_bounds__(1024) void selscan_carry_kernel(const float* __rest
 //   apply : re-walk the segment from its carry-in, replacing H[c] by H_in[c]
 constexpr int kCarrySegLen = 32;
 template <bool APPLY>
-__global__ __launch_bounds__(256) void selscan_carry_seg_kernel(const float* __restrict__ wsP,
-                                                                float* __restrict__ wsH,
-                                                                float* __restrict__ segP,
-                                                                float* __restrict__ segH,
-                                                                long long nchains, int nchunks, int nsegs) {
+__global__ __launch_bounds__(256) void selscan_carry_seg_kernel(CarryBatch cb, long long nchains) {
+    const CarryDir cd = cb.d[blockIdx.z];
+    const float* __restrict__ wsP = cd.wsP;
+    float* __restrict__ wsH = cd.wsH;
+    float* __restrict__ segP = cd.segP;
+    float* __restrict__ segH = cd.segH;
+    const int nchunks = cd.nchunks, nsegs = cd.nsegs;
     const long long chain = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
     const int seg = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (chain >= nchains || seg >= nsegs) return;

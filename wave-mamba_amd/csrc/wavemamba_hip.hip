@@ -117,23 +117,33 @@ struct ScanPlan { int NP, wpg, rows, chunk_len, nchunks; size_t ws_bytes; };
 
 static inline long long carry_nsegs(long long nchunks) { return (nchunks + kCarrySegLen - 1) / kCarrySegLen; }
 
-// phase 2 over [nchunks][nchains] summaries; `seg` = scratch for 2 * carry_nsegs(nchunks) * nchains floats
-static void launch_carry(float* wsP, float* wsH, float* seg, long long nchains, int nchunks, hipStream_t st) {
+// phase 2 over [nchunks][nchains] summaries of `ndirs` independent scans with the same chain count and the same
+// hierarchy depth (all <= 1024 chunks, or all above); d[i].segP / segH = scratch for carry_nsegs(nchunks) * nchains
+// floats each
+static void launch_carry_batch(CarryBatch cb, int ndirs, long long nchains, hipStream_t st) {
     ProfScope ps(3, st);
-    const dim3 cgrid((unsigned)((nchains + 15) / 16)), cblock(1024);
-    if (nchunks <= 1024 || !seg) {
-        hipLaunchKernelGGL(selscan_carry_kernel, cgrid, cblock, 0, st, (const float*)wsP, wsH, nchains, nchunks);
+    const dim3 cgrid((unsigned)((nchains + 15) / 16), 1, (unsigned)ndirs), cblock(1024);
+    int maxchunks = 0;
+    for (int i = 0; i < ndirs; ++i) maxchunks = cb.d[i].nchunks > maxchunks ? cb.d[i].nchunks : maxchunks;
+    if (maxchunks <= 1024 || !cb.d[0].segP) {
+        hipLaunchKernelGGL((selscan_carry_kernel<false>), cgrid, cblock, 0, st, cb, nchains);
         return;
     }
+    int maxsegs = 0;
+    for (int i = 0; i < ndirs; ++i) {
+        cb.d[i].nsegs = (int)carry_nsegs(cb.d[i].nchunks);
+        maxsegs = cb.d[i].nsegs > maxsegs ? cb.d[i].nsegs : maxsegs;
+    }
+    const dim3 grid((unsigned)((nchains + 63) / 64), (unsigned)((maxsegs + 3) / 4), (unsigned)ndirs), block(256);
+    hipLaunchKernelGGL((selscan_carry_seg_kernel<false>), grid, block, 0, st, cb, nchains);
+    hipLaunchKernelGGL((selscan_carry_kernel<true>), cgrid, cblock, 0, st, cb, nchains);
+    hipLaunchKernelGGL((selscan_carry_seg_kernel<true>), grid, block, 0, st, cb, nchains);
+}
+static void launch_carry(float* wsP, float* wsH, float* seg, long long nchains, int nchunks, hipStream_t st) {
+    CarryBatch cb{};
     const int nsegs = (int)carry_nsegs(nchunks);
-    float* segP = seg;
-    float* segH = seg + (size_t)nsegs * nchains;
-    const dim3 grid((unsigned)((nchains + 63) / 64), (unsigned)((nsegs + 3) / 4)), block(256);
-    hipLaunchKernelGGL((selscan_carry_seg_kernel<false>), grid, block, 0, st, (const float*)wsP, wsH, segP, segH,
-                       nchains, nchunks, nsegs);
-    hipLaunchKernelGGL(selscan_carry_kernel, cgrid, cblock, 0, st, (const float*)segP, segH, nchains, nsegs);
-    hipLaunchKernelGGL((selscan_carry_seg_kernel<true>), grid, block, 0, st, (const float*)wsP, wsH, segP, segH,
-                       nchains, nchunks, nsegs);
+    cb.d[0] = CarryDir{wsP, wsH, seg, seg ? seg + (size_t)nsegs * nchains : nullptr, nchunks, nsegs};
+    launch_carry_batch(cb, 1, nchains, st);
 }
 
 static int scan_plan(ScanPlan& pl, int batch, int dim, int L, int N, int G) {
@@ -229,43 +239,34 @@ static int ss2d_plan(Ss2dPlan& pl, int B, int D, int H, int W, int N, int R) {
     const long long maxchunks = pl.col_nchunks > pl.row_nchunks ? pl.col_nchunks : pl.row_nchunks;
     pl.ws_half_bytes = (size_t)maxchunks * B * D * 16 * sizeof(float);
     pl.seg_bytes = (size_t)2 * carry_nsegs(maxchunks) * B * D * 16 * sizeof(float);
-    pl.total_bytes = pl.rec_bytes + 2 * pl.ws_half_bytes + pl.seg_bytes;
+    pl.total_bytes = pl.rec_bytes + 4 * (2 * pl.ws_half_bytes + pl.seg_bytes);      // one summary set per direction
     return WM_OK;
 }
 
-template <bool REV>
-static void ss2d_launch_row(Ss2dArgs a, const Ss2dPlan& pl, bool vec, float* seg, hipStream_t st) {
+// PHASE 1 = chunk summaries (skipped by the caller when the direction is a single chunk), PHASE 3 = scan with carry-in
+template <int PHASE, bool REV>
+static void ss2d_launch_row(Ss2dArgs a, const Ss2dPlan& pl, bool vec, hipStream_t st) {
     a.chunk_len = pl.row_chunk; a.nchunks = pl.row_nchunks; a.nseg = 0;
     const dim3 grid((unsigned)pl.row_nchunks, (unsigned)a.B), block(64);
-    if (pl.row_nchunks > 1) {
-        { ProfScope ps(10, st);
-          if (vec) hipLaunchKernelGGL((ss2d_row_kernel<1, REV, true>), grid, block, 0, st, a);
-          else hipLaunchKernelGGL((ss2d_row_kernel<1, REV, false>), grid, block, 0, st, a); }
-        launch_carry(a.wsP, a.wsH, seg, (long long)a.B * a.D * 16, pl.row_nchunks, st);
-    }
-    ProfScope ps(8, st);
-    if (vec) hipLaunchKernelGGL((ss2d_row_kernel<3, REV, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((ss2d_row_kernel<3, REV, false>), grid, block, 0, st, a);
+    ProfScope ps(PHASE == 1 ? 10 : 8, st);
+    if (vec) hipLaunchKernelGGL((ss2d_row_kernel<PHASE, REV, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((ss2d_row_kernel<PHASE, REV, false>), grid, block, 0, st, a);
 }
 
-template <bool REV>
-static void ss2d_launch_col(Ss2dArgs a, const Ss2dPlan& pl, float* seg, hipStream_t st) {
+template <int PHASE, bool REV>
+static void ss2d_launch_col(Ss2dArgs a, const Ss2dPlan& pl, hipStream_t st) {
     a.chunk_len = pl.col_seg; a.nseg = pl.col_nseg; a.nchunks = (int)pl.col_nchunks;
     const int cgroups = (a.D + kColCH * kColWaves - 1) / (kColCH * kColWaves);
     const long long ntiles = (long long)((a.W + 63) / 64) * pl.col_nseg * a.B;
     const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8 * cgroups)), block(64 * kColWaves);    // XCD-aware order, see kernel
     static bool configured = false;                      // the chunk-scan image is 72 KB of dynamic LDS: opt in once
-    if (!configured) {
+    if (PHASE == 3 && !configured) {
         hipFuncSetAttribute((const void*)ss2d_col_kernel<3, REV>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             col_lds_bytes<3>());
         configured = true;
     }
-    if (pl.col_nchunks > 1) {
-        { ProfScope ps(11, st); hipLaunchKernelGGL((ss2d_col_kernel<1, REV>), grid, block, col_lds_bytes<1>(), st, a); }
-        launch_carry(a.wsP, a.wsH, seg, (long long)a.B * a.D * 16, (int)pl.col_nchunks, st);
-    }
-    ProfScope ps(9, st);
-    hipLaunchKernelGGL((ss2d_col_kernel<3, REV>), grid, block, col_lds_bytes<3>(), st, a);
+    ProfScope ps(PHASE == 1 ? 11 : 9, st);
+    hipLaunchKernelGGL((ss2d_col_kernel<PHASE, REV>), grid, block, col_lds_bytes<PHASE>(), st, a);
 }
 
 }  // namespace wm
@@ -277,7 +278,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 11; }
+int wm_abi_version(void) { return 12; }
 
 const char* wm_strerror(int code) {
     switch (code) {
@@ -539,15 +540,50 @@ int wm_ss2d_core_fwd(const float* x, const float* x_proj_weight, const float* dt
         hipLaunchKernelGGL(ss2d_proj_kernel, dim3((unsigned)blocks), dim3(128), 0, st, a, groups);
     }
     const bool vec = (a.L % 4 == 0) && aligned16(x) && aligned16(y_row_fwd) && (merged || aligned16(y_row_rev));
-    a.k = 0; a.y = y_row_fwd; a.accumulate = 0;
-    float* seg = (float*)((char*)workspace + pl.rec_bytes + 2 * pl.ws_half_bytes);
-    ss2d_launch_row<false>(a, pl, vec, seg, st);
-    a.k = 2; a.y = merged ? y_row_fwd : y_row_rev; a.accumulate = merged;
-    ss2d_launch_row<true>(a, pl, vec, seg, st);
-    a.k = 1; a.y = merged ? y_row_fwd : y_col_fwd; a.accumulate = merged;
-    ss2d_launch_col<false>(a, pl, seg, st);
-    a.k = 3; a.y = merged ? y_row_fwd : y_col_rev; a.accumulate = merged;
-    ss2d_launch_col<true>(a, pl, seg, st);
+    // Per direction k its own summary set, so that the four reduce launches, ONE set of carry launches for all four
+    // directions, and the four scan launches follow each other (the carries are a few microseconds each: 12 launches
+    // per call before).  Order of the scans = order of the accumulation into y: 0, 2, 1, 3 as before.
+    char* wsbase = (char*)workspace + pl.rec_bytes;
+    const size_t per_dir = 2 * pl.ws_half_bytes + pl.seg_bytes;
+    const long long nchains = (long long)B * D * 16;
+    float* yk[4] = {y_row_fwd, merged ? y_row_fwd : y_col_fwd, merged ? y_row_fwd : y_row_rev, merged ? y_row_fwd : y_col_rev};
+    Ss2dArgs ak[4];
+    for (int k = 0; k < 4; ++k) {
+        ak[k] = a;
+        ak[k].k = k; ak[k].y = yk[k]; ak[k].accumulate = (merged && k != 0) ? 1 : 0;
+        ak[k].wsP = (float*)(wsbase + k * per_dir);
+        ak[k].wsH = (float*)(wsbase + k * per_dir + pl.ws_half_bytes);
+    }
+    auto carry_dir = [&](int k, int nchunks) {
+        float* seg = (float*)(wsbase + k * per_dir + 2 * pl.ws_half_bytes);
+        const int nsegs = (int)carry_nsegs(nchunks);
+        return CarryDir{ak[k].wsP, ak[k].wsH, seg, seg + (size_t)nsegs * nchains, nchunks, nsegs};
+    };
+    const bool row_split = pl.row_nchunks > 1, col_split = pl.col_nchunks > 1;
+    if (row_split) { ss2d_launch_row<1, false>(ak[0], pl, vec, st); ss2d_launch_row<1, true>(ak[2], pl, vec, st); }
+    if (col_split) { ss2d_launch_col<1, false>(ak[1], pl, st); ss2d_launch_col<1, true>(ak[3], pl, st); }
+    const bool row_deep = pl.row_nchunks > 1024, col_deep = pl.col_nchunks > 1024;
+    if (row_split && col_split && row_deep == col_deep) {
+        CarryBatch cb{};
+        cb.d[0] = carry_dir(0, pl.row_nchunks); cb.d[1] = carry_dir(2, pl.row_nchunks);
+        cb.d[2] = carry_dir(1, (int)pl.col_nchunks); cb.d[3] = carry_dir(3, (int)pl.col_nchunks);
+        launch_carry_batch(cb, 4, nchains, st);
+    } else {
+        if (row_split) {
+            CarryBatch cb{};
+            cb.d[0] = carry_dir(0, pl.row_nchunks); cb.d[1] = carry_dir(2, pl.row_nchunks);
+            launch_carry_batch(cb, 2, nchains, st);
+        }
+        if (col_split) {
+            CarryBatch cb{};
+            cb.d[0] = carry_dir(1, (int)pl.col_nchunks); cb.d[1] = carry_dir(3, (int)pl.col_nchunks);
+            launch_carry_batch(cb, 2, nchains, st);
+        }
+    }
+    ss2d_launch_row<3, false>(ak[0], pl, vec, st);
+    ss2d_launch_row<3, true>(ak[2], pl, vec, st);
+    ss2d_launch_col<3, false>(ak[1], pl, st);
+    ss2d_launch_col<3, true>(ak[3], pl, st);
     return launch_status();
 }
 
@@ -797,31 +833,49 @@ int wm_layernorm2d_fwd(const float* x, const float* weight, const float* bias, f
     WM_LFSS_DISPATCH(layernorm2d_kernel, x, weight, bias, eps, y, B, (long long)L);
 }
 
-int wm_gram_fwd(const float* X, const float* Y, float* G, float* nx, float* ny, int B, int C, int64_t L,
-                void* stream) {
+}  // extern "C"
+namespace wm {
+// waves / blocks / slice of a Gram launch
+static void gram_plan(int64_t L, long long& nblk, long long& slice) {
+    // >= 512 positions per wave on large maps; small maps are latency-bound (one round trip per 32 positions of a
+    // wave), so they get down to 128 positions per wave, up to 2048 waves
+    long long waves = (L + 511) / 512, wsmall = (L + 127) / 128;
+    if (wsmall > 2048) wsmall = 2048;
+    if (waves < wsmall) waves = wsmall;
+    if (waves > 4096) waves = 4096;
+    if (waves < 1) waves = 1;
+    waves = ((waves + kGramWaves - 1) / kGramWaves) * kGramWaves;
+    slice = (L + waves - 1) / waves;
+    slice = ((slice + 31) / 32) * 32;
+    if (slice < 32) slice = 32;
+    nblk = waves / kGramWaves;
+}
+}  // namespace wm
+extern "C" {
+
+size_t wm_gram_workspace_bytes(int B, int C, int64_t L) {
+    if (B <= 0 || C <= 0 || C > 32 || L < 0) return 0;
+    long long nblk, slice;
+    gram_plan(L, nblk, slice);
+    return (size_t)B * nblk * kGramPart * sizeof(float);
+}
+
+int wm_gram_fwd(const float* X, const float* Y, float* G, float* nx, float* ny, void* workspace, size_t workspace_bytes,
+                int B, int C, int64_t L, void* stream) {
     if (B < 0 || C < 0 || L < 0) return WM_EINVAL;
     if (C > 32) return WM_EUNSUPPORTED;
     if (B == 0 || C == 0) return WM_OK;
-    if (!X || !Y || !G || !nx || !ny) return WM_ENULL;
-    if (!aligned16(X) || !aligned16(Y)) return WM_EALIGN;
+    if (!X || !Y || !G || !nx || !ny || !workspace) return WM_ENULL;
+    if (!aligned16(X) || !aligned16(Y) || !aligned16(workspace)) return WM_EALIGN;
+    long long nblk, slice;
+    gram_plan(L, nblk, slice);
+    if (workspace_bytes < (size_t)B * nblk * kGramPart * sizeof(float)) return WM_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e;
-    if (nx == G + (size_t)B * C * C && ny == nx + (size_t)B * C) {          // one allocation: one fill
-        e = hipMemsetAsync(G, 0, (size_t)B * C * (C + 2) * sizeof(float), st);
-    } else {
-        e = hipMemsetAsync(G, 0, (size_t)B * C * C * sizeof(float), st);
-        if (e == hipSuccess) e = hipMemsetAsync(nx, 0, (size_t)B * C * sizeof(float), st);
-        if (e == hipSuccess) e = hipMemsetAsync(ny, 0, (size_t)B * C * sizeof(float), st);
-    }
-    if (e != hipSuccess) return (int)e;
-    if (L == 0) return WM_OK;
-    long long waves = (L + 511) / 512;                         // >= 512 positions per wave
-    if (waves > 4096) waves = 4096;
-    waves = ((waves + kGramWaves - 1) / kGramWaves) * kGramWaves;
-    long long slice = (L + waves - 1) / waves;
-    slice = ((slice + 31) / 32) * 32;
-    const dim3 grid((unsigned)(waves / kGramWaves), (unsigned)B), block(64 * kGramWaves);
-    hipLaunchKernelGGL(gram32_kernel, grid, block, 0, st, X, Y, G, nx, ny, C, (long long)L, slice);
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(gram32_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(64 * kGramWaves), 0, st, X, Y, part, C,
+                       (long long)L, slice);
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(kGramPart / 64, (unsigned)B), dim3(256), 0, st, (const float*)part, G, nx, ny,
+                       C, (int)nblk);
     return launch_status();
 }
 
@@ -1013,7 +1067,16 @@ int wm_attn_fold(const float* G, const float* nq, const float* nk, const float* 
     return launch_status();
 }
 
-size_t wm_skff_workspace_bytes(int B, int C) { return (B <= 0 || C <= 0) ? 0 : (size_t)B * C * 4 * sizeof(float); }
+}  // extern "C"
+// blocks per plane of the SKFF reduction / apply kernels: ~16 blocks per compute unit in flight over all planes
+static long long skff_bpp_cap(long long planes) { return (256 * 16 + planes - 1) / planes; }
+extern "C" {
+
+size_t wm_skff_workspace_bytes(int B, int C) {
+    if (B <= 0 || C <= 0) return 0;
+    const long long planes = (long long)B * C;
+    return (size_t)(planes * skff_bpp_cap(planes) + 3 * planes) * sizeof(float);
+}
 
 int wm_skff_fwd(const float* x0, const float* x1, const float* x2, const float* Wdu, const float* prelu,
                 const float* Wfc, float* out, void* workspace, size_t workspace_bytes, int B, int C, int d, int H, int W,
@@ -1024,22 +1087,20 @@ int wm_skff_fwd(const float* x0, const float* x1, const float* x2, const float* 
     if (!x0 || !x1 || !x2 || !Wdu || !prelu || !Wfc || !out || !workspace) return WM_ENULL;
     if (workspace_bytes < wm_skff_workspace_bytes(B, C)) return WM_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    float* sums = (float*)workspace;                     // (B, C)
-    float* wts = sums + (size_t)B * C;                   // (B, 3, C)
-    hipError_t e = hipMemsetAsync(sums, 0, (size_t)B * C * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
     const long long HW = (long long)H * W, planes = (long long)B * C;
     if (planes > 65535) return WM_EUNSUPPORTED;
     const bool vec = (HW % 4 == 0) && aligned16(x0) && aligned16(x1) && aligned16(x2) && aligned16(out);
     long long bpp = (HW / 4 + 256 * 8 - 1) / (256 * 8);              // >= 8 float4 per thread
-    const long long cap = (256 * 16 + planes - 1) / planes;          // ~16 blocks per compute unit in flight
+    const long long cap = skff_bpp_cap(planes);
     if (bpp > cap) bpp = cap;
     if (bpp < 1) bpp = 1;
+    float* wts = (float*)workspace;                      // (B, 3, C)
+    float* part = wts + (size_t)3 * planes;              // (B, C, bpp) block partials of the plane sums
     const dim3 grid((unsigned)bpp, (unsigned)planes), block(256);
     ProfScope ps(15, st);
-    hipLaunchKernelGGL(chansum3_kernel, grid, block, 0, st, x0, x1, x2, sums, HW, vec);
-    hipLaunchKernelGGL(skff_weights_kernel, dim3((unsigned)B), dim3(64), 0, st, sums, Wdu, prelu, Wfc, wts, C, d,
-                       (float)(1.0 / (double)HW));
+    hipLaunchKernelGGL(chansum3_kernel, grid, block, 0, st, x0, x1, x2, part, HW, vec);
+    hipLaunchKernelGGL(skff_weights_kernel, dim3((unsigned)B), dim3(64), 0, st, (const float*)part, (int)bpp, Wdu, prelu, Wfc,
+                       wts, C, d, (float)(1.0 / (double)HW));
     hipLaunchKernelGGL(skff_apply_kernel, grid, block, 0, st, x0, x1, x2, wts, out, C, HW, vec);
     return launch_status();
 }

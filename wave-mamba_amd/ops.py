@@ -433,12 +433,15 @@ def gram(x, y):
     if y.shape != x.shape or C > 32 or x.dtype != torch.float32 or y.dtype != torch.float32:
         raise NotImplementedError("gram: two fp32 (B, C<=32, L) tensors of equal shape")
     x, y = x.contiguous(), y.contiguous()
-    buf = torch.empty(B * C * (C + 2), dtype=torch.float32, device=x.device)      # one allocation: one fill in the library
+    buf = torch.empty(B * C * (C + 2), dtype=torch.float32, device=x.device)
     G = buf[:B * C * C].view(B, C, C)
     nx = buf[B * C * C:B * C * (C + 1)].view(B, C)
     ny = buf[B * C * (C + 1):].view(B, C)
+    nws = int(lib.wm_gram_workspace_bytes(B, C, L))
+    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
-        check(lib.wm_gram_fwd(_ptr(x), _ptr(y), _ptr(G), _ptr(nx), _ptr(ny), B, C, L, _stream()), "wm_gram_fwd")
+        check(lib.wm_gram_fwd(_ptr(x), _ptr(y), _ptr(G), _ptr(nx), _ptr(ny), _ptr(ws), nws, B, C, L, _stream()),
+              "wm_gram_fwd")
     return G, nx, ny
 
 
