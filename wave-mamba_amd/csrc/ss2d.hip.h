@@ -61,33 +61,44 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kProjTiles = 9;
 constexpr int kProjKS = 16;                // K-steps of 4 -> D_in <= 64
 
-__global__ __launch_bounds__(128, 1) void ss2d_proj_kernel(Ss2dArgs p, int groups_per_batch) {
-    __shared__ __attribute__((aligned(16))) float s_out[2 * 4 * 32 * kRS];       // 2 waves x 18,432 B
+// The 144 A fragments (9 tiles x 16 K-steps) live in LDS, padded to 12 per K-step so that a K-step is three
+// conflict-free ds_read_b128 (operand 12 s + t of lane l at ((3 s + (t >> 2)) * 64 + l) * 4 + (t & 3)).  Held in
+// registers they cost 144 VGPRs: one wave per SIMD, nothing to overlap its store phase with (MFMA busy 53 %).  The
+// records of one direction at a time are assembled in a 4.6-KB slab per wave: 4 waves x 4.6 KB + 49 KB of fragments
+// = two workgroups per compute unit.
+constexpr int kProjWaves = 4;
+constexpr int kProjWfrag = kProjKS * 12 * 64;           // floats
+__global__ __launch_bounds__(64 * kProjWaves, 2) void ss2d_proj_kernel(Ss2dArgs p, int groups_per_batch) {
+    __shared__ __attribute__((aligned(16))) float s_w[kProjWfrag];                      // 49,152 B
+    __shared__ __attribute__((aligned(16))) float s_out[kProjWaves * 32 * kRS];         // 4 waves x 4,608 B
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 2 + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * 2;
+    const int wv = threadIdx.x >> 6;
+    const int wave = blockIdx.x * kProjWaves + wv;
+    const int nwaves = gridDim.x * kProjWaves;
     const int g4 = lane >> 4, j16 = lane & 15;
     const int C = p.R + 2 * p.N;
 
-    // A fragments: lane holds A[row = j16][kk = g4] of every (tile, K-step): W[c(row)][d = 4 s + g4]
-    float wfrag[kProjTiles][kProjKS];
-#pragma unroll
-    for (int t = 0; t < kProjTiles; ++t) {
-        int kdir, c;
-        bool ok;
-        if (t == 0) { kdir = j16 >> 2; c = j16 & 3; ok = c < p.R; }
-        else { kdir = (t - 1) >> 1; const int n = j16; ok = n < p.N; c = p.R + ((t - 1) & 1) * p.N + n; }
-#pragma unroll
-        for (int s = 0; s < kProjKS; ++s) {
-            const int d = 4 * s + g4;
-            wfrag[t][s] = (ok && d < p.D) ? p.Wx[((long long)kdir * C + c) * p.D + d] : 0.0f;
+    // A fragments: lane l holds A[row = l & 15][kk = l >> 4] of every (tile, K-step): W[c(row)][d = 4 s + kk]
+    for (int e = threadIdx.x; e < kProjKS * 12 * 64; e += 64 * kProjWaves) {
+        const int l = e & 63, o = e >> 6, sidx = o / 12, t = o - 12 * sidx;
+        const int r16 = l & 15, kk = l >> 4;
+        float v = 0.0f;
+        if (t < kProjTiles) {
+            int kdir, c;
+            bool ok;
+            if (t == 0) { kdir = r16 >> 2; c = r16 & 3; ok = c < p.R; }
+            else { kdir = (t - 1) >> 1; ok = r16 < p.N; c = p.R + ((t - 1) & 1) * p.N + r16; }
+            const int d = 4 * sidx + kk;
+            if (ok && d < p.D) v = p.Wx[((long long)kdir * C + c) * p.D + d];
         }
+        s_w[((3 * sidx + (t >> 2)) * 64 + l) * 4 + (t & 3)] = v;
     }
+    __syncthreads();
 
     const long long L = p.L;
     const long long total = (long long)p.B * groups_per_batch;          // groups of 32 positions
     // common case (D_in == 64, even L): unconditional 8-byte loads with clamped addresses - per-load
-    // predication costs more issue slots than the MFMAs it feeds (one wave per SIMD hides nothing)
+    // predication costs more issue slots than the MFMAs it feeds
     const bool fast = (p.D == 4 * kProjKS) && ((L & 1) == 0) && L >= 2;
     auto load_x = [&](long long grp, float2 (&v)[kProjKS]) {
         if (fast) {
@@ -116,10 +127,10 @@ __global__ __launch_bounds__(128, 1) void ss2d_proj_kernel(Ss2dArgs p, int group
     };
     float2 xnext[kProjKS];
     load_x(wave, xnext);
+    float* slab = s_out + wv * (32 * kRS);
     for (long long grp = wave; grp < total; grp += nwaves) {
         const int b = (int)(grp / groups_per_batch);
         const long long p0 = (grp - (long long)b * groups_per_batch) * 32;
-        const long long pj = p0 + 2 * j16;                              // this lane's 2 positions
         f32x4 acc[kProjTiles][2];
 #pragma unroll
         for (int t = 0; t < kProjTiles; ++t) { acc[t][0] = (f32x4){0, 0, 0, 0}; acc[t][1] = (f32x4){0, 0, 0, 0}; }
@@ -129,38 +140,40 @@ __global__ __launch_bounds__(128, 1) void ss2d_proj_kernel(Ss2dArgs p, int group
         load_x(grp + nwaves, xnext);                                    // in flight under the MFMAs below
 #pragma unroll
         for (int s = 0; s < kProjKS; ++s) {
+            float wf[12];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(&s_w[((3 * s + q) * 64 + lane) * 4]);
+                wf[4 * q] = w4[0]; wf[4 * q + 1] = w4[1]; wf[4 * q + 2] = w4[2]; wf[4 * q + 3] = w4[3];
+            }
 #pragma unroll
             for (int t = 0; t < kProjTiles; ++t) {
-                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[t][s], xv[s].x, acc[t][0], 0, 0, 0);
-                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[t][s], xv[s].y, acc[t][1], 0, 0, 0);
+                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t], xv[s].x, acc[t][0], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t], xv[s].y, acc[t][1], 0, 0, 0);
             }
         }
-        // D layout: lane holds rows 4*g4 .. 4*g4+3 of column j16.  Assemble the 4 x 32 records of this
-        // group in the wave's private LDS slab, then write each direction's 32 x 144 B as ONE contiguous
-        // 4608-B run of 16-byte stores (direct stores would be 16-B pieces at a 144-B stride).
-        float* slab = s_out + (threadIdx.x >> 6) * (4 * 32 * kRS);
-        __builtin_amdgcn_wave_barrier();                  // previous iteration's reads are done (in-order LDS)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int pl = 2 * j16 + i;
-            *reinterpret_cast<f32x4*>(&slab[(g4 * 32 + pl) * kRS]) = acc[0][i];     // dt_r of direction g4
-#pragma unroll
-            for (int kd = 0; kd < 4; ++kd) {
-                float* rk = &slab[(kd * 32 + pl) * kRS + kRecPad + 4 * g4];
-                *reinterpret_cast<f32x4*>(rk) = acc[1 + 2 * kd][i];
-                *reinterpret_cast<f32x4*>(rk + 16) = acc[2 + 2 * kd][i];
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
+        // D layout: lane holds rows 4*g4 .. 4*g4+3 of column j16.  Assemble the 32 records of one direction in the
+        // wave's private LDS slab, then write them as ONE contiguous 4608-B run of 16-byte stores (direct stores
+        // would be 16-B pieces at a 144-B stride).
         const int npos = (int)min((long long)32, L - p0);
 #pragma unroll
         for (int kd = 0; kd < 4; ++kd) {
+            __builtin_amdgcn_wave_barrier();              // the previous direction's reads are done (in-order LDS)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int pl = 2 * j16 + i;
+                if (g4 == kd) *reinterpret_cast<f32x4*>(&slab[pl * kRS]) = acc[0][i];        // dt_r of direction g4
+                float* rk = &slab[pl * kRS + kRecPad + 4 * g4];
+                *reinterpret_cast<f32x4*>(rk) = acc[1 + 2 * kd][i];
+                *reinterpret_cast<f32x4*>(rk + 16) = acc[2 + 2 * kd][i];
+            }
+            __builtin_amdgcn_wave_barrier();
             float* dst = p.rec + (((long long)b * 4 + kd) * L + p0) * kRS;
 #pragma unroll
             for (int it = 0; it < (32 * kRS / 4 + 63) / 64; ++it) {
                 const int f = lane + 64 * it;
                 if (4 * f < npos * kRS)
-                    *reinterpret_cast<f32x4*>(dst + 4 * f) = *reinterpret_cast<const f32x4*>(&slab[kd * 32 * kRS + 4 * f]);
+                    *reinterpret_cast<f32x4*>(dst + 4 * f) = *reinterpret_cast<const f32x4*>(&slab[4 * f]);
             }
         }
     }

@@ -535,9 +535,9 @@ int wm_ss2d_core_fwd(const float* x, const float* x_proj_weight, const float* dt
         ProfScope ps(6, st);
         const int groups = (a.L + 31) / 32;
         long long waves = (long long)B * groups;
-        int blocks = (int)((waves + 1) / 2);
-        if (blocks > 256 * 4) blocks = 256 * 4;                     // persistent: weights stay in VGPRs
-        hipLaunchKernelGGL(ss2d_proj_kernel, dim3((unsigned)blocks), dim3(128), 0, st, a, groups);
+        int blocks = (int)((waves + kProjWaves - 1) / kProjWaves);
+        if (blocks > 256 * 2) blocks = 256 * 2;                     // persistent: two workgroups per compute unit
+        hipLaunchKernelGGL(ss2d_proj_kernel, dim3((unsigned)blocks), dim3(64 * kProjWaves), 0, st, a, groups);
     }
     const bool vec = (a.L % 4 == 0) && aligned16(x) && aligned16(y_row_fwd) && (merged || aligned16(y_row_rev));
     // Per direction k its own summary set, so that the four reduce launches, ONE set of carry launches for all four
@@ -695,9 +695,9 @@ int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt
             pa.chunk_len = 0; pa.nchunks = 0; pa.nseg = 0; pa.accumulate = 0;
             const int groups = (int)((L + 31) / 32);
             long long waves = (long long)B * groups;
-            int blocks = (int)((waves + 1) / 2);
-            if (blocks > 256 * 4) blocks = 256 * 4;
-            hipLaunchKernelGGL(ss2d_proj_kernel, dim3((unsigned)blocks), dim3(128), 0, st, pa, groups);
+            int blocks = (int)((waves + kProjWaves - 1) / kProjWaves);
+            if (blocks > 256 * 2) blocks = 256 * 2;
+            hipLaunchKernelGGL(ss2d_proj_kernel, dim3((unsigned)blocks), dim3(64 * kProjWaves), 0, st, pa, groups);
         }
         for (int kk = 0; kk < 2; ++kk) {
             const int k = layout ? (kk ? 3 : 1) : (kk ? 2 : 0);
