@@ -3,8 +3,9 @@
 //
 // The thread-per-position kernels of lfss.hip.h stream their weights through SGPRs: 4096 FMAs per position need
 // ~480 s_load per wave, and PMC shows the waves waiting on them (VALU issue 28 % of a wave's life at two waves per
-// SIMD, `SQ_WAIT_INST_ANY` 31 %).  Here a wave keeps both weight matrices in 64 VGPRs as MFMA A operands for all
-// the position groups it owns, and a group of 64 positions is two 32-column MFMA tiles:
+// SIMD, `SQ_WAIT_INST_ANY` 31 %).  Here the weight matrices sit in LDS as MFMA A operands in fetch order (in 64 VGPRs
+// in the first version: two waves per SIMD instead of four), a wave owns `gpw` groups of 64 positions, and a group
+// is two 32-column MFMA tiles:
 //   * thread-per-position phase (LayerNorm over channels in registers, gates), then one v_permlane32_swap per
 //     channel pair turns [positions 0-63 of channel 2j], [.. of 2j+1] into the B operands of both tiles;
 //   * a 32x32 accumulator tile holds, per lane, position (lane & 31) and rows 8g + 4(lane >> 5) + i: 16 of the 32
@@ -13,7 +14,8 @@
 //     holds channel (j&3) + 8(j>>2) in lanes 0-31 and that + 4 in lanes 32-63, so the A operand of step j simply
 //     carries those two weight columns (the K order of a GEMM is free).
 // ln_2's affine is folded into conv1 (W1' = W1 diag(w), b1' = b1 + W1 b): exact algebra, fp32 rounding differs at
-// 1e-7.  fp32 MFMA keeps fp32 products (no operand splitting); the kernels are HBM-bound.
+// 1e-7.  fp32 MFMA keeps fp32 products (no operand splitting).  The kernels are latency-bound rather than HBM-bound
+// (DESIGN.md 4): loads are issued in explicit batches ahead of their use and ahead of the group's stores.
 // Reference: basicsr/archs/wavemamba_arch.py :491-494 (SS2D tail), :525-526 (LFSSBlock), :226-230 (ffn).
 #pragma once
 #include <hip/hip_runtime.h>
