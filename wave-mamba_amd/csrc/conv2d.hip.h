@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
     }
     float pin[2][PIT][8];
 
-    auto fetch = [&](int cc) {
+    auto fetch_in = [&](int cc) {
         // source plane of each of the chunk's 16 channels first (scalar loads of the gather indices, batched), then
         // the vector loads.  Padded channels read plane 0 of xa and are zeroed in stage() (masking here would make
         // the compiler branch around the loads and wait for each one)
@@ -161,6 +161,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
             for (int j = 0; j < 8; ++j)
 #pragma unroll
                 for (int it = 0; it < PIT; ++it) pin[half][it][j] = bj[half][j][poff[it]];
+    };
+    auto fetch_w = [&](int cc) {
         // weights: straight to LDS (LDS-DMA, 1 KiB per wave instruction, no staging registers); destination =
         // wave-uniform base + lane * 16, which is exactly the [tap][m][split][lane] fragment order
         const uint4* wsrc = a.wfrag + ((long long)cc * TAPS * a.mtot) * 128;
@@ -219,10 +221,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
             for (int i = 0; i < 16; ++i) { acc[m][r][i] = 0.0f; if (G1X1) acc1[m][r][i] = 0.0f; }
 
     const int khalf = lane >> 5, px = lane & 31;
-    for (int cc = 0; cc < a.nch; ++cc) {
-        fetch(cc);
-        stage(cc);
-        __syncthreads();
+    auto mma = [&]() {
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
             Frag16 Ah[KS][MT], Al[KS][MT];
@@ -269,7 +268,36 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
                 }
             }
         }
+    };
+    // One output-channel tile per launch leaves the registers to hold the NEXT chunk's input pixels while this chunk's
+    // MFMAs run (48 / 32 VGPRs): without it every chunk exposes a full global-load round trip between two barriers
+    // (MFMA pipe 42 % busy on the 64-channel form, which has no registers to spare for it).
+    constexpr bool PIPE = (MT == 1) && !G1X1;
+    if constexpr (PIPE) {
+        fetch_in(0);
+        fetch_w(0);
+        stage(0);
         __syncthreads();
+        for (int cc = 0; cc < a.nch; ++cc) {
+            const bool more = cc + 1 < a.nch;                        // uniform
+            if (more) fetch_in(cc + 1);
+            mma();
+            __syncthreads();                                         // every wave is done with s_in / s_w
+            if (more) {
+                fetch_w(cc + 1);
+                stage(cc + 1);
+                __syncthreads();
+            }
+        }
+    } else {
+        for (int cc = 0; cc < a.nch; ++cc) {
+            fetch_in(cc);
+            fetch_w(cc);
+            stage(cc);
+            __syncthreads();
+            mma();
+            __syncthreads();
+        }
     }
 
     // D layout of v_mfma_f32_32x32x*: column = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
