@@ -270,8 +270,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
         }
     };
     // One output-channel tile per launch leaves the registers to hold the NEXT chunk's input pixels while this chunk's
-    // MFMAs run (48 / 32 VGPRs): without it every chunk exposes a full global-load round trip between two barriers
-    // (MFMA pipe 42 % busy on the 64-channel form, which has no registers to spare for it).
+    // MFMAs run (16 PIT VGPRs): without it every chunk exposes a full global-load round trip between two barriers.
+    // The two-tile and gated forms fit it too (244 / 208 VGPRs) but lose more to the registers than they gain
+    // (-0.4 % on the whole step); the 64-channel x 16-row form spills with it.
     constexpr bool PIPE = (MT == 1) && !G1X1;
     if constexpr (PIPE) {
         fetch_in(0);
