@@ -319,6 +319,8 @@ def random_core_case(B, D, H, W, N, R, seed):
     (1, 16, 10, 14, 16, 1),      # wf = 8: d_inner 16, dt_rank 1
     (1, 48, 9, 7, 8, 3),         # odd sizes (L % 4 != 0 -> scalar paths), N = 8, R = 3
     (1, 64, 128, 128, 16, 2),    # config 1 level 1: many chunks, several row segments
+    (1, 16, 16, 2048, 16, 2),    # 512 row chunks (one-level carry) next to 2048 column chunks (two-level): separate carry batches
+    (1, 16, 8192, 16, 16, 2),    # the other way round: 2048 row chunks, few column chunks
 ])
 def test_ss2d_core_vs_oracle(B, D, H, W, N, R):
     case = random_core_case(B, D, H, W, N, R, seed=H * 100 + W)
