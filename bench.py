@@ -297,7 +297,11 @@ def main():
                       "note": "same forward, steps round-robin over the streams (that many images in flight), no HIP-event "
                               "instrumentation; serving throughput, not the contract's `value`"}
     op_boundary = scan_op_boundary(device, hp, wp) if rank == 0 else None
-    hip_graph = graph_replay(lambda: step(single=True), args.steps, device) if rank == 0 and world == 1 and args.graph else None
+    def step_on_current_stream():           # capture needs the launches on the capturing stream: no stream switch
+        with torch.no_grad():
+            return net.restoration_network(x)[:, :, :args.height, :args.width]
+
+    hip_graph = graph_replay(step_on_current_stream, args.steps, device) if rank == 0 and world == 1 and args.graph else None
     bf16 = bf16_autocast(net, x, args.steps) if rank == 0 and world == 1 and args.bf16 else None
     if world > 1:
         t = torch.tensor([elapsed], device="cpu" if share else device, dtype=torch.float64)
