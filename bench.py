@@ -57,11 +57,12 @@ def build_model(device):
 def cpu_baseline(sample_hw, uhd_hw, repeats):
     """The CPU oracle ("port") inside the same network on host cores, on a bounded sample."""
     from oracle import oracle
+    from oracle import backend as oracle_backend
     cores = oracle.usable_cpus()
     torch.set_num_threads(cores)
     oracle.set_num_threads(cores)
     net = build_model("cpu")
-    prev = arch.set_ops_backend(oracle)
+    prev = oracle_backend.set_ops_backend(oracle)
     try:
         with torch.no_grad():
             # bounded: shrink the sample until one forward takes < ~8 s on this host
@@ -79,7 +80,7 @@ def cpu_baseline(sample_hw, uhd_hw, repeats):
                 y = net.restoration_network(x)
                 times.append(time.perf_counter() - t0)
     finally:
-        arch.set_ops_backend(prev)
+        oracle_backend.set_ops_backend(prev)
     repeats = len(times)
     t = sorted(times)[len(times) // 2]
     scale = (uhd_hw[0] * uhd_hw[1]) / (sample_hw[0] * sample_hw[1])

@@ -37,6 +37,7 @@ extern "C" {
 #define WM_EALIGN (-3)      /* pointer not aligned to the element size */
 #define WM_EWORKSPACE (-4)  /* workspace too small */
 #define WM_EUNSUPPORTED (-5)/* argument combination not implemented */
+#define WM_EHIP (-6)        /* a HIP runtime call made on behalf of the launch failed (device query, function attribute) */
 
 #define WM_F32 0
 #define WM_BF16 1
@@ -116,10 +117,13 @@ int wm_selscan_bwd(const float* u, const float* delta, const float* A, const flo
  *   outputs, each (B, D, H*W) in row-major l, in the reference's return order (:478):
  *     y_row_fwd = out_y[:,0], y_row_rev = flip(out_y[:,2]), y_col_fwd, y_col_rev (column scans,
  *     transposed back).  merged != 0: only y_row_fwd is written and holds the SUM of the four
- *     (what SS2D.forward computes next, :490); the other three pointers may be NULL.
- *   Supported: N <= 16, R <= 4, D <= 64 (else WM_EUNSUPPORTED: use wm_selscan_fwd).
+ *     (what SS2D.forward computes next, :490, added in the reference's order); the other three
+ *     pointers may be NULL.  wm_lfss_mid_fwd can add the four un-merged outputs while it reads them.
+ *   Supported: N <= 32, R <= 4, D <= 64 (else WM_EUNSUPPORTED: use wm_selscan_fwd); N > 16 needs W % 4 == 0.
+ *   x and the y buffers must be 16-byte aligned when W % 4 == 0 (WM_EALIGN).
+ *   The workspace size depends on `merged` (three temporary y buffers).
  * -------------------------------------------------------------------------------------------- */
-size_t wm_ss2d_core_fwd_workspace_bytes(int B, int D, int H, int W, int N, int R);
+size_t wm_ss2d_core_fwd_workspace_bytes(int B, int D, int H, int W, int N, int R, int merged);
 int wm_ss2d_core_fwd(const float* x, const float* x_proj_weight, const float* dt_projs_weight,
                      const float* dt_projs_bias, const float* A_logs, const float* Ds,
                      float* y_row_fwd, float* y_row_rev, float* y_col_fwd, float* y_col_rev,
@@ -143,13 +147,15 @@ int wm_dwconv3x3_fwd(const float* x, const float* weight, const float* bias, flo
  *                     tok -> x (conv input), z (gate)
  *   wm_lfss_mid_fwd : transpose (:491) + out_norm (:492) + *silu(z) (:493) + out_proj (:494)
  *                     + skip_scale residual (:525) + ln_2 + ffn.conv1 (:526, :226)
- *                     ysum, z, tok -> tok1, f (input of ffn.conv2)
+ *                     ysum, z, tok -> tok1, f (input of ffn.conv2).  ny = 1: `ysum` is the merged core output;
+ *                     ny = 4: `ysum` points at four (B, D, L) buffers `ystride` floats apart in the order
+ *                     [y_row_fwd, y_row_rev, y_col_fwd, y_col_rev] and the kernel adds them (:490) as it loads
  *   wm_lfss_out_fwd : gelu gate (:227-228) + ffn.conv3 (:230) + skip_scale2 residual (:526)
  *                     fc, tok1 -> out
  * -------------------------------------------------------------------------------------------- */
 int wm_lfss_in_fwd(const float* tok, int tok_nchw, const float* ln_w, const float* ln_b, float ln_eps,
                    const float* in_proj_weight, float* x, float* z, int B, int64_t L, int C, void* stream);
-int wm_lfss_mid_fwd(const float* ysum, const float* z, const float* tok, int tok_nchw,
+int wm_lfss_mid_fwd(const float* ysum, int ny, int64_t ystride, const float* z, const float* tok, int tok_nchw,
                     const float* out_norm_w, const float* out_norm_b, float out_norm_eps,
                     const float* out_proj_weight, const float* skip_scale,
                     const float* ln2_w, const float* ln2_b, float ln2_eps,

@@ -10,6 +10,7 @@ import torch.nn.functional as F
 
 from conftest import GOLDEN, assert_close
 from oracle import oracle
+from oracle import backend as obackend
 import wave_mamba_amd as wm
 from wave_mamba_amd.archs import wavemamba_arch as arch
 
@@ -18,9 +19,9 @@ SHIPPED = dict(in_chn=3, wf=32, n_l_blocks=[1, 2, 4], n_h_blocks=[1, 1, 2], ffn_
 
 @pytest.fixture()
 def oracle_backend():
-    prev = arch.set_ops_backend(oracle)
+    prev = obackend.set_ops_backend(oracle)
     yield
-    arch.set_ops_backend(prev)
+    obackend.set_ops_backend(prev)
 
 
 @pytest.fixture(scope="module")

@@ -31,8 +31,9 @@ def _worker(rank, world, port, out_dir):
     import wave_mamba_amd as wm
     from wave_mamba_amd.archs import wavemamba_arch as arch
     from oracle import oracle
+    from oracle import backend as oracle_backend
     oracle.set_num_threads(2)
-    arch.set_ops_backend(oracle)
+    oracle_backend.set_ops_backend(oracle)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.manual_seed(0)
@@ -79,7 +80,8 @@ def test_ddp_two_ranks_match_single_process(tmp_path):
     import wave_mamba_amd as wm
     from wave_mamba_amd.archs import wavemamba_arch as arch
     from oracle import oracle
-    prev = arch.set_ops_backend(oracle)
+    from oracle import backend as oracle_backend
+    prev = oracle_backend.set_ops_backend(oracle)
     try:
         torch.manual_seed(0)
         net = wm.WaveMamba(**CFG).train()
@@ -88,7 +90,7 @@ def test_ddp_two_ranks_match_single_process(tmp_path):
         l_pix, l_freq = wm.trainer.losses(net(lq), gt)
         (l_pix + l_freq).backward()
     finally:
-        arch.set_ops_backend(prev)
+        oracle_backend.set_ops_backend(prev)
     worst = 0.0
     for k, p in net.named_parameters():
         a, b = r0["grads"][k].double(), p.grad.double()

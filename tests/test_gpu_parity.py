@@ -8,6 +8,7 @@ import torch
 
 from conftest import assert_close
 from oracle import oracle
+from oracle import backend as oracle_backend
 import wave_mamba_amd as wm
 from wave_mamba_amd.archs import wavemamba_arch as arch
 
@@ -321,6 +322,10 @@ def random_core_case(B, D, H, W, N, R, seed):
     (1, 64, 128, 128, 16, 2),    # config 1 level 1: many chunks, several row segments
     (1, 16, 16, 2048, 16, 2),    # 512 row chunks (one-level carry) next to 2048 column chunks (two-level): separate carry batches
     (1, 16, 8192, 16, 16, 2),    # the other way round: 2048 row chunks, few column chunks
+    (1, 64, 48, 40, 32, 2),      # d_state 32 (BASELINE config 5's block): 8-wave workgroups, 8-column tiles, ragged W
+    (2, 64, 33, 72, 32, 4),      # d_state 32, dt_rank 4, odd H, batch 2
+    (1, 64, 50, 52, 16, 4),      # dt_rank 4 at d_state 16; W % 16 != 0, H % 16 != 0
+    (1, 32, 272, 480, 16, 1),    # UHD level-3 map at wf = 16: column segments
 ])
 def test_ss2d_core_vs_oracle(B, D, H, W, N, R):
     case = random_core_case(B, D, H, W, N, R, seed=H * 100 + W)
@@ -372,7 +377,7 @@ def test_lfss_block_fused_vs_module_path(C, H, W):
         x = torch.randn(2, H * W, C, device=DEV)
         fused = blk(x, [H, W])
         saved = arch.LFSSBlock._fused_ok
-        arch.LFSSBlock._fused_ok = lambda self, t: False
+        arch.LFSSBlock._fused_ok = lambda self, t, width=None: False
         try:
             ref = blk(x, [H, W])
         finally:
@@ -409,7 +414,7 @@ def test_lfss_glue_kernels_c32_vs_fp64(B, L, nchw):
     assert_close(x, xz[:, :D], TOL, "lfss_in x"); assert_close(z, xz[:, D:], TOL, "lfss_in z")
     # lfss_mid
     tok1 = torch.empty(B, L, C, device=DEV); f = torch.empty(B, D, L, device=DEV)
-    check(lib.wm_lfss_mid_fwd(_ptr(ysum), _ptr(zz), _ptr(tok), int(nchw), _ptr(onw), _ptr(onb), 1e-5, _ptr(Wout), _ptr(sk1),
+    check(lib.wm_lfss_mid_fwd(_ptr(ysum), 1, 0, _ptr(zz), _ptr(tok), int(nchw), _ptr(onw), _ptr(onb), 1e-5, _ptr(Wout), _ptr(sk1),
                               _ptr(ln2w), _ptr(ln2b), 1e-5, _ptr(W1), _ptr(b1), _ptr(tok1), _ptr(f), B, L, C, _stream()), "mid")
     yy = F.layer_norm(d(ysum).transpose(1, 2), (D,), d(onw), d(onb), 1e-5) * F.silu(d(zz).transpose(1, 2))
     t1 = d(tokens) * d(sk1) + F.linear(yy, d(Wout))
@@ -424,24 +429,25 @@ def test_lfss_glue_kernels_c32_vs_fp64(B, L, nchw):
     assert_close(out.transpose(1, 2) if nchw else out, o, TOL, "lfss_out")
 
 
-def test_lfss_block_d_state_32_uses_op_boundary_scan():
-    """BASELINE config 5 flavour: LFSSBlock(32, d_state=32) is outside the fused core's range (N <= 16), so the
-    block runs the direction glue + the drop-in selective_scan_fn (N = 32 kernels).  Checked against the same
-    block on the CPU oracle backend."""
+def test_lfss_block_d_state_32_on_the_fused_core():
+    """BASELINE config 5 flavour: LFSSBlock(32, d_state=32) takes the fused HIP block path (N = 32 instantiation of
+    the SS2D core).  Checked against the same block on the CPU oracle backend; with a width that is not a multiple of
+    4 the block falls back to the direction glue + the drop-in selective_scan_fn (N = 32 kernels), same check."""
     torch.manual_seed(5)
     blk = arch.LFSSBlock(32, d_state=32, expand=2.0).eval()
-    x = torch.randn(1, 48 * 40, 32, generator=gen(9))
-    prev = arch.set_ops_backend(oracle)
-    try:
+    for (H, W) in ((48, 40), (20, 30)):
+        x = torch.randn(1, H * W, 32, generator=gen(9))
+        prev = oracle_backend.set_ops_backend(oracle)
+        try:
+            with torch.no_grad():
+                want = blk.cpu()(x, [H, W])
+        finally:
+            oracle_backend.set_ops_backend(prev)
+        blk = blk.to(DEV)
         with torch.no_grad():
-            want = blk(x, [48, 40])
-    finally:
-        arch.set_ops_backend(prev)
-    blk = blk.to(DEV)
-    with torch.no_grad():
-        assert not blk._fused_ok(x.to(DEV))
-        got = blk(x.to(DEV), [48, 40])
-    assert_close(got, want, TOL, "LFSSBlock d_state=32")
+            assert blk._fused_ok(x.to(DEV), W) == (W % 4 == 0)
+            got = blk(x.to(DEV), [H, W])
+        assert_close(got, want, TOL, f"LFSSBlock d_state=32 {H}x{W}")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -517,11 +523,11 @@ def test_hfe_block_hip_helpers_vs_module_path():
     per = torch.randn(1, 32, 40, 56, device=DEV)
     with torch.no_grad():
         fast = blk(x, per)
-        prev = arch.set_ops_backend(type("Plain", (), {})())        # a backend without any helper
+        prev = oracle_backend.set_ops_backend(type("Plain", (), {})())        # a backend without any helper
         try:
             ref = blk(x, per)
         finally:
-            arch.set_ops_backend(prev)
+            oracle_backend.set_ops_backend(prev)
     assert_close(fast, ref, TOL, "HFEBlock")
 
 

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from oracle import oracle
+from oracle import backend as oracle_backend
 import wave_mamba_amd as wm
 from wave_mamba_amd.archs import wavemamba_arch as arch
 
@@ -12,11 +13,11 @@ CFG = dict(in_chn=3, wf=8, n_l_blocks=[1, 1, 1], n_h_blocks=[1, 1, 1], ffn_scale
 
 
 def run_cpu(net, img):
-    prev = arch.set_ops_backend(oracle)
+    prev = oracle_backend.set_ops_backend(oracle)
     try:
         return wm.inference.enhance(net, img)
     finally:
-        arch.set_ops_backend(prev)
+        oracle_backend.set_ops_backend(prev)
 
 
 def test_pad_crop_quantise_psnr_cpu():

@@ -45,7 +45,7 @@ for lvl in args.levels:
     st = _stream()
     t_in = timed(lambda: check(lib.wm_lfss_in_fwd(_ptr(tok), 0, _ptr(ln1w), _ptr(ln1b), 1e-5, _ptr(Win), _ptr(x), _ptr(z),
                                                   B, L, C, st), "in"))
-    t_mid = timed(lambda: check(lib.wm_lfss_mid_fwd(_ptr(ysum), _ptr(z), _ptr(tok), 0, _ptr(onw), _ptr(onb), 1e-5, _ptr(Wout),
+    t_mid = timed(lambda: check(lib.wm_lfss_mid_fwd(_ptr(ysum), 1, 0, _ptr(z), _ptr(tok), 0, _ptr(onw), _ptr(onb), 1e-5, _ptr(Wout),
                                                     _ptr(sk1), _ptr(ln2w), _ptr(ln2b), 1e-5, _ptr(W1), _ptr(b1), _ptr(tok1),
                                                     _ptr(f), B, L, C, st), "mid"))
     t_out = timed(lambda: check(lib.wm_lfss_out_fwd(_ptr(fc), _ptr(tok1), _ptr(W3), _ptr(b3), _ptr(sk2), _ptr(out), 0,

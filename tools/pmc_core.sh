@@ -1,12 +1,14 @@
 #!/bin/bash
 # PMC passes (separate runs per counter group, MI355X_MICROARCH.md) over the fused SS2D core at UHD level 1.
-# Usage: tools/pmc_core.sh <outdir>
+# Usage: tools/pmc_core.sh <outdir> [extra bench_core.py args]
 set -u
-R=$PWD; OUT=$R/$1
+R=$PWD; OUT=$R/$1; shift
 mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python $R/tools/bench_core.py --levels 1 --iters 3 > $OUT/$name.log 2>&1; }
+run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python $R/tools/bench_core.py --levels 1 --iters 3 $EXTRA > $OUT/$name.log 2>&1; }
+EXTRA="$*"
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU
 run sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES GRBM_GUI_ACTIVE
+run sq3 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS
 cd $R

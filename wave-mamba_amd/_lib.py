@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("WAVEMAMBA_HIP_LIB") or os.path.join(HERE, "libwavemam
 
 WM_F32, WM_BF16 = 0, 1
 WM_PROF_NKERNELS = 16
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _c = ctypes
 _p, _i, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
@@ -27,12 +27,12 @@ SIGNATURES = {
     "wm_selscan_fwd": (_i, [_p] * 10 + [_p, _sz] + [_i] * 6 + [_p]),
     "wm_selscan_bwd_workspace_bytes": (_sz, [_i] * 5),
     "wm_selscan_bwd": (_i, [_p] * 15 + [_p, _sz] + [_i] * 6 + [_p]),
-    "wm_ss2d_core_fwd_workspace_bytes": (_sz, [_i] * 6),
+    "wm_ss2d_core_fwd_workspace_bytes": (_sz, [_i] * 7),
     "wm_ss2d_core_fwd": (_i, [_p] * 10 + [_i, _p, _sz] + [_i] * 6 + [_p]),
     "wm_ss2d_core_bwd_workspace_bytes": (_sz, [_i] * 6),
     "wm_ss2d_core_bwd": (_i, [_p] * 16 + [_p, _sz] + [_i] * 6 + [_p]),
     "wm_lfss_in_fwd": (_i, [_p, _i, _p, _p, _c.c_float, _p, _p, _p, _i, _i64, _i, _p]),
-    "wm_lfss_mid_fwd": (_i, [_p, _p, _p, _i, _p, _p, _c.c_float, _p, _p, _p, _p, _c.c_float, _p, _p, _p, _p,
+    "wm_lfss_mid_fwd": (_i, [_p, _i, _i64, _p, _p, _i, _p, _p, _c.c_float, _p, _p, _p, _p, _c.c_float, _p, _p, _p, _p,
                              _i, _i64, _i, _p]),
     "wm_lfss_out_fwd": (_i, [_p] * 6 + [_i, _i, _i64, _i, _p]),
     "wm_layernorm2d_fwd": (_i, [_p, _p, _p, _c.c_float, _p, _i, _i64, _i, _p]),

@@ -37,21 +37,20 @@ except ImportError:                                    # dropped into basicsr/ar
 
 
 class _OpsBackend:
-    """Where the hot-path operators come from.  The product backend is the HIP library; tests and
-    bench.py's cpu_baseline leg may install the CPU oracle here to check / time the same network.
-    Nothing in this package ever installs anything but the HIP backend."""
+    """The hot-path operators: the HIP library, always.  (The class attribute is the one place the test suite's CPU
+    oracle patches from outside - oracle/backend.py - to run the same network on host cores; nothing in this package
+    installs anything here.)"""
     impl = _hip_ops
 
 
-def set_ops_backend(backend):
-    """Install an object exposing dwt_init, iwt_init_pair, selective_scan_fn (test infrastructure)."""
-    prev = _OpsBackend.impl
-    _OpsBackend.impl = backend
-    return prev
-
-
-def get_ops_backend():
-    return _OpsBackend.impl
+def _needs_grad(module, *tensors):
+    """Autograd will want gradients through this module: grad mode is on and an input or ANY parameter of the module
+    requires grad (a block with a frozen skip_scale or frozen early layers still has trainable weights inside)."""
+    if not torch.is_grad_enabled():
+        return False
+    if any(t is not None and t.requires_grad for t in tensors):
+        return True
+    return module is not None and any(q.requires_grad for q in module.parameters())
 
 
 def _dwconv(conv, x, act="none"):
@@ -59,7 +58,7 @@ def _dwconv(conv, x, act="none"):
     streaming HIP kernel; training (autograd) and the test backends use the PyTorch conv."""
     ops = _OpsBackend.impl
     if hasattr(ops, "dwconv3x3") and x.is_cuda and x.dtype == torch.float32:
-        if not (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)):
+        if not _needs_grad(conv, x):
             return ops.dwconv3x3(x, conv.weight, conv.bias, act)
         y = ops.dwconv3x3_train(x, conv.weight, conv.bias)          # HIP forward + backward (autograd)
     else:
@@ -95,8 +94,7 @@ def _conv(conv, x, x2=None, x2_index=None, gate=None, residual=None):
     (autograd) and the test backends compose the PyTorch ops."""
     ops = _OpsBackend.impl
     if (hasattr(ops, "conv2d") and ops.conv2d_supported(x, conv.weight, x2)
-            and not (torch.is_grad_enabled() and any(t is not None and t.requires_grad
-                                                     for t in (x, x2, gate, residual, conv.weight)))):
+            and not _needs_grad(conv, x, x2, gate, residual)):
         return ops.conv2d(x, conv.weight, conv.bias, x2, x2_index, gate, residual)
     if x2 is not None:
         if x2_index is not None:
@@ -263,7 +261,9 @@ class SS2D(nn.Module):
         ops = _OpsBackend.impl
         if not (hasattr(ops, "ss2d_core") and x.is_cuda and x.dtype == torch.float32):
             return False
-        return ops.ss2d_core_supported(self.d_inner, self.d_state, self.dt_rank)
+        if not ops.ss2d_core_supported(self.d_inner, self.d_state, self.dt_rank, x.shape[-1]):
+            return False
+        return not _needs_grad(self, x) or ops.ss2d_core_bwd_supported(self.d_inner, self.d_state, self.dt_rank)
 
     def forward(self, x, **kwargs):
         B, H, W, C = x.shape
@@ -299,17 +299,18 @@ class LFSSBlock(nn.Module):
         self.ln_2 = nn.LayerNorm(hidden_dim)
         self.skip_scale2 = nn.Parameter(torch.ones(hidden_dim))
 
-    def _fused_ok(self, x):
-        """Whole-block HIP path: inference on the HIP backend for the kernel's shape range."""
+    def _fused_ok(self, x, width=None):
+        """Whole-block HIP path: inference on the HIP backend for the kernel's shape range (`width` = map width)."""
         ops = _OpsBackend.impl
         ss = self.self_attention
         if not (hasattr(ops, "lfss_block_forward") and x.is_cuda and x.dtype == torch.float32):
             return False
-        if torch.is_grad_enabled() and (x.requires_grad or self.skip_scale.requires_grad):
+        if _needs_grad(self, x):
             return False
         if ss.dropout is not None or ss.in_proj.bias is not None or ss.out_proj.bias is not None:
             return False
-        return ops.lfss_block_supported(ss.d_model, ss.d_inner, ss.d_state, ss.dt_rank, self.conv_blk.conv1.out_channels)
+        return ops.lfss_block_supported(ss.d_model, ss.d_inner, ss.d_state, ss.dt_rank,
+                                        self.conv_blk.conv1.out_channels, width)
 
     def _nchw_train_ok(self, x):
         """Training on the HIP backend: the block on NCHW planes, every operator but the gates / skips an autograd
@@ -325,7 +326,8 @@ class LFSSBlock(nn.Module):
             return False
         if not (isinstance(self.ln_1, nn.LayerNorm) and isinstance(self.ln_2, nn.LayerNorm)):
             return False
-        return ops.lfss_block_supported(ss.d_model, ss.d_inner, ss.d_state, ss.dt_rank, self.conv_blk.conv1.out_channels)
+        return (ops.lfss_block_supported(ss.d_model, ss.d_inner, ss.d_state, ss.dt_rank, self.conv_blk.conv1.out_channels)
+                and ops.ss2d_core_bwd_supported(ss.d_inner, ss.d_state, ss.dt_rank))
 
     def forward_nchw_train(self, x):
         """(B, C, H, W) -> (B, C, H, W); the same arithmetic as forward() on the (B, HW, C) view (:520-528)."""
@@ -346,7 +348,7 @@ class LFSSBlock(nn.Module):
 
     def forward(self, input, x_size):
         B, L, C = input.shape
-        if self._fused_ok(input):
+        if self._fused_ok(input, x_size[1]):
             return _OpsBackend.impl.lfss_block_forward(input, x_size, self)
         tok = input.view(B, x_size[0], x_size[1], C)
         tok = tok * self.skip_scale + self.drop_path(self.self_attention(_ln_tok(self.ln_1, tok)))
@@ -370,7 +372,7 @@ class LayerNorm2d(nn.Module):
     def forward(self, x):
         ops = _OpsBackend.impl
         if hasattr(ops, "layernorm2d") and x.is_cuda and x.dtype == torch.float32 and x.shape[1] in (8, 16, 32):
-            if not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
+            if not _needs_grad(self, x):
                 return ops.layernorm2d(x, self.weight, self.bias, self.eps)
             return ops.layernorm2d_train(x, self.weight, self.bias, self.eps)
         mu = x.mean(1, keepdim=True)
@@ -606,7 +608,7 @@ def _run_lfss_stack(blocks, x):
     (:976-979, :998-1001) never materialise; otherwise the reference's token round trip."""
     h, w = x.shape[2:]
     blocks = list(blocks)
-    if blocks and all(blk._fused_ok(x) for blk in blocks):
+    if blocks and all(blk._fused_ok(x, w) for blk in blocks):
         ops = _OpsBackend.impl
         t = x
         for i, blk in enumerate(blocks):

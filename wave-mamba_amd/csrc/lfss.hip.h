@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void lfss_in_kernel(const float* __restrict__ 
 // ---- lfss_mid: ysum, z, tok -> tok1 (B, L, C), f (B, D, L) -------------------------------------------
 template <int C>
 __global__ __launch_bounds__(256) void lfss_mid_kernel(
-    const float* __restrict__ ysum, const float* __restrict__ z, const float* __restrict__ tok, int tok_nchw,
+    const float* __restrict__ ysum, int ny, long long ystride, const float* __restrict__ z, const float* __restrict__ tok, int tok_nchw,
     const float* __restrict__ on_w, const float* __restrict__ on_b, float on_eps,
     const float* __restrict__ W_out /*(C, D)*/, const float* __restrict__ skip1,
     const float* __restrict__ ln2_w, const float* __restrict__ ln2_b, float ln2_eps,
@@ -105,7 +105,10 @@ __global__ __launch_bounds__(256) void lfss_mid_kernel(
     const long long b = idx / L, p = idx - b * L;
     float y[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) y[d] = ysum[(b * D + d) * L + p];
+    for (int d = 0; d < D; ++d) {
+        const float* q = ysum + (b * D + d) * L + p;
+        y[d] = ny == 1 ? q[0] : ((q[0] + q[ystride]) + q[2 * ystride]) + q[3 * ystride];     // y1 + y2 + y3 + y4 (:490)
+    }
     layer_norm<D>(y, on_w, on_b, on_eps);
 #pragma unroll
     for (int d = 0; d < D; ++d) y[d] *= silu_exact(z[(b * D + d) * L + p]);

@@ -1,0 +1,444 @@
+// ss2d_core.hip.h - SS2D.forward_core (/root/reference/basicsr/archs/wavemamba_arch.py:446-478) as three launches
+// for gfx950: chunk-reduce (all four directions) -> carry -> chunk-scan (all four directions).
+//
+//   xs = [x row-major | x column-major | their flips]                                              (:451-452)
+//   x_dbl[k] = x_proj_weight[k] . xs[k] -> (dt_r | B | C);  dts[k] = dt_projs_weight[k] . dt_r       (:453-455)
+//   y[k] = selective_scan(xs[k], dts[k], -exp(A_logs), B, C, Ds, dt_projs_bias, softplus)           (:465-471)
+//   flips / transposes back to row-major                                                             (:474-478)
+//
+// One kernel body serves every direction.  lane = channel (D <= 64), a wave walks ONE sequence chunk in tiles of 16
+// scan steps, a workgroup is NW waves:
+//   * the x tile [64 channels][16 steps] of a wave is BOTH its `u` operand and the B operand of the x_proj GEMM:
+//     (dt_r | B | C)[16 steps] = Wx[k] (R + 2N rows, padded to 16-row tiles) x tile, on v_mfma_f32_16x16x4_f32 (exact
+//     fp32 products, = an fmaf chain) from LDS-resident weight fragments.  x_dbl / dts / xs never exist in HBM - the
+//     first version wrote 576 B of projection records per position and re-read them in 16 direction-phase launches.
+//   * row directions (k = 0, 2): a tile is 16 consecutive row-major positions (64 B per channel row), wave-private
+//     staging, no workgroup barrier in the loop; k = 2 walks the same tiles backwards (no flip).
+//   * column directions (k = 1, 3): the NW waves of a workgroup own NW ADJACENT COLUMNS and the same 16 rows: the
+//     workgroup fetches [64 ch][16 rows][NW columns] with 4*NW-byte runs (one 64-B DRAM burst at NW = 16) and
+//     scatters the columns to the waves' tiles through LDS - no transposed copy of x or y ever exists, and the
+//     recurrence code is the row directions' code.
+//   * L-split: chunk-reduce (P = prod a, H = end state from 0) -> carry over chunks -> chunk-scan from H_in.  Every
+//     exponential is evaluated twice (once per pass): with lane = channel and N states per lane there is nothing
+//     else to repeat.  Ragged tails are masked steps (dt := 0 => a = 1, b = 0: the state passes through).
+//   * y[k] goes to the direction's own (B, D, L) buffer in row-major positions; the consumer adds the four
+//     (y1 + y2 + y3 + y4 of :490) while it reads them, so the scan launch has no read-modify-write and the four
+//     directions run concurrently, bit-reproducibly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "selscan.hip.h"
+
+#ifndef WM_CORE_A2_LDS
+#define WM_CORE_A2_LDS 0          // A * log2(e) in LDS (1) or in NP / 2 register pairs per lane (0: measured 4 % faster)
+#endif
+#ifndef WM_CORE_ABLATE
+#define WM_CORE_ABLATE 0          // timing experiments only (wrong results): 1 = no MFMA, 2 = no scan steps, 4 = no y store
+#endif
+#ifndef WM_CORE_STEP_FENCE
+#define WM_CORE_STEP_FENCE 1      // scheduling barrier after every scan step
+#endif
+
+namespace wm {
+
+typedef float core_f4 __attribute__((ext_vector_type(4)));
+
+struct CoreArgs {
+    const float* x;          // (B, D, H, W)
+    const float* Wx;         // (4, R + 2N, D)    x_proj_weight
+    const float* Wdt;        // (4, D, R)         dt_projs_weight
+    const float* dtb;        // (4, D)            dt_projs_bias
+    const float* A_logs;     // (4 D, N)
+    const float* Ds;         // (4 D)
+    float* y[4];             // y of direction k, (B, D, L), row-major positions
+    float* wsP[4];           // chunk summaries of direction k: [chunk][b * D + d][NP]
+    float* wsH[4];
+    int B, D, H, W, L, N, R;
+    int row_chunk, row_nchunks, row_wgs;        // steps per row chunk (multiple of 16), chunks, workgroups per direction
+    int dirmask;                                // bit k set: direction k runs (tools: time one direction alone)
+    int col_seg, col_nseg, col_tiles, col_wgs;  // rows per column segment (multiple of 16), segments, column tiles,
+                                                // workgroup slots per direction (col_tiles * col_nseg rounded up to 8)
+};
+
+template <int NP> struct CoreCfg {
+    static constexpr int NTB = NP / 16;                  // 16-row tiles of B (and of C)
+    static constexpr int NQ = (2 * NTB + 1 + 3) / 4;     // float4 of A operands per (K-step, lane)
+    static constexpr int RS = 2 * NP + 4;                // record: [dt_r (4) | B (NP) | C (NP)] floats
+    static constexpr int ROW = 20;                       // x tile row stride (floats): conflict-free per-lane float4
+    static constexpr int XT = 64 * ROW + 4;              // x tile stride: the column scatter is 2-way at worst
+    static constexpr int WF = 16 * NQ * 256;             // weight fragments (floats)
+    static constexpr int AF = NP * 64;                   // A * log2(e) of the workgroup's direction: [n / 2][lane] float pairs
+};
+template <int NP, int NW> constexpr int core_lds_bytes() {
+    return (CoreCfg<NP>::WF + CoreCfg<NP>::AF + NW * CoreCfg<NP>::XT + NW * 16 * CoreCfg<NP>::RS) * 4;
+}
+
+__device__ __forceinline__ void core_lds_fence() {       // LDS hand-off between the lanes of ONE wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// PHASE 1: chunk summaries.  PHASE 3: scan from the carried-in state, emits y.
+// RHI: dt_rank > 2 (the dt projection reads four record slots instead of two).
+template <int NP, int NW, int PHASE, bool RHI, bool COL, bool REV>
+__device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const int b, const int wg, float* smem) {
+    using Cfg = CoreCfg<NP>;
+    constexpr int NTB = Cfg::NTB, NQ = Cfg::NQ, RS = Cfg::RS, ROW = Cfg::ROW, XT = Cfg::XT;
+    constexpr int NT = (PHASE == 3 ? 2 * NTB : NTB) + 1;           // MFMA row tiles this phase needs: dt, B.., (C..)
+    constexpr int QPR = NW / 4;                                    // float4 per tile row of a column-mode fetch
+    float* s_w = smem;
+    v2f* s_a2 = reinterpret_cast<v2f*>(smem + Cfg::WF);
+    float* s_x = smem + Cfg::WF + Cfg::AF;
+    float* s_rec = s_x + NW * XT;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = p.D, H = p.H, W = p.W;
+    const long long L = p.L;
+    const int Cx = p.R + 2 * p.N;
+
+    // ---- x_proj_weight[k] as MFMA A operands: lane l of (K-step s, tile t) holds W[row(t, l & 15)][4 s + (l >> 4)]
+    for (int e = tid; e < Cfg::WF; e += 64 * NW) {
+        const int t4 = e & 3, l = (e >> 2) & 63, o = e >> 8;
+        const int s = o / NQ, t = 4 * (o - s * NQ) + t4;
+        const int r16 = l & 15, d = 4 * s + (l >> 4);
+        int row = -1;
+        if (t == 0) { if (r16 < p.R) row = r16; }
+        else if (t <= NTB) { const int n = 16 * (t - 1) + r16; if (n < p.N) row = p.R + n; }
+        else if (t <= 2 * NTB) { const int n = 16 * (t - 1 - NTB) + r16; if (n < p.N) row = p.R + p.N + n; }
+        s_w[e] = (row >= 0 && d < D) ? p.Wx[((long long)k * Cx + row) * D + d] : 0.0f;
+    }
+
+    // ---- per-lane (= per-channel) constants
+    const bool live = lane < D;
+    const int d = live ? lane : 0;
+    const int kd = k * D + d;
+    // A * log2(e) per (state pair, channel): in LDS (WM_CORE_A2_LDS) or in NP / 2 register pairs per lane
+    float wdt[4];
+#if WM_CORE_A2_LDS
+    if (wv == 0) {
+        float araw[NP];
+#pragma unroll
+        for (int n = 0; n < NP; ++n) araw[n] = p.A_logs[(long long)kd * p.N + min(n, p.N - 1)];
+#pragma unroll
+        for (int n = 0; n < NP; n += 2) {
+            const float a0 = (n < p.N) ? -expf(araw[n]) * 1.4426950408889634f : 0.0f;
+            const float a1 = (n + 1 < p.N) ? -expf(araw[n + 1]) * 1.4426950408889634f : 0.0f;
+            s_a2[(n / 2) * 64 + lane] = (v2f){a0, a1};
+        }
+    }
+#define WM_A2(i) s_a2[(i) * 64 + lane]
+#else
+    v2f A2r[NP / 2];
+    {
+        float araw[NP];
+#pragma unroll
+        for (int n = 0; n < NP; ++n) araw[n] = p.A_logs[(long long)kd * p.N + min(n, p.N - 1)];
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+            const float a = (n < p.N) ? -expf(araw[n]) * 1.4426950408889634f : 0.0f;
+            if (n & 1) A2r[n / 2].y = a; else A2r[n / 2].x = a;
+        }
+    }
+    (void)s_a2;
+#define WM_A2(i) A2r[i]
+#endif
+    {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wdt[r] = p.Wdt[(long long)kd * p.R + min(r, p.R - 1)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wdt[r] = (r < p.R) ? wdt[r] : 0.0f;
+    }
+    const float bias = p.dtb[kd];
+    const float Dd = p.Ds[kd];
+
+    // ---- the wave's sequence chunk
+    int t_begin, t_end;            // scan steps [t_begin, t_end) of the wave's line (row mode: l; column mode: tau)
+    long long chunk;               // summary slot, in scan order
+    bool active;                   // the wave has a sequence at all
+    int wlo = 0;                   // column mode: first image column of the workgroup's tile
+    if (!COL) {
+        const int c = wg * NW + wv;
+        active = c < p.row_nchunks;
+        chunk = c;
+        t_begin = c * p.row_chunk;
+        t_end = (int)min(L, (long long)t_begin + p.row_chunk);
+    } else {
+        const int ct = wg % p.col_tiles, sg = wg / p.col_tiles;
+        const int omega = ct * NW + wv;                  // column in scan order
+        active = omega < W;
+        chunk = (long long)omega * p.col_nseg + sg;
+        t_begin = sg * p.col_seg;
+        t_end = min(H, t_begin + p.col_seg);
+        wlo = REV ? W - NW - ct * NW : ct * NW;
+    }
+    const int ntiles = (t_end - t_begin + 15) >> 4;
+
+    __syncthreads();                                     // weight fragments visible
+    if (!COL && !active) return;                         // row mode has no workgroup barrier below
+
+    v2f h[NP / 2];
+    const long long wsrow = ((chunk * p.B + b) * D + d) * NP;
+    if (PHASE == 3 && active && chunk > 0) {
+#pragma unroll
+        for (int q = 0; q < NP / 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(p.wsH[k] + wsrow + 4 * q);
+            h[2 * q] = (v2f){v.x, v.y}; h[2 * q + 1] = (v2f){v.z, v.w};
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < NP / 2; ++n) h[n] = splat(0.0f);
+    }
+    float sum_dt = 0.0f;
+
+    const float* xb = p.x + (long long)b * D * L;
+    float* yb = (PHASE == 3) ? p.y[k] + (long long)b * D * L : nullptr;
+    float* sx = s_x + wv * XT;                           // the wave's x / y tile  [64][ROW]
+    float* srec = s_rec + wv * (16 * RS);                // the wave's record tile [16][RS]
+
+    // tile ti covers steps t0 .. t0+15 of the line; in memory that is positions / rows lo .. lo+15 ascending, and
+    // step tt sits at tile column tt (forward) or 15 - tt (reversed).  Valid tile columns: [v_lo, v_hi).
+    float4 xp[4];                                        // the next tile, in flight
+    const int trow = lane >> 2, tq = lane & 3;
+    // Loads are UNCONDITIONAL with clamped offsets (an `ok ? load : 0` compiles to a branch around the load plus
+    // register copies behind it, i.e. a wait for the load right where it was issued); invalid elements are zeroed when
+    // the tile is staged, one tile later.
+    auto tile_ok = [&](int ti, int i) -> bool {          // is float4 i of this thread inside the tile's valid region?
+        const int t0 = t_begin + 16 * ti;
+        const int tl = min(16, t_end - t0);
+        const int v_lo = REV ? 16 - tl : 0, v_hi = REV ? 16 : tl;
+        if (!COL) {
+            const int c = 4 * tq;
+            return c >= v_lo && c < v_hi && 16 * i + trow < D;    // L % 4 == 0, chunk % 16 == 0: quads all-in or all-out
+        } else {
+            const int e = i * 64 * NW + tid;
+            const int q = e % QPR, r = (e / QPR) & 15, ch = e / (QPR * 16);
+            const int wq = wlo + 4 * q;
+            return r >= v_lo && r < v_hi && wq >= 0 && wq < W && ch < D;             // W % 4 == 0
+        }
+    };
+    auto tile_off = [&](int ti, int i) -> unsigned {     // element offset of float4 i inside the batch item (D * L < 2^31)
+        const int t0 = t_begin + 16 * ti;
+        if (!COL) {
+            const int plo = REV ? ((int)L - 16 - t0) : t0;
+            return (unsigned)(16 * i + trow) * (unsigned)L + (unsigned)(plo + 4 * tq);
+        } else {
+            const int hlo = REV ? H - 16 - t0 : t0;
+            const int e = i * 64 * NW + tid;
+            const int q = e % QPR, r = (e / QPR) & 15, ch = e / (QPR * 16);
+            return ((unsigned)ch * (unsigned)H + (unsigned)(hlo + r)) * (unsigned)W + (unsigned)(wlo + 4 * q);
+        }
+    };
+    auto fetch = [&](int ti) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned off = tile_ok(ti, i) ? tile_off(ti, i) : 0u;
+            xp[i] = *reinterpret_cast<const float4*>(xb + off);
+        }
+    };
+    auto stage = [&](int ti) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 v4 = tile_ok(ti, i) ? xp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!COL) {
+                *reinterpret_cast<float4*>(&sx[(16 * i + trow) * ROW + 4 * tq]) = v4;
+            } else {
+                const int e = i * 64 * NW + tid;
+                const int q = e % QPR, r = (e / QPR) & 15, ch = e / (QPR * 16);
+                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int cc = 4 * q + j;                            // tile column = image column wlo + cc
+                    const int owner = REV ? NW - 1 - cc : cc;            // the wave that scans it
+                    s_x[owner * XT + ch * ROW + r] = v[j];
+                }
+            }
+        }
+    };
+
+    fetch(0);
+    for (int ti = 0; ti < ntiles; ++ti) {
+        stage(ti);
+        if (COL) __syncthreads(); else core_lds_fence();
+        if (ti + 1 < ntiles) fetch(ti + 1);
+        const int tl = min(16, t_end - (t_begin + 16 * ti));
+
+        if (active) {
+            // ---- projection: records of the 16 steps (tile columns) ----
+            core_f4 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = (core_f4){0.f, 0.f, 0.f, 0.f};
+            const int g4 = lane >> 4, c16 = lane & 15;
+#pragma unroll
+            for (int s = 0; s < ((WM_CORE_ABLATE & 1) ? 1 : 16); ++s) {
+                if (4 * s < D) {                                                      // uniform
+                    const float xv = sx[(4 * s + g4) * ROW + c16];
+                    float wf[4 * NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        if (4 * q < NT) {
+                            const float4 w4 = *reinterpret_cast<const float4*>(&s_w[((s * NQ + q) * 64 + lane) * 4]);
+                            wf[4 * q] = w4.x; wf[4 * q + 1] = w4.y; wf[4 * q + 2] = w4.z; wf[4 * q + 3] = w4.w;
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t], xv, acc[t], 0, 0, 0);
+                }
+            }
+            // D layout: lane holds rows 4 g4 .. 4 g4 + 3 of tile column c16
+            {
+                float* rc = srec + c16 * RS;
+                if (g4 == 0) *reinterpret_cast<core_f4*>(rc) = acc[0];
+#pragma unroll
+                for (int t = 1; t < NT; ++t) *reinterpret_cast<core_f4*>(rc + 4 + 16 * (t - 1) + 4 * g4) = acc[t];
+            }
+            core_lds_fence();
+
+            // ---- 16 scan steps ----
+            // The record addresses are wave-uniform; left to itself the compiler forms each of the ~40 per quad in an
+            // SGPR and copies it to a VGPR for its ds_read.  One opaque per-lane base per quad + compile-time offsets
+            // puts them in the instructions' offset fields instead.
+#pragma unroll 1
+            for (int q = 0; q < ((WM_CORE_ABLATE & 2) ? 0 : 4); ++q) {
+                const int cq = REV ? 3 - q : q;
+                const float4 u4 = *reinterpret_cast<const float4*>(&sx[lane * ROW + 4 * cq]);
+                const float uu[4] = {REV ? u4.w : u4.x, REV ? u4.z : u4.y, REV ? u4.y : u4.z, REV ? u4.x : u4.w};
+                int roff = 4 * cq * RS;                                   // records of tile columns 4 cq .. 4 cq + 3
+                asm volatile("" : "+v"(roff));                            // (an opaque OFFSET: the pointer stays an LDS pointer)
+                const float* rq = srec + roff;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {                          // two steps at a time (softplus on a float pair)
+                    float dtr[2];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int j = 2 * hf + jj;
+                        const float* rc = rq + (REV ? 3 - j : j) * RS;
+                        if constexpr (RHI) {
+                            const float4 dr = *reinterpret_cast<const float4*>(rc);
+                            dtr[jj] = fmaf(wdt[3], dr.w, fmaf(wdt[2], dr.z, fmaf(wdt[1], dr.y, fmaf(wdt[0], dr.x, bias))));
+                        } else {
+                            const float2 dr = *reinterpret_cast<const float2*>(rc);
+                            dtr[jj] = fmaf(wdt[1], dr.y, fmaf(wdt[0], dr.x, bias));
+                        }
+                    }
+                    const v2f sp = softplus2((v2f){dtr[0], dtr[1]});
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int j = 2 * hf + jj;
+                        const float dt = (4 * q + j < tl) ? (jj ? sp.y : sp.x) : 0.0f;      // masked step: a = 1, b = 0
+                        const float ut = uu[j];
+                        const v2f dt2 = splat(dt), du2 = splat(dt * ut);
+                        if (PHASE == 1) sum_dt += dt;
+                        v2f y2 = splat(0.0f);
+                        const float* rc = rq + (REV ? 3 - j : j) * RS + 4;
+#pragma unroll
+                        for (int r = 0; r < NP / 4; ++r) {
+                            const float4 bv = *reinterpret_cast<const float4*>(rc + 4 * r);
+                            const v2f a0 = exp2_2(dt2 * WM_A2(2 * r));
+                            const v2f a1 = exp2_2(dt2 * WM_A2(2 * r + 1));
+                            h[2 * r] = a0 * h[2 * r] + du2 * (v2f){bv.x, bv.y};
+                            h[2 * r + 1] = a1 * h[2 * r + 1] + du2 * (v2f){bv.z, bv.w};
+                            if (PHASE == 3) {
+                                const float4 cv = *reinterpret_cast<const float4*>(rc + NP + 4 * r);
+                                y2 = (v2f){cv.x, cv.y} * h[2 * r] + y2;
+                                y2 = (v2f){cv.z, cv.w} * h[2 * r + 1] + y2;
+                            }
+                        }
+                        if (PHASE == 3)      // y overwrites the consumed u (same lane, same row)
+                            sx[lane * ROW + 4 * cq + (REV ? 3 - j : j)] = fmaf(Dd, ut, y2.x + y2.y);
+#if WM_CORE_STEP_FENCE
+                        __builtin_amdgcn_sched_barrier(0);   // keep the next step's record reads out of this step's registers
+#endif
+                    }
+                }
+            }
+        }
+
+        if (PHASE == 3 && !(WM_CORE_ABLATE & 4)) {
+            if (!COL) {
+                core_lds_fence();
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (tile_ok(ti, i))
+                        *reinterpret_cast<float4*>(yb + tile_off(ti, i)) =
+                            *reinterpret_cast<const float4*>(&sx[(16 * i + trow) * ROW + 4 * tq]);
+                core_lds_fence();                        // the y tile is read before the next stage() overwrites it
+            } else {
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = i * 64 * NW + tid;
+                    const int q = e % QPR, r = (e / QPR) & 15, ch = e / (QPR * 16);
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int cc = 4 * q + j;
+                        const int owner = REV ? NW - 1 - cc : cc;
+                        v[j] = s_x[owner * XT + ch * ROW + r];
+                    }
+                    if (tile_ok(ti, i))
+                        *reinterpret_cast<float4*>(yb + tile_off(ti, i)) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+                __syncthreads();
+            }
+        } else if (COL) {
+            __syncthreads();                             // every wave is done with its tile before the next stage()
+        }
+    }
+
+    if (PHASE == 1 && active && live) {
+#pragma unroll
+        for (int q = 0; q < NP / 4; ++q) {
+            *reinterpret_cast<float4*>(p.wsH[k] + wsrow + 4 * q) =
+                make_float4(h[2 * q].x, h[2 * q].y, h[2 * q + 1].x, h[2 * q + 1].y);
+            const v2f p0 = exp2_2(splat(sum_dt) * WM_A2(2 * q));
+            const v2f p1 = exp2_2(splat(sum_dt) * WM_A2(2 * q + 1));
+            *reinterpret_cast<float4*>(p.wsP[k] + wsrow + 4 * q) = make_float4(p0.x, p0.y, p1.x, p1.y);
+        }
+    }
+}
+
+#undef WM_A2
+
+// Workgroup -> (batch, direction, slot).  Per batch: 2 * row_wgs row slots (k = 0 / 2 interleaved), then 2 * col_wgs
+// column slots (k = 1 / 3 interleaved).  Column tiles 2 i and 2 i + 1 share every 128-byte line of x and y: their
+// slots are 8 workgroup ids apart, i.e. on the same XCD (workgroup id -> XCD id % 8), whose L2 then holds the line.
+template <int NP, int NW, int PHASE, bool RHI>
+__global__ __launch_bounds__(64 * NW) void ss2d_core_kernel(CoreArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float core_smem[];
+    const int per_b = 2 * p.row_wgs + 2 * p.col_wgs;
+    const int b = blockIdx.x / per_b;
+    int r = blockIdx.x - b * per_b;
+    if (r < 2 * p.row_wgs) {
+        const int wg = r >> 1;
+        if (!((p.dirmask >> ((r & 1) * 2)) & 1)) return;
+        if (r & 1) core_body<NP, NW, PHASE, RHI, false, true>(p, 2, b, wg, core_smem);
+        else core_body<NP, NW, PHASE, RHI, false, false>(p, 0, b, wg, core_smem);
+    } else {
+        r -= 2 * p.row_wgs;
+        const int idx = r >> 1;
+        const int wg = (((idx >> 3) << 2) + (idx & 3)) * 2 + ((idx >> 2) & 1);
+        if (wg >= p.col_tiles * p.col_nseg || !((p.dirmask >> ((r & 1) * 2 + 1)) & 1)) return;
+        if (r & 1) core_body<NP, NW, PHASE, RHI, true, true>(p, 3, b, wg, core_smem);
+        else core_body<NP, NW, PHASE, RHI, true, false>(p, 1, b, wg, core_smem);
+    }
+}
+
+// merged output for callers of the plain operator (training): y0 <- ((y0 + y2) + y1) + y3, the reference's order of
+// y1 + y2 + y3 + y4 (:490: out_y[:, 0], inv_y[:, 0], wh_y, invwh_y)
+__global__ __launch_bounds__(256) void ss2d_sum4_kernel(float* __restrict__ y0, const float* __restrict__ y2,
+                                                        const float* __restrict__ y1, const float* __restrict__ y3,
+                                                        long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 a = reinterpret_cast<float4*>(y0)[i];
+    const float4 c = reinterpret_cast<const float4*>(y2)[i];
+    const float4 bq = reinterpret_cast<const float4*>(y1)[i];
+    const float4 e = reinterpret_cast<const float4*>(y3)[i];
+    a.x = ((a.x + c.x) + bq.x) + e.x; a.y = ((a.y + c.y) + bq.y) + e.y;
+    a.z = ((a.z + c.z) + bq.z) + e.z; a.w = ((a.w + c.w) + bq.w) + e.w;
+    reinterpret_cast<float4*>(y0)[i] = a;
+}
+
+}  // namespace wm

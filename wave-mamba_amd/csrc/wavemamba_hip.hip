@@ -13,6 +13,7 @@
 #include "selscan_bwd.hip.h"
 #include "dwconv.hip.h"
 #include "ss2d.hip.h"
+#include "ss2d_core.hip.h"
 #include "lfss.hip.h"
 #include "lfss_mfma.hip.h"
 #include "gram.hip.h"
@@ -248,7 +249,7 @@ template <int PHASE, bool REV>
 static void ss2d_launch_row(Ss2dArgs a, const Ss2dPlan& pl, bool vec, hipStream_t st) {
     a.chunk_len = pl.row_chunk; a.nchunks = pl.row_nchunks; a.nseg = 0;
     const dim3 grid((unsigned)pl.row_nchunks, (unsigned)a.B), block(64);
-    ProfScope ps(PHASE == 1 ? 10 : 8, st);
+    ProfScope ps(PHASE == 1 ? 11 : 9, st);
     if (vec) hipLaunchKernelGGL((ss2d_row_kernel<PHASE, REV, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((ss2d_row_kernel<PHASE, REV, false>), grid, block, 0, st, a);
 }
@@ -278,7 +279,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 12; }
+int wm_abi_version(void) { return 13; }
 
 const char* wm_strerror(int code) {
     switch (code) {
@@ -504,17 +505,13 @@ int wm_dwconv3x3_fwd(const float* x, const float* weight, const float* bias, flo
     return launch_status();
 }
 
-size_t wm_ss2d_core_fwd_workspace_bytes(int B, int D, int H, int W, int N, int R) {
-    Ss2dPlan pl;
-    if (ss2d_plan(pl, B, D, H, W, N, R) != WM_OK) return 0;
-    return pl.total_bytes;
-}
-
-int wm_ss2d_core_fwd(const float* x, const float* x_proj_weight, const float* dt_projs_weight,
+}  // extern "C"
+// The first-generation core (projection records in HBM, separate row / column kernels): kept for maps whose width is
+// not a multiple of 4 (the tile loaders of ss2d_core.hip.h are 16-byte accesses); N <= 16 only.
+static int core_fwd_legacy(const float* x, const float* x_proj_weight, const float* dt_projs_weight,
                      const float* dt_projs_bias, const float* A_logs, const float* Ds, float* y_row_fwd,
                      float* y_row_rev, float* y_col_fwd, float* y_col_rev, int merged, void* workspace,
                      size_t workspace_bytes, int B, int D, int H, int W, int N, int R, void* stream) {
-    if (B == 0 || D == 0 || H == 0 || W == 0) return (B < 0 || D < 0 || H < 0 || W < 0) ? WM_EINVAL : WM_OK;
     Ss2dPlan pl;
     int rc = ss2d_plan(pl, B, D, H, W, N, R);
     if (rc) return rc;
@@ -584,6 +581,172 @@ int wm_ss2d_core_fwd(const float* x, const float* x_proj_weight, const float* dt
     ss2d_launch_row<3, true>(ak[2], pl, vec, st);
     ss2d_launch_col<3, false>(ak[1], pl, st);
     ss2d_launch_col<3, true>(ak[3], pl, st);
+    return launch_status();
+}
+
+namespace wm {
+// ------------------------------------------------------------------------------------------------
+// SS2D core, second generation (ss2d_core.hip.h): reduce (4 directions) -> carry -> scan (4 directions)
+// ------------------------------------------------------------------------------------------------
+struct CorePlan {
+    int NP, NW;
+    int row_chunk, row_nchunks, row_wgs;
+    int col_seg, col_nseg, col_tiles, col_wgs;
+    long long col_nchunks, max_chunks;
+    size_t half_bytes, ytmp_bytes, total;       // one P (or H) array of one direction; merged-mode y buffers; everything
+};
+
+static bool core_v2_shape(int W) { return W % 4 == 0; }
+
+static int core_plan(CorePlan& pl, int B, int D, int H, int W, int N, int R, int merged) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || N <= 0 || R <= 0) return WM_EINVAL;
+    if (N > 32 || R > 4 || D > 64) return WM_EUNSUPPORTED;
+    const long long L = (long long)H * W;
+    if (L * D > 0x7fffffffLL) return WM_EUNSUPPORTED;          // 32-bit element offsets inside one batch item
+    pl.NP = N <= 16 ? 16 : 32;
+    pl.NW = pl.NP == 16 ? 16 : 8;
+#ifdef WM_CORE_NW
+    if (pl.NP == 16) pl.NW = WM_CORE_NW;
+#endif
+    const int NW = pl.NW;
+    pl.col_tiles = (W + NW - 1) / NW;
+    // One workgroup (NW waves) per compute unit is resident: aim at >= ~1.75 rounds of the 256 compute units over
+    // the four directions, without cutting columns below two tiles.
+    int nseg = 1;
+    const long long want_wgs = NW == 16 ? 448 : 896;
+    while (4LL * pl.col_tiles * nseg * B < want_wgs && H / (nseg + 1) >= 32 && nseg < 64) ++nseg;
+    int seg = (H + nseg - 1) / nseg;
+    seg = ((seg + 15) / 16) * 16;
+    pl.col_seg = seg;
+    pl.col_nseg = (H + seg - 1) / seg;
+    pl.col_nchunks = (long long)W * pl.col_nseg;
+    pl.col_wgs = ((pl.col_tiles * pl.col_nseg + 7) / 8) * 8;
+    // row directions: as many chunks as the column directions have (same per-wave work, same summary count)
+    long long want = (long long)pl.col_tiles * NW * pl.col_nseg;
+    long long cl = (L + want - 1) / want;
+    cl = ((cl + 15) / 16) * 16;
+    if (cl < 32) cl = 32;
+    pl.row_chunk = (int)cl;
+    pl.row_nchunks = (int)((L + cl - 1) / cl);
+    pl.row_wgs = (pl.row_nchunks + NW - 1) / NW;
+    pl.max_chunks = pl.col_nchunks > pl.row_nchunks ? pl.col_nchunks : pl.row_nchunks;
+    if ((long long)B * (2LL * pl.row_wgs + 2LL * pl.col_wgs) > 0x7fffffffLL) return WM_EUNSUPPORTED;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    pl.half_bytes = up((size_t)pl.max_chunks * B * D * pl.NP * sizeof(float));
+    pl.ytmp_bytes = merged ? up((size_t)B * D * L * sizeof(float)) : 0;
+    pl.total = 8 * pl.half_bytes + 3 * pl.ytmp_bytes;
+    return WM_OK;
+}
+
+template <int NP, int NW, bool RHI>
+static int core_launch(const CoreArgs& a, const CorePlan& pl, hipStream_t st) {
+    constexpr int lds = core_lds_bytes<NP, NW>();
+    // > 64 KB of dynamic LDS is an opt-in per function AND per device
+    static bool configured[64] = {};
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return WM_EHIP;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 64 || !configured[dev]) {
+            hipError_t e = hipFuncSetAttribute((const void*)ss2d_core_kernel<NP, NW, 1, RHI>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)ss2d_core_kernel<NP, NW, 3, RHI>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return WM_EHIP;
+            if (dev >= 0 && dev < 64) configured[dev] = true;
+        }
+    }
+    const dim3 grid((unsigned)(a.B * (2 * pl.row_wgs + 2 * pl.col_wgs))), block(64 * NW);
+    const bool split = pl.row_nchunks > 1 || pl.col_nchunks > 1;
+    if (split) {
+        {
+            ProfScope ps(10, st);
+            hipLaunchKernelGGL((ss2d_core_kernel<NP, NW, 1, RHI>), grid, block, lds, st, a);
+        }
+        ProfScope ps(3, st);
+        CarryBatch cb{};
+        const int order[4] = {0, 2, 1, 3};
+        for (int i = 0; i < 4; ++i) {
+            const int k = order[i];
+            cb.d[i] = CarryDir{a.wsP[k], a.wsH[k], nullptr, nullptr, (k & 1) ? (int)pl.col_nchunks : pl.row_nchunks, 0};
+        }
+        const long long nchains = (long long)a.B * a.D * NP;
+        hipLaunchKernelGGL((selscan_carry_kernel<false>), dim3((unsigned)((nchains + 15) / 16), 1, 4), dim3(1024), 0,
+                           st, cb, nchains);
+    }
+    {
+        ProfScope ps(8, st);
+        hipLaunchKernelGGL((ss2d_core_kernel<NP, NW, 3, RHI>), grid, block, lds, st, a);
+    }
+    return launch_status();
+}
+}  // namespace wm
+
+extern "C" {
+size_t wm_ss2d_core_fwd_workspace_bytes(int B, int D, int H, int W, int N, int R, int merged) {
+    if (!core_v2_shape(W)) {
+        Ss2dPlan pl;
+        if (ss2d_plan(pl, B, D, H, W, N, R) != WM_OK) return 0;
+        return pl.total_bytes;
+    }
+    CorePlan pl;
+    if (core_plan(pl, B, D, H, W, N, R, merged) != WM_OK) return 0;
+    return pl.total;
+}
+
+int wm_ss2d_core_fwd(const float* x, const float* x_proj_weight, const float* dt_projs_weight,
+                     const float* dt_projs_bias, const float* A_logs, const float* Ds, float* y_row_fwd,
+                     float* y_row_rev, float* y_col_fwd, float* y_col_rev, int merged, void* workspace,
+                     size_t workspace_bytes, int B, int D, int H, int W, int N, int R, void* stream) {
+    if (B == 0 || D == 0 || H == 0 || W == 0) return (B < 0 || D < 0 || H < 0 || W < 0) ? WM_EINVAL : WM_OK;
+    if (!core_v2_shape(W))
+        return core_fwd_legacy(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, y_row_fwd, y_row_rev,
+                               y_col_fwd, y_col_rev, merged, workspace, workspace_bytes, B, D, H, W, N, R, stream);
+    CorePlan pl;
+    int rc = core_plan(pl, B, D, H, W, N, R, merged);
+    if (rc) return rc;
+    if (!x || !x_proj_weight || !dt_projs_weight || !dt_projs_bias || !A_logs || !Ds || !y_row_fwd) return WM_ENULL;
+    if (!merged && (!y_row_rev || !y_col_fwd || !y_col_rev)) return WM_ENULL;
+    if (!workspace) return WM_ENULL;
+    if (workspace_bytes < pl.total) return WM_EWORKSPACE;
+    if (!aligned16(workspace) || !aligned16(x) || !aligned16(y_row_fwd) ||
+        (!merged && (!aligned16(y_row_rev) || !aligned16(y_col_fwd) || !aligned16(y_col_rev)))) return WM_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    CoreArgs a;
+    a.x = x; a.Wx = x_proj_weight; a.Wdt = dt_projs_weight; a.dtb = dt_projs_bias; a.A_logs = A_logs; a.Ds = Ds;
+    char* w = (char*)workspace;
+    for (int k = 0; k < 4; ++k) {
+        a.wsP[k] = (float*)(w + (size_t)(2 * k) * pl.half_bytes);
+        a.wsH[k] = (float*)(w + (size_t)(2 * k + 1) * pl.half_bytes);
+    }
+    char* yt = w + 8 * pl.half_bytes;
+    // direction k: 0 row forward, 1 column forward, 2 row reversed, 3 column reversed (the reference's xs order, :451-452)
+    a.y[0] = y_row_fwd;
+    a.y[1] = merged ? (float*)yt : y_col_fwd;
+    a.y[2] = merged ? (float*)(yt + pl.ytmp_bytes) : y_row_rev;
+    a.y[3] = merged ? (float*)(yt + 2 * pl.ytmp_bytes) : y_col_rev;
+    a.B = B; a.D = D; a.H = H; a.W = W; a.L = H * W; a.N = N; a.R = R;
+    a.row_chunk = pl.row_chunk; a.row_nchunks = pl.row_nchunks; a.row_wgs = pl.row_wgs;
+    {   // WM_CORE_DIRMASK (tools only): run a subset of the four directions, e.g. 1 = row forward alone
+        static const int mask = [] { const char* e = getenv("WM_CORE_DIRMASK"); return e ? atoi(e) : 15; }();
+        a.dirmask = mask;
+    }
+    a.col_seg = pl.col_seg; a.col_nseg = pl.col_nseg; a.col_tiles = pl.col_tiles; a.col_wgs = pl.col_wgs;
+#ifdef WM_CORE_NW
+    if (pl.NP == 16) rc = R > 2 ? core_launch<16, WM_CORE_NW, true>(a, pl, st) : core_launch<16, WM_CORE_NW, false>(a, pl, st);
+#else
+    if (pl.NP == 16) rc = R > 2 ? core_launch<16, 16, true>(a, pl, st) : core_launch<16, 16, false>(a, pl, st);
+#endif
+    else rc = R > 2 ? core_launch<32, 8, true>(a, pl, st) : core_launch<32, 8, false>(a, pl, st);
+    if (rc) return rc;
+    if (merged) {
+        const long long n4 = (long long)B * D * a.L / 4;
+        ProfScope ps(8, st);
+        hipLaunchKernelGGL(ss2d_sum4_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a.y[0], a.y[2], a.y[1],
+                           a.y[3], n4);
+    }
     return launch_status();
 }
 
@@ -773,12 +936,12 @@ int wm_lfss_in_fwd(const float* tok, int tok_nchw, const float* ln_w, const floa
     WM_LFSS_DISPATCH(lfss_in_kernel, tok, tok_nchw, ln_w, ln_b, ln_eps, in_proj_weight, x, z, B, (long long)L);
 }
 
-int wm_lfss_mid_fwd(const float* ysum, const float* z, const float* tok, int tok_nchw, const float* out_norm_w,
+int wm_lfss_mid_fwd(const float* ysum, int ny, int64_t ystride, const float* z, const float* tok, int tok_nchw, const float* out_norm_w,
                     const float* out_norm_b, float out_norm_eps, const float* out_proj_weight,
                     const float* skip_scale, const float* ln2_w, const float* ln2_b, float ln2_eps,
                     const float* conv1_weight, const float* conv1_bias, float* tok1, float* f, int B, int64_t L,
                     int C, void* stream) {
-    if (B < 0 || L < 0) return WM_EINVAL;
+    if (B < 0 || L < 0 || (ny != 1 && ny != 4)) return WM_EINVAL;
     if (B && L && (!ysum || !z || !tok || !out_norm_w || !out_norm_b || !out_proj_weight || !skip_scale || !ln2_w ||
                    !ln2_b || !conv1_weight || !conv1_bias || !tok1 || !f)) return WM_ENULL;
     if ((!tok_nchw && !aligned16(tok)) || !aligned16(tok1)) return WM_EALIGN;
@@ -789,12 +952,13 @@ int wm_lfss_mid_fwd(const float* ysum, const float* z, const float* tok, int tok
         const long long waves = (ngroups + gpw - 1) / gpw;
         hipStream_t st = (hipStream_t)stream;
         ProfScope ps(5, st);
-        hipLaunchKernelGGL(lfss_mid_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ysum, z, tok, tok_nchw,
+        hipLaunchKernelGGL(lfss_mid_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ysum, ny,
+                           (long long)ystride, z, tok, tok_nchw,
                            out_norm_w, out_norm_b, out_norm_eps, out_proj_weight, skip_scale, ln2_w, ln2_b, ln2_eps,
                            conv1_weight, conv1_bias, tok1, f, B, (long long)L, ngl, ngroups, gpw);
         return launch_status();
     }
-    WM_LFSS_DISPATCH(lfss_mid_kernel, ysum, z, tok, tok_nchw, out_norm_w, out_norm_b, out_norm_eps, out_proj_weight,
+    WM_LFSS_DISPATCH(lfss_mid_kernel, ysum, ny, (long long)ystride, z, tok, tok_nchw, out_norm_w, out_norm_b, out_norm_eps, out_proj_weight,
                      skip_scale, ln2_w, ln2_b, ln2_eps, conv1_weight, conv1_bias, tok1, f, B, (long long)L);
 }
 

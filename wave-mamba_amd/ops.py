@@ -273,8 +273,16 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
 # ------------------------------------------------------------------------------------------------
 # fused SS2D four-direction core (forward / inference)
 # ------------------------------------------------------------------------------------------------
-def ss2d_core_supported(d_inner, d_state, dt_rank):
-    """Shapes the fused HIP core covers (else: direction glue + selective_scan_fn)."""
+def ss2d_core_supported(d_inner, d_state, dt_rank, width=None):
+    """Shapes the fused HIP core covers (else: direction glue + selective_scan_fn).  d_state in (16, 32] needs a map
+    width that is a multiple of 4 (pass `width` to check it)."""
+    if d_inner > 64 or dt_rank > 4 or d_state > 32:
+        return False
+    return d_state <= 16 or width is None or width % 4 == 0
+
+
+def ss2d_core_bwd_supported(d_inner, d_state, dt_rank):
+    """Shapes wm_ss2d_core_bwd covers (training)."""
     return d_inner <= 64 and d_state <= 16 and dt_rank <= 4
 
 
@@ -284,7 +292,7 @@ def _ss2d_core_shapes(x, x_proj_weight, dt_projs_weight, A_logs):
     R, N = dt_projs_weight.shape[2], A_logs.shape[1]
     if K != 4 or D2 != D or C != R + 2 * N or dt_projs_weight.shape != (4, D, R) or A_logs.shape[0] != 4 * D:
         raise RuntimeError("ss2d_core: inconsistent parameter shapes")
-    if not ss2d_core_supported(D, N, R):
+    if not ss2d_core_supported(D, N, R, W):
         raise NotImplementedError(f"ss2d_core: d_inner={D}, d_state={N}, dt_rank={R} outside the fused kernel's range")
     return B, D, H, W, N, R
 
@@ -294,8 +302,11 @@ def _ss2d_core_fwd(f, merged):
     x = f[0]
     B, D, H, W, N, R = _ss2d_core_shapes(x, f[1], f[2], f[4])
     L = H * W
-    outs = [torch.empty((B, D, L), dtype=torch.float32, device=x.device) for _ in range(1 if merged else 4)]
-    ws_bytes = lib.wm_ss2d_core_fwd_workspace_bytes(B, D, H, W, N, R)
+    if merged:
+        outs = [torch.empty((B, D, L), dtype=torch.float32, device=x.device)]
+    else:       # one allocation, reference return order: a consumer can add the four with one base pointer + stride
+        outs = list(torch.empty((4, B, D, L), dtype=torch.float32, device=x.device).unbind(0))
+    ws_bytes = lib.wm_ss2d_core_fwd_workspace_bytes(B, D, H, W, N, R, int(bool(merged)))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     ptrs = [_ptr(o) for o in outs] + [None] * (4 - len(outs))
     with torch.cuda.device(x.device):
@@ -356,8 +367,9 @@ def ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, merg
 # ------------------------------------------------------------------------------------------------
 # LFSSBlock forward, fused (inference): lfss_in -> dwconv+SiLU -> ss2d core -> lfss_mid -> dwconv -> lfss_out
 # ------------------------------------------------------------------------------------------------
-def lfss_block_supported(C, d_inner, d_state, dt_rank, ffn_hidden):
-    return C in (8, 16, 32) and d_inner == 2 * C and ffn_hidden == 2 * C and ss2d_core_supported(d_inner, d_state, dt_rank)
+def lfss_block_supported(C, d_inner, d_state, dt_rank, ffn_hidden, width=None):
+    return (C in (8, 16, 32) and d_inner == 2 * C and ffn_hidden == 2 * C
+            and ss2d_core_supported(d_inner, d_state, dt_rank, width))
 
 
 def _w(t):
@@ -386,11 +398,13 @@ def lfss_block_forward(tok, x_size, blk, tok_nchw=False, out_nchw=False):
                                  float(blk.ln_1.eps), _ptr(_w(ss.in_proj.weight)), _ptr(x), _ptr(z), B, L, C, st),
               "wm_lfss_in_fwd")
     xc = dwconv3x3(x, ss.conv2d.weight, ss.conv2d.bias, "silu")
-    ysum = ss2d_core(xc, ss.x_proj_weight, ss.dt_projs_weight, ss.dt_projs_bias, ss.A_logs, ss.Ds, merged=True)
+    # the four directions' outputs stay separate (one (4, B, D, L) allocation); lfss_mid adds them as it loads (:490)
+    y4 = _ss2d_core_fwd([_w(t) for t in (xc, ss.x_proj_weight, ss.dt_projs_weight, ss.dt_projs_bias, ss.A_logs, ss.Ds)],
+                        merged=False)
     tok1 = torch.empty((B, L, C), dtype=torch.float32, device=dev)
     f = torch.empty((B, D, H, W), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        check(lib.wm_lfss_mid_fwd(_ptr(ysum), _ptr(z), _ptr(tok), int(tok_nchw), _ptr(_w(ss.out_norm.weight)),
+        check(lib.wm_lfss_mid_fwd(_ptr(y4[0]), 4, B * D * L, _ptr(z), _ptr(tok), int(tok_nchw), _ptr(_w(ss.out_norm.weight)),
                                   _ptr(_w(ss.out_norm.bias)), float(ss.out_norm.eps), _ptr(_w(ss.out_proj.weight)),
                                   _ptr(_w(blk.skip_scale)), _ptr(_w(blk.ln_2.weight)), _ptr(_w(blk.ln_2.bias)),
                                   float(blk.ln_2.eps), _ptr(_w(ff.conv1.weight)), _ptr(_w(ff.conv1.bias)),
