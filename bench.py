@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py - UHD (3840x2160) images/s of the Wave-Mamba forward on MI355X, with the roofline
-fraction of the dominant hot-path kernel and the CPU-oracle baseline timed beside it.
+"""bench.py - UHD (3840x2160) images/s of the Wave-Mamba forward on MI355X, with the HBM-roofline fraction of the
+hot-path operator that takes the most time (SURVEY.md 8d bytes) and the CPU-oracle network timed beside it.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" = one forward of the shipped WaveMamba (inference_wavemamba.py:71-75 config, seeded random
-init - checkpoints are not distributed) over one synthetic 1x3x2160x3840 image, reflect-padded to
-2176x3840 exactly as the reference's inference script does (:28-36), input already resident in HBM.
-N > 1: one process per GPU, each an independent replica on its own image (the path shards by image,
-no data-path collective) -> weak scaling; value = N*K images / max-over-ranks time.
+A "step" = one forward of the shipped WaveMamba (inference_wavemamba.py:71-75 config, seeded random init -
+checkpoints are not distributed) over one synthetic 1x3x2160x3840 image, reflect-padded to 2176x3840 exactly as the
+reference's inference script does (:28-36), input already resident in HBM.  N > 1: one process per GPU, each an
+independent replica on its own image (the path shards by image, no data-path collective) -> weak
+scaling; value = N*K images / max-over-ranks time.
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions).
+Definitions used in the JSON line (all from SURVEY.md section 8d, nothing else):
+  * selective-scan op = the reduce / carry / scan launches of wm_ss2d_core_fwd (SS2D.forward_core :446-478);
+    algorithmic bytes = 3584 B per scanned position (4*(3*KD + 2*K*N), KD = 256, K = 4, N = 16) - the reference call
+    signature's operands, even though xs / dts / B / C never exist in HBM here;  `fused_512B` is the SEPARATE stretch
+    definition (read x + write merged y = 512 B per position), never mixed into `frac`;
+  * Haar: 2*e*B*C*H*W per level.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -28,13 +34,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import wave_mamba_amd as wm                                     # noqa: E402
-from wave_mamba_amd.archs import wavemamba_arch as arch        # noqa: E402
 
 SHIPPED = dict(in_chn=3, wf=32, n_l_blocks=[1, 2, 4], n_h_blocks=[1, 1, 2], ffn_scale=2.0)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 SCAN_BYTES_PER_POS = {16: 3584, 32: 4096}   # 4*(3*KD + 2*K*N), KD = 256, K = 4
-# kernel classes whose HIP events are recorded inside the timed region (the candidates for `roofline`)
-TIMED_PROF = ("ss2d_row_scan", "ss2d_col_scan")
+FUSED_BYTES_PER_POS = 512        # SURVEY.md 8d "fused SS2D-core (stretch, report separately, never mix)"
+# kernel classes of the selective-scan op whose HIP events are recorded inside the timed region
+CORE_CLASSES = ("ss2d_core_reduce", "selscan_carry", "ss2d_core_scan")
+EXP_PEAK = 18.5e12               # v_exp_f32 lane-ops/s chip-wide, tools/microbench.hip on MI355X
 
 
 def pad_to(x, mult=128):
@@ -54,47 +61,91 @@ def build_model(device):
     return wm.WaveMamba(**SHIPPED).eval().to(device)
 
 
-def cpu_baseline(sample_hw, uhd_hw, repeats):
-    """The CPU oracle ("port") inside the same network on host cores, on a bounded sample."""
+def psnr_u8(a, b):
+    """PSNR after the reference's uint8 quantisation (img_util.py:67-94, comput_psnr_ssim.py:434-438)."""
+    qa, qb = (a.clamp(0, 1) * 255).round(), (b.clamp(0, 1) * 255).round()
+    mse = float((qa - qb).pow(2).mean())
+    return float("inf") if mse == 0 else float(20 * torch.log10(torch.tensor(255.0)) - 10 * torch.log10(torch.tensor(mse)))
+
+
+# ------------------------------------------------------------------------------------------------
+# rank plumbing (factored so that tests/test_bench_ranks.py can drive it under gloo on CPU)
+# ------------------------------------------------------------------------------------------------
+def rank_env(env=os.environ):
+    return int(env.get("RANK", "0")), int(env.get("WORLD_SIZE", "1")), int(env.get("LOCAL_RANK", "0"))
+
+
+def timed_steps(step, steps, warmup, sync, barrier):
+    """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + sync on both sides.
+    -> seconds on this rank."""
+    for _ in range(max(warmup, 0)):
+        step()
+    sync()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def max_over_ranks(seconds, world, device):
+    if world <= 1:
+        return float(seconds)
+    t = torch.tensor([seconds], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t)
+
+
+def whole_job_value(world, steps, units_per_step, seconds):
+    """units all ranks processed / max-over-ranks time (weak scaling: every rank does `steps` steps)."""
+    return world * steps * units_per_step / seconds
+
+
+def image_seed(rank):
+    return 1234 + rank                                 # SURVEY 8d: G(1234) on rank 0; every replica its own image
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline: the same network with the C/OpenMP oracle as hot-path backend, on host cores
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(img_padded, forwards, budget_s):
+    """1 warm-up + `forwards` timed forwards of the FULL padded UHD image on the host.
+    -> (record, output of the last forward).  If the warm-up alone exceeds `budget_s` the timed count drops to 1 and
+    the record says so."""
     from oracle import oracle
     from oracle import backend as oracle_backend
-    cores = oracle.usable_cpus()
+    cores = oracle.usable_cpus(cap=1 << 20)            # affinity mask and cgroup quota: what this process may really use
     torch.set_num_threads(cores)
     oracle.set_num_threads(cores)
     net = build_model("cpu")
-    prev = oracle_backend.set_ops_backend(oracle)
-    try:
-        with torch.no_grad():
-            # bounded: shrink the sample until one forward takes < ~8 s on this host
-            while True:
-                x = torch.rand(1, 3, *sample_hw, generator=torch.Generator().manual_seed(1234))
-                t0 = time.perf_counter()
-                y = net.restoration_network(x)                  # warm-up / probe
-                probe = time.perf_counter() - t0
-                if probe < 8.0 or min(sample_hw) <= 128:
-                    break
-                sample_hw = (sample_hw[0] // 2, sample_hw[1] // 2)
-            times = [probe] if probe > 8.0 else []
-            for _ in range(0 if times else repeats):
-                t0 = time.perf_counter()
-                y = net.restoration_network(x)
-                times.append(time.perf_counter() - t0)
-    finally:
-        oracle_backend.set_ops_backend(prev)
-    repeats = len(times)
-    t = sorted(times)[len(times) // 2]
-    scale = (uhd_hw[0] * uhd_hw[1]) / (sample_hw[0] * sample_hw[1])
+    times = []
+    with oracle_backend.ops_backend(oracle), torch.no_grad():
+        t0 = time.perf_counter()
+        y = net.restoration_network(img_padded)        # warm-up
+        warm = time.perf_counter() - t0
+        n = forwards if warm * (forwards + 1) <= budget_s else 1
+        for _ in range(n):
+            t0 = time.perf_counter()
+            y = net.restoration_network(img_padded)
+            times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    h, w = img_padded.shape[-2:]
     return {
-        "value": 1.0 / (t * scale), "unit": "images/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
-        "sample": f"1x3x{sample_hw[0]}x{sample_hw[1]} fp32 forward (median of {repeats}, {t:.2f} s), same "
-                  f"network with the C/OpenMP oracle as hot-path backend + PyTorch-CPU for the rest; "
-                  f"scaled by the padded-area ratio {scale:.2f} to one 2176x3840 image",
-    }, x, y
+        "value": 1.0 / med, "unit": "images/s", "cores": cores, "kind": "port",
+        "host_cpus": os.cpu_count(), "torch_threads": torch.get_num_threads(), "oracle_omp_threads": oracle.num_threads(),
+        "seconds_per_image": times, "warmup_seconds": warm,
+        "sample": f"the full workload: 1 warm-up + {len(times)} timed forwards of the padded 1x3x{h}x{w} image (median "
+                  f"{med:.2f} s), same network code with the C/OpenMP oracle (oracle/wavemamba_oracle.c) as hot-path "
+                  f"backend + PyTorch-CPU for the rest; threads = host cores usable by this process (affinity and "
+                  f"cgroup quota) = {cores} of os.cpu_count() = {os.cpu_count()}",
+    }, y
 
 
 def scan_op_boundary(device, hp, wp, iters=3):
-    """The drop-in selective_scan_fn (reference call signature, 3584 B/position) on the UHD level-1
-    shape (B=1, KD=256, L=hp*wp/4): HBM fraction of its chunk-scan kernel and of the whole op."""
+    """The drop-in selective_scan_fn (reference call signature, 3584 B/position) on the UHD level-1 shape (B=1, KD=256,
+    L=hp*wp/4): HBM fraction of the whole op."""
     L, dim, N, G = (hp // 2) * (wp // 2), 256, 16, 4
     g = torch.Generator(device=device).manual_seed(7)
     u = torch.randn(1, dim, L, device=device, generator=g)
@@ -114,14 +165,12 @@ def scan_op_boundary(device, hp, wp, iters=3):
     r, c, s = (prof[k][1] / iters for k in ("selscan_chunk_reduce", "selscan_carry", "selscan_chunk_scan"))
     nbytes = SCAN_BYTES_PER_POS[N] * L
     return {"shape": f"u,delta (1,{dim},{L}); B,C (1,{G},{N},{L})", "algorithmic_bytes": nbytes,
-            "chunk_scan_ms": s, "chunk_scan_frac": nbytes / (s * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "reduce_ms": r, "carry_ms": c, "whole_op_frac": nbytes / ((r + c + s) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            "reduce_ms": r, "carry_ms": c, "chunk_scan_ms": s,
+            "whole_op_frac": nbytes / ((r + c + s) * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
 def graph_replay(step, steps, device):
-    """The same step captured once into a HIP graph (torch.cuda.CUDAGraph = hipGraph on ROCm) and
-    replayed: removes the ~1000 host-side launches per forward (launch-bound stretches at the small
-    pyramid levels).  Reported next to `value`, which stays the eager, event-instrumented run."""
+    """The same step captured once into a HIP graph and replayed (optional leg)."""
     try:
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream())
@@ -143,29 +192,25 @@ def graph_replay(step, steps, device):
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
-def bf16_autocast(net, x, steps):
-    """BASELINE config 2 names bf16 inference; the reference itself is fp32-only (SURVEY: pure .bfloat16()
-    fails, autocast works).  Here: torch.autocast(bfloat16) for everything OUTSIDE the hot path (MIOpen /
-    hipBLASLt convs and GEMMs of the HFE branch); the HIP hot path keeps fp32 state and I/O.  Reported
-    beside `value` (which stays the parity-exact fp32 run) with the PSNR against the fp32 output."""
+def load_pmc(hp, wp):
+    """HBM bytes of the selective-scan op measured with rocprofv3 --pmc (tools/pmc_core.sh -> tools/pmc_traffic.py ->
+    profiles/pmc_traffic.json): per core call at each pyramid level, FETCH_SIZE corrected as
+    MI355X_MICROARCH.md prescribes (x2 for 16-byte-per-lane reads, the factor checked on a float4 copy in the same
+    session).  -> (bytes per step or None when the file does not cover this workload, the file's content)."""
     try:
-        with torch.no_grad():
-            ref = net.restoration_network(x)
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                for _ in range(2):
-                    out = net.restoration_network(x)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(steps):
-                    out = net.restoration_network(x)
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t0
-        mse = float((out.float().clamp(0, 1) - ref.clamp(0, 1)).pow(2).mean())
-        return {"images_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps,
-                "psnr_vs_fp32_db": float(10 * torch.log10(torch.tensor(1.0 / max(mse, 1e-20)))),
-                "rel_l2_vs_fp32": float((out.float() - ref).norm() / ref.norm())}
-    except Exception as e:
-        return {"error": f"{type(e).__name__}: {e}"[:300]}
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        lv = pmc["ss2d_core"]["levels"]
+        calls = {1: 2, 2: 4, 3: 8}
+        tot = 0.0
+        for lvl, n in calls.items():
+            e = lv[str(lvl)]
+            if (e["H"], e["W"]) != (hp >> lvl, wp >> lvl):
+                return None, pmc
+            tot += n * e["hbm_bytes_per_call"]
+        return tot, pmc
+    except Exception:
+        return None, None
 
 
 def main():
@@ -175,113 +220,81 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--streams", type=int, default=1,
-                    help="forwards in flight in the timed region: step i runs on HIP stream i %% STREAMS (default 1: back "
-                         "to back on one stream, so the per-kernel HIP-event durations behind `roofline` are undisturbed)")
     ap.add_argument("--concurrent", type=int, default=4,
                     help="extra untimed leg at N = 1: throughput with this many forwards in flight on separate HIP "
                          "streams, no event instrumentation (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-forwards", type=int, default=3, help="timed CPU forwards of the full UHD image (after 1 warm-up)")
+    ap.add_argument("--cpu-budget", type=float, default=240.0,
+                    help="seconds the CPU leg may take; if (1 + cpu-forwards) x warm-up time exceeds it, one timed forward")
     ap.add_argument("--graph", action="store_true", help="also time the step replayed from a HIP graph")
-    ap.add_argument("--bf16", action="store_true", help="also time torch.autocast(bfloat16) outside the hot path")
-    ap.add_argument("--cpu-sample", type=int, nargs=2, default=[512, 1024])
+    ap.add_argument("--bf16", action="store_true", help="also time the bf16-storage mode (bf16 planes between kernels)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local_rank = rank_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path is HIP-only (no CPU fallback)")
-    # self-test hook (one-GPU boxes): WM_BENCH_SHARE_GPU=1 puts every rank on cuda:0 over gloo, to exercise the
-    # multi-rank control flow (barriers, max-over-ranks reduction, rank-0-only legs); never set by the driver
-    share = os.environ.get("WM_BENCH_SHARE_GPU") == "1"
-    if share:
-        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        if share:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=device)          # RCCL on ROCm
+        dist.init_process_group(backend="nccl", device_id=device)          # RCCL on ROCm
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    # CPU baseline first (rank 0, N = 1 only), before the GPU pass
-    cpu, parity = None, None
+    img = torch.rand(1, 3, args.height, args.width, generator=torch.Generator().manual_seed(image_seed(rank)))
+    x_cpu = pad_to(img)
+    hp, wp = x_cpu.shape[-2:]
+
+    # CPU baseline first (rank 0, N = 1 only), before the GPU pass: full UHD forwards
+    cpu, y_cpu = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, xs, ys = cpu_baseline(tuple(args.cpu_sample), (2176, 3840), repeats=3)
+        cpu, y_cpu = cpu_baseline(x_cpu, args.cpu_forwards, args.cpu_budget)
 
     net = build_model(device)
-    img = torch.rand(1, 3, args.height, args.width, generator=torch.Generator().manual_seed(1234 + rank))
-    x = pad_to(img.to(device))
-    hp, wp = x.shape[-2:]
+    x = x_cpu.to(device)
 
-    if cpu is not None:   # parity of the HIP path vs the CPU-oracle path on the very same sample
+    parity = None
+    if y_cpu is not None:   # parity of the HIP path vs the CPU-oracle network on the very same UHD image
         with torch.no_grad():
-            yg = net.restoration_network(xs.to(device)).cpu()
-        tgt = torch.rand(xs.shape, generator=torch.Generator().manual_seed(4321))
+            yg = net.restoration_network(x).cpu()
+        tgt = torch.rand(y_cpu.shape, generator=torch.Generator().manual_seed(4321))
+        crop = lambda t: t[:, :, :args.height, :args.width]
+        parity = {"workload": f"the timed workload itself (1x3x{hp}x{wp}, cropped to {args.height}x{args.width} for PSNR)",
+                  "rel_l2_vs_cpu_oracle": float((yg - y_cpu).norm() / y_cpu.norm()),
+                  "max_abs_over_max_abs": float((yg - y_cpu).abs().max() / y_cpu.abs().max()),
+                  "abs_dpsnr_db": abs(psnr_u8(crop(yg), crop(tgt)) - psnr_u8(crop(y_cpu), crop(tgt))),
+                  "bars": {"rel_l2": 1e-4, "abs_dpsnr_db": 1e-3}}
+        del yg, y_cpu
 
-        def psnr(a, b):
-            qa, qb = (a.clamp(0, 1) * 255).round(), (b.clamp(0, 1) * 255).round()
-            return float(20 * torch.log10(255.0 / (qa - qb).pow(2).mean().sqrt()))
-        parity = {"rel_l2_vs_cpu_oracle": float((yg - ys).norm() / ys.norm()),
-                  "abs_dpsnr_db": abs(psnr(yg, tgt) - psnr(ys, tgt))}
-
-    # Consecutive steps (independent images) may run on `--streams` HIP streams round-robin: up to that many forwards
-    # are then in flight and the kernels of one fill the tails and the small launches of another (one stream: 23.0
-    # images/s, four: 28.6 on one MI355X) - but every individual launch stretches, so the default timed region keeps
-    # one stream and the concurrent rate is reported by the `concurrent_forwards` leg.
-    nstreams = max(1, args.streams)
-    streams = [torch.cuda.Stream(device) for _ in range(nstreams)] if nstreams > 1 else [torch.cuda.current_stream(device)]
-    counter = [0]
-
-    def step(single=False):
-        st = streams[0] if single else streams[counter[0] % nstreams]
-        counter[0] += 1
-        with torch.no_grad(), torch.cuda.stream(st):
+    def step():
+        with torch.no_grad():
             out = net.restoration_network(x)
         return out[:, :, :args.height, :args.width]
 
+    sync = torch.cuda.synchronize
+    barrier = dist.barrier if world > 1 else (lambda: None)
+    # HIP events cost ~10 us of stream time per instrumented launch, so the timed region records only the three launch
+    # classes of the selective-scan op (42 launches per step); the other classes are measured in an untimed pass below.
     for _ in range(max(args.warmup, 1)):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    # HIP events cost ~10 us of stream time per instrumented launch (353 wm:: launches per step = 3 ms,
-    # profiles/r01/README.md), so the timed region records only the scan kernel classes - the dominant
-    # kernel `roofline` reports - and the other classes are measured in an extra untimed pass below.
-    wm.ops.prof_enable(TIMED_PROF)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    prof_timed = wm.ops.prof_collect()
-    prof_steps = {k: args.steps for k in TIMED_PROF}
-    prof = {k: prof_timed[k] for k in TIMED_PROF}
-    iso, iso_elapsed = {}, None
+    wm.ops.prof_enable(CORE_CLASSES)
+    elapsed = timed_steps(step, args.steps, 0, sync, barrier)
+    prof = {k: v for k, v in wm.ops.prof_collect().items() if k in CORE_CLASSES}
+    prof_steps = {k: args.steps for k in prof}
     if rank == 0:
-        # untimed, one stream, back to back: every kernel class with the chip to itself (the timed region overlaps
-        # kernels of different forwards, which stretches each launch)
         extra = max(2, min(args.steps, 5))
-        torch.cuda.synchronize()
         wm.ops.prof_enable(True)
-        t1 = time.perf_counter()
         for _ in range(extra):
-            step(single=True)
+            step()
         torch.cuda.synchronize()
-        iso_elapsed = (time.perf_counter() - t1) / extra
         for k, v in wm.ops.prof_collect().items():
-            iso[k] = (v[0] / extra, v[1] / extra)
             if k not in prof:
                 prof[k], prof_steps[k] = v, extra
     wm.ops.prof_enable(False)
+
     concurrent = None
     if rank == 0 and world == 1 and args.concurrent > 1:
         cs = [torch.cuda.Stream(device) for _ in range(args.concurrent)]
+
         def cstep(i):
             with torch.no_grad(), torch.cuda.stream(cs[i % len(cs)]):
                 net.restoration_network(x)
@@ -298,93 +311,75 @@ def main():
                       "note": "same forward, steps round-robin over the streams (that many images in flight), no HIP-event "
                               "instrumentation; serving throughput, not the contract's `value`"}
     op_boundary = scan_op_boundary(device, hp, wp) if rank == 0 else None
-    def step_on_current_stream():           # capture needs the launches on the capturing stream: no stream switch
-        with torch.no_grad():
-            return net.restoration_network(x)[:, :, :args.height, :args.width]
-
-    hip_graph = graph_replay(step_on_current_stream, args.steps, device) if rank == 0 and world == 1 and args.graph else None
-    bf16 = bf16_autocast(net, x, args.steps) if rank == 0 and world == 1 and args.bf16 else None
-    if world > 1:
-        t = torch.tensor([elapsed], device="cpu" if share else device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+    hip_graph = graph_replay(step, args.steps, device) if rank == 0 and world == 1 and args.graph else None
+    bf16 = None
+    if rank == 0 and world == 1 and args.bf16:
+        try:
+            from wave_mamba_amd import inference
+            bf16 = inference.bench_bf16_storage(net, x, args.steps)
+        except Exception as e:
+            bf16 = {"error": f"{type(e).__name__}: {e}"[:300]}
+    elapsed = max_over_ranks(elapsed, world, device)
 
     if rank == 0:
-        # ---- per-kernel roofline table for the timed region (HIP-event durations from the library) ----
-        l1, l2, l3 = (hp // 2) * (wp // 2), (hp // 4) * (wp // 4), (hp // 8) * (wp // 8)
-        pos = scan_positions(hp, wp)                       # block-positions per image (14 LFSSBlocks)
+        pos = scan_positions(hp, wp)                       # positions scanned per image (14 LFSSBlocks)
         haar_b = 2 * 4 * 32 * hp * wp * (1 + 1 / 4 + 1 / 16)          # 2*e*B*C*H*W per level
-        # algorithmic bytes per image of each hot-path kernel class
-        algo = {
-            "haar_analysis": haar_b, "haar_synthesis": haar_b,
-            "ss2d_proj": pos * (256 + 4 * 144),            # read x (64 ch), write 4 records
-            "ss2d_row_reduce": 2 * pos * (256 + 80), "ss2d_col_reduce": 2 * pos * (256 + 80),
-            "ss2d_row_scan": 2 * pos * (256 + 144 + 256), "ss2d_col_scan": 2 * pos * (256 + 144 + 256),
-            "selscan_chunk_scan": pos * SCAN_BYTES_PER_POS[16], "selscan_chunk_reduce": pos * 2304,
-            "dwconv3x3": None,
-        }
         table = {}
         for name, (n, ms) in prof.items():
-            if not n:
-                continue
-            ks = prof_steps[name]
-            ent = {"launches_per_step": n / ks, "ms_per_step": ms / ks,
-                   "measured_in": "timed region" if name in TIMED_PROF else "untimed one-stream pass after it"}
-            if algo.get(name):
-                gbs = algo[name] * ks / (ms * 1e-3) / 1e9
-                ent.update({"algorithmic_GB_per_step": algo[name] / 1e9, "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS})
-            table[name] = ent
-        hfe_only = ("conv3x3", "conv1x1", "skff")        # HFE-branch / plumbing kernels, not the hot path
-        hot = [k for k in table if k != "dwconv3x3" and "frac" in table[k]]
-        dom = max(hot, key=lambda k: table[k]["ms_per_step"])
-        hot_ms = sum(table[k]["ms_per_step"] for k in table if k != "dwconv3x3" and k not in hfe_only)
-        hfe_ms = sum(table[k]["ms_per_step"] for k in table if k in hfe_only)
-        # transcendental ceiling of the scan kernels: KD*N = 4096 exp per block-position per pass
-        exp_peak = 18.5e12                                  # v_exp_f32 lane-ops/s, tools/microbench.hip on MI355X
-        scan_ms = sum(table[k]["ms_per_step"] for k in table if k.endswith(("_scan", "_reduce")))
-        pmc = None
-        try:                                               # measured HBM bytes per launch (rocprofv3 --pmc), if committed
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pmc = json.load(f)
-        except Exception:
-            pass
+            if n:
+                ks = prof_steps[name]
+                table[name] = {"launches_per_step": n / ks, "ms_per_step": ms / ks,
+                               "measured_in": "timed region" if name in CORE_CLASSES else "untimed pass after it"}
+        for name in ("haar_analysis", "haar_synthesis"):
+            if name in table:
+                gbs = haar_b / (table[name]["ms_per_step"] * 1e-3) / 1e9
+                table[name].update({"algorithmic_GB_per_step": haar_b / 1e9, "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS})
+        core_ms = sum(table[k]["ms_per_step"] for k in CORE_CLASSES if k in table)
+        calls = table.get("ss2d_core_scan", {}).get("launches_per_step", 0)
+        scan_bytes = SCAN_BYTES_PER_POS[16] * pos
+        achieved = scan_bytes / (core_ms * 1e-3) / 1e9 if core_ms else None
+        traffic, pmc = load_pmc(hp, wp)
+        dom = max((k for k in CORE_CLASSES if k in table), key=lambda k: table[k]["ms_per_step"], default=None)
         roof = {
-            "kernel": dom, "bound": "hbm", "achieved": table[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": table[dom]["frac"],
-            # PMC FETCH_SIZE + WRITE_SIZE measured on the UHD level-1 launch of this kernel, scaled by the ratio
-            # (measured / algorithmic) to the average launch of the timed region (launches differ by pyramid level)
-            "traffic": ((pmc or {}).get(dom, {}).get("traffic_over_algorithmic") or 0) *
-                       1e9 * table[dom]["algorithmic_GB_per_step"] / table[dom]["launches_per_step"] or None,
-            "traffic_over_algorithmic": (pmc or {}).get(dom, {}).get("traffic_over_algorithmic"),
-            "launches_per_step": table[dom]["launches_per_step"],
-            "avg_launch_ms": table[dom]["ms_per_step"] / table[dom]["launches_per_step"],
-            "algorithmic_bytes_per_launch_avg": 1e9 * table[dom]["algorithmic_GB_per_step"] / table[dom]["launches_per_step"],
-            "note": "scan kernels are bound by v_exp_f32 issue (KD*N exp per position per pass), not by HBM: "
-                    "see exp_frac; HBM fractions are reported for every hot-path kernel in roofline_table",
-            "exp_frac_scan_kernels": (2 * 4096 * pos / (scan_ms * 1e-3) / exp_peak) if scan_ms else None,
-            "hot_path_ms_per_step": hot_ms, "hfe_conv_skff_ms_per_step": hfe_ms,
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS if achieved else None,
+            "traffic": traffic,
+            "kernel": "selective-scan op of SS2D.forward_core = the reduce + carry + scan launches of wm_ss2d_core_fwd "
+                      "(wm::ss2d_core_kernel<16,16,1|3>, wm::selscan_carry_kernel): the hot-path operator with the most time",
+            "definition": "SURVEY.md 8d: 3584 B per scanned position (reference call signature) x positions per step / "
+                          "summed HIP-event duration of the op's launches in the timed region",
+            "algorithmic_bytes_per_position": SCAN_BYTES_PER_POS[16], "positions_per_step": pos,
+            "algorithmic_GB_per_step": scan_bytes / 1e9, "ms_per_step": core_ms, "op_calls_per_step": calls,
+            "per_call_avg": {"algorithmic_GB": scan_bytes / 1e9 / calls if calls else None,
+                             "ms": core_ms / calls if calls else None},
+            "dominant_kernel": None if dom is None else {
+                "class": dom, "launches_per_step": table[dom]["launches_per_step"], "ms_per_step": table[dom]["ms_per_step"],
+                "avg_launch_ms": table[dom]["ms_per_step"] / table[dom]["launches_per_step"]},
+            "traffic_over_algorithmic": traffic / scan_bytes if traffic else None,
+            "traffic_source": None if pmc is None else pmc.get("source"),
+            "fused_512B": {"note": "SURVEY.md 8d stretch definition, reported separately, never mixed into `frac`",
+                           "algorithmic_GB_per_step": FUSED_BYTES_PER_POS * pos / 1e9,
+                           "frac": FUSED_BYTES_PER_POS * pos / (core_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if core_ms else None,
+                           "traffic_over_algorithmic": traffic / (FUSED_BYTES_PER_POS * pos) if traffic else None},
+            "secondary_ceilings": {
+                "note": "the op is bound by VALU issue, not by HBM: KD*N = 4096 v_exp_f32 per position in each of the two "
+                        "passes (chunk-reduce, chunk-scan) plus four packed fp32 operations per state-step",
+                "exp_frac": (2 * 4096 * pos / (core_ms * 1e-3) / EXP_PEAK) if core_ms else None},
         }
-        if nstreams > 1 and dom in iso and iso[dom][1] > 0:
-            # the same kernel class with the chip to itself (untimed one-stream pass): in the timed region kernels of
-            # up to `streams` forwards overlap, which raises throughput and stretches every individual launch
-            gbs_iso = algo[dom] / (iso[dom][1] * 1e-3) / 1e9
-            roof["isolated"] = {"achieved": gbs_iso, "frac": gbs_iso / HBM_PEAK_GBS,
-                                "avg_launch_ms": iso[dom][1] / iso[dom][0],
-                                "ms_per_step_one_stream": 1e3 * iso_elapsed,
-                                "images_per_s_one_stream": 1.0 / iso_elapsed,
-                                "note": "one stream, back to back, events on every kernel class (~3 ms of event overhead per step)"}
+        hot_names = ("haar_analysis", "haar_synthesis", "lfss_glue", "dwconv3x3") + CORE_CLASSES
         line = {
-            "metric": "UHD (3840x2160) images/sec fwd", "value": world * args.steps / elapsed,
+            "metric": "UHD (3840x2160) images/sec fwd", "value": whole_job_value(world, args.steps, 1, elapsed),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Wave-Mamba UHD-LL inference config (wf=32, n_l=[1,2,4], n_h=[1,1,2]), "
                                    f"1x3x{args.height}x{args.width} reflect-padded to {hp}x{wp}, seeded random "
-                                   f"init, one image per GPU per step, replicas (no collective); steps round-robin "
-                                   f"over {nstreams} HIP stream(s) = forwards in flight", "streams": nstreams},
-            "roofline": roof, "roofline_table": table,
-            "selscan_op_boundary": op_boundary, "hip_graph_replay": hip_graph, "bf16_autocast": bf16,
-            "concurrent_forwards": concurrent, "cpu_baseline": cpu, "parity": parity,
+                                   f"init, one image per GPU per step, replicas (no collective), one HIP stream"},
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+            "roofline_table": table,
+            "hot_path_ms_per_step": sum(table[k]["ms_per_step"] for k in table if k in hot_names),
+            "selscan_op_boundary": op_boundary, "hip_graph_replay": hip_graph, "bf16_storage": bf16,
+            "concurrent_forwards": concurrent,
         }
         print(json.dumps(line))
     if world > 1:

@@ -286,8 +286,9 @@ int wm_skff_fwd(const float* x0, const float* x1, const float* x2, const float* 
  * class).  Disabled by default; when disabled the library records nothing.
  *   kernel ids: 0 haar analysis (dwt fwd / iwt bwd), 1 haar synthesis (iwt fwd / dwt bwd),
  *               2 scan chunk-reduce, 3 scan carry, 4 scan chunk-scan (drop-in op), 5 lfss glue (in/mid/out),
- *               6 ss2d projection, 7 depth-wise conv, 8 ss2d row chunk-scan, 9 ss2d col chunk-scan,
- *               10 ss2d row chunk-reduce, 11 ss2d col chunk-reduce, 12 selective-scan backward (all phases),
+ *               6 ss2d projection (first-generation core / backward), 7 depth-wise conv, 8 ss2d core chunk-scan
+ *               (+ the merged-output sum), 9 first-generation core chunk-scan (W % 4 != 0 only), 10 ss2d core
+ *               chunk-reduce, 11 first-generation chunk-reduce, 12 selective-scan backward (all phases),
  *               13 dense 3x3 convolution, 14 1x1 convolution, 15 SKFF (all three kernels)
  * wm_prof_enable(mask): bit k of `mask` switches recording for kernel id k (0 = off, ~0u = every class);
  * a non-zero mask also clears what was recorded before.  Two hipEventRecord calls cost ~10 us of stream

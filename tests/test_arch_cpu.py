@@ -121,10 +121,60 @@ def test_training_step_gradients(meta, oracle_backend):
     worst = 0.0
     for k, p in net.named_parameters():
         assert p.grad is not None, f"{k} got no gradient"
-        s, a = meta["grad_fingerprint"][k]
-        got = float(p.grad.double().abs().sum())
-        worst = max(worst, abs(got - a) / max(a, 1e-12))
-    assert worst < 2e-3, f"worst abs-sum grad deviation {worst:.3e}"
+        s, a = meta["grad_fingerprint"][k]                      # float64 (sum, abs-sum) of the reference's gradient
+        g = p.grad.double()
+        worst = max(worst, abs(float(g.abs().sum()) - a) / max(a, 1e-30), abs(float(g.sum()) - s) / max(a, 1e-30))
+    # 1.5 M parameters: fingerprints only (the full tensors are checked on the wf = 8 model below); measured 1.8e-5
+    assert worst < 1e-4, f"worst gradient fingerprint deviation {worst:.3e}"
+
+
+def grad_golden_case():
+    import numpy as np
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "train_grads_wf8.npz"))
+    torch.manual_seed(0)
+    net = wm.WaveMamba(in_chn=3, wf=8, n_l_blocks=[1, 1, 2], n_h_blocks=[1, 1, 1], ffn_scale=2.0).train()
+    # the seeded init reproduces the reference's (bit for bit on the build container's CPU; the transcendental inits
+    # - dt_projs_bias is an inverse softplus, :411-416 - may differ by an ulp on another host's libm): check, then run
+    # the step from the reference's very weights
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    for k, p in net.named_parameters():
+        assert torch.allclose(p.detach(), sd[k], rtol=1e-6, atol=1e-7), k
+    net.load_state_dict(sd, strict=False)
+    return net, g
+
+
+def check_grads_against_golden(net, g, bar=1e-4, bar_most=None, most=1.0):
+    """per-parameter gradients after one reference training step, full tensors:
+    ||a - b||_2 <= bar ||b||_2 and max|a - b| <= bar max|b| for every parameter tensor (and, when given, at least the
+    fraction `most` of the tensors within the tighter `bar_most`)."""
+    worst = (0.0, None)
+    devs = []
+    for k, p in net.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        ref = torch.from_numpy(g["g." + k]).double()
+        d = p.grad.detach().cpu().double() - ref
+        rel = float(d.norm() / ref.norm().clamp_min(1e-300))
+        mx = float(d.abs().max() / ref.abs().max().clamp_min(1e-300))
+        worst = max(worst, (max(rel, mx), k))
+        devs.append(max(rel, mx))
+    assert worst[0] <= bar, f"gradient of {worst[1]} deviates by {worst[0]:.3e} (bar {bar:g})"
+    if bar_most is not None:
+        ok = sum(d <= bar_most for d in devs) / len(devs)
+        assert ok >= most, f"only {100 * ok:.1f} % of the gradient tensors are within {bar_most:g}"
+    return worst
+
+
+def test_training_step_per_parameter_gradients(oracle_backend):
+    """One optimize_parameters of the reference trainer (femasr_model.py:157-185) on a wf = 8 model: every parameter's
+    gradient tensor against the reference's own autograd (tests/golden/train_grads_wf8.npz, make_golden_grads.py)."""
+    net, g = grad_golden_case()
+    pred = net(torch.from_numpy(g["lq"]))
+    l_pix, l_fft = wm.trainer.losses(pred, torch.from_numpy(g["gt"]))
+    (l_pix + l_fft).backward()
+    assert abs(float(l_pix) - g["losses"][0]) < 1e-6 and abs(float(l_fft) - g["losses"][1]) < 1e-5
+    assert_close(pred.detach(), torch.from_numpy(g["pred"]), 1e-5, "prediction")
+    check_grads_against_golden(net, g)
 
 
 def test_check_image_size_and_tiling(oracle_backend):

@@ -65,6 +65,22 @@ __global__ __launch_bounds__(256) void sum_kernel(const float4* __restrict__ in,
     if (s == 123.456f) out[0] = s;
 }
 
+// the access pattern of the SS2D core's tile loader / storer: a wave moves [64 planes][16 floats] tiles, 16 bytes per
+// lane, i.e. 64-byte runs one plane stride apart (PMC calibration of FETCH_SIZE / WRITE_SIZE for that pattern)
+__global__ __launch_bounds__(256) void run64_copy_kernel(const float* __restrict__ in, float* __restrict__ out, long long L,
+                                                         long long tiles) {
+    const int lane = threadIdx.x & 63, trow = lane >> 2, tq = lane & 3;
+    long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long stride = (long long)gridDim.x * 4;
+    for (; t < tiles; t += stride) {
+        float4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(in + (16 * i + trow) * L + 16 * t + 4 * tq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(out + (16 * i + trow) * L + 16 * t + 4 * tq) = v[i];
+    }
+}
+
 template <int MODE>
 static double run_rate(float* d, int iters, const char* name, double ops_per_iter) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -121,6 +137,15 @@ int main() {
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("plane copy, 64 planes x 1 dword per lane   %8.3f ms/iter  %8.1f GB/s (read+write)\n", ms / 5, 2.0 * 64 * L * 4 * 5 / ms * 1e-6);
+        {
+            const long long tiles = L / 16;
+            hipLaunchKernelGGL(run64_copy_kernel, dim3(4096), dim3(256), 0, 0, (const float*)a, (float*)b, L, tiles);
+            hipEventRecord(e0);
+            for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(run64_copy_kernel, dim3(4096), dim3(256), 0, 0, (const float*)a, (float*)b, L, tiles);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("64-byte-run tile copy, 64 planes (core tile pattern) %8.3f ms/iter  %8.1f GB/s (read+write)\n", ms / 5, 2.0 * 64 * L * 4 * 5 / ms * 1e-6);
+        }
         hipLaunchKernelGGL(plane_copy_kernel<128>, dim3(blocks), dim3(256), 0, 0, (const float*)a, (float*)b, L);
         hipEventRecord(e0);
         for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(plane_copy_kernel<128>, dim3(blocks), dim3(256), 0, 0, (const float*)a, (float*)b, L);

@@ -14,6 +14,7 @@ import torch
 import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import wave_mamba_amd as wm
+import bench                       # rank plumbing shared with bench.py (tests/test_bench_ranks.py drives it under gloo)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--gpus", type=int, default=1)
@@ -22,7 +23,7 @@ ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--size", type=int, default=512)
 args = ap.parse_args()
-world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+rank, world, local = bench.rank_env()
 torch.cuda.set_device(local)
 dev = torch.device("cuda", local)
 if world > 1:
@@ -31,27 +32,25 @@ torch.manual_seed(0)
 net = wm.WaveMamba(in_chn=3, wf=32, n_l_blocks=[1, 2, 4], n_h_blocks=[1, 1, 2], ffn_scale=2.0).train().to(dev)
 ddp = wm.trainer.wrap_ddp(net, dev)
 opt = wm.trainer.make_optimizer(ddp)
-g = torch.Generator().manual_seed(1234 + rank)
+g = torch.Generator().manual_seed(bench.image_seed(rank))
 lq = torch.rand(args.batch, 3, args.size, args.size, generator=g).to(dev)
 gt = torch.rand(args.batch, 3, args.size, args.size, generator=g).to(dev)
+state = {}
+
+
+def step():
+    state["losses"] = wm.trainer.train_step(ddp, opt, lq, gt)
+
+
 for _ in range(args.warmup):
-    losses = wm.trainer.train_step(ddp, opt, lq, gt)
-torch.cuda.synchronize()
-if world > 1:
-    dist.barrier()
+    step()
 wm.ops.prof_enable(True)
-t0 = time.perf_counter()
-for _ in range(args.steps):
-    losses = wm.trainer.train_step(ddp, opt, lq, gt)
-torch.cuda.synchronize()
-if world > 1:
-    dist.barrier()
-el = time.perf_counter() - t0
+el = bench.timed_steps(step, args.steps, 0, torch.cuda.synchronize, dist.barrier if world > 1 else (lambda: None))
 prof = wm.ops.prof_collect(); wm.ops.prof_enable(False)
-if world > 1:
-    t = torch.tensor([el], device=dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); el = float(t)
+el = bench.max_over_ranks(el, world, dev)
+losses = state["losses"]
 if rank == 0:
-    print(json.dumps({"metric": "training images/sec (UHD-LL config, 512x512 crops)", "value": world * args.batch * args.steps / el,
+    print(json.dumps({"metric": "training images/sec (UHD-LL config, 512x512 crops)", "value": bench.whole_job_value(world, args.steps, args.batch, el),
                       "unit": "images/s", "n_gpus": world, "steps": args.steps, "ms_per_step": 1e3 * el / args.steps,
                       "scaling": "weak", "dtype": "f32", "data": "synthetic",
                       "config": {"workload": f"batch {args.batch} x 3x{args.size}x{args.size} per GPU, L1 + 0.1 FFT loss, AdamW, DDP"},

@@ -110,8 +110,9 @@ __device__ __forceinline__ void store_rows64(float* __restrict__ plane0 /* chann
 }
 
 // ---- lfss_mid: ysum, z, tok -> tok1 (B, L, C), f (B, D, L) -------------------------------------------
+template <int NY>      // NY = 1: merged core output; NY = 4: the four directions' outputs, added here (:490)
 __global__ __launch_bounds__(256, WM_LFSS_MID_WAVES) void lfss_mid_mfma_kernel(
-    const float* __restrict__ ysum, int ny, long long ystride, const float* __restrict__ z, const float* __restrict__ tok, int tok_nchw,
+    const float* __restrict__ ysum, long long ystride, const float* __restrict__ z, const float* __restrict__ tok, int tok_nchw,
     const float* __restrict__ on_w, const float* __restrict__ on_b, float on_eps,
     const float* __restrict__ W_out /*(C, D)*/, const float* __restrict__ skip1,
     const float* __restrict__ ln2_w, const float* __restrict__ ln2_b, float ln2_eps,
@@ -154,13 +155,13 @@ __global__ __launch_bounds__(256, WM_LFSS_MID_WAVES) void lfss_mid_mfma_kernel(
         const float* yp = ysum + b * D * L + pc;
         const float* zp = z + b * D * L + pc;
         float y[D];
-        if (ny == 1) {
+        if constexpr (NY == 1) {
 #pragma unroll
             for (int d = 0; d < D; ++d) y[d] = yp[(long long)d * L];
         } else {
             // the four directions' outputs, added in the reference's order y1 + y2 + y3 + y4 (:490) =
-            // [row fwd] + [row rev] + [col fwd] + [col rev]; explicit batches of 8 channels x 4 buffers in flight
-            constexpr int YB = 8;
+            // [row fwd] + [row rev] + [col fwd] + [col rev]; explicit batches of 4 channels x 4 buffers in flight (8 x 4 spills at 128 registers)
+            constexpr int YB = 4;
 #pragma unroll
             for (int d0 = 0; d0 < D; d0 += YB) {
                 float t[4][YB];
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(256, WM_LFSS_MID_WAVES) void lfss_mid_mfma_kernel(
                     for (int i = 0; i < YB; ++i) t[q][i] = yp[q * ystride + (long long)(d0 + i) * L];
 #pragma unroll
                 for (int i = 0; i < YB; ++i) y[d0 + i] = ((t[0][i] + t[1][i]) + t[2][i]) + t[3][i];
+                __builtin_amdgcn_sched_barrier(0);       // one batch of loads in flight, not all 256 (spills)
             }
         }
         float mean = 0.0f;

@@ -289,6 +289,7 @@ const char* wm_strerror(int code) {
         case WM_EALIGN: return "pointer not aligned to its element size";
         case WM_EWORKSPACE: return "workspace too small";
         case WM_EUNSUPPORTED: return "argument combination not supported";
+        case WM_EHIP: return "a HIP runtime call made on behalf of the launch failed";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }
@@ -952,10 +953,12 @@ int wm_lfss_mid_fwd(const float* ysum, int ny, int64_t ystride, const float* z, 
         const long long waves = (ngroups + gpw - 1) / gpw;
         hipStream_t st = (hipStream_t)stream;
         ProfScope ps(5, st);
-        hipLaunchKernelGGL(lfss_mid_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ysum, ny,
-                           (long long)ystride, z, tok, tok_nchw,
-                           out_norm_w, out_norm_b, out_norm_eps, out_proj_weight, skip_scale, ln2_w, ln2_b, ln2_eps,
-                           conv1_weight, conv1_bias, tok1, f, B, (long long)L, ngl, ngroups, gpw);
+#define WM_MID(NY) hipLaunchKernelGGL(lfss_mid_mfma_kernel<NY>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ysum, \
+                           (long long)ystride, z, tok, tok_nchw,                                                                   \
+                           out_norm_w, out_norm_b, out_norm_eps, out_proj_weight, skip_scale, ln2_w, ln2_b, ln2_eps,               \
+                           conv1_weight, conv1_bias, tok1, f, B, (long long)L, ngl, ngroups, gpw)
+        if (ny == 4) WM_MID(4); else WM_MID(1);
+#undef WM_MID
         return launch_status();
     }
     WM_LFSS_DISPATCH(lfss_mid_kernel, ysum, ny, (long long)ystride, z, tok, tok_nchw, out_norm_w, out_norm_b, out_norm_eps, out_proj_weight,

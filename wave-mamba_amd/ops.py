@@ -876,7 +876,7 @@ def conv2d_supported(x, weight, x2=None):
 # ------------------------------------------------------------------------------------------------
 PROF_KERNELS = ("haar_analysis", "haar_synthesis", "selscan_chunk_reduce", "selscan_carry",
                 "selscan_chunk_scan", "lfss_glue", "ss2d_proj", "dwconv3x3",
-                "ss2d_row_scan", "ss2d_col_scan", "ss2d_row_reduce", "ss2d_col_reduce", "selscan_bwd",
+                "ss2d_core_scan", "ss2d_legacy_scan", "ss2d_core_reduce", "ss2d_legacy_reduce", "selscan_bwd",
                 "conv3x3", "conv1x1", "skff")
 
 

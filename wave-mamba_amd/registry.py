@@ -2,8 +2,8 @@
 (/root/reference/basicsr/utils/registry.py:4-82): register() as decorator or call, get(), `in`,
 iteration, keys(), and the uniqueness assertion of _do_register (:38-41).
 
-When the user's `basicsr` package is importable (the arch file dropped into basicsr/archs/), the
-real basicsr ARCH_REGISTRY is used instead, so `build_network({'type': 'WaveMamba', ...})` finds it.
+This is the registry of the stand-alone package.  Inside a basicsr tree the arch file binds to basicsr's own
+ARCH_REGISTRY (see archs/wavemamba_arch.py and INTEGRATION.md).
 """
 
 
@@ -41,15 +41,11 @@ class Registry:
         return self._obj_map.keys()
 
 
-def _resolve_arch_registry():
-    try:                                     # dropped into a real basicsr tree
-        from basicsr.utils.registry import ARCH_REGISTRY as reg
-        return reg
-    except Exception:
-        return Registry("arch")
-
-
-ARCH_REGISTRY = _resolve_arch_registry()
+# The package keeps its OWN registry.  It must not bind to basicsr's: when wavemamba_arch.py is dropped into
+# basicsr/archs/, that copy registers `WaveMamba` in basicsr's ARCH_REGISTRY itself, and importing this package from it
+# (for the operators) would otherwise register the package's class under the same name first - the uniqueness assertion
+# of basicsr's Registry._do_register (:38-41) then fails (tests/test_dropin_basicsr.py).
+ARCH_REGISTRY = Registry("arch")
 
 
 def build_network(opt):

@@ -88,11 +88,14 @@ def save_network(net, path, current_iter=-1, epoch=0, param_key="params"):
     return path
 
 
-def load_network(net, path, strict=True, param_key="params"):
+def load_network(net, path, strict=True, param_key="params", weights_only=True):
     """Counterpart of base_model.py:299-326: `param_key` falls back to 'params' when absent (None = the file is the
     bare state dict), 'module.' prefixes are dropped, and with strict=False tensors whose shape differs are skipped
-    instead of raising.  Returns (missing_keys, unexpected_keys, skipped_for_shape)."""
-    blob = torch.load(path, map_location="cpu", weights_only=False)
+    instead of raising.  Returns (missing_keys, unexpected_keys, skipped_for_shape).
+    Reference-format files hold only tensors, ints, strs and (Ordered)dicts, so they load with `weights_only=True`
+    (no arbitrary pickle code from a third-party checkpoint); pass weights_only=False for a trusted legacy file that
+    pickles other objects."""
+    blob = torch.load(path, map_location="cpu", weights_only=weights_only)
     if param_key is not None:
         if param_key not in blob and "params" in blob:
             param_key = "params"
@@ -119,10 +122,10 @@ def save_training_state(path, epoch, current_iter, optimizers, schedulers=()):
     return path
 
 
-def resume_training(path_or_state, optimizers, schedulers=()):
-    """base_model.py:359-373.  Returns (epoch, iter)."""
+def resume_training(path_or_state, optimizers, schedulers=(), weights_only=True):
+    """base_model.py:359-373.  Returns (epoch, iter).  `weights_only` as in load_network."""
     st = path_or_state if isinstance(path_or_state, dict) else torch.load(path_or_state, map_location="cpu",
-                                                                            weights_only=False)
+                                                                            weights_only=weights_only)
     if len(st["optimizers"]) != len(optimizers) or len(st["schedulers"]) != len(schedulers):
         raise ValueError("resume_training: optimizer / scheduler count differs from the saved state")
     for o, s in zip(optimizers, st["optimizers"]):
