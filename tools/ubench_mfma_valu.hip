@@ -5,13 +5,14 @@
 //   2  every wave: 1 MFMA + 8 packed FMA interleaved in one instruction stream
 //   3  waves 0-3 MFMA only, waves 4-7 packed-FMA only (one of each per SIMD)
 //   4/5/6 = 0/2/3 with the bf16 MFMA (v_mfma_f32_16x16x32_bf16)
+//   VK = 1: the VALU work is v_exp_f32 (48 per 12 MFMA) instead of v_pk_fma_f32; VK = 2: plain v_fma_f32 (96)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
-template <int MODE>
+template <int MODE, int VK>
 __global__ __launch_bounds__(512) void k(float* out, int iters) {
     const int wv = threadIdx.x >> 6;
     f4 acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -35,8 +36,16 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
                 else acc[u % 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, xb, acc[u % 3], 0, 0, 0);
             }
             if (do_valu) {
+                if constexpr (VK == 0) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = v[i] * a + b;
+                    for (int i = 0; i < 8; ++i) v[i] = v[i] * a + b;
+                } else if constexpr (VK == 1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i].x = __builtin_amdgcn_exp2f(v[i].x);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i].x = fmaf(v[i].x, a.x, b.x);
+                }
             }
         }
     }
@@ -48,12 +57,12 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
-template <int MODE> static void run(float* d, const char* name) {
+template <int MODE, int VK = 0> static void run(float* d, const char* name) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 20000;
-    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(512), 0, 0, d, 10);
+    hipLaunchKernelGGL((k<MODE, VK>), dim3(256), dim3(512), 0, 0, d, 10);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(512), 0, 0, d, iters);
+    hipLaunchKernelGGL((k<MODE, VK>), dim3(256), dim3(512), 0, 0, d, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     // per SIMD: 2 waves; per wave per iteration 12 MFMA and / or 96 packed FMA
@@ -68,5 +77,13 @@ int main() {
     run<4>(d, "bf16 MFMA 16x16x32 only");
     run<5>(d, "bf16 MFMA + pk_fma interleaved in every wave");
     run<6>(d, "bf16 MFMA waves beside pk_fma waves");
+    run<1, 1>(d, "v_exp_f32 only (48 per iteration per wave)");
+    run<2, 1>(d, "f32 MFMA + v_exp_f32 interleaved in every wave");
+    run<3, 1>(d, "f32 MFMA waves beside v_exp_f32 waves");
+    run<5, 1>(d, "bf16 MFMA + v_exp_f32 interleaved in every wave");
+    run<1, 2>(d, "v_fma_f32 only (96 per iteration per wave)");
+    run<2, 2>(d, "f32 MFMA + v_fma_f32 interleaved in every wave");
+    run<3, 2>(d, "f32 MFMA waves beside v_fma_f32 waves");
+    run<5, 2>(d, "bf16 MFMA + v_fma_f32 interleaved in every wave");
     return 0;
 }

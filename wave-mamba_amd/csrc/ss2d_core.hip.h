@@ -35,6 +35,12 @@
 #ifndef WM_CORE_ABLATE
 #define WM_CORE_ABLATE 0          // timing experiments only (wrong results): 1 = no MFMA, 2 = no scan steps, 4 = no y store
 #endif
+#ifndef WM_CORE_STAMP
+#define WM_CORE_STAMP 0           // diagnostics: per-wave s_memtime phase totals into CoreArgs::stamps (tools/core_stamps.py)
+#endif
+#ifndef WM_CORE_ROW_SYNC
+#define WM_CORE_ROW_SYNC 0        // row directions: workgroup barrier every this many tiles (0 = never), see core_body
+#endif
 #ifndef WM_CORE_STEP_FENCE
 #define WM_CORE_STEP_FENCE 1      // scheduling barrier after every scan step
 #endif
@@ -55,6 +61,7 @@ struct CoreArgs {
     float* wsH[4];
     int B, D, H, W, L, N, R;
     int row_chunk, row_nchunks, row_wgs;        // steps per row chunk (multiple of 16), chunks, workgroups per direction
+    unsigned long long* stamps;                 // WM_CORE_STAMP builds: [workgroup][wave][12] cycle totals / stamps, else unused
     int dirmask;                                // bit k set: direction k runs (tools: time one direction alone)
     int col_seg, col_nseg, col_tiles, col_wgs;  // rows per column segment (multiple of 16), segments, column tiles,
                                                 // workgroup slots per direction (col_tiles * col_nseg rounded up to 8)
@@ -73,6 +80,14 @@ template <int NP, int NW> constexpr int core_lds_bytes() {
     return (CoreCfg<NP>::WF + CoreCfg<NP>::AF + NW * CoreCfg<NP>::XT + NW * 16 * CoreCfg<NP>::RS) * 4;
 }
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() also drains the vector-memory counter
+// (s_waitcnt vmcnt(0)): in the column directions that made every barrier wait for the next tile's prefetch and for the
+// y stores of the tile just written - ~5,000 cycles per tile (tools/core_stamps.py).  Nothing in these kernels hands
+// global data from one wave to another, so the LDS counter is all a barrier has to wait for.
+__device__ __forceinline__ void core_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ void core_lds_fence() {       // LDS hand-off between the lanes of ONE wave
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -87,6 +102,9 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
     constexpr int NTB = Cfg::NTB, NQ = Cfg::NQ, RS = Cfg::RS, ROW = Cfg::ROW, XT = Cfg::XT;
     constexpr int NT = (PHASE == 3 ? 2 * NTB : NTB) + 1;           // MFMA row tiles this phase needs: dt, B.., (C..)
     constexpr int QPR = NW / 4;                                    // float4 per tile row of a column-mode fetch
+#if WM_CORE_STAMP
+    const unsigned long long st_entry = wall_clock64();          // 100 MHz, chip-wide (the cycle counter is per compute unit)
+#endif
     float* s_w = smem;
     v2f* s_a2 = reinterpret_cast<v2f*>(smem + Cfg::WF);
     float* s_x = smem + Cfg::WF + Cfg::AF;
@@ -203,33 +221,38 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
     const int trow = lane >> 2, tq = lane & 3;
     // Loads are UNCONDITIONAL with clamped offsets (an `ok ? load : 0` compiles to a branch around the load plus
     // register copies behind it, i.e. a wait for the load right where it was issued); invalid elements are zeroed when
-    // the tile is staged, one tile later.
-    auto tile_ok = [&](int ti, int i) -> bool {          // is float4 i of this thread inside the tile's valid region?
-        const int t0 = t_begin + 16 * ti;
-        const int tl = min(16, t_end - t0);
+    // the tile is staged, one tile later.  Per thread and float4 i: element offset = tbase[i] + ti * tdelta (D * L < 2^31,
+    // host check), valid iff the static mask bit i is set and the thread's tile column (row mode) / tile row (column
+    // mode) `vc` lies in the tile's valid range - only a chunk's last tile is ever partial.
+    unsigned tbase[4];
+    int smask = 0, vc, tdelta;
+    if (!COL) {
+        vc = 4 * tq;                                     // L % 4 == 0, chunk % 16 == 0: quads are all-in or all-out
+        tdelta = REV ? -16 : 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = 16 * i + trow;
+            tbase[i] = (unsigned)ch * (unsigned)L + (unsigned)((REV ? (int)L - 16 - t_begin : t_begin) + 4 * tq);
+            smask |= (ch < D) << i;
+        }
+    } else {
+        vc = (tid / QPR) & 15;                           // the same tile row for every i (64 * NW / QPR is a multiple of 16)
+        tdelta = REV ? -16 * W : 16 * W;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = i * 64 * NW + tid;
+            const int q = e % QPR, ch = e / (QPR * 16);
+            const int wq = wlo + 4 * q;                                              // W % 4 == 0
+            tbase[i] = ((unsigned)ch * (unsigned)H + (unsigned)((REV ? H - 16 - t_begin : t_begin) + vc)) * (unsigned)W + (unsigned)wq;
+            smask |= (ch < D && wq >= 0 && wq < W) << i;
+        }
+    }
+    auto tile_ok = [&](int ti, int i) -> bool {
+        const int tl = min(16, t_end - (t_begin + 16 * ti));
         const int v_lo = REV ? 16 - tl : 0, v_hi = REV ? 16 : tl;
-        if (!COL) {
-            const int c = 4 * tq;
-            return c >= v_lo && c < v_hi && 16 * i + trow < D;    // L % 4 == 0, chunk % 16 == 0: quads all-in or all-out
-        } else {
-            const int e = i * 64 * NW + tid;
-            const int q = e % QPR, r = (e / QPR) & 15, ch = e / (QPR * 16);
-            const int wq = wlo + 4 * q;
-            return r >= v_lo && r < v_hi && wq >= 0 && wq < W && ch < D;             // W % 4 == 0
-        }
+        return ((smask >> i) & 1) && vc >= v_lo && vc < v_hi;
     };
-    auto tile_off = [&](int ti, int i) -> unsigned {     // element offset of float4 i inside the batch item (D * L < 2^31)
-        const int t0 = t_begin + 16 * ti;
-        if (!COL) {
-            const int plo = REV ? ((int)L - 16 - t0) : t0;
-            return (unsigned)(16 * i + trow) * (unsigned)L + (unsigned)(plo + 4 * tq);
-        } else {
-            const int hlo = REV ? H - 16 - t0 : t0;
-            const int e = i * 64 * NW + tid;
-            const int q = e % QPR, r = (e / QPR) & 15, ch = e / (QPR * 16);
-            return ((unsigned)ch * (unsigned)H + (unsigned)(hlo + r)) * (unsigned)W + (unsigned)(wlo + 4 * q);
-        }
-    };
+    auto tile_off = [&](int ti, int i) -> unsigned { return tbase[i] + (unsigned)(ti * tdelta); };
     auto fetch = [&](int ti) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -257,11 +280,26 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
         }
     };
 
+#if WM_CORE_STAMP == 1
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long st_kernel = st_entry;
+    unsigned long long st_prev = __builtin_readcyclecounter();
+    const unsigned long long st_begin = st_prev;
+#define WM_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); st_acc[i] += now_ - st_prev; st_prev = now_; }
+#else
+#define WM_STAMP(i)
+#endif
     fetch(0);
     for (int ti = 0; ti < ntiles; ++ti) {
         stage(ti);
-        if (COL) __syncthreads(); else core_lds_fence();
-        if (ti + 1 < ntiles) fetch(ti + 1);
+        if (COL) core_barrier(); else core_lds_fence();
+        WM_STAMP(0)                                      // stage (incl. the wait for the tile's loads) + barrier
+        // The next tile's loads are issued after the first four scan steps, not here: on gfx950 loads and stores share
+        // one counter, and the compiler guards the reuse of the prefetch registers with waits that assume the loads
+        // are the youngest vector-memory operations - issued here, right behind the previous tile's y stores, they made
+        // every wave sit out the stores' latency (~2,300 cycles per tile in the column directions).
+        if (!active && ti + 1 < ntiles) fetch(ti + 1);   // (a wave without a sequence still moves its share of the tile)
+        WM_STAMP(1)
         const int tl = min(16, t_end - (t_begin + 16 * ti));
 
         if (active) {
@@ -270,20 +308,35 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = (core_f4){0.f, 0.f, 0.f, 0.f};
             const int g4 = lane >> 4, c16 = lane & 15;
+            // always all 16 K-steps (channels >= D carry zero weights and zero-filled tile rows): a run-time K count
+            // turns every step into its own branch and the compiler stops overlapping them
+            constexpr int KS = (WM_CORE_ABLATE & 1) ? 1 : 16;
+            // software pipeline: the operands of K-step s + 1 are read while the MFMAs of step s issue (left alone the
+            // compiler read, waited and multiplied one K-step at a time: 16 exposed LDS latencies per tile).  Two
+            // register sets, used alternately and fed to the MFMAs as they are: a VALU copy in between would cost its
+            // own issue slot plus the VALU-write -> MFMA-read wait states.
+            float xv[2];
+            float4 wq[2][NQ];
+            xv[0] = sx[g4 * ROW + c16];
 #pragma unroll
-            for (int s = 0; s < ((WM_CORE_ABLATE & 1) ? 1 : 16); ++s) {
-                if (4 * s < D) {                                                      // uniform
-                    const float xv = sx[(4 * s + g4) * ROW + c16];
-                    float wf[4 * NQ];
+            for (int q = 0; q < NQ; ++q)
+                if (4 * q < NT) wq[0][q] = *reinterpret_cast<const float4*>(&s_w[(q * 64 + lane) * 4]);
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        if (4 * q < NT) {
-                            const float4 w4 = *reinterpret_cast<const float4*>(&s_w[((s * NQ + q) * 64 + lane) * 4]);
-                            wf[4 * q] = w4.x; wf[4 * q + 1] = w4.y; wf[4 * q + 2] = w4.z; wf[4 * q + 3] = w4.w;
-                        }
+            for (int s = 0; s < KS; ++s) {
+                {
+                    if (s + 1 < KS) {
+                        xv[(s + 1) & 1] = sx[(4 * (s + 1) + g4) * ROW + c16];
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q)
+                            if (4 * q < NT)
+                                wq[(s + 1) & 1][q] = *reinterpret_cast<const float4*>(&s_w[(((s + 1) * NQ + q) * 64 + lane) * 4]);
                     }
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t], xv, acc[t], 0, 0, 0);
+                    for (int t = 0; t < NT; ++t) {
+                        const float4 w4 = wq[s & 1][t >> 2];
+                        const float wv_ = (t & 3) == 0 ? w4.x : (t & 3) == 1 ? w4.y : (t & 3) == 2 ? w4.z : w4.w;
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv_, xv[s & 1], acc[t], 0, 0, 0);
+                    }
                 }
             }
             // D layout: lane holds rows 4 g4 .. 4 g4 + 3 of tile column c16
@@ -294,6 +347,7 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
                 for (int t = 1; t < NT; ++t) *reinterpret_cast<core_f4*>(rc + 4 + 16 * (t - 1) + 4 * g4) = acc[t];
             }
             core_lds_fence();
+            WM_STAMP(2)                                  // projection + record write
 
             // ---- 16 scan steps ----
             // The record addresses are wave-uniform; left to itself the compiler forms each of the ~40 per quad in an
@@ -301,6 +355,7 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
             // puts them in the instructions' offset fields instead.
 #pragma unroll 1
             for (int q = 0; q < ((WM_CORE_ABLATE & 2) ? 0 : 4); ++q) {
+                if (q == 1 && ti + 1 < ntiles) fetch(ti + 1);            // uniform; see the note at the top of the tile loop
                 const int cq = REV ? 3 - q : q;
                 const float4 u4 = *reinterpret_cast<const float4*>(&sx[lane * ROW + 4 * cq]);
                 const float uu[4] = {REV ? u4.w : u4.x, REV ? u4.z : u4.y, REV ? u4.y : u4.z, REV ? u4.x : u4.w};
@@ -355,6 +410,7 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
             }
         }
 
+        WM_STAMP(3)                                      // 16 scan steps
         if (PHASE == 3 && !(WM_CORE_ABLATE & 4)) {
             if (!COL) {
                 core_lds_fence();
@@ -365,27 +421,63 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
                             *reinterpret_cast<const float4*>(&sx[(16 * i + trow) * ROW + 4 * tq]);
                 core_lds_fence();                        // the y tile is read before the next stage() overwrites it
             } else {
-                __syncthreads();
+                core_barrier();
+                float v[4][4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int e = i * 64 * NW + tid;
                     const int q = e % QPR, r = (e / QPR) & 15, ch = e / (QPR * 16);
-                    float v[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int cc = 4 * q + j;
                         const int owner = REV ? NW - 1 - cc : cc;
-                        v[j] = s_x[owner * XT + ch * ROW + r];
+                        v[i][j] = s_x[owner * XT + ch * ROW + r];
                     }
-                    if (tile_ok(ti, i))
-                        *reinterpret_cast<float4*>(yb + tile_off(ti, i)) = make_float4(v[0], v[1], v[2], v[3]);
                 }
-                __syncthreads();
+                // a fully valid tile (the usual case) stores without per-element branches: the 16 LDS reads above are
+                // in flight together instead of four read-wait-store rounds
+                const bool full = tl == 16 && D == 64 && wlo >= 0 && wlo + NW <= W;     // uniform
+                if (full) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        *reinterpret_cast<float4*>(yb + tile_off(ti, i)) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (tile_ok(ti, i))
+                            *reinterpret_cast<float4*>(yb + tile_off(ti, i)) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+                }
+                core_barrier();
             }
         } else if (COL) {
-            __syncthreads();                             // every wave is done with its tile before the next stage()
+            core_barrier();                             // every wave is done with its tile before the next stage()
         }
+        WM_STAMP(4)                                      // y store (+ barriers)
+        // Row directions need no barrier (wave-private tiles).  Free-running, the four waves of a SIMD drift apart (the
+        // scheduler favours the oldest: wave lifetimes 500 .. 1,150 us inside one workgroup, tools/core_stamps.py), but
+        // bounding the drift with a barrier every 1 / 2 / 4 tiles changed the launch time by < 1 %: off by default.
+        // (Waves that have ended - shorter last chunk, no chunk at all - no longer count towards s_barrier.)
+        if (!COL && WM_CORE_ROW_SYNC > 0 && (ti % (WM_CORE_ROW_SYNC > 0 ? WM_CORE_ROW_SYNC : 1)) == WM_CORE_ROW_SYNC - 1)
+            core_barrier();
     }
+#if WM_CORE_STAMP == 2
+    if (lane == 0 && p.stamps) {          // light mode: workgroup entry / exit only (no per-phase accumulators, no scratch)
+        unsigned long long* o = p.stamps + ((unsigned long long)blockIdx.x * NW + wv) * 12;
+        o[6] = (unsigned long long)ntiles; o[7] = (unsigned long long)k; o[8] = st_entry; o[10] = wall_clock64();
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); o[11] = xcc & 15;
+    }
+#endif
+#if WM_CORE_STAMP == 1
+    if (lane == 0 && p.stamps) {
+        unsigned long long* o = p.stamps + ((unsigned long long)blockIdx.x * NW + wv) * 12;
+        for (int i = 0; i < 5; ++i) o[i] = st_acc[i];
+        const unsigned long long st_end = __builtin_readcyclecounter();
+        o[5] = st_end - st_begin; o[6] = (unsigned long long)ntiles; o[7] = (unsigned long long)k;
+        o[8] = st_kernel; o[9] = st_begin; o[10] = st_end;
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); o[11] = xcc & 15;
+    }
+#endif
+#undef WM_STAMP
 
     if (PHASE == 1 && active && live) {
 #pragma unroll
@@ -404,8 +496,10 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
 // Workgroup -> (batch, direction, slot).  Per batch: 2 * row_wgs row slots (k = 0 / 2 interleaved), then 2 * col_wgs
 // column slots (k = 1 / 3 interleaved).  Column tiles 2 i and 2 i + 1 share every 128-byte line of x and y: their
 // slots are 8 workgroup ids apart, i.e. on the same XCD (workgroup id -> XCD id % 8), whose L2 then holds the line.
+// second launch-bound: minimum waves per SIMD (N <= 16: four, i.e. <= 128 registers - one 16-wave or two 8-wave
+// workgroups per compute unit; N = 32: two)
 template <int NP, int NW, int PHASE, bool RHI>
-__global__ __launch_bounds__(64 * NW) void ss2d_core_kernel(CoreArgs p) {
+__global__ __launch_bounds__(64 * NW, NP == 16 ? 4 : 2) void ss2d_core_kernel(CoreArgs p) {
     extern __shared__ __attribute__((aligned(16))) float core_smem[];
     const int per_b = 2 * p.row_wgs + 2 * p.col_wgs;
     const int b = blockIdx.x / per_b;

@@ -730,6 +730,13 @@ int wm_ss2d_core_fwd(const float* x, const float* x_proj_weight, const float* dt
     a.y[3] = merged ? (float*)(yt + 2 * pl.ytmp_bytes) : y_col_rev;
     a.B = B; a.D = D; a.H = H; a.W = W; a.L = H * W; a.N = N; a.R = R;
     a.row_chunk = pl.row_chunk; a.row_nchunks = pl.row_nchunks; a.row_wgs = pl.row_wgs;
+    a.stamps = nullptr;
+#if WM_CORE_STAMP
+    {   // diagnostics build: WM_CORE_STAMPS=<device pointer, decimal> receives [workgroups][waves][8] cycle totals of the scan launch
+        const char* e = getenv("WM_CORE_STAMPS");
+        a.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 10) : nullptr;
+    }
+#endif
     {   // WM_CORE_DIRMASK (tools only): run a subset of the four directions, e.g. 1 = row forward alone
         static const int mask = [] { const char* e = getenv("WM_CORE_DIRMASK"); return e ? atoi(e) : 15; }();
         a.dirmask = mask;
