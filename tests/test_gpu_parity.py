@@ -807,6 +807,46 @@ def test_conv2d_weight_update_invalidates_prepared_copy():
     ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1).float()
     assert_close(y1, ref.cpu(), 2e-5, "conv2d after in-place weight update")
     assert not torch.allclose(y0, y1)
+    # a write through .data does not bump the version counter: the explicit hook (called by WaveMamba.train() / .eval() /
+    # ._apply() and trainer.load_network) drops the stale copy
+    conv.weight.data.mul_(0.5)
+    wm.ops.conv2d_cache_clear()
+    assert_close(wm.ops.conv2d(x, conv.weight, conv.bias), y0.cpu(), 2e-5, "conv2d after .data update + cache clear")
+    # a prepared copy built on one stream and first used from another: the using stream waits for the preparation
+    wm.ops.conv2d_cache_clear()
+    side = torch.cuda.Stream(DEV)
+    torch.cuda.synchronize()
+    ya = wm.ops.conv2d(x, conv.weight, conv.bias)              # builds the copy on the current stream
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        yb = wm.ops.conv2d(x, conv.weight, conv.bias)          # same copy, other stream
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb)
+
+
+def test_fused_adamw_step_then_inference_uses_fresh_weights():
+    """a fused multi-tensor AdamW step followed by a no_grad forward must see the updated weights in the
+    inference convolutions' prepared copies."""
+    torch.manual_seed(0)
+    net = wm.WaveMamba(in_chn=3, wf=8, n_l_blocks=[1, 1, 1], n_h_blocks=[1, 1, 1], ffn_scale=2.0).to(DEV)
+    x = torch.rand(1, 3, 32, 48, generator=gen(2)).to(DEV)
+    net.eval()
+    with torch.no_grad():
+        y0 = net(x)
+    net.train()
+    opt = wm.trainer.make_optimizer(net)
+    wm.trainer.train_step(net, opt, x, torch.rand(1, 3, 32, 48, generator=gen(3)).to(DEV))
+    net.eval()
+    with torch.no_grad():
+        y1 = net(x)
+        saved = wm.ops.conv2d_supported
+        wm.ops.conv2d_supported = lambda *a, **k: False        # the same weights through PyTorch's convolutions
+        try:
+            y_ref = net(x)
+        finally:
+            wm.ops.conv2d_supported = saved
+    assert not torch.allclose(y0, y1)
+    assert_close(y1, y_ref, 1e-4, "forward after an optimizer step")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1019,6 +1059,18 @@ def test_uint8_pipeline_matches_sequential(golden):
         with torch.no_grad():
             ref = wm.ops.image_post_u8(net.restoration_network(wm.ops.image_pre_u8(t)), im.shape[0], im.shape[1])
         assert o.shape == im.shape and np.array_equal(o, ref.cpu().numpy())
+    # images large enough for the GPU to lag behind the host, shapes alternating (every slot is re-allocated and re-used
+    # while the previous forward is still queued): the cross-stream orderings of upload() are what keeps this exact
+    big = [rng.integers(0, 256, size=((520, 776, 3) if i % 2 else (392, 1000, 3)), dtype=np.uint8) for i in range(7)]
+    refs = []
+    for im in big:
+        with torch.no_grad():
+            refs.append(wm.ops.image_post_u8(net.restoration_network(wm.ops.image_pre_u8(torch.from_numpy(im).to(DEV))),
+                                             im.shape[0], im.shape[1]).cpu().numpy())
+    for rep in range(2):
+        outs = list(pipe.run(big))
+        for o, r in zip(outs, refs):
+            assert np.array_equal(o, r)
 
 
 @pytest.mark.parametrize("ks,B,Cin,Cout,H,W,bias", [(3, 2, 32, 64, 24, 40, True), (1, 1, 64, 32, 17, 33, True),

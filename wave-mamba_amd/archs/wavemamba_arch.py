@@ -713,6 +713,17 @@ class WaveMamba(nn.Module):
         self.restoration_network = UNet(in_chn=in_chn, wf=wf, n_l_blocks=n_l_blocks,
                                         n_h_blocks=n_h_blocks, ffn_scale=ffn_scale)
 
+    # The inference convolutions keep prepared (bf16-split) copies of their weights, validated by the parameters'
+    # version counters.  Writes through `.data` (EMA updates, weight surgery) do not bump those: every switch of mode
+    # and every device / dtype move drops the copies, so `net.eval()` after such an update is enough.
+    def train(self, mode=True):
+        _hip_ops.conv2d_cache_clear()
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        _hip_ops.conv2d_cache_clear()
+        return super()._apply(fn, *args, **kwargs)
+
     def print_network(self, model):
         print(model)
         print("The number of parameters: {}".format(sum(p.numel() for p in model.parameters())))

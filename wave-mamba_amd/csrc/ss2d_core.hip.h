@@ -402,8 +402,10 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
                         }
                         if (PHASE == 3)      // y overwrites the consumed u (same lane, same row)
                             sx[lane * ROW + 4 * cq + (REV ? 3 - j : j)] = fmaf(Dd, ut, y2.x + y2.y);
-#if WM_CORE_STEP_FENCE
+#if WM_CORE_STEP_FENCE == 1
                         __builtin_amdgcn_sched_barrier(0);   // keep the next step's record reads out of this step's registers
+#elif WM_CORE_STEP_FENCE == 2
+                        if (jj == 1) __builtin_amdgcn_sched_barrier(0);      // ... per pair of steps
 #endif
                     }
                 }
@@ -493,9 +495,13 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
 
 #undef WM_A2
 
-// Workgroup -> (batch, direction, slot).  Per batch: 2 * row_wgs row slots (k = 0 / 2 interleaved), then 2 * col_wgs
-// column slots (k = 1 / 3 interleaved).  Column tiles 2 i and 2 i + 1 share every 128-byte line of x and y: their
-// slots are 8 workgroup ids apart, i.e. on the same XCD (workgroup id -> XCD id % 8), whose L2 then holds the line.
+// Workgroup -> (batch, direction, slot).  Per batch: 2 * col_wgs column slots first (k = 1 / 3 interleaved), then
+// 2 * row_wgs row slots (k = 0 / 2 interleaved): the column workgroups are the long ones (a whole column segment, three
+// barriers per tile), the row workgroups are cut to about half their length by the host and fill in behind them
+// (longest-first list scheduling: with equal-length workgroups in id order the second round of the UHD level-1
+// launches ran 224 of 256 compute units for a whole workgroup lifetime).
+// Column tiles 2 i and 2 i + 1 share every 128-byte line of x and y: their slots are 8 workgroup ids apart, i.e. on the
+// same XCD (workgroup id -> XCD id % 8), whose L2 then holds the line.
 // second launch-bound: minimum waves per SIMD (N <= 16: four, i.e. <= 128 registers - one 16-wave or two 8-wave
 // workgroups per compute unit; N = 32: two)
 template <int NP, int NW, int PHASE, bool RHI>
@@ -504,18 +510,18 @@ __global__ __launch_bounds__(64 * NW, NP == 16 ? 4 : 2) void ss2d_core_kernel(Co
     const int per_b = 2 * p.row_wgs + 2 * p.col_wgs;
     const int b = blockIdx.x / per_b;
     int r = blockIdx.x - b * per_b;
-    if (r < 2 * p.row_wgs) {
-        const int wg = r >> 1;
-        if (!((p.dirmask >> ((r & 1) * 2)) & 1)) return;
-        if (r & 1) core_body<NP, NW, PHASE, RHI, false, true>(p, 2, b, wg, core_smem);
-        else core_body<NP, NW, PHASE, RHI, false, false>(p, 0, b, wg, core_smem);
-    } else {
-        r -= 2 * p.row_wgs;
+    if (r < 2 * p.col_wgs) {
         const int idx = r >> 1;
         const int wg = (((idx >> 3) << 2) + (idx & 3)) * 2 + ((idx >> 2) & 1);
         if (wg >= p.col_tiles * p.col_nseg || !((p.dirmask >> ((r & 1) * 2 + 1)) & 1)) return;
         if (r & 1) core_body<NP, NW, PHASE, RHI, true, true>(p, 3, b, wg, core_smem);
         else core_body<NP, NW, PHASE, RHI, true, false>(p, 1, b, wg, core_smem);
+    } else {
+        r -= 2 * p.col_wgs;
+        const int wg = r >> 1;
+        if (!((p.dirmask >> ((r & 1) * 2)) & 1)) return;
+        if (r & 1) core_body<NP, NW, PHASE, RHI, false, true>(p, 2, b, wg, core_smem);
+        else core_body<NP, NW, PHASE, RHI, false, false>(p, 0, b, wg, core_smem);
     }
 }
 

@@ -622,8 +622,13 @@ static int core_plan(CorePlan& pl, int B, int D, int H, int W, int N, int R, int
     pl.col_nseg = (H + seg - 1) / seg;
     pl.col_nchunks = (long long)W * pl.col_nseg;
     pl.col_wgs = ((pl.col_tiles * pl.col_nseg + 7) / 8) * 8;
-    // row directions: as many chunks as the column directions have (same per-wave work, same summary count)
-    long long want = (long long)pl.col_tiles * NW * pl.col_nseg;
+    // row directions: WM_CORE_ROW_SPLIT x as many chunks as the column directions have.  Shorter row workgroups behind
+    // the (long) column workgroups were tried to level the launch's tail: with 2x / 4x the row workgroups still arrive
+    // in whole rounds of 256, the launch time did not move and the carry grew - 1x (same per-wave work) is kept.
+#ifndef WM_CORE_ROW_SPLIT
+#define WM_CORE_ROW_SPLIT 1
+#endif
+    long long want = (long long)WM_CORE_ROW_SPLIT * pl.col_tiles * NW * pl.col_nseg;
     long long cl = (L + want - 1) / want;
     cl = ((cl + 15) / 16) * 16;
     if (cl < 32) cl = 32;

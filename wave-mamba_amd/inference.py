@@ -56,6 +56,8 @@ class UInt8Pipeline:
         self.net, self.device, self.window, self.swap_rb, self.ops = net, torch.device(device), window_size, swap_rb, ops
         self.up, self.down = torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)
         self._pin_in, self._pin_out, self._dev_in = [None, None], [None, None], [None, None]
+        self._up_done = [None, None]       # per slot: the last H2D copy out of pin_in[slot] (the host may then refill it)
+        self._consumed = [None, None]      # per slot: main-stream event after image_pre_u8 has read dev_in[slot]
 
     def _buf(self, store, slot, shape, pinned):
         t = store[slot]
@@ -69,19 +71,33 @@ class UInt8Pipeline:
     def run(self, images):
         import numpy as np
         main = torch.cuda.current_stream(self.device)
-        pending = []                                   # (pinned output, download-done event, slot)
-        out_free = [None, None]                        # events: the pinned output slot was consumed
+        pending = []                                   # (pinned output, download-done event)
         uploaded = None
         it = iter(images)
 
         def upload(img, slot):
+            """Stage `img` into slot: host -> pinned -> device on the upload stream.  Orderings (all cross-stream):
+              * the host refills pin_in[slot] only after the previous H2D copy out of it has finished;
+              * the H2D copy into dev_in[slot] waits for main's image_pre_u8 of the previous image of this slot;
+              * the device buffer is allocated with `up` current (its pool), waits for main when it is (re)allocated -
+                a fresh block may be memory that kernels still queued on main are using - and is recorded on main,
+                which reads it."""
             a = torch.from_numpy(np.ascontiguousarray(img))
+            if self._up_done[slot] is not None:
+                self._up_done[slot].synchronize()
             pin = self._buf(self._pin_in, slot, a.shape, True)
             pin.copy_(a)
-            dev = self._buf(self._dev_in, slot, a.shape, False)
             with torch.cuda.stream(self.up):
+                if self._consumed[slot] is not None:
+                    self.up.wait_event(self._consumed[slot])
+                old = self._dev_in[slot]
+                if old is None or tuple(old.shape) != tuple(a.shape):
+                    self.up.wait_stream(main)
+                dev = self._buf(self._dev_in, slot, a.shape, False)
                 dev.copy_(pin, non_blocking=True)
                 ev = torch.cuda.Event(); ev.record(self.up)
+            dev.record_stream(main)
+            self._up_done[slot] = ev
             return dev, ev
 
         nxt = next(it, None)
@@ -95,6 +111,8 @@ class UInt8Pipeline:
             main.wait_event(ev)
             h, w = dev.shape[:2]
             x = self.ops.image_pre_u8(dev, self.window, self.swap_rb)
+            c = torch.cuda.Event(); c.record(main)
+            self._consumed[slot] = c                   # dev_in[slot] may be overwritten by the upload stream after this
             y = self.net.restoration_network(x)
             res = self.ops.image_post_u8(y, h, w, self.swap_rb)
             done = torch.cuda.Event(); done.record(main)

@@ -680,17 +680,31 @@ def skff(x0, x1, x2, w_du, prelu, w_fc):
     return out
 
 
-_WFRAG_CACHE = {}      # id(weight) -> (weakref, data_ptr, version, wfrag tensor)
+_WFRAG_CACHE = {}      # id(weight) -> (weakref, data_ptr, version, wfrag tensor, prep-done event, stream it was built on)
+
+
+def conv2d_cache_clear():
+    """Drop every prepared (bf16-split) weight copy.  The cache validates an entry by (object, data_ptr, _version); a
+    write through `.data` (p.data.copy_(), basicsr-style EMA `.data.mul_().add_()`, weight surgery) does NOT bump the
+    version counter, so code that updates weights that way must call this (WaveMamba.train() / .eval() / ._apply() and
+    trainer.load_network do)."""
+    _WFRAG_CACHE.clear()
 
 
 def _conv2d_wfrag(weight, cache=True):
     """The prepared (bf16-split, fragment-ordered) copy of a (Cout, Cin, ks, ks) weight; rebuilt when the
     parameter is updated in place (`_version`) or re-allocated.  cache=False: a weight computed on the fly
-    (the folded attention), prepared every time."""
+    (the folded attention), prepared every time.  A cached copy built on another stream is waited for (event) and
+    recorded on the using stream, so multi-stream serving never reads it before the preparation kernel has finished
+    nor sees it freed under a pending launch."""
     import weakref
     key = id(weight)
+    cur = torch.cuda.current_stream(weight.device)
     ent = _WFRAG_CACHE.get(key) if cache else None
     if ent is not None and ent[0]() is weight and ent[1] == weight.data_ptr() and ent[2] == weight._version:
+        if ent[5] != cur.cuda_stream:
+            cur.wait_event(ent[4])
+            ent[3].record_stream(cur)
         return ent[3]
     lib = _lib.load()
     cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
@@ -699,8 +713,10 @@ def _conv2d_wfrag(weight, cache=True):
         check(lib.wm_conv2d_prep(_ptr(weight.detach().contiguous()), _ptr(frag), cout, cin, ks, _stream()),
               "wm_conv2d_prep")
     if cache:
+        ev = torch.cuda.Event()
+        ev.record(cur)
         _WFRAG_CACHE[key] = (weakref.ref(weight, lambda _r, k=key: _WFRAG_CACHE.pop(k, None)), weight.data_ptr(),
-                             weight._version, frag)
+                             weight._version, frag, ev, cur.cuda_stream)
     return frag
 
 

@@ -109,6 +109,8 @@ def load_network(net, path, strict=True, param_key="params", weights_only=True):
         for k in skipped:
             del state[k]
     res = target.load_state_dict(state, strict=strict)
+    from . import ops
+    ops.conv2d_cache_clear()                 # prepared weight copies of the inference convolutions
     return list(res.missing_keys), list(res.unexpected_keys), skipped
 
 
