@@ -122,22 +122,26 @@ int wm_selscan_bwd(const float* u, const float* delta, const float* A, const flo
  *   Supported: N <= 32, R <= 4, D <= 64 (else WM_EUNSUPPORTED: use wm_selscan_fwd); N > 16 needs W % 4 == 0.
  *   x and the y buffers must be 16-byte aligned when W % 4 == 0 (WM_EALIGN).
  *   The workspace size depends on `merged` (three temporary y buffers).
- * -------------------------------------------------------------------------------------------- */
+ */
 size_t wm_ss2d_core_fwd_workspace_bytes(int B, int D, int H, int W, int N, int R, int merged);
-int wm_ss2d_core_fwd(const float* x, const float* x_proj_weight, const float* dt_projs_weight,
+/*   plane_dtype: storage type of x and of the y buffers, WM_F32 or WM_BF16 (bf16-storage mode: bf16 planes between
+ *   the kernels, fp32 tiles / projection / state inside; needs W % 4 == 0).
+ */
+int wm_ss2d_core_fwd(const void* x, const float* x_proj_weight, const float* dt_projs_weight,
                      const float* dt_projs_bias, const float* A_logs, const float* Ds,
-                     float* y_row_fwd, float* y_row_rev, float* y_col_fwd, float* y_col_rev,
+                     void* y_row_fwd, void* y_row_rev, void* y_col_fwd, void* y_col_rev,
                      int merged, void* workspace, size_t workspace_bytes,
-                     int B, int D, int H, int W, int N, int R, void* stream);
+                     int B, int D, int H, int W, int N, int R, int plane_dtype, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * Depth-wise 3x3 convolution, stride 1, zero padding 1, + bias, + optional SiLU.
  * Replaces nn.Conv2d(groups=channels) + nn.SiLU of SS2D (wavemamba_arch.py:346-355, :487) and the
  * ffn's conv2 (:220, :226) in LFSSBlock.  x, y (B, C, H, W) fp32; weight (C, 1, 3, 3); bias (C) or
- * NULL; act: 0 = none, 1 = SiLU, 2 = GELU (exact erf form).  Forward only (training keeps the autograd conv).
+ * NULL; act: 0 = none, 1 = SiLU, 2 = GELU (exact erf form).  plane_dtype: storage type of x and y (WM_F32 / WM_BF16,
+ * fp32 arithmetic).  Forward only (training keeps the autograd conv).
  * -------------------------------------------------------------------------------------------- */
-int wm_dwconv3x3_fwd(const float* x, const float* weight, const float* bias, float* y,
-                     int B, int C, int H, int W, int act, void* stream);
+int wm_dwconv3x3_fwd(const void* x, const float* weight, const float* bias, void* y,
+                     int B, int C, int H, int W, int act, int plane_dtype, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * LFSSBlock / SS2D per-position glue around the scan core, fused (forward only; C in {8,16,32},
@@ -153,16 +157,19 @@ int wm_dwconv3x3_fwd(const float* x, const float* weight, const float* bias, flo
  *   wm_lfss_out_fwd : gelu gate (:227-228) + ffn.conv3 (:230) + skip_scale2 residual (:526)
  *                     fc, tok1 -> out
  * -------------------------------------------------------------------------------------------- */
+/* plane_dtype: storage type of the plane tensors x, z, ysum, f, fc (WM_F32; WM_BF16 at C = 32 - the bf16-storage
+ * mode); token tensors are always fp32. */
 int wm_lfss_in_fwd(const float* tok, int tok_nchw, const float* ln_w, const float* ln_b, float ln_eps,
-                   const float* in_proj_weight, float* x, float* z, int B, int64_t L, int C, void* stream);
-int wm_lfss_mid_fwd(const float* ysum, int ny, int64_t ystride, const float* z, const float* tok, int tok_nchw,
+                   const float* in_proj_weight, void* x, void* z, int B, int64_t L, int C, int plane_dtype, void* stream);
+int wm_lfss_mid_fwd(const void* ysum, int ny, int64_t ystride, const void* z, const float* tok, int tok_nchw,
                     const float* out_norm_w, const float* out_norm_b, float out_norm_eps,
                     const float* out_proj_weight, const float* skip_scale,
                     const float* ln2_w, const float* ln2_b, float ln2_eps,
                     const float* conv1_weight, const float* conv1_bias,
-                    float* tok1, float* f, int B, int64_t L, int C, void* stream);
-int wm_lfss_out_fwd(const float* fc, const float* tok1, const float* conv3_weight, const float* conv3_bias,
-                    const float* skip_scale2, float* out, int out_nchw, int B, int64_t L, int C, void* stream);
+                    float* tok1, void* f, int B, int64_t L, int C, int plane_dtype, void* stream);
+int wm_lfss_out_fwd(const void* fc, const float* tok1, const float* conv3_weight, const float* conv3_bias,
+                    const float* skip_scale2, float* out, int out_nchw, int B, int64_t L, int C, int plane_dtype,
+                    void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * LayerNorm2d of the HFE branch (first "next" row): per-pixel LayerNorm over the C

@@ -44,17 +44,17 @@ for lvl in args.levels:
     tok1, f, out = torch.empty(B, L, C, device=dev), torch.empty(B, D, L, device=dev), torch.empty(B, L, C, device=dev)
     st = _stream()
     t_in = timed(lambda: check(lib.wm_lfss_in_fwd(_ptr(tok), 0, _ptr(ln1w), _ptr(ln1b), 1e-5, _ptr(Win), _ptr(x), _ptr(z),
-                                                  B, L, C, st), "in"))
+                                                  B, L, C, 0, st), "in"))
     t_mid = timed(lambda: check(lib.wm_lfss_mid_fwd(_ptr(ysum), 1, 0, _ptr(z), _ptr(tok), 0, _ptr(onw), _ptr(onb), 1e-5, _ptr(Wout),
                                                     _ptr(sk1), _ptr(ln2w), _ptr(ln2b), 1e-5, _ptr(W1), _ptr(b1), _ptr(tok1),
-                                                    _ptr(f), B, L, C, st), "mid"))
+                                                    _ptr(f), B, L, C, 0, st), "mid"))
     y4 = rn(4, B, D, L)
     t_mid4 = timed(lambda: check(lib.wm_lfss_mid_fwd(_ptr(y4), 4, B * D * L, _ptr(z), _ptr(tok), 0, _ptr(onw), _ptr(onb), 1e-5, _ptr(Wout),
                                                      _ptr(sk1), _ptr(ln2w), _ptr(ln2b), 1e-5, _ptr(W1), _ptr(b1), _ptr(tok1),
-                                                     _ptr(f), B, L, C, st), "mid4"))
+                                                     _ptr(f), B, L, C, 0, st), "mid4"))
     t_sum = timed(lambda: y4[0].add_(y4[1]).add_(y4[2]).add_(y4[3]))
     t_out = timed(lambda: check(lib.wm_lfss_out_fwd(_ptr(fc), _ptr(tok1), _ptr(W3), _ptr(b3), _ptr(sk2), _ptr(out), 0,
-                                                    B, L, C, st), "out"))
+                                                    B, L, C, 0, st), "out"))
     fl = lambda bytes_pp: bytes_pp * L / 5.0e9          # ms at the 5 TB/s copy ceiling
     print(f"level {lvl} {H}x{W}: in {t_in:.3f} ms (floor {fl(640):.3f})  mid {t_mid:.3f} ms (floor {fl(1024):.3f})  mid(4y) {t_mid4:.3f} (floor {fl(1792):.3f}; torch 3 adds {t_sum:.3f})  "
           f"out {t_out:.3f} ms (floor {fl(512):.3f})  checksums {float(x.double().sum()):.6e} {float(z.double().sum()):.6e} "

@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("WAVEMAMBA_HIP_LIB") or os.path.join(HERE, "libwavemam
 
 WM_F32, WM_BF16 = 0, 1
 WM_PROF_NKERNELS = 16
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _c = ctypes
 _p, _i, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
@@ -28,20 +28,20 @@ SIGNATURES = {
     "wm_selscan_bwd_workspace_bytes": (_sz, [_i] * 5),
     "wm_selscan_bwd": (_i, [_p] * 15 + [_p, _sz] + [_i] * 6 + [_p]),
     "wm_ss2d_core_fwd_workspace_bytes": (_sz, [_i] * 7),
-    "wm_ss2d_core_fwd": (_i, [_p] * 10 + [_i, _p, _sz] + [_i] * 6 + [_p]),
+    "wm_ss2d_core_fwd": (_i, [_p] * 10 + [_i, _p, _sz] + [_i] * 7 + [_p]),
     "wm_ss2d_core_bwd_workspace_bytes": (_sz, [_i] * 6),
     "wm_ss2d_core_bwd": (_i, [_p] * 16 + [_p, _sz] + [_i] * 6 + [_p]),
-    "wm_lfss_in_fwd": (_i, [_p, _i, _p, _p, _c.c_float, _p, _p, _p, _i, _i64, _i, _p]),
+    "wm_lfss_in_fwd": (_i, [_p, _i, _p, _p, _c.c_float, _p, _p, _p, _i, _i64, _i, _i, _p]),
     "wm_lfss_mid_fwd": (_i, [_p, _i, _i64, _p, _p, _i, _p, _p, _c.c_float, _p, _p, _p, _p, _c.c_float, _p, _p, _p, _p,
-                             _i, _i64, _i, _p]),
-    "wm_lfss_out_fwd": (_i, [_p] * 6 + [_i, _i, _i64, _i, _p]),
+                             _i, _i64, _i, _i, _p]),
+    "wm_lfss_out_fwd": (_i, [_p] * 6 + [_i, _i, _i64, _i, _i, _p]),
     "wm_layernorm2d_fwd": (_i, [_p, _p, _p, _c.c_float, _p, _i, _i64, _i, _p]),
     "wm_gram_workspace_bytes": (_sz, [_i, _i, _i64]),
     "wm_gram_fwd": (_i, [_p] * 6 + [_sz, _i, _i, _i64, _p]),
     "wm_mul_sigmoid_fwd": (_i, [_p, _p, _p, _i64, _p]),
     "wm_dwconv3x3_wgrad": (_i, [_p] * 4 + [_i] * 4 + [_p]),
     "wm_layernorm2d_bwd": (_i, [_p, _p, _p, _c.c_float, _p, _p, _p, _i, _i64, _i, _p]),
-    "wm_dwconv3x3_fwd": (_i, [_p] * 4 + [_i] * 5 + [_p]),
+    "wm_dwconv3x3_fwd": (_i, [_p] * 4 + [_i] * 6 + [_p]),
     "wm_layernorm_tok_fwd": (_i, [_p, _p, _p, _c.c_float, _p, _i64, _i, _p]),
     "wm_layernorm_tok_bwd": (_i, [_p, _p, _p, _c.c_float, _p, _p, _p, _i64, _i, _p]),
     "wm_image_pre_u8": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),

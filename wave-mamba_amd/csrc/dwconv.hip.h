@@ -11,6 +11,7 @@
 // neighbouring lanes by wave shuffle (the strip edges of a wave read them from memory).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "haar.hip.h"          // bf16_t, load4 / store4 / ld1 (fp32 and bf16 overloads)
 
 namespace wm {
 
@@ -21,11 +22,12 @@ __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)
 // exact (erf) GELU, nn.GELU() default: FeedForward.project_out[1] after its depth-wise conv (reference :739-741)
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
-template <int ACT /*0 none, 1 silu, 2 gelu*/, bool VEC>
-__global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ x,
+// TP: storage type of the x / y planes (float, or bf16_t in the bf16-storage mode: fp32 arithmetic either way)
+template <int ACT /*0 none, 1 silu, 2 gelu*/, bool VEC, typename TP = float>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const TP* __restrict__ x,
                                                         const float* __restrict__ wgt,
                                                         const float* __restrict__ bias,
-                                                        float* __restrict__ y, int C, int H, int W,
+                                                        TP* __restrict__ y, int C, int H, int W,
                                                         long long planes) {
     const int lane = threadIdx.x;                        // 64 column groups = one wave per strip row
     const int cg = blockIdx.x * 64 + lane;               // column group (4 columns)
@@ -36,8 +38,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < 9; ++i) k[i] = wgt[c * 9 + i];
         const float bv = bias ? bias[c] : 0.0f;
-        const float* xp = x + plane * (long long)H * W;
-        float* yp = y + plane * (long long)H * W;
+        const TP* xp = x + plane * (long long)H * W;
+        TP* yp = y + plane * (long long)H * W;
         const int w0 = cg * 4;
         const bool colok = w0 < W;                       // whole quad in range when VEC (W % 4 == 0)
 
@@ -47,18 +49,20 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
             const bool rowok = r >= 0 && r < H;
             if (rowok && colok) {
                 if constexpr (VEC) {
-                    q = *reinterpret_cast<const float4*>(xp + (long long)r * W + w0);
+                    float t4[4];
+                    load4(xp + (long long)r * W + w0, t4);
+                    q = make_float4(t4[0], t4[1], t4[2], t4[3]);
                 } else {
-                    const float* p = xp + (long long)r * W + w0;
-                    q.x = p[0];
-                    if (w0 + 1 < W) q.y = p[1];
-                    if (w0 + 2 < W) q.z = p[2];
-                    if (w0 + 3 < W) q.w = p[3];
+                    const TP* p = xp + (long long)r * W + w0;
+                    q.x = ld1(p);
+                    if (w0 + 1 < W) q.y = ld1(p + 1);
+                    if (w0 + 2 < W) q.z = ld1(p + 2);
+                    if (w0 + 3 < W) q.w = ld1(p + 3);
                 }
             }
             float left = __shfl_up(q.w, 1), right = __shfl_down(q.x, 1);
-            if (lane == 0) left = (rowok && w0 - 1 >= 0 && w0 - 1 < W) ? xp[(long long)r * W + w0 - 1] : 0.0f;
-            if (lane == 63) right = (rowok && w0 + 4 < W) ? xp[(long long)r * W + w0 + 4] : 0.0f;
+            if (lane == 0) left = (rowok && w0 - 1 >= 0 && w0 - 1 < W) ? ld1(xp + (long long)r * W + w0 - 1) : 0.0f;
+            if (lane == 63) right = (rowok && w0 + 4 < W) ? ld1(xp + (long long)r * W + w0 + 4) : 0.0f;
             v[0] = left; v[1] = q.x; v[2] = q.y; v[3] = q.z; v[4] = q.w; v[5] = right;
         };
 
@@ -80,13 +84,13 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
                 }
                 if (colok) {
                     if constexpr (VEC) {
-                        *reinterpret_cast<float4*>(yp + (long long)h * W + w0) = make_float4(o[0], o[1], o[2], o[3]);
+                        store4(yp + (long long)h * W + w0, o);
                     } else {
-                        float* p = yp + (long long)h * W + w0;
-                        p[0] = o[0];
-                        if (w0 + 1 < W) p[1] = o[1];
-                        if (w0 + 2 < W) p[2] = o[2];
-                        if (w0 + 3 < W) p[3] = o[3];
+                        TP* p = yp + (long long)h * W + w0;
+                        st1(p, o[0]);
+                        if (w0 + 1 < W) st1(p + 1, o[1]);
+                        if (w0 + 2 < W) st1(p + 2, o[2]);
+                        if (w0 + 3 < W) st1(p + 3, o[3]);
                     }
                 }
 #pragma unroll

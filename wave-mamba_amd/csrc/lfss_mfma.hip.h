@@ -19,6 +19,7 @@
 // Reference: basicsr/archs/wavemamba_arch.py :491-494 (SS2D tail), :525-526 (LFSSBlock), :226-230 (ffn).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "haar.hip.h"          // bf16_t, ld1 / st1 (fp32 and bf16 overloads)
 
 namespace wm {
 
@@ -96,28 +97,31 @@ __device__ __forceinline__ int acc_chan(int j, int h) { return (j & 3) + 8 * (j 
 
 // two tiles' accumulators of one output row block -> 256-byte runs: after the swap, register i of `lo` is channel
 // row(i) at positions p0 .. p0 + 63 and register i of `hi` is channel row(i) + 4
-__device__ __forceinline__ void store_rows64(float* __restrict__ plane0 /* channel 0 of the 32-row block, + p0 + lane */,
+template <typename TP>
+__device__ __forceinline__ void store_rows64(TP* __restrict__ plane0 /* channel 0 of the 32-row block, + p0 + lane */,
                                              long long L, bool ok, lfss_v16f lo, lfss_v16f hi) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo[i]), __float_as_uint(hi[i]), false, false);
         if (ok) {
             const long long ro = (long long)(8 * (i >> 2) + (i & 3)) * L;
-            plane0[ro] = __uint_as_float(r[0]);
-            plane0[ro + 4 * L] = __uint_as_float(r[1]);
+            st1(plane0 + ro, __uint_as_float(r[0]));
+            st1(plane0 + ro + 4 * L, __uint_as_float(r[1]));
         }
     }
 }
 
 // ---- lfss_mid: ysum, z, tok -> tok1 (B, L, C), f (B, D, L) -------------------------------------------
-template <int NY>      // NY = 1: merged core output; NY = 4: the four directions' outputs, added here (:490)
+// NY = 1: merged core output; NY = 4: the four directions' outputs, added here (:490).  TP: storage type of the y / z / f
+// planes (float, or bf16_t in the bf16-storage mode)
+template <int NY, typename TP = float>
 __global__ __launch_bounds__(256, WM_LFSS_MID_WAVES) void lfss_mid_mfma_kernel(
-    const float* __restrict__ ysum, long long ystride, const float* __restrict__ z, const float* __restrict__ tok, int tok_nchw,
+    const TP* __restrict__ ysum, long long ystride, const TP* __restrict__ z, const float* __restrict__ tok, int tok_nchw,
     const float* __restrict__ on_w, const float* __restrict__ on_b, float on_eps,
     const float* __restrict__ W_out /*(C, D)*/, const float* __restrict__ skip1,
     const float* __restrict__ ln2_w, const float* __restrict__ ln2_b, float ln2_eps,
     const float* __restrict__ W1 /*(D, C)*/, const float* __restrict__ b1,
-    float* __restrict__ tok1, float* __restrict__ f, int B, long long L, int ngl, long long ngroups, int gpw) {
+    float* __restrict__ tok1, TP* __restrict__ f, int B, long long L, int ngl, long long ngroups, int gpw) {
     constexpr int C = 32, D = 64;
     __shared__ __attribute__((aligned(16))) float s_skip[C];
     __shared__ __attribute__((aligned(16))) float s_b1[D];
@@ -152,12 +156,12 @@ __global__ __launch_bounds__(256, WM_LFSS_MID_WAVES) void lfss_mid_mfma_kernel(
         // ---- thread-per-position: out_norm, gate ----
         const bool okl = p0 + lane < L;
         const long long pc = min(p0 + lane, L - 1);
-        const float* yp = ysum + b * D * L + pc;
-        const float* zp = z + b * D * L + pc;
+        const TP* yp = ysum + b * D * L + pc;
+        const TP* zp = z + b * D * L + pc;
         float y[D];
         if constexpr (NY == 1) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) y[d] = yp[(long long)d * L];
+            for (int d = 0; d < D; ++d) y[d] = ld1(yp + (long long)d * L);
         } else {
             // the four directions' outputs, added in the reference's order y1 + y2 + y3 + y4 (:490) =
             // [row fwd] + [row rev] + [col fwd] + [col rev]; explicit batches of 4 channels x 4 buffers in flight (8 x 4 spills at 128 registers)
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(256, WM_LFSS_MID_WAVES) void lfss_mid_mfma_kernel(
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int i = 0; i < YB; ++i) t[q][i] = yp[q * ystride + (long long)(d0 + i) * L];
+                    for (int i = 0; i < YB; ++i) t[q][i] = ld1(yp + q * ystride + (long long)(d0 + i) * L);
 #pragma unroll
                 for (int i = 0; i < YB; ++i) y[d0 + i] = ((t[0][i] + t[1][i]) + t[2][i]) + t[3][i];
                 __builtin_amdgcn_sched_barrier(0);       // one batch of loads in flight, not all 256 (spills)
@@ -187,13 +191,13 @@ __global__ __launch_bounds__(256, WM_LFSS_MID_WAVES) void lfss_mid_mfma_kernel(
         constexpr int ZB = 8;
         float zb[2][ZB];
 #pragma unroll
-        for (int i = 0; i < ZB; ++i) zb[0][i] = zp[(long long)i * L];
+        for (int i = 0; i < ZB; ++i) zb[0][i] = ld1(zp + (long long)i * L);
 #pragma unroll
         for (int d0 = 0; d0 < D; d0 += ZB) {
             const int cur = (d0 / ZB) & 1;
             if (d0 + ZB < D) {
 #pragma unroll
-                for (int i = 0; i < ZB; ++i) zb[cur ^ 1][i] = zp[(long long)(d0 + ZB + i) * L];
+                for (int i = 0; i < ZB; ++i) zb[cur ^ 1][i] = ld1(zp + (long long)(d0 + ZB + i) * L);
             }
 #pragma unroll
             for (int i = 0; i < ZB; ++i)
@@ -265,9 +269,10 @@ __global__ __launch_bounds__(256, WM_LFSS_MID_WAVES) void lfss_mid_mfma_kernel(
 
 // ---- lfss_in: tok -> x (B, D, L), z (B, D, L) ------------------------------------------------------
 // ln_1's affine is folded into in_proj (W' = W diag(w), bias' = W b).
+template <typename TP = float>
 __global__ __launch_bounds__(256, WM_LFSS_IN_WAVES) void lfss_in_mfma_kernel(
     const float* __restrict__ tok, int tok_nchw, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
-    const float* __restrict__ W_in /*(2D, C)*/, float* __restrict__ x, float* __restrict__ z, int B, long long L, int ngl,
+    const float* __restrict__ W_in /*(2D, C)*/, TP* __restrict__ x, TP* __restrict__ z, int B, long long L, int ngl,
     long long ngroups, int gpw) {
     constexpr int C = 32, D = 64;
     __shared__ __attribute__((aligned(16))) float s_bias[2 * D];
@@ -327,14 +332,15 @@ __global__ __launch_bounds__(256, WM_LFSS_IN_WAVES) void lfss_in_mfma_kernel(
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], a[1][4 * j4 + jj], acc[1], 0, 0, 0);
                 }
             }
-            float* dp = (mt < 2 ? x + (b * D + 32 * mt) * L : z + (b * D + 32 * (mt - 2)) * L) + p0 + lane;
+            TP* dp = (mt < 2 ? x + (b * D + 32 * mt) * L : z + (b * D + 32 * (mt - 2)) * L) + p0 + lane;
             store_rows64(dp, L, okl, acc[0], acc[1]);
         }
     }
 }
 
 // ---- lfss_out: fc (B, D, L), tok1 -> tok2 --------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void lfss_out_mfma_kernel(const float* __restrict__ fc, const float* __restrict__ tok1,
+template <typename TP = float>
+__global__ __launch_bounds__(256, 2) void lfss_out_mfma_kernel(const TP* __restrict__ fc, const float* __restrict__ tok1,
                                                               const float* __restrict__ W3 /*(C, C)*/,
                                                               const float* __restrict__ b3, const float* __restrict__ skip2,
                                                               float* __restrict__ out, int out_nchw, int B, long long L,
@@ -365,12 +371,12 @@ __global__ __launch_bounds__(256, 2) void lfss_out_mfma_kernel(const float* __re
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const long long pq = min(p0 + 32 * t + n, L - 1);
-            const float* fp = fc + (b * D + 4 * h) * L + pq;
+            const TP* fp = fc + (b * D + 4 * h) * L + pq;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const long long ro = (long long)(8 * (i >> 2) + (i & 3)) * L;
-                gate[t][i] = fp[ro];
-                val[t][i] = fp[ro + 32 * L];
+                gate[t][i] = ld1(fp + ro);
+                val[t][i] = ld1(fp + ro + 32 * L);
             }
             load_tile32(tok1, false, b, pq, L, h, tk[t]);
         }

@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "selscan.hip.h"
+#include "haar.hip.h"          // bf16_t and its conversions
 
 #ifndef WM_CORE_A2_LDS
 #define WM_CORE_A2_LDS 0          // A * log2(e) in LDS (1) or in NP / 2 register pairs per lane (0: measured 4 % faster)
@@ -49,14 +50,38 @@ namespace wm {
 
 typedef float core_f4 __attribute__((ext_vector_type(4)));
 
+// Storage type of the x / y planes: float, or bf16_t in the bf16-storage mode (four elements per lane access either way;
+// everything inside the kernel - LDS tiles, projection, state - is fp32).
+template <typename TP> struct CoreIO;
+template <> struct CoreIO<float> {
+    typedef float4 raw;
+    static __device__ __forceinline__ raw load(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ float4 cvt(raw r) { return r; }
+    static __device__ __forceinline__ void store(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+};
+template <> struct CoreIO<bf16_t> {
+    typedef uint2 raw;
+    static __device__ __forceinline__ raw load(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+    static __device__ __forceinline__ float4 cvt(raw r) {
+        return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                           __uint_as_float(r.y & 0xffff0000u));
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, float4 v) {
+        uint2 a;
+        a.x = (uint32_t)float_to_bf16_bits(v.x) | ((uint32_t)float_to_bf16_bits(v.y) << 16);
+        a.y = (uint32_t)float_to_bf16_bits(v.z) | ((uint32_t)float_to_bf16_bits(v.w) << 16);
+        *reinterpret_cast<uint2*>(p) = a;
+    }
+};
+
 struct CoreArgs {
-    const float* x;          // (B, D, H, W)
+    const void* x;           // (B, D, H, W), fp32 or bf16
     const float* Wx;         // (4, R + 2N, D)    x_proj_weight
     const float* Wdt;        // (4, D, R)         dt_projs_weight
     const float* dtb;        // (4, D)            dt_projs_bias
     const float* A_logs;     // (4 D, N)
     const float* Ds;         // (4 D)
-    float* y[4];             // y of direction k, (B, D, L), row-major positions
+    void* y[4];              // y of direction k, (B, D, L), row-major positions, fp32 or bf16
     float* wsP[4];           // chunk summaries of direction k: [chunk][b * D + d][NP]
     float* wsH[4];
     int B, D, H, W, L, N, R;
@@ -96,7 +121,7 @@ __device__ __forceinline__ void core_lds_fence() {       // LDS hand-off between
 
 // PHASE 1: chunk summaries.  PHASE 3: scan from the carried-in state, emits y.
 // RHI: dt_rank > 2 (the dt projection reads four record slots instead of two).
-template <int NP, int NW, int PHASE, bool RHI, bool COL, bool REV>
+template <int NP, int NW, int PHASE, bool RHI, typename TP, bool COL, bool REV>
 __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const int b, const int wg, float* smem) {
     using Cfg = CoreCfg<NP>;
     constexpr int NTB = Cfg::NTB, NQ = Cfg::NQ, RS = Cfg::RS, ROW = Cfg::ROW, XT = Cfg::XT;
@@ -210,14 +235,15 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
     }
     float sum_dt = 0.0f;
 
-    const float* xb = p.x + (long long)b * D * L;
-    float* yb = (PHASE == 3) ? p.y[k] + (long long)b * D * L : nullptr;
+    using IO = CoreIO<TP>;
+    const TP* xb = static_cast<const TP*>(p.x) + (long long)b * D * L;
+    TP* yb = (PHASE == 3) ? static_cast<TP*>(p.y[k]) + (long long)b * D * L : nullptr;
     float* sx = s_x + wv * XT;                           // the wave's x / y tile  [64][ROW]
     float* srec = s_rec + wv * (16 * RS);                // the wave's record tile [16][RS]
 
     // tile ti covers steps t0 .. t0+15 of the line; in memory that is positions / rows lo .. lo+15 ascending, and
     // step tt sits at tile column tt (forward) or 15 - tt (reversed).  Valid tile columns: [v_lo, v_hi).
-    float4 xp[4];                                        // the next tile, in flight
+    typename IO::raw xp[4];                              // the next tile, in flight (raw bits: converted when staged)
     const int trow = lane >> 2, tq = lane & 3;
     // Loads are UNCONDITIONAL with clamped offsets (an `ok ? load : 0` compiles to a branch around the load plus
     // register copies behind it, i.e. a wait for the load right where it was issued); invalid elements are zeroed when
@@ -257,13 +283,13 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned off = tile_ok(ti, i) ? tile_off(ti, i) : 0u;
-            xp[i] = *reinterpret_cast<const float4*>(xb + off);
+            xp[i] = IO::load(xb + off);
         }
     };
     auto stage = [&](int ti) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float4 v4 = tile_ok(ti, i) ? xp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v4 = tile_ok(ti, i) ? IO::cvt(xp[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (!COL) {
                 *reinterpret_cast<float4*>(&sx[(16 * i + trow) * ROW + 4 * tq]) = v4;
             } else {
@@ -419,8 +445,7 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (tile_ok(ti, i))
-                        *reinterpret_cast<float4*>(yb + tile_off(ti, i)) =
-                            *reinterpret_cast<const float4*>(&sx[(16 * i + trow) * ROW + 4 * tq]);
+                        IO::store(yb + tile_off(ti, i), *reinterpret_cast<const float4*>(&sx[(16 * i + trow) * ROW + 4 * tq]));
                 core_lds_fence();                        // the y tile is read before the next stage() overwrites it
             } else {
                 core_barrier();
@@ -442,12 +467,12 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
                 if (full) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        *reinterpret_cast<float4*>(yb + tile_off(ti, i)) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+                        IO::store(yb + tile_off(ti, i), make_float4(v[i][0], v[i][1], v[i][2], v[i][3]));
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         if (tile_ok(ti, i))
-                            *reinterpret_cast<float4*>(yb + tile_off(ti, i)) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+                            IO::store(yb + tile_off(ti, i), make_float4(v[i][0], v[i][1], v[i][2], v[i][3]));
                 }
                 core_barrier();
             }
@@ -504,7 +529,7 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
 // same XCD (workgroup id -> XCD id % 8), whose L2 then holds the line.
 // second launch-bound: minimum waves per SIMD (N <= 16: four, i.e. <= 128 registers - one 16-wave or two 8-wave
 // workgroups per compute unit; N = 32: two)
-template <int NP, int NW, int PHASE, bool RHI>
+template <int NP, int NW, int PHASE, bool RHI, typename TP = float>
 __global__ __launch_bounds__(64 * NW, NP == 16 ? 4 : 2) void ss2d_core_kernel(CoreArgs p) {
     extern __shared__ __attribute__((aligned(16))) float core_smem[];
     const int per_b = 2 * p.row_wgs + 2 * p.col_wgs;
@@ -514,31 +539,33 @@ __global__ __launch_bounds__(64 * NW, NP == 16 ? 4 : 2) void ss2d_core_kernel(Co
         const int idx = r >> 1;
         const int wg = (((idx >> 3) << 2) + (idx & 3)) * 2 + ((idx >> 2) & 1);
         if (wg >= p.col_tiles * p.col_nseg || !((p.dirmask >> ((r & 1) * 2 + 1)) & 1)) return;
-        if (r & 1) core_body<NP, NW, PHASE, RHI, true, true>(p, 3, b, wg, core_smem);
-        else core_body<NP, NW, PHASE, RHI, true, false>(p, 1, b, wg, core_smem);
+        if (r & 1) core_body<NP, NW, PHASE, RHI, TP, true, true>(p, 3, b, wg, core_smem);
+        else core_body<NP, NW, PHASE, RHI, TP, true, false>(p, 1, b, wg, core_smem);
     } else {
         r -= 2 * p.col_wgs;
         const int wg = r >> 1;
         if (!((p.dirmask >> ((r & 1) * 2)) & 1)) return;
-        if (r & 1) core_body<NP, NW, PHASE, RHI, false, true>(p, 2, b, wg, core_smem);
-        else core_body<NP, NW, PHASE, RHI, false, false>(p, 0, b, wg, core_smem);
+        if (r & 1) core_body<NP, NW, PHASE, RHI, TP, false, true>(p, 2, b, wg, core_smem);
+        else core_body<NP, NW, PHASE, RHI, TP, false, false>(p, 0, b, wg, core_smem);
     }
 }
 
 // merged output for callers of the plain operator (training): y0 <- ((y0 + y2) + y1) + y3, the reference's order of
 // y1 + y2 + y3 + y4 (:490: out_y[:, 0], inv_y[:, 0], wh_y, invwh_y)
-__global__ __launch_bounds__(256) void ss2d_sum4_kernel(float* __restrict__ y0, const float* __restrict__ y2,
-                                                        const float* __restrict__ y1, const float* __restrict__ y3,
+template <typename TP>
+__global__ __launch_bounds__(256) void ss2d_sum4_kernel(TP* __restrict__ y0, const TP* __restrict__ y2,
+                                                        const TP* __restrict__ y1, const TP* __restrict__ y3,
                                                         long long n4) {
+    using IO = CoreIO<TP>;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
-    float4 a = reinterpret_cast<float4*>(y0)[i];
-    const float4 c = reinterpret_cast<const float4*>(y2)[i];
-    const float4 bq = reinterpret_cast<const float4*>(y1)[i];
-    const float4 e = reinterpret_cast<const float4*>(y3)[i];
+    float4 a = IO::cvt(IO::load(y0 + 4 * i));
+    const float4 c = IO::cvt(IO::load(y2 + 4 * i));
+    const float4 bq = IO::cvt(IO::load(y1 + 4 * i));
+    const float4 e = IO::cvt(IO::load(y3 + 4 * i));
     a.x = ((a.x + c.x) + bq.x) + e.x; a.y = ((a.y + c.y) + bq.y) + e.y;
     a.z = ((a.z + c.z) + bq.z) + e.z; a.w = ((a.w + c.w) + bq.w) + e.w;
-    reinterpret_cast<float4*>(y0)[i] = a;
+    IO::store(y0 + 4 * i, a);
 }
 
 }  // namespace wm

@@ -279,7 +279,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 13; }
+int wm_abi_version(void) { return 14; }
 
 const char* wm_strerror(int code) {
     switch (code) {
@@ -485,20 +485,28 @@ int wm_selscan_bwd(const float* u, const float* delta, const float* A, const flo
     return vec ? bwd_launch<32, true>(a, pl, seg, dA, dD, dbias, st) : bwd_launch<32, false>(a, pl, seg, dA, dD, dbias, st);
 }
 
-int wm_dwconv3x3_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int C,
-                     int H, int W, int act, void* stream) {
+int wm_dwconv3x3_fwd(const void* x, const float* weight, const float* bias, void* y, int B, int C,
+                     int H, int W, int act, int plane_dtype, void* stream) {
     if (B < 0 || C < 0 || H < 0 || W < 0) return WM_EINVAL;
-    if (act < 0 || act > 2) return WM_EUNSUPPORTED;
+    if (act < 0 || act > 2 || (plane_dtype != WM_F32 && plane_dtype != WM_BF16)) return WM_EUNSUPPORTED;
     const long long planes = (long long)B * C;
     if (planes == 0 || H == 0 || W == 0) return WM_OK;
     if (!x || !weight || !y) return WM_ENULL;
-    const bool vec = (W % 4 == 0) && aligned16(x) && aligned16(y);
+    const bool vec = (W % 4 == 0) && aligned16(x) && aligned16(y);      // (bf16: 8-byte accesses, covered by the same test)
     const dim3 block(64, 4);
     const dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 4 * kDwRows - 1) / (4 * kDwRows)),
                     (unsigned)(planes < 65535 ? planes : 65535));
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(7, st);
-#define WM_DW(ACT, VEC) hipLaunchKernelGGL((dwconv3x3_kernel<ACT, VEC>), grid, block, 0, st, x, weight, bias, y, C, H, W, planes)
+#define WM_DW(ACT, VEC)                                                                                                  \
+    do {                                                                                                                 \
+        if (plane_dtype == WM_F32)                                                                                       \
+            hipLaunchKernelGGL((dwconv3x3_kernel<ACT, VEC, float>), grid, block, 0, st, (const float*)x, weight, bias,   \
+                               (float*)y, C, H, W, planes);                                                              \
+        else                                                                                                             \
+            hipLaunchKernelGGL((dwconv3x3_kernel<ACT, VEC, bf16_t>), grid, block, 0, st, (const bf16_t*)x, weight, bias, \
+                               (bf16_t*)y, C, H, W, planes);                                                             \
+    } while (0)
     if (act == 1) { if (vec) WM_DW(1, true); else WM_DW(1, false); }
     else if (act == 2) { if (vec) WM_DW(2, true); else WM_DW(2, false); }
     else          { if (vec) WM_DW(0, true); else WM_DW(0, false); }
@@ -644,7 +652,7 @@ static int core_plan(CorePlan& pl, int B, int D, int H, int W, int N, int R, int
     return WM_OK;
 }
 
-template <int NP, int NW, bool RHI>
+template <int NP, int NW, bool RHI, typename TP>
 static int core_launch(const CoreArgs& a, const CorePlan& pl, hipStream_t st) {
     constexpr int lds = core_lds_bytes<NP, NW>();
     // > 64 KB of dynamic LDS is an opt-in per function AND per device
@@ -655,10 +663,10 @@ static int core_launch(const CoreArgs& a, const CorePlan& pl, hipStream_t st) {
     {
         std::lock_guard<std::mutex> lk(mu);
         if (dev < 0 || dev >= 64 || !configured[dev]) {
-            hipError_t e = hipFuncSetAttribute((const void*)ss2d_core_kernel<NP, NW, 1, RHI>,
+            hipError_t e = hipFuncSetAttribute((const void*)ss2d_core_kernel<NP, NW, 1, RHI, TP>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e == hipSuccess)
-                e = hipFuncSetAttribute((const void*)ss2d_core_kernel<NP, NW, 3, RHI>,
+                e = hipFuncSetAttribute((const void*)ss2d_core_kernel<NP, NW, 3, RHI, TP>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) return WM_EHIP;
             if (dev >= 0 && dev < 64) configured[dev] = true;
@@ -669,7 +677,7 @@ static int core_launch(const CoreArgs& a, const CorePlan& pl, hipStream_t st) {
     if (split) {
         {
             ProfScope ps(10, st);
-            hipLaunchKernelGGL((ss2d_core_kernel<NP, NW, 1, RHI>), grid, block, lds, st, a);
+            hipLaunchKernelGGL((ss2d_core_kernel<NP, NW, 1, RHI, TP>), grid, block, lds, st, a);
         }
         ProfScope ps(3, st);
         CarryBatch cb{};
@@ -684,7 +692,7 @@ static int core_launch(const CoreArgs& a, const CorePlan& pl, hipStream_t st) {
     }
     {
         ProfScope ps(8, st);
-        hipLaunchKernelGGL((ss2d_core_kernel<NP, NW, 3, RHI>), grid, block, lds, st, a);
+        hipLaunchKernelGGL((ss2d_core_kernel<NP, NW, 3, RHI, TP>), grid, block, lds, st, a);
     }
     return launch_status();
 }
@@ -692,6 +700,7 @@ static int core_launch(const CoreArgs& a, const CorePlan& pl, hipStream_t st) {
 
 extern "C" {
 size_t wm_ss2d_core_fwd_workspace_bytes(int B, int D, int H, int W, int N, int R, int merged) {
+    // (sized for fp32 planes; bf16 planes need less for the merged mode's temporaries)
     if (!core_v2_shape(W)) {
         Ss2dPlan pl;
         if (ss2d_plan(pl, B, D, H, W, N, R) != WM_OK) return 0;
@@ -702,14 +711,18 @@ size_t wm_ss2d_core_fwd_workspace_bytes(int B, int D, int H, int W, int N, int R
     return pl.total;
 }
 
-int wm_ss2d_core_fwd(const float* x, const float* x_proj_weight, const float* dt_projs_weight,
-                     const float* dt_projs_bias, const float* A_logs, const float* Ds, float* y_row_fwd,
-                     float* y_row_rev, float* y_col_fwd, float* y_col_rev, int merged, void* workspace,
-                     size_t workspace_bytes, int B, int D, int H, int W, int N, int R, void* stream) {
+int wm_ss2d_core_fwd(const void* x, const float* x_proj_weight, const float* dt_projs_weight,
+                     const float* dt_projs_bias, const float* A_logs, const float* Ds, void* y_row_fwd,
+                     void* y_row_rev, void* y_col_fwd, void* y_col_rev, int merged, void* workspace,
+                     size_t workspace_bytes, int B, int D, int H, int W, int N, int R, int plane_dtype, void* stream) {
     if (B == 0 || D == 0 || H == 0 || W == 0) return (B < 0 || D < 0 || H < 0 || W < 0) ? WM_EINVAL : WM_OK;
-    if (!core_v2_shape(W))
-        return core_fwd_legacy(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, y_row_fwd, y_row_rev,
-                               y_col_fwd, y_col_rev, merged, workspace, workspace_bytes, B, D, H, W, N, R, stream);
+    if (plane_dtype != WM_F32 && plane_dtype != WM_BF16) return WM_EUNSUPPORTED;
+    if (!core_v2_shape(W)) {
+        if (plane_dtype != WM_F32) return WM_EUNSUPPORTED;
+        return core_fwd_legacy((const float*)x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, (float*)y_row_fwd,
+                               (float*)y_row_rev, (float*)y_col_fwd, (float*)y_col_rev, merged, workspace, workspace_bytes, B, D,
+                               H, W, N, R, stream);
+    }
     CorePlan pl;
     int rc = core_plan(pl, B, D, H, W, N, R, merged);
     if (rc) return rc;
@@ -730,9 +743,9 @@ int wm_ss2d_core_fwd(const float* x, const float* x_proj_weight, const float* dt
     char* yt = w + 8 * pl.half_bytes;
     // direction k: 0 row forward, 1 column forward, 2 row reversed, 3 column reversed (the reference's xs order, :451-452)
     a.y[0] = y_row_fwd;
-    a.y[1] = merged ? (float*)yt : y_col_fwd;
-    a.y[2] = merged ? (float*)(yt + pl.ytmp_bytes) : y_row_rev;
-    a.y[3] = merged ? (float*)(yt + 2 * pl.ytmp_bytes) : y_col_rev;
+    a.y[1] = merged ? (void*)yt : y_col_fwd;
+    a.y[2] = merged ? (void*)(yt + pl.ytmp_bytes) : y_row_rev;
+    a.y[3] = merged ? (void*)(yt + 2 * pl.ytmp_bytes) : y_col_rev;
     a.B = B; a.D = D; a.H = H; a.W = W; a.L = H * W; a.N = N; a.R = R;
     a.row_chunk = pl.row_chunk; a.row_nchunks = pl.row_nchunks; a.row_wgs = pl.row_wgs;
     a.stamps = nullptr;
@@ -747,18 +760,26 @@ int wm_ss2d_core_fwd(const float* x, const float* x_proj_weight, const float* dt
         a.dirmask = mask;
     }
     a.col_seg = pl.col_seg; a.col_nseg = pl.col_nseg; a.col_tiles = pl.col_tiles; a.col_wgs = pl.col_wgs;
-#ifdef WM_CORE_NW
-    if (pl.NP == 16) rc = R > 2 ? core_launch<16, WM_CORE_NW, true>(a, pl, st) : core_launch<16, WM_CORE_NW, false>(a, pl, st);
-#else
-    if (pl.NP == 16) rc = R > 2 ? core_launch<16, 16, true>(a, pl, st) : core_launch<16, 16, false>(a, pl, st);
+#ifndef WM_CORE_NW
+#define WM_CORE_NW 16
 #endif
-    else rc = R > 2 ? core_launch<32, 8, true>(a, pl, st) : core_launch<32, 8, false>(a, pl, st);
+#define WM_CORE_GO(TP)                                                                                                        \
+    do {                                                                                                                      \
+        if (pl.NP == 16) rc = R > 2 ? core_launch<16, WM_CORE_NW, true, TP>(a, pl, st) : core_launch<16, WM_CORE_NW, false, TP>(a, pl, st); \
+        else rc = R > 2 ? core_launch<32, 8, true, TP>(a, pl, st) : core_launch<32, 8, false, TP>(a, pl, st);                  \
+    } while (0)
+    if (plane_dtype == WM_F32) WM_CORE_GO(float); else WM_CORE_GO(bf16_t);
+#undef WM_CORE_GO
     if (rc) return rc;
     if (merged) {
         const long long n4 = (long long)B * D * a.L / 4;
         ProfScope ps(8, st);
-        hipLaunchKernelGGL(ss2d_sum4_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a.y[0], a.y[2], a.y[1],
-                           a.y[3], n4);
+        if (plane_dtype == WM_F32)
+            hipLaunchKernelGGL(ss2d_sum4_kernel<float>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (float*)a.y[0],
+                               (const float*)a.y[2], (const float*)a.y[1], (const float*)a.y[3], n4);
+        else
+            hipLaunchKernelGGL(ss2d_sum4_kernel<bf16_t>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (bf16_t*)a.y[0],
+                               (const bf16_t*)a.y[2], (const bf16_t*)a.y[1], (const bf16_t*)a.y[3], n4);
     }
     return launch_status();
 }
@@ -931,8 +952,10 @@ int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt
     } while (0)
 
 int wm_lfss_in_fwd(const float* tok, int tok_nchw, const float* ln_w, const float* ln_b, float ln_eps,
-                   const float* in_proj_weight, float* x, float* z, int B, int64_t L, int C, void* stream) {
+                   const float* in_proj_weight, void* x_, void* z_, int B, int64_t L, int C, int plane_dtype, void* stream) {
     if (B < 0 || L < 0) return WM_EINVAL;
+    if (plane_dtype != WM_F32 && !(plane_dtype == WM_BF16 && C == 32)) return WM_EUNSUPPORTED;    // bf16 planes: C = 32 kernels
+    float* x = (float*)x_; float* z = (float*)z_;
     if (B && L && (!tok || !ln_w || !ln_b || !in_proj_weight || !x || !z)) return WM_ENULL;
     if (!tok_nchw && !aligned16(tok)) return WM_EALIGN;
     if (C == 32 && B && L) {
@@ -942,19 +965,25 @@ int wm_lfss_in_fwd(const float* tok, int tok_nchw, const float* ln_w, const floa
         const long long waves = (ngroups + gpw - 1) / gpw;
         hipStream_t st = (hipStream_t)stream;
         ProfScope ps(5, st);
-        hipLaunchKernelGGL(lfss_in_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, tok, tok_nchw, ln_w, ln_b,
-                           ln_eps, in_proj_weight, x, z, B, (long long)L, ngl, ngroups, gpw);
+        if (plane_dtype == WM_F32)
+            hipLaunchKernelGGL(lfss_in_mfma_kernel<float>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, tok, tok_nchw, ln_w,
+                               ln_b, ln_eps, in_proj_weight, x, z, B, (long long)L, ngl, ngroups, gpw);
+        else
+            hipLaunchKernelGGL(lfss_in_mfma_kernel<bf16_t>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, tok, tok_nchw, ln_w,
+                               ln_b, ln_eps, in_proj_weight, (bf16_t*)x_, (bf16_t*)z_, B, (long long)L, ngl, ngroups, gpw);
         return launch_status();
     }
     WM_LFSS_DISPATCH(lfss_in_kernel, tok, tok_nchw, ln_w, ln_b, ln_eps, in_proj_weight, x, z, B, (long long)L);
 }
 
-int wm_lfss_mid_fwd(const float* ysum, int ny, int64_t ystride, const float* z, const float* tok, int tok_nchw, const float* out_norm_w,
+int wm_lfss_mid_fwd(const void* ysum_, int ny, int64_t ystride, const void* z_, const float* tok, int tok_nchw, const float* out_norm_w,
                     const float* out_norm_b, float out_norm_eps, const float* out_proj_weight,
                     const float* skip_scale, const float* ln2_w, const float* ln2_b, float ln2_eps,
-                    const float* conv1_weight, const float* conv1_bias, float* tok1, float* f, int B, int64_t L,
-                    int C, void* stream) {
+                    const float* conv1_weight, const float* conv1_bias, float* tok1, void* f_, int B, int64_t L,
+                    int C, int plane_dtype, void* stream) {
     if (B < 0 || L < 0 || (ny != 1 && ny != 4)) return WM_EINVAL;
+    if (plane_dtype != WM_F32 && !(plane_dtype == WM_BF16 && C == 32)) return WM_EUNSUPPORTED;
+    const float* ysum = (const float*)ysum_; const float* z = (const float*)z_; float* f = (float*)f_;
     if (B && L && (!ysum || !z || !tok || !out_norm_w || !out_norm_b || !out_proj_weight || !skip_scale || !ln2_w ||
                    !ln2_b || !conv1_weight || !conv1_bias || !tok1 || !f)) return WM_ENULL;
     if ((!tok_nchw && !aligned16(tok)) || !aligned16(tok1)) return WM_EALIGN;
@@ -965,11 +994,12 @@ int wm_lfss_mid_fwd(const float* ysum, int ny, int64_t ystride, const float* z, 
         const long long waves = (ngroups + gpw - 1) / gpw;
         hipStream_t st = (hipStream_t)stream;
         ProfScope ps(5, st);
-#define WM_MID(NY) hipLaunchKernelGGL(lfss_mid_mfma_kernel<NY>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ysum, \
-                           (long long)ystride, z, tok, tok_nchw,                                                                   \
+#define WM_MID(NY, TP) hipLaunchKernelGGL((lfss_mid_mfma_kernel<NY, TP>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, \
+                           (const TP*)ysum_, (long long)ystride, (const TP*)z_, tok, tok_nchw,                                     \
                            out_norm_w, out_norm_b, out_norm_eps, out_proj_weight, skip_scale, ln2_w, ln2_b, ln2_eps,               \
-                           conv1_weight, conv1_bias, tok1, f, B, (long long)L, ngl, ngroups, gpw)
-        if (ny == 4) WM_MID(4); else WM_MID(1);
+                           conv1_weight, conv1_bias, tok1, (TP*)f_, B, (long long)L, ngl, ngroups, gpw)
+        if (plane_dtype == WM_F32) { if (ny == 4) WM_MID(4, float); else WM_MID(1, float); }
+        else { if (ny == 4) WM_MID(4, bf16_t); else WM_MID(1, bf16_t); }
 #undef WM_MID
         return launch_status();
     }
@@ -977,9 +1007,11 @@ int wm_lfss_mid_fwd(const float* ysum, int ny, int64_t ystride, const float* z, 
                      skip_scale, ln2_w, ln2_b, ln2_eps, conv1_weight, conv1_bias, tok1, f, B, (long long)L);
 }
 
-int wm_lfss_out_fwd(const float* fc, const float* tok1, const float* conv3_weight, const float* conv3_bias,
-                    const float* skip_scale2, float* out, int out_nchw, int B, int64_t L, int C, void* stream) {
+int wm_lfss_out_fwd(const void* fc_, const float* tok1, const float* conv3_weight, const float* conv3_bias,
+                    const float* skip_scale2, float* out, int out_nchw, int B, int64_t L, int C, int plane_dtype, void* stream) {
     if (B < 0 || L < 0) return WM_EINVAL;
+    if (plane_dtype != WM_F32 && !(plane_dtype == WM_BF16 && C == 32)) return WM_EUNSUPPORTED;
+    const float* fc = (const float*)fc_;
     if (B && L && (!fc || !tok1 || !conv3_weight || !conv3_bias || !skip_scale2 || !out)) return WM_ENULL;
     if (!aligned16(tok1) || (!out_nchw && !aligned16(out))) return WM_EALIGN;
     if (C == 32 && B && L) {
@@ -989,8 +1021,12 @@ int wm_lfss_out_fwd(const float* fc, const float* tok1, const float* conv3_weigh
         const long long waves = (ngroups + gpw - 1) / gpw;
         hipStream_t st = (hipStream_t)stream;
         ProfScope ps(5, st);
-        hipLaunchKernelGGL(lfss_out_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, fc, tok1, conv3_weight,
-                           conv3_bias, skip_scale2, out, out_nchw, B, (long long)L, ngl, ngroups, gpw);
+        if (plane_dtype == WM_F32)
+            hipLaunchKernelGGL(lfss_out_mfma_kernel<float>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, fc, tok1,
+                               conv3_weight, conv3_bias, skip_scale2, out, out_nchw, B, (long long)L, ngl, ngroups, gpw);
+        else
+            hipLaunchKernelGGL(lfss_out_mfma_kernel<bf16_t>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, (const bf16_t*)fc_,
+                               tok1, conv3_weight, conv3_bias, skip_scale2, out, out_nchw, B, (long long)L, ngl, ngroups, gpw);
         return launch_status();
     }
     WM_LFSS_DISPATCH(lfss_out_kernel, fc, tok1, conv3_weight, conv3_bias, skip_scale2, out, out_nchw, B, (long long)L);

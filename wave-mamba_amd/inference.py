@@ -131,3 +131,36 @@ class UInt8Pipeline:
         for p, e in pending:
             e.synchronize()
             yield p.numpy().copy()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# bf16-storage mode (BASELINE config 2 as worded; ops.set_plane_dtype)
+# ------------------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def bench_bf16_storage(net, x, steps, warmup=2):
+    """Time `steps` forwards with the LFSSBlock-internal planes stored as bfloat16 (fp32 arithmetic and state inside
+    every kernel, fp32 tokens between blocks, fp32 HFE branch) and compare with the fp32 forward of the same input:
+    PSNR on [0, 1]-clamped float outputs, PSNR after the reference's uint8 quantisation, relative l2."""
+    import time
+    from . import ops
+    prev = ops.set_plane_dtype(torch.float32)
+    try:
+        ref = net.restoration_network(x)
+        ops.set_plane_dtype(torch.bfloat16)
+        for _ in range(max(warmup, 1)):
+            out = net.restoration_network(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = net.restoration_network(x)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        ops.set_plane_dtype(prev)
+    mse = float((out.clamp(0, 1) - ref.clamp(0, 1)).double().pow(2).mean())
+    return {"images_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps,
+            "psnr_vs_fp32_db": float("inf") if mse == 0 else float(10 * torch.log10(torch.tensor(1.0 / mse))),
+            "psnr_u8_vs_fp32_db": psnr_uint8(to_uint8(out), to_uint8(ref)),
+            "rel_l2_vs_fp32": float((out - ref).norm() / ref.norm()),
+            "note": "bf16 planes between the kernels of every LFSSBlock (x, z, conv outputs, the four scan outputs, f, fc); "
+                    "fp32 tiles / projections / scan state / statistics inside the kernels, fp32 tokens, fp32 HFE branch"}

@@ -44,6 +44,30 @@ def _ptr(t):
 
 
 # ------------------------------------------------------------------------------------------------
+# bf16-storage mode (BASELINE config 2 as worded): the plane tensors an LFSSBlock hands from kernel to kernel - x, z,
+# the conv outputs, the four scan outputs, f, fc - are stored as bfloat16; every kernel computes in fp32 (tiles,
+# projections, scan state, LayerNorm statistics) and the token tensors between blocks stay fp32.  Off by default:
+# the parity bars of the fp32 path (1e-4 per tensor) cannot hold at 8 mantissa bits; bench.py --bf16 and
+# tests/test_gpu_parity.py report the PSNR against the fp32 output.
+# ------------------------------------------------------------------------------------------------
+_PLANE_DTYPE = torch.float32
+
+
+def set_plane_dtype(dtype):
+    """torch.float32 (default) or torch.bfloat16: storage of the LFSSBlock-internal plane tensors on the fused inference
+    path (shipped width C = 32 only).  Returns the previous setting."""
+    global _PLANE_DTYPE
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("plane dtype must be torch.float32 or torch.bfloat16")
+    prev, _PLANE_DTYPE = _PLANE_DTYPE, dtype
+    return prev
+
+
+def get_plane_dtype():
+    return _PLANE_DTYPE
+
+
+# ------------------------------------------------------------------------------------------------
 # Haar DWT / IWT
 # ------------------------------------------------------------------------------------------------
 class _DWT(torch.autograd.Function):
@@ -298,20 +322,21 @@ def _ss2d_core_shapes(x, x_proj_weight, dt_projs_weight, A_logs):
 
 
 def _ss2d_core_fwd(f, merged):
+    """f[0] = x (fp32 or bf16 planes: the outputs take the same storage type), f[1:] fp32 parameters."""
     lib = _lib.load()
     x = f[0]
     B, D, H, W, N, R = _ss2d_core_shapes(x, f[1], f[2], f[4])
     L = H * W
     if merged:
-        outs = [torch.empty((B, D, L), dtype=torch.float32, device=x.device)]
+        outs = [torch.empty((B, D, L), dtype=x.dtype, device=x.device)]
     else:       # one allocation, reference return order: a consumer can add the four with one base pointer + stride
-        outs = list(torch.empty((4, B, D, L), dtype=torch.float32, device=x.device).unbind(0))
+        outs = list(torch.empty((4, B, D, L), dtype=x.dtype, device=x.device).unbind(0))
     ws_bytes = lib.wm_ss2d_core_fwd_workspace_bytes(B, D, H, W, N, R, int(bool(merged)))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     ptrs = [_ptr(o) for o in outs] + [None] * (4 - len(outs))
     with torch.cuda.device(x.device):
         check(lib.wm_ss2d_core_fwd(*[_ptr(t) for t in f], *ptrs, int(bool(merged)), _ptr(ws), ws_bytes,
-                                   B, D, H, W, N, R, _stream()), "wm_ss2d_core_fwd")
+                                   B, D, H, W, N, R, _dtype_code(x, "ss2d_core"), _stream()), "wm_ss2d_core_fwd")
     return outs
 
 
@@ -360,7 +385,10 @@ def ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, merg
     args = (x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
     if torch.is_grad_enabled() and any(t.requires_grad for t in args):
         return _SS2DCoreFn.apply(bool(merged), *args)
-    outs = _ss2d_core_fwd([t.detach().contiguous().float() for t in args], merged)
+    xin = x.detach().contiguous()
+    if xin.dtype != torch.bfloat16:                # bf16 planes stay bf16 (outputs too); anything else computes in fp32
+        xin = xin.float()
+    outs = _ss2d_core_fwd([xin] + [t.detach().contiguous().float() for t in args[1:]], merged)
     return outs[0] if merged else tuple(outs)
 
 
@@ -391,29 +419,31 @@ def lfss_block_forward(tok, x_size, blk, tok_nchw=False, out_nchw=False):
     tok = tok.contiguous().float()
     dev = tok.device
     st = _stream()
-    x = torch.empty((B, D, H, W), dtype=torch.float32, device=dev)
-    z = torch.empty((B, D, L), dtype=torch.float32, device=dev)
+    pd = _PLANE_DTYPE if C == 32 else torch.float32           # bf16 planes: the C = 32 kernels
+    code = WM_F32 if pd == torch.float32 else WM_BF16
+    x = torch.empty((B, D, H, W), dtype=pd, device=dev)
+    z = torch.empty((B, D, L), dtype=pd, device=dev)
     with torch.cuda.device(dev):
         check(lib.wm_lfss_in_fwd(_ptr(tok), int(tok_nchw), _ptr(_w(blk.ln_1.weight)), _ptr(_w(blk.ln_1.bias)),
-                                 float(blk.ln_1.eps), _ptr(_w(ss.in_proj.weight)), _ptr(x), _ptr(z), B, L, C, st),
+                                 float(blk.ln_1.eps), _ptr(_w(ss.in_proj.weight)), _ptr(x), _ptr(z), B, L, C, code, st),
               "wm_lfss_in_fwd")
     xc = dwconv3x3(x, ss.conv2d.weight, ss.conv2d.bias, "silu")
     # the four directions' outputs stay separate (one (4, B, D, L) allocation); lfss_mid adds them as it loads (:490)
-    y4 = _ss2d_core_fwd([_w(t) for t in (xc, ss.x_proj_weight, ss.dt_projs_weight, ss.dt_projs_bias, ss.A_logs, ss.Ds)],
+    y4 = _ss2d_core_fwd([xc] + [_w(t) for t in (ss.x_proj_weight, ss.dt_projs_weight, ss.dt_projs_bias, ss.A_logs, ss.Ds)],
                         merged=False)
     tok1 = torch.empty((B, L, C), dtype=torch.float32, device=dev)
-    f = torch.empty((B, D, H, W), dtype=torch.float32, device=dev)
+    f = torch.empty((B, D, H, W), dtype=pd, device=dev)
     with torch.cuda.device(dev):
         check(lib.wm_lfss_mid_fwd(_ptr(y4[0]), 4, B * D * L, _ptr(z), _ptr(tok), int(tok_nchw), _ptr(_w(ss.out_norm.weight)),
                                   _ptr(_w(ss.out_norm.bias)), float(ss.out_norm.eps), _ptr(_w(ss.out_proj.weight)),
                                   _ptr(_w(blk.skip_scale)), _ptr(_w(blk.ln_2.weight)), _ptr(_w(blk.ln_2.bias)),
                                   float(blk.ln_2.eps), _ptr(_w(ff.conv1.weight)), _ptr(_w(ff.conv1.bias)),
-                                  _ptr(tok1), _ptr(f), B, L, C, st), "wm_lfss_mid_fwd")
+                                  _ptr(tok1), _ptr(f), B, L, C, code, st), "wm_lfss_mid_fwd")
     fc = dwconv3x3(f, ff.conv2.weight, ff.conv2.bias, "none")
     out = torch.empty((B, C, H, W) if out_nchw else (B, L, C), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         check(lib.wm_lfss_out_fwd(_ptr(fc), _ptr(tok1), _ptr(_w(ff.conv3.weight)), _ptr(_w(ff.conv3.bias)),
-                                  _ptr(_w(blk.skip_scale2)), _ptr(out), int(out_nchw), B, L, C, st),
+                                  _ptr(_w(blk.skip_scale2)), _ptr(out), int(out_nchw), B, L, C, code, st),
               "wm_lfss_out_fwd")
     return out
 
@@ -587,20 +617,20 @@ def mul_sigmoid(a, b):
 # ------------------------------------------------------------------------------------------------
 def dwconv3x3(x, weight, bias=None, act="none"):
     """F.conv2d(x, weight, bias, stride=1, padding=1, groups=C) [+ SiLU / exact GELU when act == 'silu' / 'gelu'] for a
-    (C, 1, 3, 3) weight, NCHW fp32, forward only (no autograd graph is recorded)."""
+    (C, 1, 3, 3) weight, NCHW fp32 (or bf16 planes: fp32 arithmetic, bf16 storage), forward only (no autograd graph is
+    recorded)."""
     lib = _lib.load()
     _require_cuda("dwconv3x3", x, weight, bias)
     B, C, H, W = x.shape
     if weight.shape != (C, 1, 3, 3):
         raise RuntimeError(f"dwconv3x3: weight must be ({C}, 1, 3, 3), got {tuple(weight.shape)}")
-    if x.dtype != torch.float32:
-        raise RuntimeError("dwconv3x3: float32 only")
+    code = _dtype_code(x, "dwconv3x3")
     x = x.contiguous()
     y = torch.empty_like(x)
     with torch.cuda.device(x.device):
-        check(lib.wm_dwconv3x3_fwd(_ptr(x), _ptr(weight.detach().contiguous()),
-                                   _ptr(None if bias is None else bias.detach().contiguous()), _ptr(y),
-                                   B, C, H, W, {"none": 0, "silu": 1, "gelu": 2}[act], _stream()), "wm_dwconv3x3_fwd")
+        check(lib.wm_dwconv3x3_fwd(_ptr(x), _ptr(weight.detach().contiguous().float()),
+                                   _ptr(None if bias is None else bias.detach().contiguous().float()), _ptr(y),
+                                   B, C, H, W, {"none": 0, "silu": 1, "gelu": 2}[act], code, _stream()), "wm_dwconv3x3_fwd")
     return y
 
 
