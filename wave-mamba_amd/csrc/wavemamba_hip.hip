@@ -619,11 +619,34 @@ static int core_plan(CorePlan& pl, int B, int D, int H, int W, int N, int R, int
 #endif
     const int NW = pl.NW;
     pl.col_tiles = (W + NW - 1) / NW;
-    // One workgroup (NW waves) per compute unit is resident: aim at >= ~1.75 rounds of the 256 compute units over
-    // the four directions, without cutting columns below two tiles.
+    // Segments per column.  `slots` workgroups are resident at once (NW = 16: one per compute unit; NW = 8: two), all
+    // of about the same length, so a launch takes ceil(workgroups / slots) rounds of (tiles per workgroup + a prologue
+    // worth ~0.7 tile: weight fragments into LDS, exp of A_logs, carried-in state).  Take the segment count that
+    // minimises rounds x length.  (A fixed ">= 1.75 rounds" target gave the UHD level-3 maps 444 five-tile workgroups
+    // = two rounds, the second 73 % full; two segments per column = 234 nine-tile workgroups in ONE round.)
+    const auto row_wgs_for = [&](int nsg, int sg_rows) {
+        long long want_c = (long long)pl.col_tiles * NW * nsg;
+        long long c = (L + want_c - 1) / want_c;
+        c = ((c + 15) / 16) * 16;
+        if (c < 32) c = 32;
+        (void)sg_rows;
+        return (int)((((L + c - 1) / c) + NW - 1) / NW);
+    };
+    const long long slots = 256LL * (16 / NW);
     int nseg = 1;
-    const long long want_wgs = NW == 16 ? 448 : 896;
-    while (4LL * pl.col_tiles * nseg * B < want_wgs && H / (nseg + 1) >= 32 && nseg < 64) ++nseg;
+    {
+        double best = 1e300;
+        for (int n = 1; n <= 64; ++n) {
+            int sg = (H + n - 1) / n;
+            sg = ((sg + 15) / 16) * 16;
+            if (n > 1 && sg < 32) break;
+            const int nn = (H + sg - 1) / sg;
+            const long long wgs = (long long)B * (2LL * pl.col_tiles * nn + 2LL * row_wgs_for(nn, sg));
+            const long long rounds = (wgs + slots - 1) / slots;
+            const double cost = (double)rounds * (sg / 16 + 0.7);
+            if (cost < best * 0.98) { best = cost; nseg = nn; }
+        }
+    }
     int seg = (H + nseg - 1) / nseg;
     seg = ((seg + 15) / 16) * 16;
     pl.col_seg = seg;
