@@ -7,7 +7,7 @@
  * FFI on this path is the pybind module `selective_scan_cuda.{fwd,bwd}` of the third-party package
  * `mamba_ssm`, reached through `selective_scan_fn` (basicsr/archs/wavemamba_arch.py:6, :383,
  * :465-471).  Each entry point below names the reference interface it replaces.  The Python host
- * side (wave-mamba_amd/ops.py) binds these symbols with ctypes and mirrors the reference's
+ * side (wave_mamba_amd/ops.py) binds these symbols with ctypes and mirrors the reference's
  * operator surface (same names, argument meaning, error behaviour).
  *
  * Conventions

@@ -1,7 +1,7 @@
 """Python face of the CPU oracle (oracle/wavemamba_oracle.c).  TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this module; the
-product package (wave-mamba_amd/) never does.  It exposes the same operator names as
+product package (wave_mamba_amd/) never does.  It exposes the same operator names as
 wave_mamba_amd.ops (dwt_init, iwt_init, iwt_init_pair, selective_scan_fn) on CPU tensors, backed by
 the plain-C restatement of the reference algorithms, so the very same network code can be run and
 timed on host cores as the checker / CPU baseline.

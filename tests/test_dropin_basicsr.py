@@ -37,7 +37,7 @@ def basicsr_tree(tmp_path):
         "        if e.is_file() and not e.name.startswith('.'):\n            yield e.name\n")
     shutil.copy(os.path.join(REF, "utils", "registry.py"), pkg / "utils" / "registry.py")      # the real registry
     shutil.copy(os.path.join(REF, "archs", "__init__.py"), pkg / "archs" / "__init__.py")      # the real auto-scan
-    shutil.copy(os.path.join(ROOT, "wave-mamba_amd", "archs", "wavemamba_arch.py"), pkg / "archs" / "wavemamba_arch.py")
+    shutil.copy(os.path.join(ROOT, "wave_mamba_amd", "archs", "wavemamba_arch.py"), pkg / "archs" / "wavemamba_arch.py")
     saved = {k: v for k, v in sys.modules.items() if k == "basicsr" or k.startswith("basicsr.")}
     for k in saved:
         del sys.modules[k]

@@ -1,7 +1,6 @@
-"""wave-mamba_amd: MI355X-native (gfx950) implementation of the Wave-Mamba hot path.
+"""wave_mamba_amd: MI355X-native (gfx950) implementation of the Wave-Mamba hot path.
 
-The directory name carries a hyphen (it is the project's name); import it as `wave_mamba_amd`
-(the one-line alias module at the repo root) or `importlib.import_module("wave-mamba_amd")`.
+(`wave-mamba_amd/`, the project's hyphenated name, is a symlink to this directory.)
 
     ops.dwt_init / ops.iwt_init / ops.selective_scan_fn   hand-written HIP behind a C ABI
     archs.wavemamba_arch.WaveMamba                        the reference's registry entry, re-built

@@ -1,6 +1,6 @@
 """Build the gfx950 HIP library (and nothing else) in-tree with hipcc.
 
-    python -m wave_mamba_amd.build         # or: python wave-mamba_amd/build.py
+    python -m wave_mamba_amd.build         # or: python wave_mamba_amd/build.py
 
 hipcc cross-compiles for gfx950 without a GPU; the resulting libwavemamba_hip.so sits next to this
 file (git-ignored, but it travels to the GPU box with the gpurun snapshot).
@@ -38,7 +38,7 @@ def build(force=False, verbose=True):
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-Wno-unused-value", SRC, "-o", LIB + ".tmp"]
     if verbose:
-        print("[wave-mamba_amd] " + " ".join(cmd), file=sys.stderr)
+        print("[wave_mamba_amd] " + " ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
     os.replace(LIB + ".tmp", LIB)
     return LIB
