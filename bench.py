@@ -234,10 +234,19 @@ def main():
     rank, world, local_rank = rank_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path is HIP-only (no CPU fallback)")
+    # self-test hook for one-GPU boxes (never set by the driver): WM_BENCH_SHARE_GPU=1 puts every rank on cuda:0 over gloo,
+    # to run the real N > 1 control flow (env parsing, barriers, max-over-ranks reduction, rank-0-only legs) on hardware;
+    # the throughput of such a run means nothing (the ranks share one GPU)
+    share = os.environ.get("WM_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)          # RCCL on ROCm
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)      # RCCL on ROCm
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     img = torch.rand(1, 3, args.height, args.width, generator=torch.Generator().manual_seed(image_seed(rank)))
@@ -319,7 +328,7 @@ def main():
             bf16 = inference.bench_bf16_storage(net, x, args.steps)
         except Exception as e:
             bf16 = {"error": f"{type(e).__name__}: {e}"[:300]}
-    elapsed = max_over_ranks(elapsed, world, device)
+    elapsed = max_over_ranks(elapsed, world, "cpu" if share else device)
 
     if rank == 0:
         pos = scan_positions(hp, wp)                       # positions scanned per image (14 LFSSBlocks)
@@ -371,7 +380,7 @@ def main():
             "metric": "UHD (3840x2160) images/sec fwd", "value": whole_job_value(world, args.steps, 1, elapsed),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (WM_BENCH_SHARE_GPU self-test: ranks share one GPU)" if share else ""),
             "config": {"workload": f"Wave-Mamba UHD-LL inference config (wf=32, n_l=[1,2,4], n_h=[1,1,2]), "
                                    f"1x3x{args.height}x{args.width} reflect-padded to {hp}x{wp}, seeded random "
                                    f"init, one image per GPU per step, replicas (no collective), one HIP stream"},
