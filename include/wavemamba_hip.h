@@ -222,7 +222,15 @@ int wm_mul_sigmoid_fwd(const float* a, const float* b, float* out, int64_t n, vo
  *                     Cin = Ca + Cb and the same ks.  H * W < 2^31.
  *   wm_conv2d_gated_fwd  y = conv3x3(x; wfrag3) * sigmoid(conv1x1(x; wfrag1) + bias1) over the same (concatenated /
  *                     gathered) input: PAConv's k3(x) * sigmoid(k2(x)) (:694-697) in one kernel - the 1x1 shares the
- *                     3x3's centre-tap operand fragments.  wfrag3 / wfrag1 prepared with ks = 3 / 1 for (Cout, Ca + Cb). */
+ *                     3x3's centre-tap operand fragments.  wfrag3 / wfrag1 prepared with ks = 3 / 1 for (Cout, Ca + Cb).
+ *   wm_conv2d_select  which 3x3 kernel serves wm_conv2d_fwd / wm_conv2d_gated_fwd: 0 (default) by problem size - the
+ *                     persistent wave-specialised kernel (one workgroup per compute unit, producer waves fetch / split
+ *                     / stage, consumer waves multiply: conv2d_ws.hip.h) when every compute unit gets a few tiles, the
+ *                     first-generation kernel otherwise; 1 always the first generation; 2 the wave-specialised one
+ *                     wherever its limits allow (a batch element of each tensor < 4 GiB, <= 128 gathered channels, not
+ *                     gate and residual together).  Both accumulate in the same order: results are bit-identical.
+ *                     Process-wide; WM_CONV_WS=0 in the environment = select(1).  WM_EINVAL for another mode. */
+int wm_conv2d_select(int mode);
 size_t wm_conv2d_wfrag_bytes(int Cout, int Cin, int ks);
 int wm_conv2d_prep(const float* weight, void* wfrag, int Cout, int Cin, int ks, void* stream);
 int wm_conv2d_fwd(const float* xa, const float* xb, const int* xb_index, const void* wfrag, const float* bias,

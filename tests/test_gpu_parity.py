@@ -805,13 +805,22 @@ def test_dwconv3x3_vs_torch(shape, act):
 # :993/:1006, :1015-1037).  Floating-point kernel of standard ops -> the fp64 PyTorch CPU composition is the
 # reference; bar: 2e-5 relative (three bf16 products per term: <= 3 * 2^-18 per product; measured ~4e-6)
 # ------------------------------------------------------------------------------------------------
+@pytest.fixture(params=["first_gen", "wave_specialised"])
+def conv3x3_impl(request):
+    """Run the test once per 3x3 kernel (the automatic choice would send these small shapes to the first-generation
+    one only)."""
+    wm.ops.conv2d_select(wm.ops.CONV3X3_FIRST_GEN if request.param == "first_gen" else wm.ops.CONV3X3_WAVE_SPECIALISED)
+    yield request.param
+    wm.ops.conv2d_select(wm.ops.CONV3X3_AUTO)
+
+
 @pytest.mark.parametrize("ks", [3, 1])
 @pytest.mark.parametrize("B,Ca,Cb,Cout,H,W,bias", [
     (1, 64, 0, 64, 70, 50, True), (2, 64, 0, 32, 33, 65, False), (1, 32, 32, 32, 40, 96, True),
     (1, 32, 0, 96, 16, 32, True), (1, 3, 0, 32, 40, 64, True), (2, 32, 0, 3, 64, 96, True),
     (1, 16, 8, 40, 5, 7, False), (1, 64, 0, 64, 1, 1, True), (1, 48, 0, 64, 31, 33, False),
     (1, 64, 0, 64, 160, 256, False), (1, 12, 0, 32, 24, 40, True), (1, 192, 0, 32, 9, 17, True)])
-def test_conv2d_vs_torch(ks, B, Ca, Cb, Cout, H, W, bias):
+def test_conv2d_vs_torch(conv3x3_impl, ks, B, Ca, Cb, Cout, H, W, bias):
     import torch.nn.functional as F
     gg = gen(Ca * 100 + Cout + H + ks)
     xa = torch.randn(B, Ca, H, W, generator=gg)
@@ -827,7 +836,7 @@ def test_conv2d_vs_torch(ks, B, Ca, Cb, Cout, H, W, bias):
 @pytest.mark.parametrize("ks", [3, 1])
 @pytest.mark.parametrize("B,Ca,Csrc,Cb,Cout,H,W", [(1, 32, 32, 32, 64, 24, 40), (2, 32, 32, 32, 64, 9, 33),
                                                   (2, 16, 24, 8, 32, 17, 31)])
-def test_conv2d_gather_gate_residual(ks, B, Ca, Csrc, Cb, Cout, H, W):
+def test_conv2d_gather_gate_residual(conv3x3_impl, ks, B, Ca, Csrc, Cb, Cout, H, W):
     """cat([x, gather(p, idx)]) as operand, `* sigmoid(gate)` and `+ residual` in the epilogue: the PAConv /
     HFEBlock composition of the reference (:666, :694-697, :713, :849-853)."""
     import torch.nn.functional as F
@@ -1036,7 +1045,7 @@ def test_batched_forward_equals_per_image_forward():
 
 @pytest.mark.parametrize("B,Ca,Csrc,Cb,Cout,H,W", [(1, 32, 32, 32, 64, 24, 40), (2, 32, 32, 32, 64, 9, 33),
                                                   (1, 64, 0, 0, 64, 31, 17), (2, 16, 24, 8, 40, 17, 31)])
-def test_conv2d_gated_vs_torch(B, Ca, Csrc, Cb, Cout, H, W):
+def test_conv2d_gated_vs_torch(conv3x3_impl, B, Ca, Csrc, Cb, Cout, H, W):
     """PAConv's k3(x) * sigmoid(k2(x)) (reference :694-697) in one kernel, on cat([x, gather(p, idx)])."""
     import torch.nn.functional as F
     gg = gen(B * 17 + Cout)
@@ -1054,6 +1063,64 @@ def test_conv2d_gated_vs_torch(B, Ca, Csrc, Cb, Cout, H, W):
         got = wm.ops.conv2d_gated(*cu(x, w3, w1, b1))
     ref = F.conv2d(xin.double(), w3.double(), None, padding=1) * torch.sigmoid(F.conv2d(xin.double(), w1.double(), b1.double()))
     assert_close(got, ref.float(), 2e-5, f"conv2d_gated {(B, Ca, Cb, Cout, H, W)}")
+
+
+@pytest.mark.parametrize("B,Ca,Csrc,Cb,Cout,H,W", [
+    (1, 64, 0, 0, 64, 136, 256),       # interior tiles only (64 x 8 tiles divide the image): the predicate-free stores
+    (2, 32, 32, 32, 64, 70, 150),      # ragged right / bottom tiles, concatenated + gathered operand, batch 2
+    (1, 3, 0, 0, 32, 50, 130),         # one partial 16-channel chunk
+    (1, 32, 0, 0, 3, 64, 192),         # a partial row tile (channel guards)
+    (1, 80, 40, 24, 96, 40, 70),       # five chunks + a half, three row tiles (a 2-tile and a 1-tile launch)
+    (3, 16, 8, 8, 40, 7, 5)])          # an image smaller than a tile
+def test_conv3x3_kernels_bit_identical(B, Ca, Csrc, Cb, Cout, H, W):
+    """The persistent wave-specialised 3x3 (conv2d_ws.hip.h) against the first-generation kernel on the same inputs, every
+    fused form: same MFMA sequence per output element -> equal bit for bit (any difference is an indexing / hand-off bug,
+    not rounding).  Each form is also run twice on the wave-specialised kernel (a race between producer and consumer
+    waves would show as run-to-run differences)."""
+    gg = gen(B * 7 + Ca + Cout + W)
+    x = torch.randn(B, Ca, H, W, generator=gg)
+    p = torch.randn(B, Csrc, H, W, generator=gg) if Cb else None
+    idx = torch.randint(0, Csrc, (B, Cb), generator=gg) if Cb else None
+    w3 = torch.randn(Cout, Ca + Cb, 3, 3, generator=gg) / (3 * (Ca + Cb) ** 0.5)
+    w1 = torch.randn(Cout, Ca + Cb, 1, 1, generator=gg) / (Ca + Cb) ** 0.5
+    b = torch.randn(Cout, generator=gg)
+    gate = torch.randn(B, Cout, H, W, generator=gg)
+    res = torch.randn(B, Cout, H, W, generator=gg)
+    xd, pd, idxd, w3d, w1d, bd, gd, rd = cu(x, p, idx, w3, w1, b, gate, res)
+    forms = {
+        "plain": lambda: wm.ops.conv2d(xd, w3d, bd, pd, idxd),
+        "no bias": lambda: wm.ops.conv2d(xd, w3d, None, pd, idxd),
+        "gate": lambda: wm.ops.conv2d(xd, w3d, bd, pd, idxd, gate=gd),
+        "residual": lambda: wm.ops.conv2d(xd, w3d, bd, pd, idxd, residual=rd),
+        "k3 * sigmoid(k2)": lambda: wm.ops.conv2d_gated(xd, w3d, w1d, bd, pd, idxd),
+    }
+    try:
+        for name, fn in forms.items():
+            wm.ops.conv2d_select(wm.ops.CONV3X3_FIRST_GEN)
+            ref = fn()
+            wm.ops.conv2d_select(wm.ops.CONV3X3_WAVE_SPECIALISED)
+            got, again = fn(), fn()
+            assert torch.equal(got, ref), f"{name}: max |diff| {float((got - ref).abs().max()):.3e}"
+            assert torch.equal(got, again), f"{name}: the wave-specialised kernel is not reproducible"
+    finally:
+        wm.ops.conv2d_select(wm.ops.CONV3X3_AUTO)
+
+
+def test_conv3x3_auto_choice_at_uhd_level1_is_bit_identical_too():
+    """At UHD level 1 the automatic choice is the wave-specialised kernel (16 tiles per compute unit, the chunk pipeline
+    running across tile boundaries): same bits as the first-generation kernel on a 64 -> 64 and a gated 64 -> 64."""
+    gg = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(1, 64, 1088, 1920, device=DEV, generator=gg)
+    w3 = torch.randn(64, 64, 3, 3, device=DEV, generator=gg) / 24
+    w1 = torch.randn(64, 64, 1, 1, device=DEV, generator=gg) / 8
+    b1 = torch.randn(64, device=DEV, generator=gg)
+    try:
+        auto = wm.ops.conv2d(x, w3), wm.ops.conv2d_gated(x, w3, w1, b1)
+        wm.ops.conv2d_select(wm.ops.CONV3X3_FIRST_GEN)
+        ref = wm.ops.conv2d(x, w3), wm.ops.conv2d_gated(x, w3, w1, b1)
+    finally:
+        wm.ops.conv2d_select(wm.ops.CONV3X3_AUTO)
+    assert torch.equal(auto[0], ref[0]) and torch.equal(auto[1], ref[1])
 
 
 @pytest.mark.parametrize("shape", [(2, 40, 56, 32), (1, 7, 9, 64), (3, 130, 16), (5, 8)])

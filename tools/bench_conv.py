@@ -20,11 +20,13 @@ shapes = [  # (Ca, Cb, Cout, H, W, bias)
 ]
 if len(sys.argv) > 1 and sys.argv[1] == "one":
     shapes = shapes[:1]
+if len(sys.argv) > 1 and sys.argv[1] == "l1":
+    shapes = shapes[:3] + shapes[7:]
 if len(sys.argv) > 1 and sys.argv[1] == "small":
     shapes = [(64, 0, 64, 70, 50, True), (16, 8, 40, 33, 65, True), (3, 0, 32, 40, 64, True), (32, 0, 3, 64, 96, False)]
 
 
-def timeit(fn, n=5):
+def timeit(fn, n=int(os.environ.get("WM_BENCH_N", "5"))):
     fn(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):
@@ -48,7 +50,8 @@ for ca, cb, co, H, W, hb in shapes:
         a = a[:, :, :hh, :ww].double()
         return float((a - ref64).norm() / ref64.norm()), float((a - ref64).abs().max() / ref64.abs().max())
     t_wm = timeit(lambda: wm.ops.conv2d(xa, w, b, xb))
-    t_mi = timeit(lambda: F.conv2d(xin if xb is None else torch.cat([xa, xb], 1), w, b, padding=KS // 2))
+    t_mi = float("nan") if os.environ.get("WM_NO_MIOPEN") else \
+        timeit(lambda: F.conv2d(xin if xb is None else torch.cat([xa, xb], 1), w, b, padding=KS // 2))
     flops = 2.0 * KS * KS * (ca + cb) * co * H * W
     byts = 4.0 * (ca + cb + co) * H * W
     print(f"Cin {ca}+{cb} Cout {co} {H}x{W}: wm {t_wm:.3f} ms ({flops / t_wm / 1e9:.0f} TFLOP/s fp32-equiv, "

@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("WAVEMAMBA_HIP_LIB") or os.path.join(HERE, "libwavemam
 
 WM_F32, WM_BF16 = 0, 1
 WM_PROF_NKERNELS = 16
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _c = ctypes
 _p, _i, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
@@ -56,6 +56,7 @@ SIGNATURES = {
     "wm_conv2d_prep": (_i, [_p, _p, _i, _i, _i, _p]),
     "wm_conv2d_fwd": (_i, [_p] * 8 + [_i] * 8 + [_p]),
     "wm_conv2d_gated_fwd": (_i, [_p] * 7 + [_i] * 7 + [_p]),
+    "wm_conv2d_select": (_i, [_i]),
     "wm_prof_enable": (None, [ctypes.c_uint]),
     "wm_prof_collect": (_i, [_c.POINTER(_i), _c.POINTER(_c.c_double)]),
 }

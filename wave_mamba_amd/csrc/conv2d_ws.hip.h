@@ -1,0 +1,455 @@
+// conv2d_ws.hip.h - the dense 3x3 convolution of conv2d.hip.h as a persistent, wave-specialised kernel.
+//
+// Same arithmetic (three bf16 products per fp32 product, v_mfma_f32_32x32x16_bf16, same fragment layouts, same prepared
+// weights, same fused concatenation / gather / 1x1 gate / bias / sigmoid gate / residual) and the same reference call
+// sites as conv2d_mfma_kernel<3, ...>; what changes is who does what, when.  Measured on conv2d_mfma_kernel at UHD
+// level 1, 64 -> 64 (tools/_ab_conv.sh, tools/ubench_tile_fetch.hip): 0.59 ms = operand fetch 0.17 (alone, at its own
+// throughput bound) + stores 0.10 + convert / LDS / MFMA 0.35 - the sum of the phases: two co-resident workgroups
+// started together stay in phase (both fetch, then both multiply), so nothing overlaps.  Here one workgroup of eight
+// waves owns a compute unit for the whole launch and walks a list of tiles:
+//   waves 4-7 (producers): global loads of the 16-channel chunk two steps ahead (registers, two sets), bf16 hi / lo
+//            split and LDS store of the chunk one step ahead, LDS-DMA of its weights;
+//   waves 0-3 (consumers): B / A fragment reads and MFMAs of the current chunk, and the tile's epilogue.
+// One LDS-only barrier per chunk (s_waitcnt lgkmcnt(0); s_barrier - __syncthreads() would drain the producers'
+// loads in flight); LDS double-buffered; the chunk stream runs across tile boundaries, so the first fetch of a tile
+// hides under the previous tile's MFMAs.
+#pragma once
+#include <type_traits>
+#include "conv2d.hip.h"
+
+namespace wm {
+
+constexpr int kWsTW = 64;             // tile width: two MFMA column tiles (a staged row is 2 whole cache lines + 2 halo pixels)
+
+template <int RW, int MT, bool G1X1>
+struct ConvWsCfg {
+    static constexpr int PW = kWsTW + 2;                 // staged row pitch in pixels
+    static constexpr int TH = 2 * RW;                    // tile rows: consumer wave (w & 1, w >> 1) owns a 32-pixel x RW-row block
+    static constexpr int NPIX = (TH + 2) * PW;           // staged pixels per chunk
+    static constexpr int PIT = (NPIX + 255) / 256;       // staged pixels per producer thread
+    static constexpr int W_ITEMS = 9 * MT * 2 * 64;      // 16-byte weight fragments per chunk
+    static constexpr int W1_ITEMS = G1X1 ? MT * 2 * 64 : 0;
+    static constexpr int BUF_ITEMS = 4 * NPIX + W_ITEMS + W1_ITEMS;
+    static constexpr int LDS_BYTES = 2 * BUF_ITEMS * 16 + 2 * MT * 32 * 4;      // + bias, bias1 of the launch's channels
+};
+
+// the tile list of a workgroup: XCD x = g & 7 owns a contiguous band of the (batch x rows x columns) tile order, its
+// workgroups take the band's tiles round-robin (neighbouring tiles run at the same time on the same L2)
+struct ConvWsTiles {
+    int tiles_x, ntiles_img, first, stride, count;
+    __device__ ConvWsTiles(int B, int H, int W, int TH, int g, int G) {
+        tiles_x = (W + kWsTW - 1) / kWsTW;
+        ntiles_img = tiles_x * ((H + TH - 1) / TH);
+        const int ntiles = ntiles_img * B, nper = (ntiles + 7) / 8;
+        const int x = g & 7, slot = g >> 3;
+        stride = G >> 3;
+        first = x * nper + slot;
+        const int end = min((x + 1) * nper, ntiles);
+        count = first < end ? (end - first + stride - 1) / stride : 0;
+    }
+    __device__ void locate(int j, int TH, int& b, int& h0, int& w0) const {
+        const int t = first + j * stride;
+        b = t / ntiles_img;
+        const int ti = t - b * ntiles_img;
+        h0 = (ti / tiles_x) * TH;
+        w0 = (ti % tiles_x) * kWsTW;
+    }
+};
+
+#ifndef WM_CV_STAMP
+#define WM_CV_STAMP 0                 // measurement builds: phase time stamps of workgroup 0 (tools/conv_stamps.py)
+#endif
+#if WM_CV_STAMP
+__device__ unsigned long long g_cv_stamps[2 * 128 * 8];
+#define CV_STAMP(role, it, k) do { if (WM_CV_STAMP && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && (it) < 128) \
+        g_cv_stamps[((role) * 128 + (it)) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CV_STAMP(role, it, k) do { } while (0)
+#endif
+
+// LDS store the compiler does not see as one: after an LDS-DMA (tracked by vmcnt) it orders every LDS access it can
+// see behind s_waitcnt vmcnt(0) - which here would also drain the pixel loads issued a moment ago.  The weights land
+// in another region of the buffer; the step's closing s_waitcnt covers both counters.
+using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
+template <int OFF>
+__device__ __forceinline__ void ws_lds_store16(unsigned addr, const uint4& v) {
+    u32x4_t d = {v.x, v.y, v.z, v.w};
+    asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(addr), "v"(d), "n"(OFF) : "memory");
+}
+
+__device__ __forceinline__ void ws_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int RW, int MT, bool G1X1, bool EPI>
+__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const Conv2dArgs a, const int B) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cv_smem[];
+    using Cfg = ConvWsCfg<RW, MT, G1X1>;
+    constexpr int PW = Cfg::PW, TH = Cfg::TH, NPIX = Cfg::NPIX, PIT = Cfg::PIT;
+    constexpr int W_ITEMS = Cfg::W_ITEMS, W1_ITEMS = Cfg::W1_ITEMS, BUF = Cfg::BUF_ITEMS;
+    uint4* const smem = reinterpret_cast<uint4*>(cv_smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const ConvWsTiles tl(B, a.H, a.W, TH, (int)blockIdx.x, (int)gridDim.x);
+    if (tl.count == 0) return;
+    const int nch = a.nch;
+    const int n_it = tl.count * nch;                       // chunk steps of this workgroup
+    const int H = a.H, W = a.W;
+    const long long HW = (long long)H * W;
+
+    if (tid < 2 * MT * 32) {                               // biases of this launch's output channels -> LDS
+        const int which = tid / (MT * 32), ch = a.mbase * 32 + tid % (MT * 32);
+        const float* src = which ? a.bias1 : a.bias;
+        reinterpret_cast<float*>(smem + 2 * BUF)[tid] = (src && ch < a.Cout) ? src[ch] : 0.0f;
+    }
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int ptid = tid - 256, pw = wave - 4;
+        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)cv_smem;
+        static_assert(2 * NPIX * 16 < 65536, "the lo plane sits within the ds_write offset field");
+        float pin[2][2][PIT][8];                           // [set][k-half][pixel][channel]
+        // all-ones / zero per staged pixel of the set: inside the image?  Kept opaque to the compiler (an asm barrier
+        // on the mask, not on the data): a select on a condition it can trace back to the load makes it predicate every
+        // load per lane - one exec-masked branch and one wait per load
+        unsigned okm[2][PIT];
+        int ccs[2] = {0, 0};                               // chunk index held by the set
+        unsigned poff[PIT];                                // byte offset of the staged pixel in a channel plane
+        unsigned okF[PIT];
+        int jf = -1, ccf = nch - 1;                        // fetch cursor: (tile ordinal, chunk)
+        const float* xaF = a.xa;
+        const float* xbF = a.xa;
+        // gather indices of the cursor's batch element: lane l holds xb_idx[b][l] and xb_idx[b][64 + l] (Cb <= 128, host
+        // check), read back with v_readlane - an index load inside the channel loop is a vector load the compiler waits
+        // for with vmcnt(0), draining every pixel load in flight, once per channel
+        int idxv0 = 0, idxv1 = 0, bF = -1;
+
+        auto fetch_w = [&](int buf, int cc) {
+            uint4* s_w = smem + buf * BUF + 4 * NPIX;
+            const uint4* wsrc = a.wfrag + ((long long)cc * 9 * a.mtot) * 128;
+            constexpr int W_IT = (W_ITEMS + 255) / 256;
+#pragma unroll
+            for (int it = 0; it < W_IT; ++it) {
+                const int item0 = it * 256 + pw * 64;     // wave-uniform
+                if (W_ITEMS % 256 == 0 || item0 < W_ITEMS) {
+                    const int tm = item0 >> 7, tap = tm / MT, m = tm - tap * MT;
+                    const uint4* g = wsrc + (tap * a.mtot + a.mbase + m) * 128 + (item0 & 64) + lane;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(s_w + item0), 16, 0, 0);
+                }
+            }
+            if constexpr (G1X1) {
+                uint4* s_w1 = s_w + W_ITEMS;
+                const uint4* w1src = a.wfrag1 + ((long long)cc * a.mtot) * 128;
+                const int item0 = pw * 64;
+                if (item0 < W1_ITEMS) {
+                    const uint4* g = w1src + (a.mbase + (item0 >> 7)) * 128 + (item0 & 64) + lane;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(s_w1 + item0), 16, 0, 0);
+                }
+            }
+        };
+        // the fetch cursor moves to the next chunk (and tile): staged-pixel offsets and masks of the new tile
+        auto advance = [&]() {
+            if (++ccf == nch) {                            // uniform
+                ccf = 0; ++jf;
+                int b, h0, w0;
+                tl.locate(jf, TH, b, h0, w0);
+#pragma unroll
+                for (int it = 0; it < PIT; ++it) {
+                    const int p = ptid + it * 256;
+                    const int pr = p / PW, pc = p - pr * PW;
+                    const int h = h0 - 1 + pr, w = w0 - 1 + pc;
+                    const bool ok = p < NPIX && h >= 0 && h < H && w >= 0 && w < W;
+                    okF[it] = ok ? 0xffffffffu : 0u;
+                    poff[it] = ok ? (unsigned)(h * W + w) * 4u : 0u;
+                    asm volatile("" : "+v"(okF[it]), "+v"(poff[it]));
+                }
+                if (b != bF) {                             // uniform; once per batch element
+                    bF = b;
+                    xaF = a.xa + (long long)b * a.Ca * HW;
+                    xbF = a.xb ? a.xb + (long long)b * a.Cbsrc * HW : a.xa;
+                    if (a.xb_idx) {
+                        const int* idx = a.xb_idx + (long long)b * a.Cb;
+                        idxv0 = lane < a.Cb ? idx[lane] : 0;
+                        idxv1 = lane + 64 < a.Cb ? idx[lane + 64] : 0;
+                        asm volatile("" : "+v"(idxv0), "+v"(idxv1));       // waited for here, once, not at every v_readlane
+                    }
+                }
+            }
+        };
+        // loads of one 8-channel half of the cursor's chunk: one base pointer per source and 32-bit element offsets
+        // (channel * H * W + pixel; the host checks that a source fits 2^32 bytes).  Padded channels read channel 0 and
+        // are zeroed in stage_half (masking here would make the compiler branch around every load)
+        auto fetch_half = [&](auto SETC, auto HALFC) {
+            constexpr int S = decltype(SETC)::value, half = decltype(HALFC)::value;
+            if (half == 0) {
+                ccs[S] = ccf;
+#pragma unroll
+                for (int it = 0; it < PIT; ++it) okm[S][it] = okF[it];
+            }
+            const int c0 = ccf * 16 + half * 8;            // first of the 8 channels (uniform)
+            const bool from_a = c0 < a.Ca;
+            const int cl = from_a ? c0 : c0 - a.Ca;
+            const int cn = (from_a ? a.Ca : a.Cb) - cl;
+            const char* src = reinterpret_cast<const char*>(from_a ? xaF : xbF);
+            const bool gather = !from_a && a.xb_idx;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool cok = j < cn;
+                const int cg = cl + j;
+                const int ch = !cok ? 0 : !gather ? cg
+                             : cg < 64 ? __builtin_amdgcn_readlane(idxv0, cg) : __builtin_amdgcn_readlane(idxv1, cg - 64);
+                const unsigned choff = (unsigned)ch * (unsigned)HW * 4u;
+#pragma unroll
+                for (int it = 0; it < PIT; ++it)
+                    pin[S][half][it][j] = *reinterpret_cast<const float*>(src + (size_t)(choff + poff[it]));
+            }
+        };
+        auto stage_half = [&](auto SETC, auto HALFC, int buf) {
+            constexpr int S = decltype(SETC)::value, half = decltype(HALFC)::value;
+            const unsigned s_in = lds_base + (unsigned)(buf * BUF + half * NPIX + ptid) * 16u;
+            const int c0 = ccs[S] * 16 + half * 8;
+            const int cn = c0 < a.Ca ? a.Ca - c0 : a.Ca + a.Cb - c0;       // valid channels of this 8-group (uniform)
+#pragma unroll
+            for (int it = 0; it < PIT; ++it) {
+                const int p = ptid + it * 256;
+                if (NPIX % 256 == 0 || p < NPIX) {
+                    Frag16 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = j < cn ? __builtin_bit_cast(float, __builtin_bit_cast(unsigned, pin[S][half][it][j]) & okm[S][it]) : 0.0f;
+                        const __bf16 hv = (__bf16)v;
+                        hi.v[j] = hv;
+                        lo.v[j] = (__bf16)(v - (float)hv);
+                    }
+                    ws_lds_store16<0>(s_in + it * 4096u, hi.u);
+                    ws_lds_store16<2 * NPIX * 16>(s_in + it * 4096u, lo.u);
+                }
+            }
+        };
+        using C0 = std::integral_constant<int, 0>;
+        using C1 = std::integral_constant<int, 1>;
+        // one producer step: weights of the chunk being staged (LDS-DMA), then, half by half, the loads of the chunk two
+        // steps ahead into set SF and the split + LDS store of the chunk one step ahead out of set SS - the conversion
+        // fills the time the wave would otherwise stand at a load the memory pipe has not accepted yet
+        auto step = [&](auto SF, auto SS, bool do_fetch, bool do_stage, int buf, int i) {
+            CV_STAMP(1, i, 0);
+            if (do_stage) fetch_w(buf, ccs[decltype(SS)::value]);
+            if (do_fetch) { advance(); fetch_half(SF, C0{}); }
+            CV_STAMP(1, i, 1);
+            if (do_stage) stage_half(SS, C0{}, buf);
+            if (do_fetch) fetch_half(SF, C1{});
+            CV_STAMP(1, i, 2);
+            if (do_stage) stage_half(SS, C1{}, buf);
+            __builtin_amdgcn_s_waitcnt(0x0070);           // vmcnt(0) lgkmcnt(0): weights landed, LDS stores done
+            CV_STAMP(1, i, 3);
+            ws_barrier_lds();
+            CV_STAMP(1, i, 4);
+        };
+
+        // chunk 0 -> buffer 0; chunk 1 in flight
+        advance(); fetch_half(C0{}, C0{}); fetch_half(C0{}, C1{});
+        fetch_w(0, ccs[0]);
+        if (n_it > 1) { advance(); fetch_half(C1{}, C0{}); fetch_half(C1{}, C1{}); }
+        stage_half(C0{}, C0{}, 0); stage_half(C0{}, C1{}, 0);
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        ws_barrier_lds();
+        for (int i = 0; i < n_it; i += 2) {
+            // step i: consumers on buffer 0; chunk i + 1 (set 1) -> buffer 1; chunk i + 2 -> set 0
+            step(C0{}, C1{}, i + 2 < n_it, i + 1 < n_it, 1, i);
+            if (i + 1 >= n_it) break;
+            // step i + 1: consumers on buffer 1; chunk i + 2 (set 0) -> buffer 0; chunk i + 3 -> set 1
+            step(C1{}, C0{}, i + 3 < n_it, i + 2 < n_it, 0, i + 1);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    f32x16_t acc[MT][RW];
+    f32x16_t acc1[G1X1 ? MT : 1][G1X1 ? RW : 1];
+    auto zero_acc = [&](auto MC) {
+        constexpr int m = decltype(MC)::value;
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc[m][r][i] = 0.0f; if (G1X1) acc1[m][r][i] = 0.0f; }
+    };
+    using M0 = std::integral_constant<int, 0>;
+    using M1 = std::integral_constant<int, MT - 1>;       // the second row tile (MT <= 2)
+    static_assert(MT <= 2, "at most two row tiles per launch");
+    zero_acc(M0{});
+    if (MT > 1) zero_acc(M1{});
+    const int khalf = lane >> 5, px = lane & 31;
+    const int cw = wave & 1, rg = wave >> 1;                 // this wave's 32-pixel column block and row group
+
+    const bool full = (a.mbase + MT) * 32 <= a.Cout;                 // uniform: no channel guard on the stores
+    const float* s_bias = reinterpret_cast<const float*>(smem + 2 * BUF);          // [MT * 32] bias, [MT * 32] bias1
+    const unsigned HWb = (unsigned)HW * 4u;
+    // tile j of this workgroup: interior, with whole row tiles?  (uniform) - the store path without predicates
+    auto tile_fast = [&](int j, int& b, int& h0, int& w0) {
+        tl.locate(j, TH, b, h0, w0);
+        return full && h0 + TH <= H && w0 + kWsTW <= W;
+    };
+
+    auto mma = [&](int buf) {
+        const uint4* s_in = smem + buf * BUF;
+        const uint4* s_w = s_in + 4 * NPIX;
+        const uint4* s_w1 = s_w + W_ITEMS;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            Frag16 Ah[3][MT], Al[3][MT];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    Ah[ky][m].u = s_w[(((ky * 3 + kx) * MT + m) * 2 + 0) * 64 + lane];
+                    Al[ky][m].u = s_w[(((ky * 3 + kx) * MT + m) * 2 + 1) * 64 + lane];
+                }
+#pragma unroll
+            for (int j = 0; j < RW + 2; ++j) {
+                const int pidx = (rg * RW + j) * PW + cw * 32 + px + kx;
+                Frag16 Bh, Bl;
+                Bh.u = s_in[khalf * NPIX + pidx];
+                Bl.u = s_in[(2 + khalf) * NPIX + pidx];
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int r = j - ky;
+                        if (r < 0 || r >= RW) continue;
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                term == 2 ? Al[ky][m].v : Ah[ky][m].v, term == 1 ? Bl.v : Bh.v, acc[m][r], 0, 0, 0);
+                    }
+                if constexpr (G1X1) {
+                    if (kx == 1 && j >= 1 && j < RW + 1) {             // centre tap: staged row j is output row j - 1
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            Frag16 Wh, Wl;
+                            Wh.u = s_w1[(m * 2 + 0) * 64 + lane];
+                            Wl.u = s_w1[(m * 2 + 1) * 64 + lane];
+                            f32x16_t c1 = acc1[m][j - 1];
+                            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wh.v, Bh.v, c1, 0, 0, 0);
+                            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wh.v, Bl.v, c1, 0, 0, 0);
+                            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wl.v, Bh.v, c1, 0, 0, 0);
+                            acc1[m][j - 1] = c1;
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    // D layout of v_mfma_f32_32x32x*: column = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+    // The epilogue must not wait on vmcnt between its stores (a wait for ANY load also waits for every earlier store's
+    // write acknowledgement: 2-3 k cycles, once per 16-channel block - measured 22 k cycles per tile): the biases come
+    // from LDS, and the gate / residual operands (EPI, one 32-channel row tile per launch) are all loaded before the
+    // first store.
+    auto epilogue = [&](int j, auto MC) {
+        constexpr int m = decltype(MC)::value;
+        int b, h0, w0;
+        const bool fast = tile_fast(j, b, h0, w0);
+        const int w = w0 + cw * 32 + px;
+        float ev[EPI ? RW : 1][16];                       // EPI: the gate XOR the residual operand (host check)
+        const float* const eptr = a.gate ? a.gate : a.res;
+        const bool is_gate = a.gate != nullptr;
+        if (fast) {
+            // interior tile, whole row tiles (uniform): no lane or channel predicates - one pointer per tensor, 32-bit byte
+            // offsets (the host checks that a batch element of y fits 2^32 bytes), three instructions per store
+            const size_t bo = (size_t)b * a.Cout * HW * 4;
+            char* yb = reinterpret_cast<char*>(a.y) + bo;
+            const char* eb = reinterpret_cast<const char*>(eptr) + bo;
+            if constexpr (EPI) {
+                const unsigned o0 = (unsigned)(((a.mbase * 32 + 4 * khalf) * H + h0 + rg * RW) * W + w) * 4u;
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const unsigned o = o0 + (unsigned)(r * W) * 4u + (unsigned)((i & 3) + 8 * (i >> 2)) * HWb;
+                        ev[r][i] = *reinterpret_cast<const float*>(eb + (size_t)o);
+                    }
+            }
+            {
+                float bv[16], b1v[G1X1 ? 16 : 1];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int cl = m * 32 + 4 * khalf + (i & 3) + 8 * (i >> 2);
+                    bv[i] = s_bias[cl];
+                    if (G1X1) b1v[i] = s_bias[MT * 32 + cl];
+                }
+                const unsigned o0 = (unsigned)((((a.mbase + m) * 32 + 4 * khalf) * H + h0 + rg * RW) * W + w) * 4u;
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const unsigned o = o0 + (unsigned)(r * W) * 4u + (unsigned)((i & 3) + 8 * (i >> 2)) * HWb;
+                        float v = acc[m][r][i] + bv[i];
+                        if constexpr (G1X1) v = v / (1.0f + __expf(-(acc1[m][r][i] + b1v[i])));
+                        if constexpr (EPI) v = is_gate ? v / (1.0f + __expf(-ev[r][i])) : v + ev[r][i];
+                        *reinterpret_cast<float*>(yb + (size_t)o) = v;
+                    }
+            }
+            return;
+        }
+        if constexpr (EPI) {
+            static_assert(!EPI || MT == 1, "gate / residual operands: one row tile per launch");
+            const int chb = a.mbase * 32 + 4 * khalf;
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const int h = h0 + rg * RW + r;
+                const bool in = h < H && w < W;
+                const long long o = (((long long)b * a.Cout + chb) * H + min(h, H - 1)) * W + min(w, W - 1);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int dc = (i & 3) + 8 * (i >> 2);
+                    const bool ok = in && (full || chb + dc < a.Cout);
+                    ev[r][i] = ok ? eptr[o + dc * HW] : 0.0f;
+                }
+            }
+        }
+        {
+            const int chb = (a.mbase + m) * 32 + 4 * khalf;
+            float bv[16], b1v[G1X1 ? 16 : 1];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int cl = m * 32 + 4 * khalf + (i & 3) + 8 * (i >> 2);
+                bv[i] = s_bias[cl];
+                if (G1X1) b1v[i] = s_bias[MT * 32 + cl];
+            }
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const int h = h0 + rg * RW + r;
+                if (h >= H || w >= W) continue;
+                const long long o = (((long long)b * a.Cout + chb) * H + h) * W + w;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int dc = (i & 3) + 8 * (i >> 2);
+                    float v = acc[m][r][i] + bv[i];
+                    if constexpr (G1X1) v = v / (1.0f + __expf(-(acc1[m][r][i] + b1v[i])));
+                    if constexpr (EPI) v = is_gate ? v / (1.0f + __expf(-ev[r][i])) : v + ev[r][i];
+                    if (full || chb + dc < a.Cout) a.y[o + dc * HW] = v;
+                }
+            }
+        }
+    };
+
+    ws_barrier_lds();                                      // buffer 0 holds chunk 0
+    int cc = 0, j = 0;
+    for (int i = 0; i < n_it; ++i) {
+        CV_STAMP(0, i, 0);
+        mma(i & 1);
+        CV_STAMP(0, i, 1);
+        ws_barrier_lds();                                  // this buffer is free; the other one is ready
+        CV_STAMP(0, i, 2);
+        if (++cc == nch) {
+            epilogue(j, M0{});
+            if (MT > 1) epilogue(j, M1{});
+            zero_acc(M0{});
+            if (MT > 1) zero_acc(M1{});
+            cc = 0; ++j;
+        }
+        CV_STAMP(0, i, 3);
+    }
+}
+
+}  // namespace wm

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -18,6 +19,7 @@
 #include "lfss_mfma.hip.h"
 #include "gram.hip.h"
 #include "conv2d.hip.h"
+#include "conv2d_ws.hip.h"
 #include "hfe.hip.h"
 #include "ss2d_bwd.hip.h"
 #include "imageio.hip.h"
@@ -279,7 +281,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 14; }
+int wm_abi_version(void) { return 15; }
 
 const char* wm_strerror(int code) {
     switch (code) {
@@ -1379,6 +1381,62 @@ static int conv2d_launch(const wm::Conv2dArgs& a, int B, hipStream_t st) {
     return launch_status();
 }
 
+// Which 3x3 kernel: the persistent wave-specialised one (conv2d_ws.hip.h, one workgroup per compute unit) where it
+// pays - enough 64 x 8 tiles that every compute unit pipelines a few (UHD levels 1 and 2 and full resolution; at level 3
+// a workgroup gets one or two tiles and the first-generation kernel is 20-30 % faster), at most one epilogue operand and
+// then a single 32-channel row tile (two launches re-reading the input lose to the first-generation kernel's one) - and
+// where its 32-bit offsets hold.  wm_conv2d_select() pins the choice (parity tests run both on the same inputs: the
+// accumulation order per output element is the same, so the results are bit-identical); WM_CONV_WS=0 in the
+// environment is the same as select(1).
+static std::atomic<int> g_conv_select{-1};
+static int conv_select_mode() {
+    int m = g_conv_select.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("WM_CONV_WS");
+        m = (e && e[0] == '0') ? 1 : 0;
+        g_conv_select.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+static bool conv_ws_enabled(const wm::Conv2dArgs& a, int B, bool gated) {
+    const int mode = conv_select_mode();
+    if (mode == 1) return false;
+    // 32-bit byte offsets inside one batch element of every tensor; gather indices in two registers
+    const long long cmax = std::max(std::max(a.Ca, a.xb ? a.Cbsrc : 0), a.Cout);
+    if (cmax * a.H * a.W * 4 >= (1ll << 32) || (a.xb_idx && a.Cb > 128)) return false;
+    if (a.gate && a.res) return false;
+    if (mode == 2) return true;
+    if ((a.gate || a.res) && a.mtot > 1) return false;
+    const int th = gated ? 4 : 8;                           // tile rows of the launch that would run
+    const long long ntiles = (long long)B * ((a.W + wm::kWsTW - 1) / wm::kWsTW) * ((a.H + th - 1) / th);
+    return ntiles >= 768;
+}
+
+template <int RW, int MT, bool G1X1 = false, bool EPI = false>
+static int conv2d_ws_launch(const wm::Conv2dArgs& a, int B, hipStream_t st) {
+    using Cfg = wm::ConvWsCfg<RW, MT, G1X1>;
+    static bool configured[64] = {};
+    static int ncu[64] = {};
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return WM_EHIP;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!configured[dev]) {
+            if (hipFuncSetAttribute((const void*)wm::conv3x3_ws_kernel<RW, MT, G1X1, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    Cfg::LDS_BYTES) != hipSuccess) return WM_EHIP;
+            if (hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return WM_EHIP;
+            configured[dev] = true;
+        }
+    }
+    const long long ntiles = (long long)B * ((a.W + wm::kWsTW - 1) / wm::kWsTW) * ((a.H + Cfg::TH - 1) / Cfg::TH);
+    if (ntiles >= (1ll << 31)) return WM_EUNSUPPORTED;
+    const int cus = std::max(8, ncu[dev] & ~7);
+    const int G = (int)std::min<long long>(cus, ((ntiles + 7) / 8) * 8);
+    hipLaunchKernelGGL((wm::conv3x3_ws_kernel<RW, MT, G1X1, EPI>), dim3((unsigned)G), dim3(512), Cfg::LDS_BYTES, st, a, B);
+    return launch_status();
+}
+
 extern "C" {
 
 int wm_conv2d_fwd(const float* xa, const float* xb, const int* xb_index, const void* wfrag, const float* bias,
@@ -1407,9 +1465,19 @@ int wm_conv2d_fwd(const float* xa, const float* xb, const int* xb_index, const v
 #ifndef WM_CONV_RW1
 #define WM_CONV_RW1 3
 #endif
+#ifndef WM_CONV_WS_RW2
+#define WM_CONV_WS_RW2 4
+#endif
+#ifndef WM_CONV_WS_RW1
+#define WM_CONV_WS_RW1 4
+#endif
             // 32 output channels: 12-row tiles (49 KB of LDS: three workgroups per compute unit, staging slots 93 % used)
             // beat 16-row tiles (two workgroups, 80 %) by 4-13 %; 64 channels keep 16 rows (two accumulator sets)
-            if (left >= 2) { rc = conv2d_launch<3, 4, 2>(a, B, st); mb += 2; }
+            if (conv_ws_enabled(a, B, false)) {
+                if (gate || residual) { rc = conv2d_ws_launch<WM_CONV_WS_RW1, 1, false, true>(a, B, st); mb += 1; }
+                else if (left >= 2) { rc = conv2d_ws_launch<WM_CONV_WS_RW2, 2>(a, B, st); mb += 2; }
+                else { rc = conv2d_ws_launch<WM_CONV_WS_RW1, 1>(a, B, st); mb += 1; }
+            } else if (left >= 2) { rc = conv2d_launch<3, 4, 2>(a, B, st); mb += 2; }
             else { rc = conv2d_launch<3, WM_CONV_RW1, 1>(a, B, st); mb += 1; }
         } else {
             // 1x1 is bandwidth-bound: never read the input twice (3 row tiles in one launch on an 8-row tile)
@@ -1444,12 +1512,27 @@ int wm_conv2d_gated_fwd(const float* xa, const float* xb, const int* xb_index, c
         // two 32-channel x 16-row launches at UHD level 1, 64 -> 64); a last odd row tile takes the 16-row form
         a.mbase = mb;
         int rc;
-        if (a.mtot - mb >= 2) { rc = conv2d_launch<3, 2, 2, true>(a, B, st); mb += 2; }
+        if (conv_ws_enabled(a, B, true)) {
+            if (a.mtot - mb >= 2) { rc = conv2d_ws_launch<2, 2, true>(a, B, st); mb += 2; }
+            else { rc = conv2d_ws_launch<4, 1, true>(a, B, st); mb += 1; }
+        } else if (a.mtot - mb >= 2) { rc = conv2d_launch<3, 2, 2, true>(a, B, st); mb += 2; }
         else { rc = conv2d_launch<3, 4, 1, true>(a, B, st); mb += 1; }
         if (rc) return rc;
     }
     return WM_OK;
 }
+
+int wm_conv2d_select(int mode) {
+    if (mode < 0 || mode > 2) return WM_EINVAL;
+    g_conv_select.store(mode, std::memory_order_relaxed);
+    return WM_OK;
+}
+
+#if WM_CV_STAMP
+int wm_debug_conv_stamps(unsigned long long* out) {      // host buffer of 2 * 128 * 8 values
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wm::g_cv_stamps), sizeof(unsigned long long) * 2 * 128 * 8);
+}
+#endif
 
 void wm_prof_enable(unsigned mask) {
     std::lock_guard<std::mutex> lk(g_prof.mu);

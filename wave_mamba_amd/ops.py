@@ -713,6 +713,16 @@ def skff(x0, x1, x2, w_du, prelu, w_fc):
 _WFRAG_CACHE = {}      # id(weight) -> (weakref, data_ptr, version, wfrag tensor, prep-done event, stream it was built on)
 
 
+CONV3X3_AUTO, CONV3X3_FIRST_GEN, CONV3X3_WAVE_SPECIALISED = 0, 1, 2
+
+
+def conv2d_select(mode=CONV3X3_AUTO):
+    """Which 3x3 kernel serves `conv2d` / `conv2d_gated` (wm_conv2d_select): by problem size (default), always the
+    first-generation kernel, or the persistent wave-specialised one wherever its limits allow.  Process-wide; the two
+    kernels accumulate in the same order, so this never changes a result (tests assert bit-equality)."""
+    check(_lib.load().wm_conv2d_select(int(mode)), "wm_conv2d_select")
+
+
 def conv2d_cache_clear():
     """Drop every prepared (bf16-split) weight copy.  The cache validates an entry by (object, data_ptr, _version); a
     write through `.data` (p.data.copy_(), basicsr-style EMA `.data.mul_().add_()`, weight surgery) does NOT bump the
