@@ -1388,6 +1388,16 @@ static int conv2d_launch(const wm::Conv2dArgs& a, int B, hipStream_t st) {
 // where its 32-bit offsets hold.  wm_conv2d_select() pins the choice (parity tests run both on the same inputs: the
 // accumulation order per output element is the same, so the results are bit-identical); WM_CONV_WS=0 in the
 // environment is the same as select(1).
+// rows per consumer wave (tile = 64 x 2 RW pixels) of the wave-specialised launches: two row tiles, one row tile, gated
+#ifndef WM_CONV_WS_RW2
+#define WM_CONV_WS_RW2 4
+#endif
+#ifndef WM_CONV_WS_RW1
+#define WM_CONV_WS_RW1 4
+#endif
+#ifndef WM_CONV_WS_RWG
+#define WM_CONV_WS_RWG 2
+#endif
 static std::atomic<int> g_conv_select{-1};
 static int conv_select_mode() {
     int m = g_conv_select.load(std::memory_order_relaxed);
@@ -1407,7 +1417,7 @@ static bool conv_ws_enabled(const wm::Conv2dArgs& a, int B, bool gated) {
     if (a.gate && a.res) return false;
     if (mode == 2) return true;
     if ((a.gate || a.res) && a.mtot > 1) return false;
-    const int th = gated ? 4 : 8;                           // tile rows of the launch that would run
+    const int th = gated ? 2 * WM_CONV_WS_RWG : 8;          // tile rows of the launch that would run
     const long long ntiles = (long long)B * ((a.W + wm::kWsTW - 1) / wm::kWsTW) * ((a.H + th - 1) / th);
     return ntiles >= 768;
 }
@@ -1465,12 +1475,6 @@ int wm_conv2d_fwd(const float* xa, const float* xb, const int* xb_index, const v
 #ifndef WM_CONV_RW1
 #define WM_CONV_RW1 3
 #endif
-#ifndef WM_CONV_WS_RW2
-#define WM_CONV_WS_RW2 4
-#endif
-#ifndef WM_CONV_WS_RW1
-#define WM_CONV_WS_RW1 4
-#endif
             // 32 output channels: 12-row tiles (49 KB of LDS: three workgroups per compute unit, staging slots 93 % used)
             // beat 16-row tiles (two workgroups, 80 %) by 4-13 %; 64 channels keep 16 rows (two accumulator sets)
             if (conv_ws_enabled(a, B, false)) {
@@ -1513,7 +1517,7 @@ int wm_conv2d_gated_fwd(const float* xa, const float* xb, const int* xb_index, c
         a.mbase = mb;
         int rc;
         if (conv_ws_enabled(a, B, true)) {
-            if (a.mtot - mb >= 2) { rc = conv2d_ws_launch<2, 2, true>(a, B, st); mb += 2; }
+            if (a.mtot - mb >= 2) { rc = conv2d_ws_launch<WM_CONV_WS_RWG, 2, true>(a, B, st); mb += 2; }
             else { rc = conv2d_ws_launch<4, 1, true>(a, B, st); mb += 1; }
         } else if (a.mtot - mb >= 2) { rc = conv2d_launch<3, 2, 2, true>(a, B, st); mb += 2; }
         else { rc = conv2d_launch<3, 4, 1, true>(a, B, st); mb += 1; }
