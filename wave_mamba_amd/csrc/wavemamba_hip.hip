@@ -256,18 +256,28 @@ static void ss2d_launch_row(Ss2dArgs a, const Ss2dPlan& pl, bool vec, hipStream_
     else hipLaunchKernelGGL((ss2d_row_kernel<PHASE, REV, false>), grid, block, 0, st, a);
 }
 
+// > 64 KB of dynamic LDS is an opt-in per kernel function AND per device: one flag per (instantiation, device).
+// `flags` is the caller's function-local static array; returns WM_OK or WM_EHIP.
+static int lds_optin(const void* fn, int bytes, bool (&flags)[64]) {
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return WM_EHIP;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!flags[dev]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return WM_EHIP;
+        flags[dev] = true;
+    }
+    return WM_OK;
+}
+
 template <int PHASE, bool REV>
 static void ss2d_launch_col(Ss2dArgs a, const Ss2dPlan& pl, hipStream_t st) {
     a.chunk_len = pl.col_seg; a.nseg = pl.col_nseg; a.nchunks = (int)pl.col_nchunks;
     const int cgroups = (a.D + kColCH * kColWaves - 1) / (kColCH * kColWaves);
     const long long ntiles = (long long)((a.W + 63) / 64) * pl.col_nseg * a.B;
     const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8 * cgroups)), block(64 * kColWaves);    // XCD-aware order, see kernel
-    static bool configured = false;                      // the chunk-scan image is 72 KB of dynamic LDS: opt in once
-    if (PHASE == 3 && !configured) {
-        hipFuncSetAttribute((const void*)ss2d_col_kernel<3, REV>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            col_lds_bytes<3>());
-        configured = true;
-    }
+    static bool configured[64] = {};                     // the chunk-scan image is 72 KB of dynamic LDS
+    if (PHASE == 3) (void)lds_optin((const void*)ss2d_col_kernel<3, REV>, col_lds_bytes<3>(), configured);   // a failure shows at the launch
     ProfScope ps(PHASE == 1 ? 11 : 9, st);
     hipLaunchKernelGGL((ss2d_col_kernel<PHASE, REV>), grid, block, col_lds_bytes<PHASE>(), st, a);
 }
@@ -1368,12 +1378,10 @@ template <int KS, int RW, int MT, bool G1X1 = false>
 static int conv2d_launch(const wm::Conv2dArgs& a, int B, hipStream_t st) {
     constexpr int PAD = KS / 2;
     constexpr int smem = ((4 * RW + 2 * PAD) * (wm::kCvTW + 2 * PAD) * 4 + (KS * KS + (G1X1 ? 1 : 0)) * MT * 2 * 64) * 16;   // input planes + weights
-    static bool configured = false;                      // > 64 KB of LDS needs the opt-in, once per instantiation
-    if (!configured && smem > 65536) {
-        hipError_t e = hipFuncSetAttribute((const void*)wm::conv2d_mfma_kernel<KS, RW, MT, G1X1>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
+    static bool configured[64] = {};
+    if (smem > 65536) {
+        const int rc = wm::lds_optin((const void*)wm::conv2d_mfma_kernel<KS, RW, MT, G1X1>, smem, configured);
+        if (rc) return rc;
     }
     const int ntiles = ((a.W + wm::kCvTW - 1) / wm::kCvTW) * ((a.H + 4 * RW - 1) / (4 * RW));
     const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8), (unsigned)B);
