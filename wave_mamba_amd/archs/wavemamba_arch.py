@@ -24,6 +24,8 @@ imports every `*_arch.py`, and the registry resolution in `registry.py` then bin
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -644,12 +646,29 @@ class DownFRG(nn.Module):
         self.h_blk = nn.Sequential(*[HFEBlock(dim, match_factor=1, ffn_expansion_factor=1)
                                      for _ in range(n_h_blocks)])
 
-    def forward(self, x, x_d):
+    def forward(self, x, x_d, side=None):
+        """`side`: a second CUDA stream for the high-frequency branch (UNet.forward, inference only).  The branch needs
+        nothing but this level's sub-bands and `low`, and nothing needs it before the matching up group: issued on its
+        own stream it runs under the deeper levels' kernels (whose grids - 130 k positions at level 3 - leave compute
+        units idle).  Returns (low, high); with `side`, `high` is complete on `side` (the caller joins)."""
         ll, hl, lh, hh = self.dwt(x)
+        if side is None:
+            low = _run_lfss_stack(self.l_blk, _conv(self.l_conv, ll, x_d))
+            high = self.h_fusion([hl, lh, hh])
+            for blk in self.h_blk:
+                high = blk(high, low)
+            return low, high
+        main = torch.cuda.current_stream(x.device)
+        side.wait_stream(main)                         # the sub-bands are ready
+        with torch.cuda.stream(side):
+            high = self.h_fusion([hl, lh, hh])
         low = _run_lfss_stack(self.l_blk, _conv(self.l_conv, ll, x_d))
-        high = self.h_fusion([hl, lh, hh])
-        for blk in self.h_blk:
-            high = blk(high, low)
+        side.wait_stream(main)                         # low is ready
+        with torch.cuda.stream(side):
+            for blk in self.h_blk:
+                high = blk(high, low)
+        for t in (hl, lh, hh, low):                    # allocated on `main`, read on `side`
+            t.record_stream(side)
         return low, high
 
 
@@ -672,8 +691,26 @@ class upFRG(nn.Module):
         return self.iwt(low, _conv(self.h_out_conv, x_h))
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(x, n):
+    """The per-device side streams of the inference forward ((None,) * n off a GPU)."""
+    if not x.is_cuda:
+        return (None,) * n
+    key = (x.device.index if x.device.index is not None else torch.cuda.current_device())
+    sts = _SIDE_STREAMS.get(key)
+    if sts is None or len(sts) < n:
+        sts = _SIDE_STREAMS[key] = tuple(torch.cuda.Stream(device=x.device) for _ in range(n))
+    return sts[:n]
+
+
 class UNet(nn.Module):
     """Three-level wavelet U-Net (reference :1011-1063)."""
+
+    # inference: the down path's high-frequency branches on side streams (DownFRG.forward); WM_TWO_STREAMS=0 or
+    # `net.restoration_network.two_streams = False` for the single-stream order
+    two_streams = os.environ.get("WM_TWO_STREAMS", "1") != "0"
 
     def __init__(self, in_chn=3, wf=48, n_l_blocks=[1, 1, 2], n_h_blocks=[1, 1, 1], ffn_scale=2):
         super().__init__()
@@ -692,12 +729,20 @@ class UNet(nn.Module):
     def forward(self, x):
         img = x
         d1, d2, d3 = (_conv(ps[1], ps[0](img)) for ps in (self.ps_down1, self.ps_down2, self.ps_down3))
-        low, high1 = self.down_group1(_conv(self.conv_01, img), d1)
-        low, high2 = self.down_group2(low, d2)
-        low, high3 = self.down_group3(low, d3)
-        low = self.up_group3(low, high3)
-        low = self.up_group2(low, high2)
-        low = self.up_group1(low, high1)
+        # one side stream per level: level 1's branch (the largest) is not needed before the last up group
+        sides = _side_streams(x, 3) if self.two_streams and not _needs_grad(self, x) else (None, None, None)
+        low, high1 = self.down_group1(_conv(self.conv_01, img), d1, sides[0])
+        low, high2 = self.down_group2(low, d2, sides[1])
+        low, high3 = self.down_group3(low, d3, sides[2])
+
+        def join(high, side):                          # the branch becomes an input of the main stream
+            if side is not None:
+                torch.cuda.current_stream(x.device).wait_stream(side)
+                high.record_stream(torch.cuda.current_stream(x.device))     # allocated on `side`, read on `main`
+            return high
+        low = self.up_group3(low, join(high3, sides[2]))
+        low = self.up_group2(low, join(high2, sides[1]))
+        low = self.up_group1(low, join(high1, sides[0]))
         return _conv(self.last, low, residual=img)
 
 
