@@ -224,6 +224,9 @@ def main():
                     help="extra untimed leg at N = 1: throughput with this many forwards in flight on separate HIP "
                          "streams, no event instrumentation (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="profiling runs: skip the untimed single-stream pass, the op-boundary leg and the concurrent leg, so "
+                         "that a kernel trace of the command holds warm-up and timed steps only")
     ap.add_argument("--cpu-forwards", type=int, default=3, help="timed CPU forwards of the full UHD image (after 1 warm-up)")
     ap.add_argument("--cpu-budget", type=float, default=240.0,
                     help="seconds the CPU leg may take; if (1 + cpu-forwards) x warm-up time exceeds it, one timed forward")
@@ -289,8 +292,14 @@ def main():
     elapsed = timed_steps(step, args.steps, 0, sync, barrier)
     prof = {k: v for k, v in wm.ops.prof_collect().items() if k in CORE_CLASSES}
     prof_steps = {k: args.steps for k in prof}
-    if rank == 0:
+    iso = {}
+    if rank == 0 and not args.timed_only:
+        # the untimed pass runs the single-stream order: every launch alone on the GPU (in the timed region the down
+        # path's high-frequency branches run on side streams under the main stream's kernels, which lengthens both)
         extra = max(2, min(args.steps, 5))
+        unet = net.restoration_network
+        two = getattr(unet, "two_streams", False)
+        unet.two_streams = False
         wm.ops.prof_enable(True)
         for _ in range(extra):
             step()
@@ -298,10 +307,13 @@ def main():
         for k, v in wm.ops.prof_collect().items():
             if k not in prof:
                 prof[k], prof_steps[k] = v, extra
+            elif k in CORE_CLASSES and v[0]:
+                iso[k] = v[1] / extra
+        unet.two_streams = two
     wm.ops.prof_enable(False)
 
     concurrent = None
-    if rank == 0 and world == 1 and args.concurrent > 1:
+    if rank == 0 and world == 1 and args.concurrent > 1 and not args.timed_only:
         cs = [torch.cuda.Stream(device) for _ in range(args.concurrent)]
 
         def cstep(i):
@@ -319,7 +331,7 @@ def main():
         concurrent = {"streams": len(cs), "steps": kc, "images_per_s": kc / ce, "ms_per_image": 1e3 * ce / kc,
                       "note": "same forward, steps round-robin over the streams (that many images in flight), no HIP-event "
                               "instrumentation; serving throughput, not the contract's `value`"}
-    op_boundary = scan_op_boundary(device, hp, wp) if rank == 0 else None
+    op_boundary = scan_op_boundary(device, hp, wp) if rank == 0 and not args.timed_only else None
     hip_graph = graph_replay(step, args.steps, device) if rank == 0 and world == 1 and args.graph else None
     bf16 = None
     if rank == 0 and world == 1 and args.bf16:
@@ -370,6 +382,13 @@ def main():
                            "algorithmic_GB_per_step": FUSED_BYTES_PER_POS * pos / 1e9,
                            "frac": FUSED_BYTES_PER_POS * pos / (core_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if core_ms else None,
                            "traffic_over_algorithmic": traffic / (FUSED_BYTES_PER_POS * pos) if traffic else None},
+            "isolated": None if len(iso) != len(CORE_CLASSES) else {
+                "note": "the same launches with nothing else on the GPU (untimed single-stream pass after the timed region); "
+                        "`achieved` / `frac` above are the contract's: durations inside the timed region, where side-stream "
+                        "kernels of the high-frequency branch share the compute units with them",
+                "ms_per_step": sum(iso.values()),
+                "achieved": scan_bytes / (sum(iso.values()) * 1e-3) / 1e9,
+                "frac": scan_bytes / (sum(iso.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "secondary_ceilings": {
                 "note": "the op is bound by VALU issue, not by HBM: KD*N = 4096 v_exp_f32 per position in each of the two "
                         "passes (chunk-reduce, chunk-scan) plus four packed fp32 operations per state-step",
@@ -383,7 +402,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (WM_BENCH_SHARE_GPU self-test: ranks share one GPU)" if share else ""),
             "config": {"workload": f"Wave-Mamba UHD-LL inference config (wf=32, n_l=[1,2,4], n_h=[1,1,2]), "
                                    f"1x3x{args.height}x{args.width} reflect-padded to {hp}x{wp}, seeded random "
-                                   f"init, one image per GPU per step, replicas (no collective), one HIP stream"},
+                                   f"init, one image per GPU per step, replicas (no collective); one forward at a time, "
+                                   f"its down-path high-frequency branches on side streams: "
+                                   f"{bool(getattr(net.restoration_network, 'two_streams', False))}"},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
             "roofline_table": table,
             "hot_path_ms_per_step": sum(table[k]["ms_per_step"] for k in table if k in hot_names),

@@ -26,11 +26,11 @@ assert rc == 0, rc
 st = np.frombuffer(buf, dtype=np.uint64).reshape(2, 128, 8).astype(np.int64)
 t0 = st[0, 0, 0]
 print("consumer wave 0: step | mma | barrier wait | epilogue | step total")
-for i in range(0, 12):
+for i in range(0, 16):
     c = st[0, i]
     nxt = st[0, i + 1, 0]
     print(f"  {i:3d} start {c[0] - t0:8d}  mma {c[1] - c[0]:6d}  wait {c[2] - c[1]:6d}  epi {c[3] - c[2]:6d}  total {nxt - c[0]:6d}")
 print("producer wave 4: step | issue (DMA + loads) | stage | vmcnt wait | barrier wait")
-for i in range(0, 12):
+for i in range(0, 16):
     p = st[1, i]
     print(f"  {i:3d} start {p[0] - t0:8d}  issue {p[1] - p[0]:6d}  stage {p[2] - p[1]:6d}  vmcnt {p[3] - p[2]:6d}  barrier {p[4] - p[3]:6d}")

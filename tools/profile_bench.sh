@@ -2,7 +2,7 @@
 # rocprofv3 kernel trace + stats of the default bench command (GPU box).  Usage: tools/profile_bench.sh <outdir>
 set -u
 R=$PWD; OUT=$R/$1; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --concurrent 0 > $OUT/bench_line.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --timed-only > $OUT/bench_line.json 2> $OUT/bench.err
 cd $R
 python tools/step_breakdown.py $OUT/trace/bench_kernel_trace.csv 3 > $OUT/bench_per_step_kernel_breakdown.txt
 python - "$OUT" <<'PY'
