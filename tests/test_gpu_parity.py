@@ -1043,6 +1043,35 @@ def test_batched_forward_equals_per_image_forward():
     assert_close(both, one.cpu(), 1e-5, "batch of 2 vs two single images")
 
 
+def test_multi_stream_forward_is_the_single_stream_forward():
+    """UNet.forward issues each DownFRG's high-frequency branch on a side stream (inference).  Same kernels on the same
+    inputs: the output must equal the single-stream order bit for bit - also back to back without a host
+    synchronisation in between (a missing cross-stream ordering or a buffer the allocator handed out too early shows as a
+    difference), from a non-default current stream, and with a batch."""
+    net = wm.WaveMamba(in_chn=3, wf=32, n_l_blocks=[1, 2, 4], n_h_blocks=[1, 1, 2], ffn_scale=2.0).eval().to(DEV)
+    unet = net.restoration_network
+    xs = [torch.rand(1, 3, 264, 392, generator=gen(41)).to(DEV), torch.rand(2, 3, 136, 200, generator=gen(42)).to(DEV)]
+    assert unet.two_streams
+    try:
+        with torch.no_grad():
+            unet.two_streams = False
+            refs = [unet(x) for x in xs]
+            unet.two_streams = True
+            for _ in range(3):                                       # back to back: no synchronisation between forwards
+                outs = [unet(x) for x in xs]
+            other = torch.cuda.Stream(DEV)
+            other.wait_stream(torch.cuda.current_stream(DEV))
+            with torch.cuda.stream(other):
+                outs_other = [unet(x) for x in xs]
+            torch.cuda.current_stream(DEV).wait_stream(other)
+    finally:
+        unet.two_streams = True
+    torch.cuda.synchronize()
+    for r, o, oo in zip(refs, outs, outs_other):
+        assert torch.equal(r, o), f"max |diff| {float((r - o).abs().max()):.3e}"
+        assert torch.equal(r, oo), f"from a non-default stream: max |diff| {float((r - oo).abs().max()):.3e}"
+
+
 @pytest.mark.parametrize("B,Ca,Csrc,Cb,Cout,H,W", [(1, 32, 32, 32, 64, 24, 40), (2, 32, 32, 32, 64, 9, 33),
                                                   (1, 64, 0, 0, 64, 31, 17), (2, 16, 24, 8, 40, 17, 31)])
 def test_conv2d_gated_vs_torch(conv3x3_impl, B, Ca, Csrc, Cb, Cout, H, W):

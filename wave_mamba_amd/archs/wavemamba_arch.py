@@ -646,7 +646,7 @@ class DownFRG(nn.Module):
         self.h_blk = nn.Sequential(*[HFEBlock(dim, match_factor=1, ffn_expansion_factor=1)
                                      for _ in range(n_h_blocks)])
 
-    def forward(self, x, x_d, side=None):
+    def forward(self, x, x_d, side=None, x_d_ready=None):
         """`side`: a second CUDA stream for the high-frequency branch (UNet.forward, inference only).  The branch needs
         nothing but this level's sub-bands and `low`, and nothing needs it before the matching up group: issued on its
         own stream it runs under the deeper levels' kernels (whose grids - 130 k positions at level 3 - leave compute
@@ -662,6 +662,9 @@ class DownFRG(nn.Module):
         side.wait_stream(main)                         # the sub-bands are ready
         with torch.cuda.stream(side):
             high = self.h_fusion([hl, lh, hh])
+        if x_d_ready is not None:                      # x_d was computed on `side` (UNet.forward)
+            main.wait_event(x_d_ready)
+            x_d.record_stream(main)
         low = _run_lfss_stack(self.l_blk, _conv(self.l_conv, ll, x_d))
         side.wait_stream(main)                         # low is ready
         with torch.cuda.stream(side):
@@ -683,8 +686,12 @@ class upFRG(nn.Module):
         self.h_blk = nn.Sequential(*[HFEBlock(dim, match_factor=1, ffn_expansion_factor=1)
                                      for _ in range(n_h_blocks)])
 
-    def forward(self, x_l, x_h):
+    def forward(self, x_l, x_h, join=None):
+        """`join`: makes a side-stream `x_h` (DownFRG.forward) an input of the current stream - called only after this
+        group's LFSS stack, which does not need it, has been issued."""
         low = _run_lfss_stack(self.l_blk, x_l)
+        if join is not None:
+            x_h = join(x_h)
         for blk in self.h_blk:
             x_h = blk(x_h, low)
         # reference: iwt(cat([x_l, h_out_conv(x_h)], 1)); the pair form skips the concatenation
@@ -728,21 +735,36 @@ class UNet(nn.Module):
 
     def forward(self, x):
         img = x
-        d1, d2, d3 = (_conv(ps[1], ps[0](img)) for ps in (self.ps_down1, self.ps_down2, self.ps_down3))
         # one side stream per level: level 1's branch (the largest) is not needed before the last up group
         sides = _side_streams(x, 3) if self.two_streams and not _needs_grad(self, x) else (None, None, None)
-        low, high1 = self.down_group1(_conv(self.conv_01, img), d1, sides[0])
-        low, high2 = self.down_group2(low, d2, sides[1])
-        low, high3 = self.down_group3(low, d3, sides[2])
+        pss = (self.ps_down1, self.ps_down2, self.ps_down3)
+        if sides[0] is None:
+            d, d_ready = [_conv(ps[1], ps[0](img)) for ps in pss], (None, None, None)
+        else:                                          # the pixel-unshuffled inputs of the three l_convs: off the main chain too
+            main = torch.cuda.current_stream(x.device)
+            d, d_ready = [], []
+            for ps, side in zip(pss, sides):
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    d.append(_conv(ps[1], ps[0](img)))
+                    d_ready.append(side.record_event())
+            img.record_stream(sides[0]); img.record_stream(sides[1]); img.record_stream(sides[2])
+        low, high1 = self.down_group1(_conv(self.conv_01, img), d[0], sides[0], d_ready[0])
+        low, high2 = self.down_group2(low, d[1], sides[1], d_ready[1])
+        low, high3 = self.down_group3(low, d[2], sides[2], d_ready[2])
 
-        def join(high, side):                          # the branch becomes an input of the main stream
-            if side is not None:
+        def joiner(side):                              # the branch becomes an input of the main stream, as late as possible
+            if side is None:
+                return None
+
+            def join(high):
                 torch.cuda.current_stream(x.device).wait_stream(side)
                 high.record_stream(torch.cuda.current_stream(x.device))     # allocated on `side`, read on `main`
-            return high
-        low = self.up_group3(low, join(high3, sides[2]))
-        low = self.up_group2(low, join(high2, sides[1]))
-        low = self.up_group1(low, join(high1, sides[0]))
+                return high
+            return join
+        low = self.up_group3(low, high3, joiner(sides[2]))
+        low = self.up_group2(low, high2, joiner(sides[1]))
+        low = self.up_group1(low, high1, joiner(sides[0]))
         return _conv(self.last, low, residual=img)
 
 
