@@ -514,9 +514,14 @@ class CMTAttention(nn.Module):
             self.matching_transformation = Matching_transformation(
                 dim=dim, match_factor=match_factor, ffn_expansion_factor=ffn_expansion_factor, bias=bias)
 
-    def forward(self, x, perception, residual=None):
+    def qkv_of(self, x):
+        """The part of `forward` that needs `x` alone (UNet.forward runs it ahead of time on a side stream)."""
+        return _dwconv(self.qkv_dwconv, _conv(self.qkv, x))
+
+    def forward(self, x, perception, residual=None, qkv=None):
+        q, k, v = (self.qkv_of(x) if qkv is None else qkv).chunk(3, dim=1)
+        x = v                                              # from here on only shape / device / dtype of `x` matter
         b, c, h, w = x.shape
-        q, k, v = _dwconv(self.qkv_dwconv, _conv(self.qkv, x)).chunk(3, dim=1)
         if self.matching is True:
             q = self.matching_transformation(q, perception)
         heads = self.num_heads
@@ -566,9 +571,13 @@ class HFEBlock(nn.Module):
                                bias=bias, ffn_matching=ffn_matching)
         self.LayerNorm = LayerNorm2d(dim)
 
-    def forward(self, x, perception):
+    def qkv_of(self, x):
+        """dwconv(qkv(norm1(x))): everything of the block that does not need `perception`."""
+        return self.attn.qkv_of(self.norm1(x))
+
+    def forward(self, x, perception, qkv=None):
         p = self.LayerNorm(perception)
-        x = self.attn(self.norm1(x), p, residual=x)              # x + attn(...): the add rides in the 1x1 epilogue
+        x = self.attn(self.norm1(x) if qkv is None else None, p, residual=x, qkv=qkv)   # x + attn(...): the add rides in the 1x1 epilogue
         return self.ffn(self.norm2(x), p, residual=x)
 
 
@@ -690,10 +699,11 @@ class upFRG(nn.Module):
         """`join`: makes a side-stream `x_h` (DownFRG.forward) an input of the current stream - called only after this
         group's LFSS stack, which does not need it, has been issued."""
         low = _run_lfss_stack(self.l_blk, x_l)
+        qkv0 = None
         if join is not None:
-            x_h = join(x_h)
-        for blk in self.h_blk:
-            x_h = blk(x_h, low)
+            x_h, qkv0 = join(x_h)
+        for i, blk in enumerate(self.h_blk):
+            x_h = blk(x_h, low, qkv=qkv0 if i == 0 else None)
         # reference: iwt(cat([x_l, h_out_conv(x_h)], 1)); the pair form skips the concatenation
         return self.iwt(low, _conv(self.h_out_conv, x_h))
 
@@ -753,18 +763,23 @@ class UNet(nn.Module):
         low, high2 = self.down_group2(low, d[1], sides[1], d_ready[1])
         low, high3 = self.down_group3(low, d[2], sides[2], d_ready[2])
 
-        def joiner(side):                              # the branch becomes an input of the main stream, as late as possible
+        def joiner(side, up_group, high):              # the branch becomes an input of the main stream, as late as possible
             if side is None:
                 return None
+            with torch.cuda.stream(side):              # ... after the part of the up group's first HFEBlock that needs only it
+                qkv = up_group.h_blk[0].qkv_of(high) if len(up_group.h_blk) else None
 
             def join(high):
-                torch.cuda.current_stream(x.device).wait_stream(side)
-                high.record_stream(torch.cuda.current_stream(x.device))     # allocated on `side`, read on `main`
-                return high
+                main = torch.cuda.current_stream(x.device)
+                main.wait_stream(side)
+                for t in (high, qkv):                  # allocated on `side`, read on `main`
+                    if t is not None:
+                        t.record_stream(main)
+                return high, qkv
             return join
-        low = self.up_group3(low, high3, joiner(sides[2]))
-        low = self.up_group2(low, high2, joiner(sides[1]))
-        low = self.up_group1(low, high1, joiner(sides[0]))
+        low = self.up_group3(low, high3, joiner(sides[2], self.up_group3, high3))
+        low = self.up_group2(low, high2, joiner(sides[1], self.up_group2, high2))
+        low = self.up_group1(low, high1, joiner(sides[0], self.up_group1, high1))
         return _conv(self.last, low, residual=img)
 
 
