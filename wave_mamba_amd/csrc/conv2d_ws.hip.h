@@ -21,12 +21,13 @@ namespace wm {
 
 constexpr int kWsTW = 64;             // tile width: two MFMA column tiles (a staged row is 2 whole cache lines + 2 halo pixels)
 
-template <int RW, int MT, bool G1X1>
+template <int RW, int MT, bool G1X1, int NPW = 4>
 struct ConvWsCfg {
+    static constexpr int NPT = 64 * NPW;                 // producer threads (NPW producer waves behind the 4 consumer waves)
     static constexpr int PW = kWsTW + 2;                 // staged row pitch in pixels
     static constexpr int TH = 2 * RW;                    // tile rows: consumer wave (w & 1, w >> 1) owns a 32-pixel x RW-row block
     static constexpr int NPIX = (TH + 2) * PW;           // staged pixels per chunk
-    static constexpr int PIT = (NPIX + 255) / 256;       // staged pixels per producer thread
+    static constexpr int PIT = (NPIX + NPT - 1) / NPT;   // staged pixels per producer thread
     static constexpr int W_ITEMS = 9 * MT * 2 * 64;      // 16-byte weight fragments per chunk
     static constexpr int W1_ITEMS = G1X1 ? MT * 2 * 64 : 0;
     static constexpr int BUF_ITEMS = 4 * NPIX + W_ITEMS + W1_ITEMS;
@@ -79,11 +80,11 @@ __device__ __forceinline__ void ws_lds_store16(unsigned addr, const uint4& v) {
 
 __device__ __forceinline__ void ws_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int RW, int MT, bool G1X1, bool EPI>
-__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const Conv2dArgs a, const int B) {
+template <int RW, int MT, bool G1X1, bool EPI, int NPW = 4>
+__global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void conv3x3_ws_kernel(const Conv2dArgs a, const int B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cv_smem[];
-    using Cfg = ConvWsCfg<RW, MT, G1X1>;
-    constexpr int PW = Cfg::PW, TH = Cfg::TH, NPIX = Cfg::NPIX, PIT = Cfg::PIT;
+    using Cfg = ConvWsCfg<RW, MT, G1X1, NPW>;
+    constexpr int PW = Cfg::PW, TH = Cfg::TH, NPIX = Cfg::NPIX, PIT = Cfg::PIT, NPT = Cfg::NPT;
     constexpr int W_ITEMS = Cfg::W_ITEMS, W1_ITEMS = Cfg::W1_ITEMS, BUF = Cfg::BUF_ITEMS;
     uint4* const smem = reinterpret_cast<uint4*>(cv_smem);
 
@@ -125,11 +126,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const Conv2dArgs a, 
         auto fetch_w = [&](int buf, int cc) {
             uint4* s_w = smem + buf * BUF + 4 * NPIX;
             const uint4* wsrc = a.wfrag + ((long long)cc * 9 * a.mtot) * 128;
-            constexpr int W_IT = (W_ITEMS + 255) / 256;
+            constexpr int W_IT = (W_ITEMS + NPT - 1) / NPT;
 #pragma unroll
             for (int it = 0; it < W_IT; ++it) {
-                const int item0 = it * 256 + pw * 64;     // wave-uniform
-                if (W_ITEMS % 256 == 0 || item0 < W_ITEMS) {
+                const int item0 = it * NPT + pw * 64;     // wave-uniform
+                if (W_ITEMS % NPT == 0 || item0 < W_ITEMS) {
                     const int tm = item0 >> 7, tap = tm / MT, m = tm - tap * MT;
                     const uint4* g = wsrc + (tap * a.mtot + a.mbase + m) * 128 + (item0 & 64) + lane;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const Conv2dArgs a, 
                 tl.locate(jf, TH, b, h0, w0);
 #pragma unroll
                 for (int it = 0; it < PIT; ++it) {
-                    const int p = ptid + it * 256;
+                    const int p = ptid + it * NPT;
                     const int pr = p / PW, pc = p - pr * PW;
                     const int h = h0 - 1 + pr, w = w0 - 1 + pc;
                     const bool ok = p < NPIX && h >= 0 && h < H && w >= 0 && w < W;
@@ -211,8 +212,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const Conv2dArgs a, 
             const int cn = c0 < a.Ca ? a.Ca - c0 : a.Ca + a.Cb - c0;       // valid channels of this 8-group (uniform)
 #pragma unroll
             for (int it = 0; it < PIT; ++it) {
-                const int p = ptid + it * 256;
-                if (NPIX % 256 == 0 || p < NPIX) {
+                const int p = ptid + it * NPT;
+                if (NPIX % NPT == 0 || p < NPIX) {
                     Frag16 hi, lo;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -221,8 +222,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const Conv2dArgs a, 
                         hi.v[j] = hv;
                         lo.v[j] = (__bf16)(v - (float)hv);
                     }
-                    ws_lds_store16<0>(s_in + it * 4096u, hi.u);
-                    ws_lds_store16<2 * NPIX * 16>(s_in + it * 4096u, lo.u);
+                    ws_lds_store16<0>(s_in + it * (NPT * 16u), hi.u);
+                    ws_lds_store16<2 * NPIX * 16>(s_in + it * (NPT * 16u), lo.u);
                 }
             }
         };

@@ -1406,6 +1406,9 @@ static int conv2d_launch(const wm::Conv2dArgs& a, int B, hipStream_t st) {
 #ifndef WM_CONV_WS_RWG
 #define WM_CONV_WS_RWG 2
 #endif
+#ifndef WM_CONV_WS_NPW1
+#define WM_CONV_WS_NPW1 4              // producer waves of the one-row-tile launches
+#endif
 static std::atomic<int> g_conv_select{-1};
 static int conv_select_mode() {
     int m = g_conv_select.load(std::memory_order_relaxed);
@@ -1430,9 +1433,9 @@ static bool conv_ws_enabled(const wm::Conv2dArgs& a, int B, bool gated) {
     return ntiles >= 768;
 }
 
-template <int RW, int MT, bool G1X1 = false, bool EPI = false>
+template <int RW, int MT, bool G1X1 = false, bool EPI = false, int NPW = 4>
 static int conv2d_ws_launch(const wm::Conv2dArgs& a, int B, hipStream_t st) {
-    using Cfg = wm::ConvWsCfg<RW, MT, G1X1>;
+    using Cfg = wm::ConvWsCfg<RW, MT, G1X1, NPW>;
     static bool configured[64] = {};
     static int ncu[64] = {};
     static std::mutex mu;
@@ -1441,7 +1444,7 @@ static int conv2d_ws_launch(const wm::Conv2dArgs& a, int B, hipStream_t st) {
     {
         std::lock_guard<std::mutex> lk(mu);
         if (!configured[dev]) {
-            if (hipFuncSetAttribute((const void*)wm::conv3x3_ws_kernel<RW, MT, G1X1, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute((const void*)wm::conv3x3_ws_kernel<RW, MT, G1X1, EPI, NPW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     Cfg::LDS_BYTES) != hipSuccess) return WM_EHIP;
             if (hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return WM_EHIP;
             configured[dev] = true;
@@ -1451,7 +1454,7 @@ static int conv2d_ws_launch(const wm::Conv2dArgs& a, int B, hipStream_t st) {
     if (ntiles >= (1ll << 31)) return WM_EUNSUPPORTED;
     const int cus = std::max(8, ncu[dev] & ~7);
     const int G = (int)std::min<long long>(cus, ((ntiles + 7) / 8) * 8);
-    hipLaunchKernelGGL((wm::conv3x3_ws_kernel<RW, MT, G1X1, EPI>), dim3((unsigned)G), dim3(512), Cfg::LDS_BYTES, st, a, B);
+    hipLaunchKernelGGL((wm::conv3x3_ws_kernel<RW, MT, G1X1, EPI, NPW>), dim3((unsigned)G), dim3(256 + 64 * NPW), Cfg::LDS_BYTES, st, a, B);
     return launch_status();
 }
 
@@ -1488,7 +1491,7 @@ int wm_conv2d_fwd(const float* xa, const float* xb, const int* xb_index, const v
             if (conv_ws_enabled(a, B, false)) {
                 if (gate || residual) { rc = conv2d_ws_launch<WM_CONV_WS_RW1, 1, false, true>(a, B, st); mb += 1; }
                 else if (left >= 2) { rc = conv2d_ws_launch<WM_CONV_WS_RW2, 2>(a, B, st); mb += 2; }
-                else { rc = conv2d_ws_launch<WM_CONV_WS_RW1, 1>(a, B, st); mb += 1; }
+                else { rc = conv2d_ws_launch<WM_CONV_WS_RW1, 1, false, false, WM_CONV_WS_NPW1>(a, B, st); mb += 1; }
             } else if (left >= 2) { rc = conv2d_launch<3, 4, 2>(a, B, st); mb += 2; }
             else { rc = conv2d_launch<3, WM_CONV_RW1, 1>(a, B, st); mb += 1; }
         } else {
