@@ -48,6 +48,13 @@ def test_argument_validation_returns_before_launch():
     assert lib.wm_selscan_fwd(*([None] * 10), None, 0, 1, 8, 16, 4, 2, 1, None) == -2
     assert lib.wm_selscan_fwd(*([None] * 10), None, 0, 1, 8, 16, 4, 3, 1, None) == -1   # dim % G
     assert lib.wm_selscan_fwd(*([None] * 10), None, 0, 1, 8, 16, 40, 2, 1, None) == -5  # N > 32
+    # the 3x3 kernel selector is host state: 0 / 1 / 2 accepted, anything else WM_EINVAL (and the mode stays)
+    assert lib.wm_conv2d_select(3) == -1 and lib.wm_conv2d_select(-1) == -1
+    assert lib.wm_conv2d_select(2) == 0 and lib.wm_conv2d_select(1) == 0 and lib.wm_conv2d_select(0) == 0
+    # convolution arguments are checked before any device work: kernel size, NULLs, fragment alignment
+    assert lib.wm_conv2d_fwd(*([None] * 8), 1, 32, 0, 0, 32, 8, 8, 5, None) == -5           # ks = 5
+    assert lib.wm_conv2d_fwd(*([None] * 8), 1, 32, 0, 0, 32, 8, 8, 3, None) == -2           # NULL tensors
+    assert lib.wm_conv2d_fwd(*([None] * 8), 0, 32, 0, 0, 32, 8, 8, 3, None) == 0            # empty batch
     # empty problems are a no-op
     assert lib.wm_dwt2d_fwd(None, None, None, None, None, 0, 3, 4, 4, 0, None) == 0
     assert lib.wm_selscan_fwd(*([None] * 10), None, 0, 0, 8, 16, 4, 2, 1, None) == 0
