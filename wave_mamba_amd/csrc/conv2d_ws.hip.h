@@ -2,11 +2,13 @@
 //
 // Same arithmetic (three bf16 products per fp32 product, v_mfma_f32_32x32x16_bf16, same fragment layouts, same prepared
 // weights, same fused concatenation / gather / 1x1 gate / bias / sigmoid gate / residual) and the same reference call
-// sites as conv2d_mfma_kernel<3, ...>; what changes is who does what, when.  Measured on conv2d_mfma_kernel at UHD
-// level 1, 64 -> 64 (tools/_ab_conv.sh, tools/ubench_tile_fetch.hip): 0.59 ms = operand fetch 0.17 (alone, at its own
-// throughput bound) + stores 0.10 + convert / LDS / MFMA 0.35 - the sum of the phases: two co-resident workgroups
+// sites as conv2d_mfma_kernel<3, ...> - results are bit-identical (tests/test_gpu_parity.py::
+// test_conv3x3_kernels_bit_identical); what changes is who does what, when.  Measured on conv2d_mfma_kernel at UHD
+// level 1, 64 -> 64 (load / MFMA ablation builds, tools/ubench_tile_fetch.hip): 0.59 ms = operand fetch 0.17 (alone, at
+// its own throughput bound) + stores 0.10 + convert / LDS / MFMA 0.35 - the sum of the phases: two co-resident workgroups
 // started together stay in phase (both fetch, then both multiply), so nothing overlaps.  Here one workgroup of eight
-// waves owns a compute unit for the whole launch and walks a list of tiles:
+// waves owns a compute unit for the whole launch and walks a list of 64 x 8 pixel tiles (0.48 ms for that convolution;
+// DESIGN.md 4 has the stamps, what each fix bought and what did not help):
 //   waves 4-7 (producers): global loads of the 16-channel chunk two steps ahead (registers, two sets), bf16 hi / lo
 //            split and LDS store of the chunk one step ahead, LDS-DMA of its weights;
 //   waves 0-3 (consumers): B / A fragment reads and MFMAs of the current chunk, and the tile's epilogue.
