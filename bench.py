@@ -39,7 +39,7 @@ SHIPPED = dict(in_chn=3, wf=32, n_l_blocks=[1, 2, 4], n_h_blocks=[1, 1, 2], ffn_
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 SCAN_BYTES_PER_POS = {16: 3584, 32: 4096}   # 4*(3*KD + 2*K*N), KD = 256, K = 4
 FUSED_BYTES_PER_POS = 512        # SURVEY.md 8d "fused SS2D-core (stretch, report separately, never mix)"
-# kernel classes of the selective-scan op whose HIP events are recorded inside the timed region
+# kernel classes of the selective-scan op whose HIP events are recorded in the instrumented pass
 CORE_CLASSES = ("ss2d_core_reduce", "selscan_carry", "ss2d_core_scan")
 EXP_PEAK = 18.5e12               # v_exp_f32 lane-ops/s chip-wide, tools/microbench.hip on MI355X
 
@@ -192,6 +192,75 @@ def graph_replay(step, steps, device):
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
+SCAN_BWD_BYTES_PER_POS = 6144    # 4*(5*KD + 4*K*N): reads u, delta, dy, B, C + writes du, ddelta, dB, dC
+
+
+def train_leg(device, steps, with_cpu_loss, batch=8, size=512):
+    """BASELINE config 3 on ONE GPU (optional leg, rank 0): `steps` optimize_parameters() of the shipped config on a
+    synthetic batch of 8 x 3 x 512 x 512 pairs (femasr_model.py:157-185: forward, L1 + 0.1 FFT-L1, backward, AdamW) -
+    images/s, the backward of the selective-scan op as a fraction of the HBM roofline on SURVEY.md 8d's 6144 B per
+    position, and the first step's loss against the same network on the host with the CPU oracle as hot-path backend."""
+    torch.manual_seed(0)
+    net = wm.WaveMamba(**SHIPPED).train().to(device)
+    opt = wm.trainer.make_optimizer(net)
+    g = torch.Generator().manual_seed(image_seed(0))
+    lq_cpu, gt_cpu = torch.rand(batch, 3, size, size, generator=g), torch.rand(batch, 3, size, size, generator=g)
+    lq, gt = lq_cpu.to(device), gt_cpu.to(device)
+    loss_parity = None
+    with torch.no_grad():
+        l_pix, l_fft = wm.trainer.losses(net(lq), gt)
+    first = (float(l_pix), float(l_fft))
+    if with_cpu_loss:
+        from oracle import oracle
+        from oracle import backend as oracle_backend
+        torch.manual_seed(0)
+        net_cpu = wm.WaveMamba(**SHIPPED).train()
+        with oracle_backend.ops_backend(oracle), torch.no_grad():
+            c_pix, c_fft = wm.trainer.losses(net_cpu(lq_cpu), gt_cpu)
+        loss_parity = {"gpu": first, "cpu_oracle_network": (float(c_pix), float(c_fft)),
+                       "rel_diff": max(abs(first[0] - float(c_pix)) / float(c_pix), abs(first[1] - float(c_fft)) / float(c_fft)),
+                       "bar": 1e-6}
+        del net_cpu
+    state = {}
+
+    def step():
+        state["losses"] = wm.trainer.train_step(net, opt, lq, gt)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    wm.ops.prof_enable(("selscan_bwd", "ss2d_core_reduce", "ss2d_core_scan", "selscan_carry"))
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    prof = wm.ops.prof_collect()
+    wm.ops.prof_enable(False)
+    pos = batch * scan_positions(size, size)
+    bwd_ms = prof["selscan_bwd"][1] / steps
+    fwd_ms = sum(prof[k][1] for k in CORE_CLASSES) / steps
+    res = {"workload": f"BASELINE config 3 on one GPU: batch {batch} x 3x{size}x{size} synthetic pairs, shipped config, "
+                       f"L1 + 0.1 FFT-L1, AdamW(5e-4, wd 1e-3, betas (0.9, 0.99)); no DDP at N = 1",
+           "images_per_s": steps * batch / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
+           "scan_positions_per_step": pos,
+           "selective_scan_backward": {
+               "kernels": "wm_ss2d_core_bwd (transposes, projection, chunked adjoint scan, projection backward, reductions)",
+               "ms_per_step": bwd_ms, "algorithmic_bytes_per_position": SCAN_BWD_BYTES_PER_POS,
+               "algorithmic_GB_per_step": SCAN_BWD_BYTES_PER_POS * pos / 1e9,
+               "frac": SCAN_BWD_BYTES_PER_POS * pos / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if bwd_ms else None},
+           "selective_scan_forward": {"ms_per_step": fwd_ms,
+                                      "frac": SCAN_BYTES_PER_POS[16] * pos / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fwd_ms else None},
+           "losses_after_steps": state["losses"], "first_step_loss_parity": loss_parity,
+           "peak_mem_GB": torch.cuda.max_memory_allocated(device) / 2 ** 30}
+    del net, opt
+    torch.cuda.empty_cache()
+    return res
+
+
 def load_pmc(hp, wp):
     """HBM bytes of the selective-scan op measured with rocprofv3 --pmc (tools/pmc_core.sh -> tools/pmc_traffic.py ->
     profiles/pmc_traffic.json): per core call at each pyramid level, FETCH_SIZE corrected as
@@ -200,6 +269,9 @@ def load_pmc(hp, wp):
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
+        if pmc.get("build_id") != wm._lib.build_id():       # counters of another binary are not this binary's traffic
+            return None, {"source": f"profiles/pmc_traffic.json describes build {pmc.get('build_id')}, the loaded library "
+                                    f"is {wm._lib.build_id()}: not quoted"}
         lv = pmc["ss2d_core"]["levels"]
         calls = {1: 2, 2: 4, 3: 8}
         tot = 0.0
@@ -231,7 +303,11 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=240.0,
                     help="seconds the CPU leg may take; if (1 + cpu-forwards) x warm-up time exceeds it, one timed forward")
     ap.add_argument("--graph", action="store_true", help="also time the step replayed from a HIP graph")
-    ap.add_argument("--bf16", action="store_true", help="also time the bf16-storage mode (bf16 planes between kernels)")
+    ap.add_argument("--no-train", action="store_true",
+                    help="skip the training leg (BASELINE config 3 on one GPU: batch 8 x 512 x 512, rank 0, N = 1)")
+    ap.add_argument("--train-steps", type=int, default=5)
+    ap.add_argument("--no-bf16", action="store_true",
+                    help="skip the bf16-storage leg (BASELINE config 2 as worded: bf16 planes between the kernels; rank 0, N = 1)")
     args = ap.parse_args()
 
     rank, world, local_rank = rank_env()
@@ -284,12 +360,12 @@ def main():
 
     sync = torch.cuda.synchronize
     barrier = dist.barrier if world > 1 else (lambda: None)
-    # HIP events cost ~10 us of stream time per instrumented launch, so the timed region records only the three launch
-    # classes of the selective-scan op (42 launches per step); the other classes are measured in an untimed pass below.
-    for _ in range(max(args.warmup, 1)):
-        step()
+    # `value` comes from an UN-instrumented pass: warm-up, then exactly K steps between barriers.  The roofline numbers come
+    # from a second pass of K steps with HIP events around the launches of the selective-scan op (~10 us of stream time per
+    # instrumented launch, 42 per step) - its wall time is reported next to it, never as `value`.
+    elapsed = timed_steps(step, args.steps, max(args.warmup, 1), sync, barrier)
     wm.ops.prof_enable(CORE_CLASSES)
-    elapsed = timed_steps(step, args.steps, 0, sync, barrier)
+    elapsed_instr = timed_steps(step, args.steps, 0, sync, barrier)
     prof = {k: v for k, v in wm.ops.prof_collect().items() if k in CORE_CLASSES}
     prof_steps = {k: args.steps for k in prof}
     iso = {}
@@ -334,12 +410,18 @@ def main():
     op_boundary = scan_op_boundary(device, hp, wp) if rank == 0 and not args.timed_only else None
     hip_graph = graph_replay(step, args.steps, device) if rank == 0 and world == 1 and args.graph else None
     bf16 = None
-    if rank == 0 and world == 1 and args.bf16:
+    if rank == 0 and world == 1 and not args.no_bf16 and not args.timed_only:
         try:
             from wave_mamba_amd import inference
             bf16 = inference.bench_bf16_storage(net, x, args.steps)
         except Exception as e:
             bf16 = {"error": f"{type(e).__name__}: {e}"[:300]}
+    train = None
+    if rank == 0 and world == 1 and not args.no_train and not args.timed_only:
+        try:
+            train = train_leg(device, args.train_steps, with_cpu_loss=not args.no_cpu_baseline)
+        except Exception as e:
+            train = {"error": f"{type(e).__name__}: {e}"[:300]}
     elapsed = max_over_ranks(elapsed, world, "cpu" if share else device)
 
     if rank == 0:
@@ -350,7 +432,8 @@ def main():
             if n:
                 ks = prof_steps[name]
                 table[name] = {"launches_per_step": n / ks, "ms_per_step": ms / ks,
-                               "measured_in": "timed region" if name in CORE_CLASSES else "untimed pass after it"}
+                               "measured_in": "instrumented pass (multi-stream, as timed)" if name in CORE_CLASSES
+                               else "single-stream pass after it"}
         for name in ("haar_analysis", "haar_synthesis"):
             if name in table:
                 gbs = haar_b / (table[name]["ms_per_step"] * 1e-3) / 1e9
@@ -368,7 +451,9 @@ def main():
             "kernel": "selective-scan op of SS2D.forward_core = the reduce + carry + scan launches of wm_ss2d_core_fwd "
                       "(wm::ss2d_core_kernel<16,16,1|3>, wm::selscan_carry_kernel): the hot-path operator with the most time",
             "definition": "SURVEY.md 8d: 3584 B per scanned position (reference call signature) x positions per step / "
-                          "summed HIP-event duration of the op's launches in the timed region",
+                          "summed HIP-event duration of the op's launches in the instrumented pass (K steps right after the "
+                          "timed region, same step, same streams)",
+            "instrumented_pass_ms_per_step": 1e3 * elapsed_instr / args.steps,
             "algorithmic_bytes_per_position": SCAN_BYTES_PER_POS[16], "positions_per_step": pos,
             "algorithmic_GB_per_step": scan_bytes / 1e9, "ms_per_step": core_ms, "op_calls_per_step": calls,
             "per_call_avg": {"algorithmic_GB": scan_bytes / 1e9 / calls if calls else None,
@@ -384,7 +469,7 @@ def main():
                            "traffic_over_algorithmic": traffic / (FUSED_BYTES_PER_POS * pos) if traffic else None},
             "isolated": None if len(iso) != len(CORE_CLASSES) else {
                 "note": "the same launches with nothing else on the GPU (untimed single-stream pass after the timed region); "
-                        "`achieved` / `frac` above are the contract's: durations inside the timed region, where side-stream "
+                        "`achieved` / `frac` above are the contract's: durations in the step as it is timed, where side-stream "
                         "kernels of the high-frequency branch share the compute units with them",
                 "ms_per_step": sum(iso.values()),
                 "achieved": scan_bytes / (sum(iso.values()) * 1e-3) / 1e9,
@@ -409,7 +494,7 @@ def main():
             "roofline_table": table,
             "hot_path_ms_per_step": sum(table[k]["ms_per_step"] for k in table if k in hot_names),
             "selscan_op_boundary": op_boundary, "hip_graph_replay": hip_graph, "bf16_storage": bf16,
-            "concurrent_forwards": concurrent,
+            "concurrent_forwards": concurrent, "training_config3_one_gpu": train,
         }
         print(json.dumps(line))
     if world > 1:

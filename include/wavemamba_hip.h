@@ -44,6 +44,10 @@ extern "C" {
 
 /* ABI version of this header (bumped on any signature change). */
 int wm_abi_version(void);
+/* Identity of the sources this binary was compiled from: the first 16 hex digits of a sha256 over csrc/ and this header
+ * (wave_mamba_amd/build.py passes it as -DWM_BUILD_ID; "unknown" for a bare hipcc build).  Measurements that describe
+ * one binary (profiles/pmc_traffic.json) carry it, and bench.py quotes them only for the binary that is loaded. */
+const char* wm_build_id(void);
 const char* wm_strerror(int code);
 
 /* --------------------------------------------------------------------------------------------
@@ -124,14 +128,29 @@ int wm_selscan_bwd(const float* u, const float* delta, const float* A, const flo
  *   The workspace size depends on `merged` (three temporary y buffers).
  */
 size_t wm_ss2d_core_fwd_workspace_bytes(int B, int D, int H, int W, int N, int R, int merged);
+/*   Host-only: the work split wm_ss2d_core_fwd uses for this shape (no GPU needed; tests and tools).
+ *   out[0..9] = waves per workgroup, rows per column segment, segments per column, column tiles, column workgroup slots
+ *   per direction, steps per row chunk, row chunks, row workgroups per direction, workgroups per launch, estimated
+ *   launch length in row-tile times x 100 under the dispatch model (wavemamba_hip.hip: core_makespan).
+ *   W % 4 != 0 (first-generation kernels): WM_EUNSUPPORTED.
+ */
+int wm_ss2d_core_plan(int B, int D, int H, int W, int N, int R, int* out10);
 /*   plane_dtype: storage type of x and of the y buffers, WM_F32 or WM_BF16 (bf16-storage mode: bf16 planes between
  *   the kernels, fp32 tiles / projection / state inside; needs W % 4 == 0).
+ */
+/*   prepared: NULL, or the buffer wm_ss2d_core_prep filled from THESE parameters (wm_ss2d_core_prep_bytes(N) bytes,
+ *   16-byte aligned): the bf16-split x_proj weight fragments, A * log2(e) and the per-channel constants the kernels
+ *   read.  With NULL the call prepares them itself into the workspace (one more small launch); inference callers whose
+ *   parameters do not change keep one prepared buffer per SS2D module.
  */
 int wm_ss2d_core_fwd(const void* x, const float* x_proj_weight, const float* dt_projs_weight,
                      const float* dt_projs_bias, const float* A_logs, const float* Ds,
                      void* y_row_fwd, void* y_row_rev, void* y_col_fwd, void* y_col_rev,
-                     int merged, void* workspace, size_t workspace_bytes,
+                     int merged, void* workspace, size_t workspace_bytes, const void* prepared,
                      int B, int D, int H, int W, int N, int R, int plane_dtype, void* stream);
+size_t wm_ss2d_core_prep_bytes(int N);
+int wm_ss2d_core_prep(const float* x_proj_weight, const float* dt_projs_weight, const float* dt_projs_bias,
+                      const float* A_logs, const float* Ds, void* prepared, int D, int N, int R, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * Depth-wise 3x3 convolution, stride 1, zero padding 1, + bias, + optional SiLU.
@@ -152,7 +171,7 @@ int wm_dwconv3x3_fwd(const void* x, const float* weight, const float* bias, void
  *   wm_lfss_mid_fwd : transpose (:491) + out_norm (:492) + *silu(z) (:493) + out_proj (:494)
  *                     + skip_scale residual (:525) + ln_2 + ffn.conv1 (:526, :226)
  *                     ysum, z, tok -> tok1, f (input of ffn.conv2).  ny = 1: `ysum` is the merged core output;
- *                     ny = 4: `ysum` points at four (B, D, L) buffers `ystride` floats apart in the order
+ *                     ny = 4: `ysum` points at four (B, D, L) buffers `ystride` ELEMENTS of the plane dtype apart in the order
  *                     [y_row_fwd, y_row_rev, y_col_fwd, y_col_rev] and the kernel adds them (:490) as it loads
  *   wm_lfss_out_fwd : gelu gate (:227-228) + ffn.conv3 (:230) + skip_scale2 residual (:526)
  *                     fc, tok1 -> out
@@ -170,6 +189,13 @@ int wm_lfss_mid_fwd(const void* ysum, int ny, int64_t ystride, const void* z, co
 int wm_lfss_out_fwd(const void* fc, const float* tok1, const float* conv3_weight, const float* conv3_bias,
                     const float* skip_scale2, float* out, int out_nchw, int B, int64_t L, int C, int plane_dtype,
                     void* stream);
+/* wm_lfss_out_fwd with the gated ffn's depth-wise 3x3 (conv2, wavemamba_arch.py:220, :226) folded in: takes conv1's
+ * output planes f (B, 2C, H, W) instead of conv2's, so `fc` never exists in HBM (-512 B per position, one launch less
+ * per LFSSBlock).  Bit-identical to wm_dwconv3x3_fwd(act = none) + wm_lfss_out_fwd on fp32 planes.
+ * C == 32 and W % 32 == 0 only (WM_EUNSUPPORTED otherwise: use the two calls).  conv2_bias may be NULL. */
+int wm_lfss_out_conv_fwd(const void* f, const float* conv2_weight, const float* conv2_bias, const float* tok1,
+                         const float* conv3_weight, const float* conv3_bias, const float* skip_scale2, float* out,
+                         int out_nchw, int B, int H, int W, int C, int plane_dtype, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * LayerNorm2d of the HFE branch (first "next" row): per-pixel LayerNorm over the C
@@ -246,7 +272,7 @@ int wm_conv2d_gated_fwd(const float* xa, const float* xb, const int* xb_index, c
  *                   the merged forward pass the same pointer four times.
  *   dx (B, D, H, W), dx_proj_weight (4, R + 2N, D), ddt_projs_weight (4, D, R), ddt_projs_bias (4, D),
  *   dA_logs (4 D, N), dDs (4 D): overwritten.
- * Same limits as the forward (N <= 16, R <= 4, D <= 64); workspace wm_ss2d_core_bwd_workspace_bytes(...), 16-byte aligned. */
+ * Limits: N <= 32, R <= 4, D <= 64; workspace wm_ss2d_core_bwd_workspace_bytes(...), 16-byte aligned. */
 size_t wm_ss2d_core_bwd_workspace_bytes(int B, int D, int H, int W, int N, int R);
 int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt_projs_weight,
                      const float* dt_projs_bias, const float* A_logs, const float* Ds, const float* dy_row_fwd,

@@ -239,6 +239,36 @@ def main():
         yout = blk(xin, [8, 12])
     save("lfss_block.npz", x=npy(xin), y=npy(yout),
          **{"p." + k: npy(v) for k, v in blk.state_dict().items()})
+    # the d_state = 32 block of BASELINE config 5, TRAINABLE: output, and the reference autograd's gradients w.r.t. the
+    # input and every parameter for dy = randn (in fp32, and - the truth both are judged against, see make_golden_grads.py -
+    # the same code in float64)
+    torch.manual_seed(0)
+    blk = arch.LFSSBlock(32, d_state=32, expand=2.0).train()
+    with torch.no_grad():
+        blk.skip_scale.add_(0.1 * torch.randn(32, generator=gen(3)))
+        blk.skip_scale2.add_(0.1 * torch.randn(32, generator=gen(4)))
+        blk.self_attention.A_logs.add_(0.3 * torch.randn(blk.self_attention.A_logs.shape, generator=gen(11)))
+    xin = torch.randn(2, 16 * 12, 32, generator=gen(1234)).requires_grad_(True)
+    dy = torch.randn(2, 16 * 12, 32, generator=gen(4321))
+    yout = blk(xin, [16, 12])
+    params = dict(blk.named_parameters())
+    grads = torch.autograd.grad(yout, [xin] + list(params.values()), dy)
+    blk64 = arch.LFSSBlock(32, d_state=32, expand=2.0).train()
+    blk64.load_state_dict(blk.state_dict())
+    blk64 = blk64.double()
+    saved = (torch.Tensor.float, torch.float, torch.float32)
+    torch.Tensor.float = lambda self, *a, **k: self.double()
+    torch.float = torch.float32 = torch.float64
+    try:
+        x64 = xin.detach().double().requires_grad_(True)
+        y64 = blk64(x64, [16, 12])
+        g64 = torch.autograd.grad(y64, [x64] + list(blk64.parameters()), dy.double())
+    finally:
+        torch.Tensor.float, torch.float, torch.float32 = saved
+    save("lfss_block_n32.npz", x=npy(xin), y=npy(yout), dy=npy(dy), dx=npy(grads[0]), dx_f64=npy(g64[0]), y_f64=npy(y64),
+         **{"p." + k: npy(v) for k, v in blk.state_dict().items()},
+         **{"g." + k: npy(g) for k, g in zip(params, grads[1:])},
+         **{"t." + k: npy(g) for k, g in zip(params, g64[1:])})
 
     # ---- (v)+(vi) full network -----------------------------------------------------------------
     # tiny config WITH weights (does not rely on RNG-order equivalence of the re-implementation)
@@ -285,6 +315,27 @@ def main():
     meta["train_losses"] = [float(l_pix), float(l_fft)]
     meta["grad_fingerprint"] = {k: [float(p.grad.double().sum()), float(p.grad.double().abs().sum())]
                                 for k, p in net.named_parameters()}
+    # the same step of the same code in float64 (the truth the fp32 fingerprints above and the build's gradients are both
+    # measured against): the reference forces fp32 at :123, :457-463 and asserts it at :472, :489, so for this run
+    # Tensor.float maps to .double() and torch.float / torch.float32 name float64; nothing else is touched
+    net64 = arch.WaveMamba(in_chn=3, wf=32, n_l_blocks=[1, 2, 4], n_h_blocks=[1, 1, 2], ffn_scale=2.0).train()
+    net64.load_state_dict(net.state_dict())
+    net64 = net64.double()
+    saved = (torch.Tensor.float, torch.float, torch.float32)
+    torch.Tensor.float = lambda self, *a, **k: self.double()
+    torch.float = torch.float32 = torch.float64
+    try:
+        p64 = net64(lq.double())
+        pf = torch.fft.rfft2(p64); gf = torch.fft.rfft2(gt.double())
+        (F.l1_loss(p64, gt.double()) +
+         0.1 * F.l1_loss(torch.stack([pf.real, pf.imag], -1), torch.stack([gf.real, gf.imag], -1))).backward()
+    finally:
+        torch.Tensor.float, torch.float, torch.float32 = saved
+    meta["grad_fingerprint_f64"] = {k: [float(p.grad.sum()), float(p.grad.abs().sum())] for k, p in net64.named_parameters()}
+    # how far the reference's own fp32 gradients are from that truth, per tensor (rel l2): the yardstick of the GPU test
+    meta["grad_ref32_vs_f64"] = {k: float((net.get_parameter(k).grad.double() - p.grad).norm() / p.grad.norm().clamp_min(1e-300))
+                                 for k, p in net64.named_parameters()}
+    print("  reference fp32 gradients vs float64 truth: worst tensor %.3e" % max(meta["grad_ref32_vs_f64"].values()))
     with open(os.path.join(OUT_DIR, "model_shipped_meta.json"), "w") as f:
         json.dump(meta, f, indent=0)
     print("  wrote model_shipped_meta.json:", len(meta["keys"]), "keys,", meta["n_params"], "params")

@@ -101,3 +101,43 @@ def test_training_state_resume(tmp_path):
         pass
     else:
         raise AssertionError("optimizer count mismatch must raise")
+
+
+# ---- the optimizer step itself (femasr_model.py:122-135 setup_optimizers, :157-185 optimize_parameters) ---------------
+def _opt_golden():
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    return np.load(os.path.join(GOLDEN, "train_grads_wf8.npz")), np.load(os.path.join(GOLDEN, "train_opt_wf8.npz"))
+
+
+def _net_with_golden_grads(device):
+    """The wf = 8 model at the reference's weights with the REFERENCE's gradients of step 1 in .grad."""
+    g, o = _opt_golden()
+    torch.manual_seed(0)
+    net = wm.WaveMamba(in_chn=3, wf=8, n_l_blocks=[1, 1, 2], n_h_blocks=[1, 1, 1], ffn_scale=2.0).train()
+    net.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}, strict=False)
+    net = net.to(device)
+    for k, p in net.named_parameters():
+        p.grad = torch.from_numpy(g["g." + k]).to(device)
+    return net, g, o
+
+
+def check_optimizer_arithmetic(device):
+    """trainer.make_optimizer + step on the reference's own gradients reproduces the reference's parameters after
+    optimizer_g.step() (tests/golden/train_opt_wf8.npz, make_golden_grads.py): AdamW lr 5e-4, weight decay 1e-3, betas
+    (0.9, 0.99), every parameter in the one group - <= 1e-6 relative per tensor (measured: bit-equal or 1 ulp)."""
+    net, g, o = _net_with_golden_grads(device)
+    opt = trainer.make_optimizer(net)
+    assert len(opt.param_groups) == 1 and len(opt.param_groups[0]["params"]) == len(list(net.parameters()))
+    opt.step()
+    worst = 0.0
+    for k, p in net.named_parameters():
+        ref = torch.from_numpy(o["p1." + k]).double()
+        worst = max(worst, float((p.detach().cpu().double() - ref).norm() / ref.norm().clamp_min(1e-30)))
+    assert worst <= 1e-6, f"parameters after the optimizer step deviate by {worst:.3e}"
+    return worst
+
+
+def test_optimizer_step_matches_reference_on_reference_gradients():
+    check_optimizer_arithmetic("cpu")

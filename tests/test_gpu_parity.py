@@ -5,8 +5,9 @@ the reference's operation order); selective scan and anything containing it <= 1
 (l2 and max-abs) per tensor in fp32."""
 import pytest
 import torch
+import torch.nn.functional as F
 
-from conftest import assert_close
+from conftest import assert_close, rel_err
 from oracle import oracle
 from oracle import backend as oracle_backend
 import wave_mamba_amd as wm
@@ -14,16 +15,15 @@ from wave_mamba_amd.archs import wavemamba_arch as arch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-# Per-parameter gradients of one training step on the GPU path (SURVEY.md 8c / 8d ask 1e-4 per tensor).  Measured on
-# MI355X (tools/grad_deviation.py): 392 of the 395 tensors of the wf = 8 model are within 1e-4, the worst three sit at
-# 1.2-1.5e-4 - all in the deepest block, whose 8 x 8 map makes every gradient a short sum with cancellation (|g| 1e-7 ..
-# 1e-3 against 1e-1 elsewhere).  The deviation does not come from one kernel: with the convolutions on MIOpen's fp32
-# kernels the worst is 1.3e-4, with the fused core replaced by the drop-in scan 1.2e-4 (a scalar `temperature`); the CPU
-# oracle path, same network code, is at 5.6e-6 against the same goldens (tests/test_arch_cpu.py, bar 1e-4).  Hence:
-# every tensor <= 2e-4 AND at least 98 % of the tensors <= 1e-4.
-GRAD_BAR = 2e-4
-GRAD_BAR_MOST = 1e-4
-GRAD_FP_BAR = 5e-4     # (sum, abs-sum) fingerprints of the shipped config: worst 3.3e-4, a scalar with |g| = 4e-6
+# Gradients (<= 1e-4 per tensor).  A parameter gradient that is a short, cancelling sum (the 8 x 8 maps
+# of the deepest block: |g| 1e-7 .. 1e-3 against 1e-1 elsewhere) is only defined to a few 1e-5 in fp32 by ANY
+# implementation, the reference's included.  The yardstick is therefore the FLOAT64 evaluation of the reference's own
+# code (tests/golden/train_grads_wf8_f64.npz, model_shipped_meta.json: grad_fingerprint_f64; make_golden*.py):
+#     err(build, truth) <= max(1e-4, 2 err(reference fp32, truth))   per tensor - no other allowance.
+def truth_bar(err_ref):
+    return max(1e-4, 2.0 * err_ref)
+
+
 TOL = 1e-4
 
 
@@ -107,20 +107,33 @@ def test_dwt_iwt_backward_is_the_adjoint():
     assert torch.equal(torch.cat([dl, dh], 1), dy)
 
 
-def test_dwt_full_size_round_trip_and_energy():
-    # BASELINE config 4 at its full size (UHDLOL4K: batch 4 x 32 x 2160 x 4096, 4.5 GB), 3 levels; properties
-    # (round trip, energy, linearity) instead of an oracle
-    x = torch.randn(4, 32, 2160, 4096, generator=gen(7)).to(DEV)
-    cur, pyramid = x, []
-    for _ in range(3):
+def test_dwt_full_size_bit_exact_and_properties():
+    """BASELINE config 4 at its full size (UHDLOL4K: batch 4 x 32 x 2160 x 4096 fp32 = 4.5 GB, 3 DWT + 3 IWT levels):
+    every sub-band of every level and every reconstruction BIT-EXACT against the CPU oracle over the whole tensor (the
+    oracle runs one batch item at a time to bound host memory; the GPU calls are the full-size ones), plus the
+    size-independent properties (energy, round trip, linearity)."""
+    x_cpu = torch.randn(4, 32, 2160, 4096, generator=gen(7))
+    x = x_cpu.to(DEV)
+    cur, cur_cpu, pyramid = x, x_cpu, []
+    for level in range(3):
         ll, hl, lh, hh = wm.ops.dwt_init(cur)
+        want = [oracle.dwt_raw(cur_cpu[b:b + 1]) for b in range(cur_cpu.shape[0])]
+        for i, (name, got) in enumerate(zip(("ll", "hl", "lh", "hh"), (ll, hl, lh, hh))):
+            for b in range(cur_cpu.shape[0]):
+                assert torch.equal(got[b:b + 1].cpu(), want[b][i]), f"level {level + 1} {name} batch {b}"
         e_in = cur.double().pow(2).sum()
         e_out = sum(t.double().pow(2).sum() for t in (ll, hl, lh, hh))
         assert abs(float(e_out / e_in) - 1.0) < 1e-6          # orthogonal transform
         pyramid.append((hl, lh, hh))
-        cur = ll
+        cur, cur_cpu = ll, torch.cat([w[0] for w in want], 0)
+        del want
+    del cur_cpu
     for hl, lh, hh in reversed(pyramid):
-        cur = wm.ops.iwt_init(torch.cat([cur, hl, lh, hh], 1))
+        cat = torch.cat([cur, hl, lh, hh], 1)
+        cur = wm.ops.iwt_init(cat)
+        for b in range(cat.shape[0]):
+            assert torch.equal(cur[b:b + 1].cpu(), oracle.iwt_raw(cat[b:b + 1].cpu())), f"IWT to {tuple(cur.shape)} batch {b}"
+        del cat
     assert float((cur - x).abs().max()) < 5e-6
     # linearity: DWT(a + 2b) == DWT(a) + 2 DWT(b) up to rounding
     a, b = x[:, :4, :256, :512].contiguous(), torch.randn(1, 4, 256, 512, generator=gen(8)).to(DEV)
@@ -268,12 +281,43 @@ def test_scan_backward_golden(golden, tag):
     (1, 8, 1, 4, 2),             # L = 1
 ])
 def test_scan_backward_vs_oracle(batch, dim, L, N, G):
+    """du / ddelta / dB / dC against the CPU oracle at 1e-4.  dA / dD / dbias are sums over batch and L of products of
+    both signs: they are judged like every reduced gradient - against a float64 evaluation of the same recurrence
+    (autograd through the sequential definition, the oracle's fp32 result measured against it too)."""
     case = random_scan_case(batch, dim, L, N, G, seed=7 + L)
     dy = torch.randn(batch, dim, L, generator=gen(L))
     _, grads = hip_scan_grads(*case, dy)
     want = oracle.selscan_bwd_raw(*case, dy, True)
+    truth = scan_grads_f64(*case, dy)
     for name, got, ref in zip(GRAD_NAMES, grads, want):
-        assert_close(got, ref, 2e-4 if name in ("dA", "dD", "dbias") else TOL, f"{name}")
+        if name in ("dA", "dD", "dbias") and float(truth[name].abs().max()) == 0.0:      # L = 1: dA is exactly zero
+            assert float(got.abs().max()) <= 1e-6, f"{name}: expected zeros, max abs {float(got.abs().max()):.3e}"
+        elif name in ("dA", "dD", "dbias"):
+            e_ref = max(rel_err(ref.double(), truth[name]))
+            e_got = max(rel_err(got.cpu().double(), truth[name]))
+            assert e_got <= truth_bar(e_ref), f"{name}: {e_got:.3e} vs float64 truth (oracle fp32: {e_ref:.3e})"
+        else:
+            assert_close(got, ref, TOL, f"{name}")
+
+
+def scan_grads_f64(u, delta, A, Bm, Cm, D, bias, dy):
+    """The selective-scan definition in float64 with autograd: truth for the reduced gradients."""
+    leaves = [t.double().requires_grad_(True) for t in (u, delta, A, Bm, Cm, D, bias)]
+    u_, dl, A_, B_, C_, D_, b_ = leaves
+    batch, dim, L = u_.shape
+    N, G = A_.shape[1], B_.shape[1]
+    dt = F.softplus(dl + b_.view(1, dim, 1))
+    Bf = B_.repeat_interleave(dim // G, dim=1)          # (b, dim, N, L)
+    Cf = C_.repeat_interleave(dim // G, dim=1)
+    h = torch.zeros(batch, dim, N, dtype=torch.float64)
+    ys = []
+    # (unbind, not indexing: the backward of `t[..., i]` allocates a full-size zero tensor per step)
+    for dt_t, du_t, B_t, C_t in zip(dt.unbind(2), (dt * u_).unbind(2), Bf.unbind(3), Cf.unbind(3)):
+        h = torch.exp(dt_t[..., None] * A_.view(1, dim, N)) * h + du_t[..., None] * B_t
+        ys.append((h * C_t).sum(-1))
+    y = torch.stack(ys, 2) + u_ * D_.view(1, dim, 1)
+    g = torch.autograd.grad(y, leaves, dy.double())
+    return dict(zip(GRAD_NAMES, g))
 
 
 def test_training_step_on_gpu_matches_reference(golden):
@@ -289,37 +333,56 @@ def test_training_step_on_gpu_matches_reference(golden):
     l_pix, l_fft = wm.trainer.losses(net(lq), gt)
     (l_pix + l_fft).backward()
     assert abs(float(l_pix.detach()) - meta["train_losses"][0]) < 1e-5
-    worst = (0.0, None)
+    # (sum, abs-sum) fingerprints only at 1.5 M parameters (the full tensors are checked on the wf = 8 model below):
+    # the build's and the reference's fp32 fingerprints against the float64 ones
+    fp = lambda a, b: max(abs(a[0] - b[0]), abs(a[1] - b[1])) / max(b[1], 1e-30)
+    bad = []
     for k, p in net.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
-        s, a = meta["grad_fingerprint"][k]
         g = p.grad.double()
-        dev = max(abs(float(g.abs().sum()) - a), abs(float(g.sum()) - s)) / max(a, 1e-30)
-        worst = max(worst, (dev, k))
-    # fingerprints only at 1.5 M parameters; the full tensors are checked on the wf = 8 model below
-    assert worst[0] < GRAD_FP_BAR, f"gradient fingerprint of {worst[1]} deviates by {worst[0]:.3e}"
+        truth = meta["grad_fingerprint_f64"][k]
+        e_got = fp((float(g.sum()), float(g.abs().sum())), truth)
+        e_ref = max(fp(meta["grad_fingerprint"][k], truth), meta["grad_ref32_vs_f64"][k])
+        if e_got > truth_bar(e_ref):
+            bad.append((e_got, e_ref, k))
+    assert not bad, "gradient fingerprints off the float64 truth (build, reference fp32, name): " + \
+        "; ".join("%.3e %.3e %s" % b for b in sorted(bad, reverse=True)[:5])
 
 
 def test_training_step_per_parameter_gradients_on_gpu():
     """One reference training step (femasr_model.py:157-185) on the HIP training path - SS2D core forward / backward,
-    DWT / IWT, depth-wise conv, LayerNorms, convolutions' input gradients in HIP, the rest PyTorch autograd - against
-    the reference's own per-parameter gradient tensors (tests/golden/train_grads_wf8.npz): rel-l2 and max-abs <= 1e-4."""
-    from test_arch_cpu import check_grads_against_golden, grad_golden_case
+    DWT / IWT, depth-wise conv, LayerNorms, convolutions' input gradients in HIP, the rest PyTorch autograd: every
+    parameter's gradient TENSOR against the float64 evaluation of the reference's code, judged against what the
+    reference's own fp32 autograd (tests/golden/train_grads_wf8.npz) achieves on the same tensor."""
+    import numpy as np, os
+    from conftest import GOLDEN
+    from test_arch_cpu import grad_golden_case
     net, g = grad_golden_case()
+    t = np.load(os.path.join(GOLDEN, "train_grads_wf8_f64.npz"))
     net = net.to(DEV)
     pred = net(torch.from_numpy(g["lq"]).to(DEV))
     l_pix, l_fft = wm.trainer.losses(pred, torch.from_numpy(g["gt"]).to(DEV))
     (l_pix + l_fft).backward()
     assert abs(float(l_pix.detach()) - g["losses"][0]) < 1e-6
     assert_close(pred.detach(), torch.from_numpy(g["pred"]), 1e-5, "prediction")
-    worst = check_grads_against_golden(net, g, bar=GRAD_BAR, bar_most=GRAD_BAR_MOST, most=0.98)
-    print(f"worst per-parameter gradient deviation {worst[0]:.3e} ({worst[1]})")
+    bad, worst = [], (0.0, 0.0, None)
+    for k, p in net.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        truth = torch.from_numpy(t["t." + k])
+        e_got = max(rel_err(p.grad.detach().cpu().double(), truth))
+        e_ref = max(rel_err(torch.from_numpy(g["g." + k]).double(), truth))
+        worst = max(worst, (e_got, e_ref, k))
+        if e_got > truth_bar(e_ref):
+            bad.append((e_got, e_ref, k))
+    print("worst per-parameter gradient error vs float64 truth: %.3e (reference fp32 %.3e) %s" % worst)
+    assert not bad, "gradients off the float64 truth (build, reference fp32, name): " + \
+        "; ".join("%.3e %.3e %s" % b for b in sorted(bad, reverse=True)[:8])
 
 
 # ------------------------------------------------------------------------------------------------
 # fused SS2D four-direction core (reference SS2D.forward_core, :446-478)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tag", ["s16", "sq16", "d8"])
+@pytest.mark.parametrize("tag", ["s16", "sq16", "s32", "d8"])
 def test_ss2d_core_golden(golden, tag):
     g = golden("scan")          # captured from the reference's real forward_core
     args = cu(g[f"{tag}_core_x"], g[f"{tag}_x_proj_weight"], g[f"{tag}_dt_projs_weight"],
@@ -442,10 +505,10 @@ def test_lfss_block_config5_full_size():
     assert_close(fused, ref, TOL, "config 5 LFSSBlock")
 
 
-def test_uhd_forward_full_size_vs_cpu_oracle_network():
-    """BASELINE config 2 end to end on the product path: ONE full 2176 x 3840 forward (the padded UHD frame of
-    inference_wavemamba.py:28-36, :99-113) against the same network on the host with the CPU oracle as hot-path backend
-    (about a minute of CPU time): rel-l2 <= 1e-4 and |dPSNR| <= 1e-3 dB after the reference's uint8 quantisation."""
+@pytest.fixture(scope="module")
+def uhd_cpu_oracle():
+    """The padded UHD frame of inference_wavemamba.py:28-36, :99-113 and its forward through the same network on the host
+    with the CPU oracle as hot-path backend (about a minute of CPU time; shared by the fp32 and the bf16-storage test)."""
     import bench
     img = torch.rand(1, 3, 2160, 3840, generator=gen(1234))
     x = bench.pad_to(img)
@@ -455,13 +518,48 @@ def test_uhd_forward_full_size_vs_cpu_oracle_network():
     net = bench.build_model("cpu")
     with oracle_backend.ops_backend(oracle), torch.no_grad():
         want = net.restoration_network(x)
-    net = net.to(DEV)
+    return x, want, net
+
+
+def test_uhd_forward_full_size_vs_cpu_oracle_network(uhd_cpu_oracle):
+    """BASELINE config 2 end to end on the product path (fp32): ONE full 2176 x 3840 forward against the CPU-oracle
+    network: rel-l2 <= 1e-4 and |dPSNR| <= 1e-3 dB after the reference's uint8 quantisation."""
+    import bench
+    x, want, net = uhd_cpu_oracle
+    net = bench.build_model(DEV)
     with torch.no_grad():
         got = net.restoration_network(x.to(DEV)).cpu()
+    l2, mx = rel_err(got, want)
+    print(f"UHD forward vs CPU-oracle network: rel-l2 {l2:.3e}, max-abs / max-abs {mx:.3e}")
     assert_close(got, want, TOL, "UHD forward")
     tgt = torch.rand(1, 3, 2160, 3840, generator=gen(4321))
     crop = lambda t: t[:, :, :2160, :3840]
     assert abs(bench.psnr_u8(crop(got), tgt) - bench.psnr_u8(crop(want), tgt)) <= 1e-3
+
+
+def test_uhd_forward_bf16_storage_vs_cpu_oracle_network(uhd_cpu_oracle):
+    """BASELINE config 2 AS WORDED (bf16) at its real size: the bf16-storage mode (bf16 planes between the kernels of
+    every LFSSBlock, fp32 arithmetic inside) on the full 2176 x 3840 frame against the fp32 CPU-oracle network.  No 1e-4
+    bar can hold at 8 mantissa bits (the reference itself under torch.autocast(bfloat16) is 59.6 dB from its fp32
+    output); stated bars: PSNR >= 60 dB on the [0, 1] outputs, >= 55 dB after uint8 quantisation
+    (measured on MI355X: 70.1 / 60.4 dB)."""
+    import bench
+    from wave_mamba_amd import inference
+    x, want, _ = uhd_cpu_oracle
+    net = bench.build_model(DEV)
+    prev = wm.ops.set_plane_dtype(torch.bfloat16)
+    try:
+        with torch.no_grad():
+            got = net.restoration_network(x.to(DEV)).cpu()
+    finally:
+        wm.ops.set_plane_dtype(prev)
+    crop = lambda t: t[:, :, :2160, :3840]
+    mse = float((crop(got).clamp(0, 1) - crop(want).clamp(0, 1)).double().pow(2).mean())
+    psnr = float(10 * torch.log10(torch.tensor(1.0 / mse)))
+    psnr8 = inference.psnr_uint8(inference.to_uint8(crop(got)), inference.to_uint8(crop(want)))
+    print(f"bf16 storage at UHD vs fp32 CPU-oracle network: PSNR {psnr:.1f} dB, after uint8 {psnr8:.1f} dB, "
+          f"rel-l2 {rel_err(got, want)[0]:.2e}")
+    assert psnr >= 60.0 and psnr8 >= 55.0
 
 
 def test_core_abi_error_codes_from_real_calls():
@@ -478,10 +576,19 @@ def test_core_abi_error_codes_from_real_calls():
     p = lambda t: t.data_ptr()
     yp = [p(ys[i]) for i in range(4)]
 
-    def call(xp=p(x), wsp=p(ws), wsb=need, y0=yp[0], n=N, h=H):
+    def call(xp=p(x), wsp=p(ws), wsb=need, y0=yp[0], n=N, h=H, prep=None):
         return lib.wm_ss2d_core_fwd(xp, p(Wx), p(Wdt), p(bias), p(A_logs), p(Ds), y0, yp[1], yp[2], yp[3], 0, wsp, wsb,
-                                    B, D, h, W, n, R, 0, torch.cuda.current_stream().cuda_stream)
+                                    prep, B, D, h, W, n, R, 0, torch.cuda.current_stream().cuda_stream)
     assert call() == 0
+    # the prepared-parameters form gives the same bits as the self-preparing call
+    y_self = ys.clone()
+    pb = torch.empty(lib.wm_ss2d_core_prep_bytes(N), dtype=torch.uint8, device=DEV)
+    assert lib.wm_ss2d_core_prep(p(Wx), p(Wdt), p(bias), p(A_logs), p(Ds), p(pb), D, N, R,
+                                 torch.cuda.current_stream().cuda_stream) == 0
+    ys.zero_()
+    assert call(prep=p(pb)) == 0 and torch.equal(ys, y_self)
+    assert call(prep=p(pb) + 4) == -3                     # WM_EALIGN (prepared buffer)
+    assert lib.wm_ss2d_core_prep_bytes(64) == 0
     assert call(wsb=need - 1) == -4                       # WM_EWORKSPACE
     assert call(wsp=p(ws) + 4) == -3                      # WM_EALIGN (workspace)
     assert call(xp=p(x) + 4) == -3                        # WM_EALIGN (x: 16-byte tile loads)
@@ -537,6 +644,49 @@ def test_lfss_block_fused_vs_module_path(C, H, W):
         finally:
             arch.LFSSBlock._fused_ok = saved
     assert_close(fused, ref, TOL, f"LFSSBlock C={C}")
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 40, 96), (2, 3, 32), (1, 1, 64), (2, 2, 32), (1, 17, 480), (1, 5, 160)])
+@pytest.mark.parametrize("nchw", [False, True])
+def test_lfss_out_with_depthwise_conv_folded_in(B, H, W, nchw):
+    """wm_lfss_out_conv_fwd (the ffn's depth-wise 3x3 inside the closing kernel) against
+    wm_dwconv3x3_fwd + wm_lfss_out_fwd: BIT-identical on fp32 planes - interior tiles, first / last rows, one-row and
+    two-row maps, a row that is one tile (both column edges in it), batch 2, an odd number of 32-position tiles - and
+    both against the fp64 composition of reference :226-230 (conv2 -> gelu(x1) * x2 -> conv3, then * skip + tok1)."""
+    from wave_mamba_amd import _lib
+    from wave_mamba_amd.ops import _ptr, _stream, check
+    lib = _lib.load()
+    C, D, L = 32, 64, H * W
+    g = torch.Generator(device=DEV); g.manual_seed(B * 1000 + H * 10 + W)
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    f, tok1 = rn(B, D, H, W), rn(B, L, C)
+    w2, b2, w3, b3, sk = rn(D, 1, 3, 3) * 0.3, rn(D) * 0.2, rn(C, C, 1, 1) * 0.2, rn(C) * 0.2, rn(C) * 0.3 + 1
+    shape = (B, C, H, W) if nchw else (B, L, C)
+    fused, unfused = torch.empty(shape, device=DEV), torch.empty(shape, device=DEV)
+    check(lib.wm_lfss_out_conv_fwd(_ptr(f), _ptr(w2), _ptr(b2), _ptr(tok1), _ptr(w3), _ptr(b3), _ptr(sk), _ptr(fused),
+                                   int(nchw), B, H, W, C, 0, _stream()), "wm_lfss_out_conv_fwd")
+    fc = wm.ops.dwconv3x3(f, w2, b2, "none")
+    check(lib.wm_lfss_out_fwd(_ptr(fc), _ptr(tok1), _ptr(w3), _ptr(b3), _ptr(sk), _ptr(unfused), int(nchw), B, L, C, 0,
+                              _stream()), "wm_lfss_out_fwd")
+    assert torch.equal(fused, unfused)
+    fc64 = F.conv2d(f.double(), w2.double(), b2.double(), padding=1, groups=D)
+    gv = F.gelu(fc64[:, :C]) * fc64[:, C:]
+    want = F.conv2d(gv, w3.double(), b3.double()) + (tok1.double() * sk.double()).transpose(1, 2).reshape(B, C, H, W)
+    if not nchw:
+        want = want.reshape(B, C, L).transpose(1, 2)
+    assert_close(fused, want.float(), 1e-5, "lfss_out with conv2 folded in vs fp64")
+    # no bias, bf16 planes (fp32 arithmetic on the rounded input)
+    fb16 = f.bfloat16()
+    check(lib.wm_lfss_out_conv_fwd(_ptr(fb16), _ptr(w2), None, _ptr(tok1), _ptr(w3), _ptr(b3), _ptr(sk), _ptr(fused),
+                                   int(nchw), B, H, W, C, 1, _stream()), "wm_lfss_out_conv_fwd bf16")
+    fc64 = F.conv2d(f.bfloat16().double(), w2.double(), None, padding=1, groups=D)
+    gv = F.gelu(fc64[:, :C]) * fc64[:, C:]
+    want = F.conv2d(gv, w3.double(), b3.double()) + (tok1.double() * sk.double()).transpose(1, 2).reshape(B, C, H, W)
+    if not nchw:
+        want = want.reshape(B, C, L).transpose(1, 2)
+    assert_close(fused, want.float(), 1e-5, "bf16 planes, no conv2 bias")
+    assert lib.wm_lfss_out_conv_fwd(_ptr(f), _ptr(w2), _ptr(b2), _ptr(tok1), _ptr(w3), _ptr(b3), _ptr(sk), _ptr(fused),
+                                    int(nchw), B, H, W - 4, C, 0, _stream()) == -5       # W % 32 != 0: WM_EUNSUPPORTED
 
 
 @pytest.mark.parametrize("B,L", [(1, 64), (2, 1000), (3, 37), (1, 4097)])
@@ -981,9 +1131,54 @@ def test_dwconv3x3_gelu(shape):
 # ------------------------------------------------------------------------------------------------
 # fused SS2D core backward (wm_ss2d_core_bwd) against the reference's autograd of forward_core
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tag", ["s16", "sq16", "d8"])
+def core_grads_f64(x, Wx, Wdt, bias, A_logs, Ds, dys):
+    """SS2D.forward_core (:446-478) with the sequential scan definition, all in float64, through autograd: the truth for
+    the fused backward.  dys: four (B, D, L) tensors in the reference's return order, or one (merged)."""
+    leaves = [t.detach().cpu().double().requires_grad_(True) for t in (x, Wx, Wdt, bias, A_logs, Ds)]
+    x_, Wx_, Wdt_, b_, Al_, Ds_ = leaves
+    B, D, H, W = x_.shape
+    L, K = H * W, 4
+    R, N = Wdt_.shape[2], Al_.shape[1]
+    xs = torch.stack([x_.view(B, -1, L), x_.transpose(2, 3).contiguous().view(B, -1, L)], dim=1).view(B, 2, -1, L)
+    xs = torch.cat([xs, torch.flip(xs, dims=[-1])], dim=1)
+    x_dbl = torch.einsum("b k d l, k c d -> b k c l", xs, Wx_)
+    dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
+    dts = torch.einsum("b k r l, k d r -> b k d l", dts, Wdt_)
+    u = xs.reshape(B, K * D, L)
+    dt = F.softplus(dts.reshape(B, K * D, L) + b_.reshape(1, -1, 1))
+    A = -torch.exp(Al_)
+    Bf = Bs.repeat_interleave(D, dim=1)                 # (B, K D, N, L)
+    Cf = Cs.repeat_interleave(D, dim=1)
+    h = torch.zeros(B, K * D, N, dtype=torch.float64)
+    ys = []
+    for dt_t, du_t, B_t, C_t in zip(dt.unbind(2), (dt * u).unbind(2), Bf.unbind(3), Cf.unbind(3)):
+        h = torch.exp(dt_t[..., None] * A.view(1, K * D, N)) * h + du_t[..., None] * B_t
+        ys.append((h * C_t).sum(-1))
+    out = (torch.stack(ys, 2) + u * Ds_.view(1, -1, 1)).view(B, K, -1, L)
+    inv = torch.flip(out[:, 2:4], dims=[-1]).view(B, 2, -1, L)
+    wh = out[:, 1].view(B, -1, W, H).transpose(2, 3).contiguous().view(B, -1, L)
+    invwh = inv[:, 1].view(B, -1, W, H).transpose(2, 3).contiguous().view(B, -1, L)
+    outs = (out[:, 0], inv[:, 0], wh, invwh)
+    dys = [d.detach().cpu().double() for d in dys]
+    if len(dys) == 1:
+        return torch.autograd.grad(sum(outs), leaves, dys[0])
+    return torch.autograd.grad(outs, leaves, dys)
+
+
+def assert_vs_truth(got, ref, truth, what):
+    """err(got, truth) <= max(1e-4, 2 err(ref, truth)): `ref` is the fp32 result the build is compared with."""
+    e_got, e_ref = max(rel_err(got, truth)), max(rel_err(ref, truth))
+    assert e_got <= truth_bar(e_ref), f"{what}: {e_got:.3e} vs float64 truth (fp32 reference: {e_ref:.3e})"
+
+
+# ------------------------------------------------------------------------------------------------
+# fused SS2D core backward (wm_ss2d_core_bwd) against the reference's autograd of forward_core
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["s16", "sq16", "s32", "d8"])       # s32: d_state 32 (BASELINE config 5's block)
 def test_ss2d_core_backward_golden(golden, tag):
-    """Gradients of the reference's real SS2D.forward_core (tests/golden/make_golden.py) for four random dys."""
+    """Gradients of the reference's real SS2D.forward_core (tests/golden/make_golden.py) for four random dys: within
+    1e-4 of the reference's fp32 autograd, or - the parameter gradients are sums over every position - judged with it
+    against the float64 evaluation of the same formula."""
     g = golden("scan")
     names = ("core_x", "x_proj_weight", "dt_projs_weight", "dt_projs_bias", "A_logs", "Ds")
     args = [t.clone().requires_grad_(True) for t in cu(*[g[f"{tag}_{n}"] for n in names])]
@@ -991,16 +1186,17 @@ def test_ss2d_core_backward_golden(golden, tag):
     dys = cu(*[g[f"{tag}_core_dy{i}"] for i in range(4)])
     grads = torch.autograd.grad(ys, args, dys)
     refs = ("core_dx", "core_dx_proj_weight", "core_ddt_projs_weight", "core_ddt_projs_bias", "core_dA_logs", "core_dDs")
-    for got, rn in zip(grads, refs):
-        assert_close(got, g[f"{tag}_{rn}"], 2e-4, f"{tag} {rn}")
+    truth = core_grads_f64(*args, dys)
+    for got, rn, tr in zip(grads, refs, truth):
+        assert_vs_truth(got, g[f"{tag}_{rn}"], tr, f"{tag} {rn}")
 
 
 @pytest.mark.parametrize("B,D,H,W,N,R", [(1, 64, 12, 20, 16, 2), (2, 32, 7, 9, 16, 2), (1, 16, 33, 5, 8, 1),
-                                         (1, 64, 40, 48, 16, 4)])
+                                         (1, 64, 40, 48, 16, 4), (1, 64, 24, 20, 32, 2), (2, 64, 9, 7, 24, 3)])
 @pytest.mark.parametrize("merged", [True, False])
 def test_ss2d_core_backward_vs_unfused_autograd(B, D, H, W, N, R, merged):
     """Fused backward against PyTorch autograd through the direction glue + the HIP op-boundary scan (itself checked
-    against the reference goldens and the oracle above)."""
+    against the reference goldens and the oracle above), both judged against the float64 evaluation."""
     x, Wx, Wdt, bias, A_logs, Ds = [t.to(DEV).requires_grad_(True) for t in random_core_case(B, D, H, W, N, R, seed=H + W)]
     L = H * W
 
@@ -1020,15 +1216,35 @@ def test_ss2d_core_backward_vs_unfused_autograd(B, D, H, W, N, R, merged):
     params = [x, Wx, Wdt, bias, A_logs, Ds]
     gg = torch.Generator(device=DEV).manual_seed(5)
     if merged:
-        dy = torch.randn(B, D, L, device=DEV, generator=gg)
-        ref = torch.autograd.grad(sum(unfused()), params, dy)
-        got = torch.autograd.grad(wm.ops.ss2d_core(*params, merged=True), params, dy)
+        dys = [torch.randn(B, D, L, device=DEV, generator=gg)]
+        ref = torch.autograd.grad(sum(unfused()), params, dys[0])
+        got = torch.autograd.grad(wm.ops.ss2d_core(*params, merged=True), params, dys[0])
     else:
         dys = [torch.randn(B, D, L, device=DEV, generator=gg) for _ in range(4)]
         ref = torch.autograd.grad(unfused(), params, dys)
         got = torch.autograd.grad(wm.ops.ss2d_core(*params), params, dys)
-    for a, b, nm in zip(got, ref, ("dx", "dWx", "dWdt", "dbias", "dA_logs", "dDs")):
-        assert_close(a, b, 2e-4, f"fused core bwd {nm} {(B, D, H, W, N, R)} merged={merged}")
+    truth = core_grads_f64(*params, dys)
+    for a, b, tr, nm in zip(got, ref, truth, ("dx", "dWx", "dWdt", "dbias", "dA_logs", "dDs")):
+        assert_vs_truth(a, b, tr, f"fused core bwd {nm} {(B, D, H, W, N, R)} merged={merged}")
+
+
+def test_trainable_lfss_block_d_state_32(golden):
+    """BASELINE config 5's block in training: LFSSBlock(32, d_state=32) forward + backward on the HIP training path
+    (fused core forward wm_ss2d_core_fwd, backward wm_ss2d_core_bwd at N = 32) against the REFERENCE's autograd
+    (tests/golden/lfss_block_n32.npz: output, dx, every parameter gradient, in fp32 and in float64)."""
+    g = golden("lfss_block_n32")
+    blk = arch.LFSSBlock(32, d_state=32, expand=2.0).train()
+    blk.load_state_dict({k[2:]: v for k, v in g.items() if k.startswith("p.")}, strict=True)
+    blk = blk.to(DEV)
+    x = g["x"].to(DEV).requires_grad_(True)
+    assert wm.ops.ss2d_core_bwd_supported(64, 32, 2)
+    y = blk(x, [16, 12])
+    assert_close(y, g["y"], TOL, "LFSSBlock(d_state=32) output")
+    params = dict(blk.named_parameters())
+    grads = torch.autograd.grad(y, [x] + list(params.values()), g["dy"].to(DEV))
+    assert_vs_truth(grads[0], g["dx"], g["dx_f64"], "dx")
+    for k, got in zip(params, grads[1:]):
+        assert_vs_truth(got, g["g." + k], g["t." + k], f"gradient of {k}")
 
 
 def test_batched_forward_equals_per_image_forward():
@@ -1228,8 +1444,10 @@ def test_uint8_pipeline_matches_sequential(golden):
 
 @pytest.mark.parametrize("ks,B,Cin,Cout,H,W,bias", [(3, 2, 32, 64, 24, 40, True), (1, 1, 64, 32, 17, 33, True),
                                                     (3, 1, 3, 32, 16, 32, False), (1, 2, 12, 32, 9, 20, True)])
-def test_conv2d_train_gradients_vs_torch_autograd(ks, B, Cin, Cout, H, W, bias):
-    import torch.nn.functional as F
+@pytest.mark.parametrize("fast", [False, True])
+def test_conv2d_train_gradients_vs_torch_autograd(ks, B, Cin, Cout, H, W, bias, fast):
+    """Both training modes of the dense convolutions against the fp64 convolution: the default (ATen fp32, bar 2e-6) and
+    the opt-in split-bf16 matrix-core kernel for forward and input gradient (bars 2e-5 / 5e-5)."""
     gg = gen(ks * 10 + Cin)
     x = torch.randn(B, Cin, H, W, generator=gg)
     w = torch.randn(Cout, Cin, ks, ks, generator=gg) / (ks * Cin ** 0.5)
@@ -1239,11 +1457,15 @@ def test_conv2d_train_gradients_vs_torch_autograd(ks, B, Cin, Cout, H, W, bias):
     ref = F.conv2d(ps[0], ps[1], ps[2] if bias else None, padding=ks // 2)
     gref = torch.autograd.grad(ref, ps, gy.double())
     qs = [t.to(DEV).requires_grad_(True) for t in (x, w)] + ([b.to(DEV).requires_grad_(True)] if bias else [])
-    got = wm.ops.conv2d_train(qs[0], qs[1], qs[2] if bias else None)
-    ggot = torch.autograd.grad(got, qs, gy.to(DEV))
-    assert_close(got.detach(), ref.detach().float(), 2e-5, "conv2d_train forward")
+    prev = wm.ops.set_train_conv_bf16x3(fast)
+    try:
+        got = wm.ops.conv2d_train(qs[0], qs[1], qs[2] if bias else None)
+        ggot = torch.autograd.grad(got, qs, gy.to(DEV))
+    finally:
+        wm.ops.set_train_conv_bf16x3(prev)
+    assert_close(got.detach(), ref.detach().float(), 2e-5 if fast else 2e-6, "conv2d_train forward")
     for a, r, nm in zip(ggot, gref, ("gx", "gw", "gb")):
-        assert_close(a, r.float(), 5e-5, f"conv2d_train {nm} ks={ks}")
+        assert_close(a, r.float(), 5e-5 if fast else 2e-6, f"conv2d_train {nm} ks={ks}")
 
 
 @pytest.mark.parametrize("T,O,I", [(5000, 128, 32), (777, 32, 64), (64, 16, 16), (3, 64, 16), (100003, 32, 32)])
@@ -1302,3 +1524,105 @@ def test_forward_is_bit_reproducible():
         o1 = net.restoration_network(img)
         o2 = net.restoration_network(img)
     assert torch.equal(o1, o2)
+
+
+# ------------------------------------------------------------------------------------------------
+# optimizer step and checkpoints on the GPU (femasr_model.py:157-185, base_model.py:214-261)
+# ------------------------------------------------------------------------------------------------
+def test_optimizer_step_arithmetic_on_gpu():
+    """The fused multi-tensor AdamW the trainer uses on a GPU, fed the REFERENCE's gradients, lands on the reference's
+    post-step parameters (<= 1e-6 relative per tensor)."""
+    from test_checkpoint import check_optimizer_arithmetic
+    print(f"worst parameter deviation after optimizer_g.step(): {check_optimizer_arithmetic(DEV):.2e}")
+
+
+def test_two_training_steps_on_gpu_vs_reference():
+    """trainer.train_step twice from the reference's weights on the HIP training path against the reference's two
+    optimize_parameters() (tests/golden/train_opt_wf8.npz).  What is well-posed to compare: Adam's first update is
+    lr * g / (|g| + eps) - a sign function of every gradient element - so a parameter element whose gradient is below the
+    fp32 noise of ANY implementation moves by +-lr either way; the per-tensor bars are therefore on the UPDATE
+    (p1 - p0: rel-l2 <= 5e-2, i.e. < 0.07 % of the elements with a flipped sign) and on the parameters (<= 2e-5 of
+    their norm), and the losses of the second step's forward - a smooth function of all of it - within 1e-5 relative."""
+    import numpy as np, os
+    from conftest import GOLDEN
+    from test_checkpoint import _net_with_golden_grads
+    net, g, o = _net_with_golden_grads(DEV)
+    for p in net.parameters():
+        p.grad = None
+    opt = wm.trainer.make_optimizer(net)
+    lq, gt = torch.from_numpy(g["lq"]).to(DEV), torch.from_numpy(g["gt"]).to(DEV)
+    l1 = wm.trainer.train_step(net, opt, lq, gt)
+    assert abs(l1["l_pix"] - g["losses"][0]) < 1e-6 and abs(l1["l_freq"] - g["losses"][1]) < 1e-5
+    worst_u, worst_p = 0.0, 0.0
+    for k, p in net.named_parameters():
+        p0, p1 = torch.from_numpy(g["w." + k]).double(), torch.from_numpy(o["p1." + k]).double()
+        got = p.detach().cpu().double()
+        worst_u = max(worst_u, float(((got - p0) - (p1 - p0)).norm() / (p1 - p0).norm().clamp_min(1e-30)))
+        worst_p = max(worst_p, float((got - p1).norm() / p1.norm().clamp_min(1e-30)))
+    print(f"after step 1: worst update deviation {worst_u:.2e}, worst parameter deviation {worst_p:.2e}")
+    assert worst_u <= 5e-2 and worst_p <= 2e-5
+    l2 = wm.trainer.train_step(net, opt, lq, gt)
+    assert abs(l2["l_pix"] - o["losses2"][0]) <= 1e-5 * o["losses2"][0], (l2, o["losses2"])
+    assert abs(l2["l_freq"] - o["losses2"][1]) <= 1e-5 * o["losses2"][1], (l2, o["losses2"])
+
+
+def test_checkpoint_round_trip_on_gpu(tmp_path):
+    """save_network from a GPU model -> reference-format file (CPU tensors, 'params' key) -> load_network into a fresh
+    GPU model -> the HIP forward is BIT-equal (prepared weight copies of the convolutions are rebuilt on load); training
+    state (optimizer moments) resumes bit-equal too."""
+    torch.manual_seed(0)
+    cfg = dict(in_chn=3, wf=32, n_l_blocks=[1, 2, 4], n_h_blocks=[1, 1, 2], ffn_scale=2.0)
+    a = wm.WaveMamba(**cfg).eval().to(DEV)
+    x = torch.rand(1, 3, 128, 192, generator=gen(5)).to(DEV)
+    with torch.no_grad():
+        ya = a(x)
+    path = wm.trainer.save_network(a, str(tmp_path / "net_g_latest.pth"), current_iter=7, epoch=1)
+    blob = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(blob) == {"params", "iter", "epoch"} and all(v.device.type == "cpu" for v in blob["params"].values())
+    torch.manual_seed(1)
+    b = wm.WaveMamba(**cfg).eval().to(DEV)
+    with torch.no_grad():
+        assert not torch.equal(b(x), ya)                     # different weights (and its conv fragments are now cached)
+    assert wm.trainer.load_network(b, path) == ([], [], [])
+    with torch.no_grad():
+        assert torch.equal(b(x), ya)
+    # training state
+    a.train(); b.train()
+    oa, ob = wm.trainer.make_optimizer(a), wm.trainer.make_optimizer(b)
+    lq, gt = torch.rand(1, 3, 64, 64, generator=gen(6)).to(DEV), torch.rand(1, 3, 64, 64, generator=gen(7)).to(DEV)
+    wm.trainer.train_step(a, oa, lq, gt)
+    wm.trainer.save_network(a, str(tmp_path / "net_g_1.pth"), 1)
+    sp = wm.trainer.save_training_state(str(tmp_path / "1.state"), 0, 1, [oa])
+    wm.trainer.load_network(b, str(tmp_path / "net_g_1.pth"))
+    assert wm.trainer.resume_training(sp, [ob]) == (0, 1)
+    for (ka, va), (kb, vb) in zip(oa.state_dict()["state"].items(), ob.state_dict()["state"].items()):
+        assert all(torch.equal(va[n].cpu(), vb[n].cpu()) for n in ("exp_avg", "exp_avg_sq")), ka
+
+
+def test_training_step_at_config3_size():
+    """BASELINE config 3 per GPU: ONE optimize_parameters() of the shipped config on a synthetic batch of 8 x 3 x 512 x 512
+    pairs on the HIP training path: the loss equals the same network's on the host with the CPU oracle as hot-path backend
+    to 1e-6 relative, every parameter receives a finite gradient, the optimizer moves every parameter."""
+    import bench
+    torch.manual_seed(0)
+    net = wm.WaveMamba(**bench.SHIPPED).train().to(DEV)
+    g = gen(bench.image_seed(0))
+    lq, gt = torch.rand(8, 3, 512, 512, generator=g), torch.rand(8, 3, 512, 512, generator=g)
+    cores = oracle.usable_cpus(cap=1 << 20)
+    torch.set_num_threads(cores); oracle.set_num_threads(cores)
+    torch.manual_seed(0)
+    net_cpu = wm.WaveMamba(**bench.SHIPPED).train()
+    with oracle_backend.ops_backend(oracle), torch.no_grad():
+        c_pix, c_fft = wm.trainer.losses(net_cpu(lq), gt)
+    before = [p.detach().clone() for p in net.parameters()]
+    opt = wm.trainer.make_optimizer(net)
+    opt.zero_grad(set_to_none=True)
+    l_pix, l_fft = wm.trainer.losses(net(lq.to(DEV)), gt.to(DEV))
+    (l_pix + l_fft).backward()
+    print(f"config-3 step: l_pix {float(l_pix):.7f} (CPU oracle {float(c_pix):.7f}), l_fft {float(l_fft):.7f} ({float(c_fft):.7f})")
+    assert abs(float(l_pix) - float(c_pix)) <= 1e-6 * float(c_pix)
+    assert abs(float(l_fft) - float(c_fft)) <= 1e-6 * float(c_fft)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    opt.step()
+    moved = sum(int(not torch.equal(a, b.detach())) for a, b in zip(before, net.parameters()))
+    assert moved == len(before)

@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("WAVEMAMBA_HIP_LIB") or os.path.join(HERE, "libwavemam
 
 WM_F32, WM_BF16 = 0, 1
 WM_PROF_NKERNELS = 16
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _c = ctypes
 _p, _i, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
@@ -18,6 +18,7 @@ _p, _i, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
 # name -> (restype, argtypes); mirrors include/wavemamba_hip.h one to one
 SIGNATURES = {
     "wm_abi_version": (_i, []),
+    "wm_build_id": (_c.c_char_p, []),
     "wm_strerror": (_c.c_char_p, [_i]),
     "wm_dwt2d_fwd": (_i, [_p] * 5 + [_i] * 5 + [_p]),
     "wm_dwt2d_bwd": (_i, [_p] * 5 + [_i] * 5 + [_p]),
@@ -28,13 +29,17 @@ SIGNATURES = {
     "wm_selscan_bwd_workspace_bytes": (_sz, [_i] * 5),
     "wm_selscan_bwd": (_i, [_p] * 15 + [_p, _sz] + [_i] * 6 + [_p]),
     "wm_ss2d_core_fwd_workspace_bytes": (_sz, [_i] * 7),
-    "wm_ss2d_core_fwd": (_i, [_p] * 10 + [_i, _p, _sz] + [_i] * 7 + [_p]),
+    "wm_ss2d_core_plan": (_i, [_i] * 6 + [_c.POINTER(_i)]),
+    "wm_ss2d_core_fwd": (_i, [_p] * 10 + [_i, _p, _sz, _p] + [_i] * 7 + [_p]),
+    "wm_ss2d_core_prep_bytes": (_sz, [_i]),
+    "wm_ss2d_core_prep": (_i, [_p] * 6 + [_i] * 3 + [_p]),
     "wm_ss2d_core_bwd_workspace_bytes": (_sz, [_i] * 6),
     "wm_ss2d_core_bwd": (_i, [_p] * 16 + [_p, _sz] + [_i] * 6 + [_p]),
     "wm_lfss_in_fwd": (_i, [_p, _i, _p, _p, _c.c_float, _p, _p, _p, _i, _i64, _i, _i, _p]),
     "wm_lfss_mid_fwd": (_i, [_p, _i, _i64, _p, _p, _i, _p, _p, _c.c_float, _p, _p, _p, _p, _c.c_float, _p, _p, _p, _p,
                              _i, _i64, _i, _i, _p]),
     "wm_lfss_out_fwd": (_i, [_p] * 6 + [_i, _i, _i64, _i, _i, _p]),
+    "wm_lfss_out_conv_fwd": (_i, [_p] * 8 + [_i] * 6 + [_p]),
     "wm_layernorm2d_fwd": (_i, [_p, _p, _p, _c.c_float, _p, _i, _i64, _i, _p]),
     "wm_gram_workspace_bytes": (_sz, [_i, _i, _i64]),
     "wm_gram_fwd": (_i, [_p] * 6 + [_sz, _i, _i, _i64, _p]),
@@ -81,17 +86,25 @@ def load():
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:
         raise WaveMambaHipError(f"cannot load {LIB_PATH}: {e}") from e
+    ab = bool(os.environ.get("WAVEMAMBA_HIP_LIB")) and os.environ.get("WAVEMAMBA_HIP_AB") == "1"   # tools: older A/B builds
     for name, (res, args) in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
+            if ab:
+                continue
             raise WaveMambaHipError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.wm_abi_version() != ABI_VERSION:
+    if lib.wm_abi_version() != ABI_VERSION and not ab:
         raise WaveMambaHipError(f"ABI mismatch: library {lib.wm_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+def build_id():
+    """The loaded library's source identity (build.py: source_id)."""
+    return load().wm_build_id().decode()
 
 
 def check(code, what):

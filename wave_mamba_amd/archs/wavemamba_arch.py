@@ -19,8 +19,8 @@ LayerNorm2d, depth-wise convolutions).  Training takes the HIP kernels that have
 depth-wise conv, the LayerNorms) and PyTorch autograd for the rest.
 
 This file can be dropped into a `basicsr/archs/` folder: the auto-scan (`archs/__init__.py:12-16`)
-imports every `*_arch.py`, and the registry resolution in `registry.py` then binds to the real
-`basicsr.utils.registry.ARCH_REGISTRY`.
+imports every `*_arch.py`; inside a `basicsr` tree the import below takes the real `basicsr.utils.registry.ARCH_REGISTRY`,
+inside this package the package's own `registry.py` (two registries, never one name registered twice).
 """
 import math
 
@@ -103,7 +103,7 @@ def _conv(conv, x, x2=None, x2_index=None, gate=None, residual=None):
             x2 = torch.gather(x2, 1, x2_index.long()[:, :, None, None].expand(-1, -1, x2.shape[2], x2.shape[3]))
         x = torch.cat([x, x2], dim=1)
     if hasattr(ops, "conv2d_train") and ops.conv2d_supported(x, conv.weight) and torch.is_grad_enabled():
-        y = ops.conv2d_train(x, conv.weight, conv.bias)             # HIP forward + input gradient (autograd)
+        y = ops.conv2d_train(x, conv.weight, conv.bias)             # fp32 (ATen) by default, split-bf16 HIP as a fast mode
     else:
         y = conv(x)
     if gate is not None:
@@ -263,7 +263,7 @@ class SS2D(nn.Module):
         ops = _OpsBackend.impl
         if not (hasattr(ops, "ss2d_core") and x.is_cuda and x.dtype == torch.float32):
             return False
-        if not ops.ss2d_core_supported(self.d_inner, self.d_state, self.dt_rank, x.shape[-1]):
+        if not ops.ss2d_core_supported(self.d_inner, self.d_state, self.dt_rank, x.shape[-1], x.shape[-2]):
             return False
         return not _needs_grad(self, x) or ops.ss2d_core_bwd_supported(self.d_inner, self.d_state, self.dt_rank)
 
@@ -301,8 +301,8 @@ class LFSSBlock(nn.Module):
         self.ln_2 = nn.LayerNorm(hidden_dim)
         self.skip_scale2 = nn.Parameter(torch.ones(hidden_dim))
 
-    def _fused_ok(self, x, width=None):
-        """Whole-block HIP path: inference on the HIP backend for the kernel's shape range (`width` = map width)."""
+    def _fused_ok(self, x, width=None, height=None):
+        """Whole-block HIP path: inference on the HIP backend for the kernel's shape range (`width`, `height` of the map)."""
         ops = _OpsBackend.impl
         ss = self.self_attention
         if not (hasattr(ops, "lfss_block_forward") and x.is_cuda and x.dtype == torch.float32):
@@ -312,7 +312,7 @@ class LFSSBlock(nn.Module):
         if ss.dropout is not None or ss.in_proj.bias is not None or ss.out_proj.bias is not None:
             return False
         return ops.lfss_block_supported(ss.d_model, ss.d_inner, ss.d_state, ss.dt_rank,
-                                        self.conv_blk.conv1.out_channels, width)
+                                        self.conv_blk.conv1.out_channels, width, height)
 
     def _nchw_train_ok(self, x):
         """Training on the HIP backend: the block on NCHW planes, every operator but the gates / skips an autograd
@@ -350,7 +350,7 @@ class LFSSBlock(nn.Module):
 
     def forward(self, input, x_size):
         B, L, C = input.shape
-        if self._fused_ok(input, x_size[1]):
+        if self._fused_ok(input, x_size[1], x_size[0]):
             return _OpsBackend.impl.lfss_block_forward(input, x_size, self)
         tok = input.view(B, x_size[0], x_size[1], C)
         tok = tok * self.skip_scale + self.drop_path(self.self_attention(_ln_tok(self.ln_1, tok)))
@@ -619,7 +619,7 @@ def _run_lfss_stack(blocks, x):
     (:976-979, :998-1001) never materialise; otherwise the reference's token round trip."""
     h, w = x.shape[2:]
     blocks = list(blocks)
-    if blocks and all(blk._fused_ok(x, w) for blk in blocks):
+    if blocks and all(blk._fused_ok(x, w, h) for blk in blocks):
         ops = _OpsBackend.impl
         t = x
         for i, blk in enumerate(blocks):
@@ -712,10 +712,13 @@ _SIDE_STREAMS = {}
 
 
 def _side_streams(x, n):
-    """The per-device side streams of the inference forward ((None,) * n off a GPU)."""
+    """The side streams of the inference forward, per (device, the stream the forward is issued on): forwards in flight
+    on different main streams (multi-stream serving, bench.py's concurrent leg) must not share side streams, or each
+    one's join would also wait for the others' high-frequency work.  ((None,) * n off a GPU.)"""
     if not x.is_cuda:
         return (None,) * n
-    key = (x.device.index if x.device.index is not None else torch.cuda.current_device())
+    dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    key = (dev, torch.cuda.current_stream(x.device).cuda_stream)
     sts = _SIDE_STREAMS.get(key)
     if sts is None or len(sts) < n:
         sts = _SIDE_STREAMS[key] = tuple(torch.cuda.Stream(device=x.device) for _ in range(n))

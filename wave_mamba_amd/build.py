@@ -24,6 +24,18 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: cannot build libwavemamba_hip.so")
 
 
+def source_id():
+    """sha256 over the library's sources (csrc/*.hip, csrc/*.hip.h, include/wavemamba_hip.h), first 16 hex digits: compiled
+    into the library (wm_build_id) so that measurements taken on one binary (profiles/pmc_traffic.json) are never quoted
+    for another."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in DEPS:
+        with open(d, "rb") as f:
+            h.update(os.path.basename(d).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def is_stale():
     if not os.path.exists(LIB):
         return True
@@ -36,7 +48,7 @@ def build(force=False, verbose=True):
     if not force and not is_stale():
         return LIB
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-value", SRC, "-o", LIB + ".tmp"]
+           "-Wno-unused-value", f'-DWM_BUILD_ID="{source_id()}"', SRC, "-o", LIB + ".tmp"]
     if verbose:
         print("[wave_mamba_amd] " + " ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

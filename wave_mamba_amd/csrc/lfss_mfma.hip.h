@@ -400,4 +400,121 @@ __global__ __launch_bounds__(256, 2) void lfss_out_mfma_kernel(const TP* __restr
     }
 }
 
+// ---- lfss_out with the gated ffn's depth-wise 3x3 folded in: f (B, D, H, W), tok1 -> tok2 -------------------------
+// SURVEY.md 8f rank 2 / reference :226-230: fc = dwconv3x3(f) + bias;  gelu(fc[:C]) * fc[C:] -> conv3 -> * skip.  The
+// unfused pair wrote fc (256 B per position) and read it back in the next launch.  A depth-wise tap needs no other
+// channel, so the nine taps of the 32 channels a lane owns are simply loaded (the eight neighbours sit in the same or
+// adjacent 128-byte lines: first-level cache hits; 288 dword loads per lane and 32-position tile against 1,024 cycles
+// of fp32 MFMA) and reduced in the depth-wise kernel's own order (bias, then the taps row by row), so fused and unfused
+// results are bit-identical.  Needs W % 32 == 0: a 32-position tile then lies inside one image row, row validity is
+// wave-uniform, and only the first / last tile of a row has a lane with a missing column neighbour.
+template <bool EDGE, typename TP>
+__device__ __forceinline__ void dwconv_gate_tile(const TP* __restrict__ fb /* + b D L */, const float* __restrict__ s_cw,
+                                                 long long L, int W, long long pq /* row W + w0 + n, clamped */, int h,
+                                                 bool up, bool down, bool left, bool right, float (&g)[16]) {
+    // channel of register i: gate 8 (i >> 2) + (i & 3) + 4 h, value = that + 32
+#pragma unroll
+    for (int i0 = 0; i0 < 16; i0 += 4) {
+        float tp[2][4][9];
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = i0 + ii;
+                const TP* cp = fb + (long long)(8 * (i >> 2) + (i & 3) + 4 * h + 32 * v) * L + pq;
+#pragma unroll
+                for (int dr = 0; dr < 3; ++dr)
+#pragma unroll
+                    for (int dc = 0; dc < 3; ++dc) {
+                        if constexpr (EDGE) {
+                            const bool ok = (dr != 0 || up) && (dr != 2 || down) && (dc != 0 || left) && (dc != 2 || right);
+                            tp[v][ii][3 * dr + dc] = ok ? ld1(cp + (long long)(dr - 1) * W + (dc - 1)) : 0.0f;
+                        } else {
+                            tp[v][ii][3 * dr + dc] = ld1(cp + (long long)(dr - 1) * W + (dc - 1));
+                        }
+                    }
+            }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = i0 + ii;
+            float fc[2];
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const float* wk = s_cw + (8 * (i >> 2) + (i & 3) + 4 * h + 32 * v) * 12;      // [9 taps | bias | 0 0]
+                const float4 w0 = *reinterpret_cast<const float4*>(wk), w1 = *reinterpret_cast<const float4*>(wk + 4),
+                             w2 = *reinterpret_cast<const float4*>(wk + 8);
+                float acc = w2.y;
+                acc = fmaf(w0.x, tp[v][ii][0], acc); acc = fmaf(w0.y, tp[v][ii][1], acc); acc = fmaf(w0.z, tp[v][ii][2], acc);
+                acc = fmaf(w0.w, tp[v][ii][3], acc); acc = fmaf(w1.x, tp[v][ii][4], acc); acc = fmaf(w1.y, tp[v][ii][5], acc);
+                acc = fmaf(w1.z, tp[v][ii][6], acc); acc = fmaf(w1.w, tp[v][ii][7], acc); acc = fmaf(w2.x, tp[v][ii][8], acc);
+                fc[v] = acc;
+            }
+            g[i] = gelu_erf(fc[0]) * fc[1];
+        }
+    }
+}
+
+template <typename TP = float>
+__global__ __launch_bounds__(256, 2) void lfss_out_conv_mfma_kernel(
+    const TP* __restrict__ f, const float* __restrict__ cw /*(D, 3, 3)*/, const float* __restrict__ cbias /*(D) or null*/,
+    const float* __restrict__ tok1, const float* __restrict__ W3 /*(C, C)*/, const float* __restrict__ b3,
+    const float* __restrict__ skip2, float* __restrict__ out, int out_nchw, int B, int H, int W, int ngl, long long ngroups,
+    int gpw) {
+    constexpr int C = 32, D = 64;
+    __shared__ __attribute__((aligned(16))) float s_b3[C];
+    __shared__ __attribute__((aligned(16))) float s_skip[C];
+    __shared__ __attribute__((aligned(16))) float s_cw[D * 12];
+    const long long L = (long long)H * W;
+    const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x < C) { s_b3[threadIdx.x] = b3[threadIdx.x]; s_skip[threadIdx.x] = skip2[threadIdx.x]; }
+    for (int e = threadIdx.x; e < D * 12; e += 256) {
+        const int c = e / 12, q = e - 12 * c;
+        s_cw[e] = q < 9 ? cw[c * 9 + q] : (q == 9 && cbias ? cbias[c] : 0.0f);
+    }
+    float A[C / 2];
+#pragma unroll
+    for (int j = 0; j < C / 2; ++j) A[j] = W3[n * C + (j & 3) + 8 * (j >> 2) + 4 * h];
+    __syncthreads();
+    float sk[16];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const float4 s4 = *reinterpret_cast<const float4*>(&s_skip[8 * gq + 4 * h]);
+        sk[4 * gq] = s4.x; sk[4 * gq + 1] = s4.y; sk[4 * gq + 2] = s4.z; sk[4 * gq + 3] = s4.w;
+    }
+    const long long g0 = (long long)blockIdx.x * 4 * gpw + wv;     // the block's waves walk adjacent groups together
+    for (int gi = 0; gi < gpw; ++gi) {
+        const long long g = g0 + 4 * gi;
+        if (g >= ngroups) break;
+        const long long b = g / ngl;
+        const long long p0 = (g - b * ngl) * 64;
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t) {
+            const long long pt = p0 + 32 * t;                       // first position of the tile (wave-uniform)
+            if (pt >= L) break;                                     // (L % 64 == 32: the last group has one tile)
+            const int row = (int)(pt / W), w0 = (int)(pt - (long long)row * W);
+            const long long pos = pt + n;
+            const bool up = row > 0, down = row < H - 1;
+            const bool edge = !up || !down || w0 == 0 || w0 + 32 == W;               // wave-uniform
+            float gt[16], tk[16];
+            const TP* fb = f + b * D * L;
+            if (edge) dwconv_gate_tile<true, TP>(fb, s_cw, L, W, pos, h, up, down, w0 + n > 0, w0 + n < W - 1, gt);
+            else dwconv_gate_tile<false, TP>(fb, s_cw, L, W, pos, h, true, true, true, true, gt);
+            load_tile32(tok1, false, b, pos, L, h, tk);
+            lfss_v16f acc;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 bb = *reinterpret_cast<const float4*>(&s_b3[8 * gq + 4 * h]);
+                acc[4 * gq] = bb.x; acc[4 * gq + 1] = bb.y; acc[4 * gq + 2] = bb.z; acc[4 * gq + 3] = bb.w;
+            }
+#pragma unroll
+            for (int j = 0; j < C / 2; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[j], gt[j], acc, 0, 0, 0);
+            float o[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[i] = fmaf(tk[i], sk[i], acc[i]);
+            store_tile32(out, out_nchw != 0, b, pos, L, h, o);
+        }
+    }
+}
+
 }  // namespace wm

@@ -72,18 +72,21 @@ __device__ __forceinline__ v2f exp2_2(v2f x) {
 }
 
 // F.softplus(beta=1, threshold=20) = log1p(exp(x)) below the threshold, on two values at once.
-// Hardware v_exp_f32 / v_log_f32 (base 2, ~1 ulp) with the w = 1 + e compensation of log1p:
-//   log1p(e) = log(w) * e / (w - 1), which cancels the rounding of 1 + e exactly.
+// Hardware v_exp_f32 / v_log_f32 (base 2, ~1 ulp).  log1p(e) from w = fl(1 + e): the rounding error of that addition,
+// d = (w - 1) - e, is exact in fp32, and log1p(e) = log(w - d) = log(w) - d / w + O(d^2).  Below w = 2 the division is
+// dropped (d (1 - 1 / w) <= 2^-24 (w - 1): 1e-7 of the result, which is ~ w - 1 there); from w = 2 on the whole correction
+// is (d / w <= 2^-24 against log(w) >= 0.69).  w == 1 (e below half an ulp of 1) gives 0 - (0 - e) = e with no special
+// case.  (The first version divided: log(w) * e / (w - 1), two v_rcp_f32 and two packed multiplies more per pair.)
 __device__ __forceinline__ v2f softplus2(v2f x) {
     const v2f e = exp2_2(x * 1.4426950408889634f);
     const v2f w = e + 1.0f;
-    const v2f wm1 = w - 1.0f;
-    const v2f lg = (v2f){__builtin_amdgcn_logf(w.x), __builtin_amdgcn_logf(w.y)} * 0.6931471805599453f;
-    const v2f rc = (v2f){__builtin_amdgcn_rcpf(wm1.x), __builtin_amdgcn_rcpf(wm1.y)};
-    const v2f lp = lg * (e * rc);
+    v2f d = (w - 1.0f) - e;
+    d.x = w.x < 2.0f ? d.x : 0.0f;
+    d.y = w.y < 2.0f ? d.y : 0.0f;
+    const v2f lp = (v2f){__builtin_amdgcn_logf(w.x), __builtin_amdgcn_logf(w.y)} * 0.6931471805599453f - d;
     v2f r;
-    r.x = x.x > 20.0f ? x.x : (w.x == 1.0f ? e.x : lp.x);
-    r.y = x.y > 20.0f ? x.y : (w.y == 1.0f ? e.y : lp.y);
+    r.x = x.x > 20.0f ? x.x : lp.x;
+    r.y = x.y > 20.0f ? x.y : lp.y;
     return r;
 }
 

@@ -165,20 +165,21 @@ __device__ __forceinline__ void fused_load_rows(const float* __restrict__ base, 
         else *reinterpret_cast<float4*>(&s[r * kBRow + 4 * tq]) = v;
     }
 }
-// record tile (16 positions x [dt_r(4) | B(16) | C(16)]) -> s_dtr [tt][4], s_B [tt][16], s_C [tt][16]
-template <bool REV>
+// record tile (16 positions x [dt_r(4) | B(NP) | C(NP)]) -> s_dtr [tt][4], s_B [tt][NP], s_C [tt][NP]
+template <bool REV, int NP>
 __device__ __forceinline__ void fused_load_rec(const float* __restrict__ rec, const FusedTile<REV>& ft, int lane,
                                                float* __restrict__ s_dtr, float* __restrict__ s_B, float* __restrict__ s_C) {
-    constexpr int RS = 36;
+    constexpr int RS = 4 + 2 * NP;                                // 36 (N <= 16) or 68 floats per position
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int f = lane + 64 * j;                              // float4 index inside the 16 x 36 tile
+    for (int j = 0; j < (kBT * RS / 4 + 63) / 64; ++j) {
+        const int f = lane + 64 * j;                              // float4 index inside the 16 x RS tile
         if (f < kBT * RS / 4) {
             const int col = (4 * f) / RS, within = 4 * f - col * RS;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (col >= ft.c_lo && col < ft.c_hi) v = *reinterpret_cast<const float4*>(rec + ft.plo * RS + 4 * f);
             const int tt = REV ? kBT - 1 - col : col;
-            float* dst = within == 0 ? s_dtr + tt * 4 : (within < 20 ? s_B + tt * 16 + (within - 4) : s_C + tt * 16 + (within - 20));
+            float* dst = within == 0 ? s_dtr + tt * 4
+                                     : (within < 4 + NP ? s_B + tt * NP + (within - 4) : s_C + tt * NP + (within - 4 - NP));
             *reinterpret_cast<float4*>(dst) = v;
         }
     }
@@ -204,12 +205,11 @@ __device__ __forceinline__ void bwd_load_A(const ScanBwdArgs& p, int d, v2f (&A2
 template <int NP, bool VEC, bool REV>
 __device__ __forceinline__ void fused_load_all(const ScanBwdArgs& p, const BwdTileIdx& ix, int t0, int tl, int lane,
                                                float* s_u, float* s_d, float* s_dy, float* s_B, float* s_C, float* s_dtr) {
-    static_assert(NP == 16, "fused core: N <= 16");
     const FusedTile<REV> ft(p.L, t0, tl);
     const long long rowbase = ((long long)ix.b * p.dim + ix.ch0) * p.L;
     fused_load_rows<REV, VEC>(p.u + rowbase, p.L, ft, ix.nch, lane, s_u);
     fused_load_rows<REV, VEC>(p.dy + rowbase, p.L, ft, ix.nch, lane, s_dy);
-    fused_load_rec<REV>(p.rec + ix.b * p.rec_bstride, ft, lane, s_dtr, s_B, s_C);
+    fused_load_rec<REV, NP>(p.rec + ix.b * p.rec_bstride, ft, lane, s_dtr, s_B, s_C);
     __syncthreads();
     float wdt[4];
 #pragma unroll
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64) void selscan_bwd_reduce_kernel(ScanBwdArgs p) {
         bwd_load_rows<VEC>(p.dy + rowbase, L, t0, t_end, ix.nch, lane, s_dy);
         bwd_load_bc<NP, VEC>(p.Bm + bcbase, L, t0, t_end, p.N, lane, s_B);
         bwd_load_bc<NP, VEC>(p.Cm + bcbase, L, t0, t_end, p.N, lane, s_C);
-    } else if constexpr (NP == 16) {
+    } else {
         fused_load_all<NP, VEC, MODE == 2>(p, ix, t0, tl, lane, s_u, s_d, s_dy, s_B, s_C, s_dtr);
     }
     __syncthreads();
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
         bwd_load_rows<VEC>(p.dy + rowbase, L, t0, t_end, ix.nch, lane, s_dy);
         bwd_load_bc<NP, VEC>(p.Bm + bcbase, L, t0, t_end, p.N, lane, s_B);
         bwd_load_bc<NP, VEC>(p.Cm + bcbase, L, t0, t_end, p.N, lane, s_C);
-    } else if constexpr (NP == 16) {
+    } else {
         fused_load_all<NP, VEC, MODE == 2>(p, ix, t0, tl, lane, s_u, s_d, s_dy, s_B, s_C, s_dtr);
     }
 
@@ -574,8 +574,8 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
         // gradient planes in x_proj row order: [0, R) d dt_r, [R, R+N) dB, [R+N, R+2N) dC
         float* dpl = p.dplanes + ix.b * p.dpl_bstride;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int rr = 16 * i + trow;                              // s_red row: 0..15 dB, 16..31 dC, 32..35 d dt_r
+        for (int i = 0; i < (2 * NP + 4 + 15) / 16; ++i) {
+            const int rr = 16 * i + trow;                              // s_red row: [0, NP) dB, [NP, 2 NP) dC, then 4 x d dt_r
             int plane = -1;
             if (rr < NP) { if (rr < p.N) plane = p.R + rr; }
             else if (rr < 2 * NP) { if (rr - NP < p.N) plane = p.R + p.N + (rr - NP); }

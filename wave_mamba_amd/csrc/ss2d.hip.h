@@ -179,6 +179,88 @@ __global__ __launch_bounds__(64 * kProjWaves, 2) void ss2d_proj_kernel(Ss2dArgs 
     }
 }
 
+// The same projection for d_state in (16, 32] (BASELINE config 5's block; training only - the inference core projects inside
+// its scan kernels): records [dt_r (4) | B (32) | C (32)] = 68 floats of the TWO directions (kA, kB) one layout of the
+// backward uses (row layout: 0 and 2, transposed layout: 1 and 3), rec (B, 2, L, 68).  Row tiles: 0 = dt_r rows of
+// all four directions (as above), 1 + 4 i + {0, 1, 2, 3} = B[0:16], B[16:32], C[0:16], C[16:32] of direction i of the pair:
+// nine tiles again, the same K loop.
+constexpr int kRS32 = kRecPad + 64;
+__global__ __launch_bounds__(64 * kProjWaves, 2) void ss2d_proj32_kernel(Ss2dArgs p, int groups_per_batch, int kA, int kB) {
+    __shared__ __attribute__((aligned(16))) float s_w[kProjWfrag];                      // 49,152 B
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int wave = blockIdx.x * kProjWaves + wv;
+    const int nwaves = gridDim.x * kProjWaves;
+    const int g4 = lane >> 4, j16 = lane & 15;
+    const int C = p.R + 2 * p.N;
+    for (int e = threadIdx.x; e < kProjKS * 12 * 64; e += 64 * kProjWaves) {
+        const int l = e & 63, o = e >> 6, sidx = o / 12, t = o - 12 * sidx;
+        const int r16 = l & 15, kk = l >> 4;
+        float v = 0.0f;
+        if (t < kProjTiles) {
+            int kdir, c;
+            bool ok;
+            if (t == 0) { kdir = r16 >> 2; c = r16 & 3; ok = c < p.R; }
+            else {
+                const int q = (t - 1) & 3, n = 16 * (q & 1) + r16;        // q: B lo, B hi, C lo, C hi
+                kdir = (t - 1) >> 2 ? kB : kA; ok = n < p.N; c = p.R + (q >> 1) * p.N + n;
+            }
+            const int d = 4 * sidx + kk;
+            if (ok && d < p.D) v = p.Wx[((long long)kdir * C + c) * p.D + d];
+        }
+        s_w[((3 * sidx + (t >> 2)) * 64 + l) * 4 + (t & 3)] = v;
+    }
+    __syncthreads();
+    const long long L = p.L;
+    const long long total = (long long)p.B * groups_per_batch;          // groups of 32 positions
+    for (long long grp = wave; grp < total; grp += nwaves) {
+        const int b = (int)(grp / groups_per_batch);
+        const long long p0 = (grp - (long long)b * groups_per_batch) * 32;
+        const long long pj = p0 + 2 * j16;
+        const float* xb = p.x + (long long)b * p.D * L;
+        f32x4 acc[kProjTiles][2];
+#pragma unroll
+        for (int t = 0; t < kProjTiles; ++t) { acc[t][0] = (f32x4){0, 0, 0, 0}; acc[t][1] = (f32x4){0, 0, 0, 0}; }
+#pragma unroll
+        for (int s = 0; s < kProjKS; ++s) {
+            const int d = 4 * s + g4;
+            float x0 = 0.0f, x1 = 0.0f;
+            if (d < p.D) {
+                const float* q = xb + (long long)d * L + pj;
+                if (pj < L) x0 = q[0];
+                if (pj + 1 < L) x1 = q[1];
+            }
+            float wf[12];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(&s_w[((3 * s + q) * 64 + lane) * 4]);
+                wf[4 * q] = w4[0]; wf[4 * q + 1] = w4[1]; wf[4 * q + 2] = w4[2]; wf[4 * q + 3] = w4[3];
+            }
+#pragma unroll
+            for (int t = 0; t < kProjTiles; ++t) {
+                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t], x0, acc[t][0], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t], x1, acc[t][1], 0, 0, 0);
+            }
+        }
+        // D layout: lane holds rows 4 g4 .. 4 g4 + 3 of column j16: 16-byte pieces straight into the records (this path
+        // serves training at d_state 32 only; the N <= 16 kernel assembles whole records in LDS first)
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            const int kd = pi ? kB : kA;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const long long pos = pj + i;
+                if (pos < L) {
+                    float* rk = p.rec + (((long long)b * 2 + pi) * L + pos) * kRS32;
+                    if (g4 == kd) *reinterpret_cast<f32x4*>(rk) = acc[0][i];                  // dt_r of direction g4
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(rk + kRecPad + 4 * g4 + 16 * q) = acc[1 + 4 * pi + q][i];
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 2. row-major directions (k = 0 forward, k = 2 reversed): lane = channel
 // ------------------------------------------------------------------------------------------------

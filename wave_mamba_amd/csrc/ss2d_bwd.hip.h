@@ -57,12 +57,13 @@ struct ProjBwdArgs {
 
 // dx[b][d][p] += sum_kk sum_c Wx_kk[c][d] g[b][kk][c][p].  One thread = one position with its 2 CP gradient values in
 // registers; the two weight matrices sit in LDS transposed ([d][kk * CP + c], 16-byte broadcast reads).
-// grid (ceil(L / 256), B), block (256).  D <= 64, CP <= 36.
+// grid (ceil(L / 256), B), block (256).  D <= 64, CP <= CPP = 36 (d_state <= 16) or 68 (d_state <= 32).
+template <int CPP>
 __global__ __launch_bounds__(256) void projbwd_dx_kernel(const ProjBwdArgs a) {
-    constexpr int KP = 72;                                           // padded row: 2 * 36
+    constexpr int KP = 2 * CPP;                                      // padded row: both directions
     __shared__ __attribute__((aligned(16))) float s_w[64 * KP];
     for (int e = threadIdx.x; e < 64 * KP; e += 256) {
-        const int d = e / KP, q = e - d * KP, kk = q / 36, c = q - kk * 36;
+        const int d = e / KP, q = e - d * KP, kk = q / CPP, c = q - kk * CPP;
         s_w[e] = (d < a.D && c < a.CP) ? (kk ? a.Wx1 : a.Wx0)[(long long)c * a.D + d] : 0.0f;
     }
     __syncthreads();
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void projbwd_dx_kernel(const ProjBwdArgs a) {
     for (int kk = 0; kk < 2; ++kk) {
         const float* gp = a.g + (((long long)b * 2 + kk) * a.CP) * a.L + p;
 #pragma unroll
-        for (int c = 0; c < 36; ++c) g[kk * 36 + c] = c < a.CP ? gp[(long long)c * a.L] : 0.0f;
+        for (int c = 0; c < CPP; ++c) g[kk * CPP + c] = c < a.CP ? gp[(long long)c * a.L] : 0.0f;
     }
     float* o = a.dx + (long long)b * a.D * a.L + p;
     for (int d = 0; d < a.D; ++d) {
@@ -97,9 +98,10 @@ constexpr int kPgWaves = 16;
 // as 16-byte runs of 4 consecutive positions (rows = planes), 3 x 4 output tiles (48 x 64), block-level sum by LDS
 // atomics (16 waves per block: 4 resident waves per SIMD hide the load latency), then one global atomic per element
 // per block.  grid (blocks, B, 2), block (64 * kPgWaves).
+template <int RT /* 16-row tiles of gradient planes: 3 (CP <= 48) or 5 (CP <= 80) */>
 __global__ __launch_bounds__(64 * kPgWaves) void projgrad_kernel(const ProjBwdArgs a, long long slice) {
-    __shared__ float s_part[48 * 64];                               // the block's waves meet here by LDS atomics
-    for (int e = threadIdx.x; e < 48 * 64; e += 64 * kPgWaves) s_part[e] = 0.0f;
+    __shared__ float s_part[16 * RT * 64];                          // the block's waves meet here by LDS atomics
+    for (int e = threadIdx.x; e < 16 * RT * 64; e += 64 * kPgWaves) s_part[e] = 0.0f;
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.y, kk = blockIdx.z;
@@ -109,9 +111,9 @@ __global__ __launch_bounds__(64 * kPgWaves) void projgrad_kernel(const ProjBwdAr
     const float* gb = a.g + (((long long)b * 2 + kk) * a.CP) * a.L;
     const float* xb = a.x + (long long)b * a.D * a.L;
     const bool vec = (a.L & 3) == 0;
-    pg_f4 acc[3][4];
+    pg_f4 acc[RT][4];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (pg_f4){0.f, 0.f, 0.f, 0.f};
     auto load4 = [&](const float* base, int row, int nrows, long long l) -> float4 {
@@ -130,15 +132,15 @@ __global__ __launch_bounds__(64 * kPgWaves) void projgrad_kernel(const ProjBwdAr
     };
     for (long long l0 = l_begin; l0 < l_end; l0 += 16) {
         const long long l = l0 + 4 * kq;
-        float4 ga[3], xa[4];
+        float4 ga[RT], xa[4];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) ga[i] = load4(gb, i16 + 16 * i, a.CP, l);
+        for (int i = 0; i < RT; ++i) ga[i] = load4(gb, i16 + 16 * i, a.CP, l);
 #pragma unroll
         for (int j = 0; j < 4; ++j) xa[j] = load4(xb, i16 + 16 * j, a.D, l);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float gv = c == 0 ? ga[i].x : c == 1 ? ga[i].y : c == 2 ? ga[i].z : ga[i].w;
@@ -148,14 +150,14 @@ __global__ __launch_bounds__(64 * kPgWaves) void projgrad_kernel(const ProjBwdAr
     }
     // D layout: lane holds rows 4 kq .. 4 kq + 3 of column i16
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) atomicAdd(&s_part[(16 * i + 4 * kq + r) * 64 + 16 * j + i16], acc[i][j][r]);
     __syncthreads();
     float* dW = kk ? a.dWx1 : a.dWx0;
-    for (int e = threadIdx.x; e < 48 * 64; e += 64 * kPgWaves) {
+    for (int e = threadIdx.x; e < 16 * RT * 64; e += 64 * kPgWaves) {
         const float t = s_part[e];
         const int c = e >> 6, d = e & 63;
         if (c < a.CP && d < a.D) atomicAdd(dW + (long long)c * a.D + d, t);

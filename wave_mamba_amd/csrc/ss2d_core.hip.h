@@ -9,9 +9,16 @@
 // One kernel body serves every direction.  lane = channel (D <= 64), a wave walks ONE sequence chunk in tiles of 16
 // scan steps, a workgroup is NW waves:
 //   * the x tile [64 channels][16 steps] of a wave is BOTH its `u` operand and the B operand of the x_proj GEMM:
-//     (dt_r | B | C)[16 steps] = Wx[k] (R + 2N rows, padded to 16-row tiles) x tile, on v_mfma_f32_16x16x4_f32 (exact
-//     fp32 products, = an fmaf chain) from LDS-resident weight fragments.  x_dbl / dts / xs never exist in HBM - the
-//     first version wrote 576 B of projection records per position and re-read them in 16 direction-phase launches.
+//     (dt_r | B | C)[16 steps] = Wx[k] (R + 2N rows, padded to 16-row tiles) x tile.  Both operands are split into two
+//     bf16 terms (v = hi + lo, |v - hi - lo| <= 2^-17 |v|) and the product is accumulated in fp32 as hi*hi + hi*lo +
+//     lo*hi on v_mfma_f32_16x16x32_bf16 (two K-steps of 32 channels, 6 matrix instructions per 16-row tile): ~4e-6
+//     relative on (dt_r | B | C) against the contract's 1e-4, the same split every dense convolution of this library
+//     uses.  The fp32-input matrix instructions (v_mfma_f32_16x16x4_f32, exact products; build with
+//     -DWM_CORE_PROJ_F32=1) run at the fp32 VECTOR rate and their time ADDS to the recurrence's VALU time (round 2:
+//     2.1 of 14.1 ms per UHD step); the bf16 ones are 16x faster per FLOP and run beside the VALU.  Weight fragments
+//     (pre-split, fragment-ordered), A * log2(e) and the per-channel constants come from a once-per-call prep kernel
+//     (ss2d_core_prep_kernel): a workgroup's prologue is one 12-KB copy into LDS.  x_dbl / dts / xs never exist in
+//     HBM - the first version wrote 576 B of projection records per position and re-read them in 16 launches.
 //   * row directions (k = 0, 2): a tile is 16 consecutive row-major positions (64 B per channel row), wave-private
 //     staging, no workgroup barrier in the loop; k = 2 walks the same tiles backwards (no flip).
 //   * column directions (k = 1, 3): the NW waves of a workgroup own NW ADJACENT COLUMNS and the same 16 rows: the
@@ -30,8 +37,8 @@
 #include "selscan.hip.h"
 #include "haar.hip.h"          // bf16_t and its conversions
 
-#ifndef WM_CORE_A2_LDS
-#define WM_CORE_A2_LDS 0          // A * log2(e) in LDS (1) or in NP / 2 register pairs per lane (0: measured 4 % faster)
+#ifndef WM_CORE_PROJ_F32
+#define WM_CORE_PROJ_F32 0        // 1 = x_proj on v_mfma_f32_16x16x4_f32 (exact fp32 products; round-2 kernel), 0 = bf16 x 3
 #endif
 #ifndef WM_CORE_ABLATE
 #define WM_CORE_ABLATE 0          // timing experiments only (wrong results): 1 = no MFMA, 2 = no scan steps, 4 = no y store
@@ -41,6 +48,9 @@
 #endif
 #ifndef WM_CORE_ROW_SYNC
 #define WM_CORE_ROW_SYNC 0        // row directions: workgroup barrier every this many tiles (0 = never), see core_body
+#endif
+#ifndef WM_CORE_INTERLEAVE
+#define WM_CORE_INTERLEAVE 0      // experiment: alternate column / row workgroup slots every this many ids (0 = columns first)
 #endif
 #ifndef WM_CORE_STEP_FENCE
 #define WM_CORE_STEP_FENCE 1      // scheduling barrier after every scan step
@@ -88,21 +98,97 @@ struct CoreArgs {
     int row_chunk, row_nchunks, row_wgs;        // steps per row chunk (multiple of 16), chunks, workgroups per direction
     unsigned long long* stamps;                 // WM_CORE_STAMP builds: [workgroup][wave][12] cycle totals / stamps, else unused
     int dirmask;                                // bit k set: direction k runs (tools: time one direction alone)
+    const float* prep;                          // ss2d_core_prep_kernel's output: 4 x CoreCfg<NP>::PREP floats
     int col_seg, col_nseg, col_tiles, col_wgs;  // rows per column segment (multiple of 16), segments, column tiles,
                                                 // workgroup slots per direction (col_tiles * col_nseg rounded up to 8)
 };
 
 template <int NP> struct CoreCfg {
     static constexpr int NTB = NP / 16;                  // 16-row tiles of B (and of C)
-    static constexpr int NQ = (2 * NTB + 1 + 3) / 4;     // float4 of A operands per (K-step, lane)
+    static constexpr int NT3 = 2 * NTB + 1;              // row tiles of x_proj: dt_r | B.. | C..
+    static constexpr int NQ = (2 * NTB + 1 + 3) / 4;     // (fp32 projection) float4 of A operands per (K-step, lane)
     static constexpr int RS = 2 * NP + 4;                // record: [dt_r (4) | B (NP) | C (NP)] floats
     static constexpr int ROW = 20;                       // x tile row stride (floats): conflict-free per-lane float4
     static constexpr int XT = 64 * ROW + 4;              // x tile stride: the column scatter is 2-way at worst
-    static constexpr int WF = 16 * NQ * 256;             // weight fragments (floats)
-    static constexpr int AF = NP * 64;                   // A * log2(e) of the workgroup's direction: [n / 2][lane] float pairs
+#if WM_CORE_PROJ_F32
+    static constexpr int WF = 16 * NQ * 256;             // weight fragments in LDS (floats)
+#else
+    static constexpr int WF = NT3 * 1024;                // [tile][K-step (2)][hi | lo][lane] x 8 bf16 = 1 KB each
+#endif
+    // prep buffer of ONE direction (floats): bf16 weight fragments | A * log2(e) as [n / 2][lane] pairs |
+    // [wdt0 wdt1 wdt2 wdt3 bias D][lane]
+    static constexpr int P_WF = NT3 * 1024;
+    static constexpr int P_A2 = P_WF;
+    static constexpr int P_LC = P_A2 + NP * 64;
+    static constexpr int PREP = P_LC + 6 * 64;
 };
 template <int NP, int NW> constexpr int core_lds_bytes() {
-    return (CoreCfg<NP>::WF + CoreCfg<NP>::AF + NW * CoreCfg<NP>::XT + NW * 16 * CoreCfg<NP>::RS) * 4;
+    return (CoreCfg<NP>::WF + NW * CoreCfg<NP>::XT + NW * 16 * CoreCfg<NP>::RS) * 4;
+}
+
+typedef __bf16 core_bf2 __attribute__((ext_vector_type(2)));
+typedef __bf16 core_bf8 __attribute__((ext_vector_type(8)));
+typedef float core_f2 __attribute__((ext_vector_type(2)));
+
+// v -> (hi, lo) bf16 with v ~ hi + lo (round to nearest even twice): v_cvt_pk_bf16_f32, two bit operations, one
+// packed subtract, v_cvt_pk_bf16_f32 per pair of values
+__device__ __forceinline__ void core_split2(float a, float b, core_bf2& hi, core_bf2& lo) {
+    const core_f2 p = {a, b};
+    hi = __builtin_convertvector(p, core_bf2);
+    lo = __builtin_convertvector(p - __builtin_convertvector(hi, core_f2), core_bf2);
+}
+
+// Once per call: everything a workgroup's prologue used to compute from the parameters (22 k cycles per workgroup and
+// pass in round 2: 7 % of a UHD level-3 workgroup's life).  Block k = direction k.
+//   fragments: lane l = (r16 = l & 15, g4 = l >> 4) of (tile t, K-step s2) holds W[row(t, r16)][32 s2 + 4 j + g4],
+//   j = 0..7 - the K order of a matrix product is free, and this one lets the B operands be read from the x tile
+//   [channel][step] with the bank-conflict-free stride of the fp32 kernel (g4 -> one tile row apart).
+template <int NP>
+__global__ __launch_bounds__(256) void ss2d_core_prep_kernel(const float* __restrict__ Wx, const float* __restrict__ Wdt,
+                                                             const float* __restrict__ dtb, const float* __restrict__ A_logs,
+                                                             const float* __restrict__ Ds, float* __restrict__ prep, int D, int N,
+                                                             int R) {
+    using Cfg = CoreCfg<NP>;
+    constexpr int NTB = Cfg::NTB;
+    const int k = blockIdx.x;
+    float* out = prep + (long long)k * Cfg::PREP;
+    const int Cx = R + 2 * N;
+    uint32_t* wf = reinterpret_cast<uint32_t*>(out);
+    for (int e = threadIdx.x; e < Cfg::NT3 * 2 * 64 * 4; e += 256) {        // one (hi, lo) bf16 pair-of-pairs per item
+        const int jp = e & 3, l = (e >> 2) & 63, s2 = (e >> 8) & 1, t = e >> 9;
+        const int r16 = l & 15, g4 = l >> 4;
+        int row = -1;
+        if (t == 0) { if (r16 < R) row = r16; }
+        else if (t <= NTB) { const int n = 16 * (t - 1) + r16; if (n < N) row = R + n; }
+        else { const int n = 16 * (t - 1 - NTB) + r16; if (n < N) row = R + N + n; }
+        float v[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int d = 32 * s2 + 4 * (2 * jp + i) + g4;
+            v[i] = (row >= 0 && d < D) ? Wx[((long long)k * Cx + row) * D + d] : 0.0f;
+        }
+        core_bf2 hi, lo;
+        core_split2(v[0], v[1], hi, lo);
+        const int base = ((t * 2 + s2) * 2) * 256 + l * 4 + jp;          // [tile][K-step][split][lane][4 dwords]
+        wf[base] = *reinterpret_cast<uint32_t*>(&hi);
+        wf[base + 256] = *reinterpret_cast<uint32_t*>(&lo);
+    }
+    for (int e = threadIdx.x; e < NP * 64; e += 256) {
+        const int lane = e & 63, n = e >> 6;
+        float a = 0.0f;
+        if (lane < D && n < N) a = -expf(A_logs[((long long)k * D + lane) * N + n]) * 1.4426950408889634f;
+        out[Cfg::P_A2 + ((n >> 1) * 64 + lane) * 2 + (n & 1)] = a;
+    }
+    for (int e = threadIdx.x; e < 6 * 64; e += 256) {
+        const int lane = e & 63, c = e >> 6;
+        float v = 0.0f;
+        if (lane < D) {
+            const long long kd = (long long)k * D + lane;
+            if (c < 4) v = c < R ? Wdt[kd * R + c] : 0.0f;
+            else v = c == 4 ? dtb[kd] : Ds[kd];
+        }
+        out[Cfg::P_LC + e] = v;
+    }
 }
 
 // Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() also drains the vector-memory counter
@@ -131,70 +217,52 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
     const unsigned long long st_entry = wall_clock64();          // 100 MHz, chip-wide (the cycle counter is per compute unit)
 #endif
     float* s_w = smem;
-    v2f* s_a2 = reinterpret_cast<v2f*>(smem + Cfg::WF);
-    float* s_x = smem + Cfg::WF + Cfg::AF;
+    float* s_x = smem + Cfg::WF;
     float* s_rec = s_x + NW * XT;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = p.D, H = p.H, W = p.W;
     const long long L = p.L;
-    const int Cx = p.R + 2 * p.N;
+    const float* prep = p.prep + (long long)k * Cfg::PREP;
 
+#if WM_CORE_PROJ_F32
     // ---- x_proj_weight[k] as MFMA A operands: lane l of (K-step s, tile t) holds W[row(t, l & 15)][4 s + (l >> 4)]
-    for (int e = tid; e < Cfg::WF; e += 64 * NW) {
-        const int t4 = e & 3, l = (e >> 2) & 63, o = e >> 8;
-        const int s = o / NQ, t = 4 * (o - s * NQ) + t4;
-        const int r16 = l & 15, d = 4 * s + (l >> 4);
-        int row = -1;
-        if (t == 0) { if (r16 < p.R) row = r16; }
-        else if (t <= NTB) { const int n = 16 * (t - 1) + r16; if (n < p.N) row = p.R + n; }
-        else if (t <= 2 * NTB) { const int n = 16 * (t - 1 - NTB) + r16; if (n < p.N) row = p.R + p.N + n; }
-        s_w[e] = (row >= 0 && d < D) ? p.Wx[((long long)k * Cx + row) * D + d] : 0.0f;
+    {
+        const int Cx = p.R + 2 * p.N;
+        for (int e = tid; e < Cfg::WF; e += 64 * NW) {
+            const int t4 = e & 3, l = (e >> 2) & 63, o = e >> 8;
+            const int s = o / NQ, t = 4 * (o - s * NQ) + t4;
+            const int r16 = l & 15, d = 4 * s + (l >> 4);
+            int row = -1;
+            if (t == 0) { if (r16 < p.R) row = r16; }
+            else if (t <= NTB) { const int n = 16 * (t - 1) + r16; if (n < p.N) row = p.R + n; }
+            else if (t <= 2 * NTB) { const int n = 16 * (t - 1 - NTB) + r16; if (n < p.N) row = p.R + p.N + n; }
+            s_w[e] = (row >= 0 && d < D) ? p.Wx[((long long)k * Cx + row) * D + d] : 0.0f;
+        }
     }
+#else
+    // ---- the bf16 weight fragments of the row tiles this pass needs (dt_r, B.. and, in the scan pass, C..): one
+    // 16-byte copy per thread
+    {
+        const uint4* gw = reinterpret_cast<const uint4*>(prep);
+        uint4* sw4 = reinterpret_cast<uint4*>(s_w);
+        for (int e = tid; e < NT * 256; e += 64 * NW) sw4[e] = gw[e];
+    }
+#endif
 
-    // ---- per-lane (= per-channel) constants
+    // ---- per-lane (= per-channel) constants, prepared once per call
     const bool live = lane < D;
     const int d = live ? lane : 0;
-    const int kd = k * D + d;
-    // A * log2(e) per (state pair, channel): in LDS (WM_CORE_A2_LDS) or in NP / 2 register pairs per lane
-    float wdt[4];
-#if WM_CORE_A2_LDS
-    if (wv == 0) {
-        float araw[NP];
+    v2f A2r[NP / 2];                                     // A * log2(e) per state pair (in LDS instead: 4 % slower)
 #pragma unroll
-        for (int n = 0; n < NP; ++n) araw[n] = p.A_logs[(long long)kd * p.N + min(n, p.N - 1)];
-#pragma unroll
-        for (int n = 0; n < NP; n += 2) {
-            const float a0 = (n < p.N) ? -expf(araw[n]) * 1.4426950408889634f : 0.0f;
-            const float a1 = (n + 1 < p.N) ? -expf(araw[n + 1]) * 1.4426950408889634f : 0.0f;
-            s_a2[(n / 2) * 64 + lane] = (v2f){a0, a1};
-        }
-    }
-#define WM_A2(i) s_a2[(i) * 64 + lane]
-#else
-    v2f A2r[NP / 2];
-    {
-        float araw[NP];
-#pragma unroll
-        for (int n = 0; n < NP; ++n) araw[n] = p.A_logs[(long long)kd * p.N + min(n, p.N - 1)];
-#pragma unroll
-        for (int n = 0; n < NP; ++n) {
-            const float a = (n < p.N) ? -expf(araw[n]) * 1.4426950408889634f : 0.0f;
-            if (n & 1) A2r[n / 2].y = a; else A2r[n / 2].x = a;
-        }
-    }
-    (void)s_a2;
+    for (int i = 0; i < NP / 2; ++i) A2r[i] = *reinterpret_cast<const v2f*>(prep + Cfg::P_A2 + (i * 64 + lane) * 2);
 #define WM_A2(i) A2r[i]
-#endif
-    {
+    float wdt[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) wdt[r] = p.Wdt[(long long)kd * p.R + min(r, p.R - 1)];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) wdt[r] = (r < p.R) ? wdt[r] : 0.0f;
-    }
-    const float bias = p.dtb[kd];
-    const float Dd = p.Ds[kd];
+    for (int r = 0; r < 4; ++r) wdt[r] = prep[Cfg::P_LC + r * 64 + lane];
+    const float bias = prep[Cfg::P_LC + 4 * 64 + lane];
+    const float Dd = prep[Cfg::P_LC + 5 * 64 + lane];
 
     // ---- the wave's sequence chunk
     int t_begin, t_end;            // scan steps [t_begin, t_end) of the wave's line (row mode: l; column mode: tau)
@@ -326,7 +394,8 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
         // every wave sit out the stores' latency (~2,300 cycles per tile in the column directions).
         if (!active && ti + 1 < ntiles) fetch(ti + 1);   // (a wave without a sequence still moves its share of the tile)
         WM_STAMP(1)
-        const int tl = min(16, t_end - (t_begin + 16 * ti));
+        // (wave-uniform: the per-step mask below is then a scalar compare + one v_cndmask, not a vector compare)
+        const int tl = __builtin_amdgcn_readfirstlane(min(16, t_end - (t_begin + 16 * ti)));
 
         if (active) {
             // ---- projection: records of the 16 steps (tile columns) ----
@@ -334,6 +403,7 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = (core_f4){0.f, 0.f, 0.f, 0.f};
             const int g4 = lane >> 4, c16 = lane & 15;
+#if WM_CORE_PROJ_F32
             // always all 16 K-steps (channels >= D carry zero weights and zero-filled tile rows): a run-time K count
             // turns every step into its own branch and the compiler stops overlapping them
             constexpr int KS = (WM_CORE_ABLATE & 1) ? 1 : 16;
@@ -365,6 +435,36 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
                     }
                 }
             }
+#else
+            // B operands: lane (c16 = step, g4) of K-step s2 holds channels 32 s2 + 4 j + g4, j = 0..7 (the prep kernel's K
+            // order) of tile column c16, split into bf16 hi / lo.  Channels >= D: zero-filled tile rows, zero weights.
+            {
+                const uint4* sw4 = reinterpret_cast<const uint4*>(s_w) + lane;
+                constexpr int S2 = (WM_CORE_ABLATE & 1) ? 0 : 2;
+#pragma unroll
+                for (int s2 = 0; s2 < S2; ++s2) {
+                    float xf[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xf[j] = sx[(32 * s2 + 4 * j + g4) * ROW + c16];
+                    core_bf8 xh, xl;
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        core_bf2 h2, l2;
+                        core_split2(xf[j], xf[j + 1], h2, l2);
+                        xh[j] = h2[0]; xh[j + 1] = h2[1]; xl[j] = l2[0]; xl[j + 1] = l2[1];
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const uint4 wh4 = sw4[((t * 2 + s2) * 2 + 0) * 64], wl4 = sw4[((t * 2 + s2) * 2 + 1) * 64];
+                        const core_bf8 wh = *reinterpret_cast<const core_bf8*>(&wh4);
+                        const core_bf8 wl = *reinterpret_cast<const core_bf8*>(&wl4);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+#endif
             // D layout: lane holds rows 4 g4 .. 4 g4 + 3 of tile column c16
             {
                 float* rc = srec + c16 * RS;
@@ -535,14 +635,29 @@ __global__ __launch_bounds__(64 * NW, NP == 16 ? 4 : 2) void ss2d_core_kernel(Co
     const int per_b = 2 * p.row_wgs + 2 * p.col_wgs;
     const int b = blockIdx.x / per_b;
     int r = blockIdx.x - b * per_b;
-    if (r < 2 * p.col_wgs) {
+    bool col;
+#if WM_CORE_INTERLEAVE
+    // experiment: column and row slots alternate in blocks of WM_CORE_INTERLEAVE workgroup ids (= one dispatch round of
+    // the chip) while both last, so that with two workgroups per compute unit (NW = 8) a compute unit holds one
+    // barrier-paced column workgroup and one free-running row workgroup
+    {
+        constexpr int Q = WM_CORE_INTERLEAVE;
+        const int nc = 2 * p.col_wgs, nr = 2 * p.row_wgs;
+        const int m = (min(nc, nr) / Q) * Q;
+        if (r < 2 * m) { const int j = r / Q; col = !(j & 1); r = (j >> 1) * Q + (r - j * Q); }
+        else { r -= 2 * m; col = r < nc - m; r = m + (col ? r : r - (nc - m)); }
+    }
+#else
+    col = r < 2 * p.col_wgs;
+    if (!col) r -= 2 * p.col_wgs;
+#endif
+    if (col) {
         const int idx = r >> 1;
         const int wg = (((idx >> 3) << 2) + (idx & 3)) * 2 + ((idx >> 2) & 1);
         if (wg >= p.col_tiles * p.col_nseg || !((p.dirmask >> ((r & 1) * 2 + 1)) & 1)) return;
         if (r & 1) core_body<NP, NW, PHASE, RHI, TP, true, true>(p, 3, b, wg, core_smem);
         else core_body<NP, NW, PHASE, RHI, TP, true, false>(p, 1, b, wg, core_smem);
     } else {
-        r -= 2 * p.col_wgs;
         const int wg = r >> 1;
         if (!((p.dirmask >> ((r & 1) * 2)) & 1)) return;
         if (r & 1) core_body<NP, NW, PHASE, RHI, TP, false, true>(p, 2, b, wg, core_smem);

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <array>
 #include <atomic>
 #include <mutex>
 #include <vector>
@@ -291,7 +292,12 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 15; }
+int wm_abi_version(void) { return 16; }
+
+#ifndef WM_BUILD_ID
+#define WM_BUILD_ID "unknown"
+#endif
+const char* wm_build_id(void) { return WM_BUILD_ID; }
 
 const char* wm_strerror(int code) {
     switch (code) {
@@ -614,10 +620,70 @@ struct CorePlan {
     int row_chunk, row_nchunks, row_wgs;
     int col_seg, col_nseg, col_tiles, col_wgs;
     long long col_nchunks, max_chunks;
-    size_t half_bytes, ytmp_bytes, total;       // one P (or H) array of one direction; merged-mode y buffers; everything
+    size_t half_bytes, ytmp_bytes, prep_bytes, total;   // one P (or H) array of one direction; merged-mode y buffers;
+                                                        // the prep kernel's output; everything
 };
 
 static bool core_v2_shape(int W) { return W % 4 == 0; }
+
+// Length of one core launch (in row-tile times) under the dispatch model of core_plan's comment, replaying
+// ss2d_core_kernel's blockIdx -> (direction, slot) mapping.  Costs measured on MI355X (tools/bench_core.py with
+// WM_CORE_DIRMASK, gpurun_out r3a): a 16-wave tile round takes the same 15.7 us (chunk-scan) / 13.4 us (chunk-reduce) in
+// a column workgroup (68 tiles, one round of 240: 1.065 / 0.919 ms) as in a row workgroup (60 tiles: 0.942 / 0.790 ms),
+// so kColTile = 1; a workgroup costs about one tile round on top of its tiles (UHD level 2: 240 workgroups of 34 tiles
+// in one round 1.07 ms, 512 of 17 / 15 tiles in two rounds 1.12 ms; level 3: 234 of 9 tiles 0.319 ms, 222 with 10-tile
+// row workgroups 0.340 ms) - launch, LDS fill, carried-in state, and above all the drain: a compute unit holds one
+// workgroup, and the next one starts only when the slowest of its 16 waves has finished.
+// Returns early (a value >= bound) once the launch is known to be no better than `bound`.
+#ifndef WM_CORE_COST_COL
+#define WM_CORE_COST_COL 1.0
+#endif
+#ifndef WM_CORE_COST_WG
+#define WM_CORE_COST_WG 1.0
+#endif
+static double core_makespan(const CorePlan& pl, int B, int H, double bound) {
+    const double kColTile = WM_CORE_COST_COL, kWgStart = WM_CORE_COST_WG, kCarry = 0.0005;
+    const int slots = 32 * (16 / pl.NW);
+    double freeat[8][64];
+    for (int x = 0; x < 8; ++x) for (int i = 0; i < slots; ++i) freeat[x][i] = 0.0;
+    const long long per_b = 2LL * pl.row_wgs + 2LL * pl.col_wgs;
+    const long long total = (long long)B * per_b;
+    const int row_tiles = pl.row_chunk / 16;
+    double span = 0.0;
+    {   // lower bound: all work spread evenly
+        double work = 0.0;
+        for (int sg = 0; sg < pl.col_nseg; ++sg) {
+            const int rows = (H - sg * pl.col_seg) < pl.col_seg ? (H - sg * pl.col_seg) : pl.col_seg;
+            work += 2.0 * B * pl.col_tiles * (((rows + 15) / 16) * kColTile + kWgStart);
+        }
+        work += 2.0 * B * pl.row_wgs * (row_tiles + kWgStart);
+        if (work / (8.0 * slots) >= bound) return work / (8.0 * slots);
+    }
+    for (long long i = 0; i < total; ++i) {
+        const long long r = i % per_b;
+        double cost;
+        if (r < 2LL * pl.col_wgs) {
+            const int idx = (int)(r >> 1);
+            const int wg = (((idx >> 3) << 2) + (idx & 3)) * 2 + ((idx >> 2) & 1);
+            if (wg >= pl.col_tiles * pl.col_nseg) continue;
+            const int sg = wg / pl.col_tiles;
+            const int rows = (H - sg * pl.col_seg) < pl.col_seg ? (H - sg * pl.col_seg) : pl.col_seg;
+            cost = ((rows + 15) / 16) * kColTile + kWgStart;
+        } else {
+            const long long wg = (r - 2LL * pl.col_wgs) >> 1;
+            long long c0 = wg * pl.NW;                                        // first chunk of the workgroup
+            if (c0 >= pl.row_nchunks) continue;
+            cost = row_tiles + kWgStart;                                       // (the very last chunk may be shorter)
+        }
+        double* f = freeat[i & 7];
+        int best = 0;
+        for (int j = 1; j < slots; ++j) if (f[j] < f[best]) best = j;
+        f[best] += cost;
+        if (f[best] > span) { span = f[best]; if (span >= bound) return span; }
+    }
+    const long long chunks = pl.col_nchunks > pl.row_nchunks ? pl.col_nchunks : pl.row_nchunks;
+    return span + kCarry * (double)chunks;
+}
 
 static int core_plan(CorePlan& pl, int B, int D, int H, int W, int N, int R, int merged) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || N <= 0 || R <= 0) return WM_EINVAL;
@@ -631,64 +697,73 @@ static int core_plan(CorePlan& pl, int B, int D, int H, int W, int N, int R, int
 #endif
     const int NW = pl.NW;
     pl.col_tiles = (W + NW - 1) / NW;
-    // Segments per column.  `slots` workgroups are resident at once (NW = 16: one per compute unit; NW = 8: two), all
-    // of about the same length, so a launch takes ceil(workgroups / slots) rounds of (tiles per workgroup + a prologue
-    // worth ~0.7 tile: weight fragments into LDS, exp of A_logs, carried-in state).  Take the segment count that
-    // minimises rounds x length.  (A fixed ">= 1.75 rounds" target gave the UHD level-3 maps 444 five-tile workgroups
-    // = two rounds, the second 73 % full; two segments per column = 234 nine-tile workgroups in ONE round.)
-    const auto row_wgs_for = [&](int nsg, int sg_rows) {
-        long long want_c = (long long)pl.col_tiles * NW * nsg;
-        long long c = (L + want_c - 1) / want_c;
-        c = ((c + 15) / 16) * 16;
-        if (c < 32) c = 32;
-        (void)sg_rows;
-        return (int)((((L + c - 1) / c) + NW - 1) / NW);
+    // Work split.  Column workgroups: one per (NW-column tile, segment of `col_seg` rows); row workgroups: NW waves with
+    // one chunk of `row_chunk` steps each.  Workgroup i goes to XCD i % 8 and there to the first of 32 compute units
+    // (x 2 workgroups at NW = 8) that frees up - so a launch is list scheduling in workgroup-id order, and its length
+    // is decided by how the LAST workgroups fill the machine.  Round 2 gave the row workgroups the column workgroups'
+    // length: 480 equal workgroups on 256 compute units at UHD level 1 = 2 rounds, the second 7/8 full, and halving or
+    // quartering the row chunks changes nothing (480 k / 256 is never whole).  Now the plan is searched: every
+    // (segments per column, tiles per row chunk) pair is replayed through that dispatch model with measured per-tile
+    // costs (core_makespan) and the shortest launch wins, e.g. level 1: 240 column workgroups of 68 tiles + 272 row
+    // workgroups of 60.  Plans are cached per shape (the search replays ~10^5 workgroups).
+    const long long RT = (L / 16 + NW - 1) / NW;                    // row workgroup-tiles per direction (L % 16 == 0: W % 4, H ...)
+    struct Cand { int seg, nseg, row_chunk; };
+    auto fill = [&](const Cand& c) {
+        pl.col_seg = c.seg; pl.col_nseg = c.nseg;
+        pl.col_nchunks = (long long)W * pl.col_nseg;
+        pl.col_wgs = ((pl.col_tiles * pl.col_nseg + 7) / 8) * 8;
+        pl.row_chunk = c.row_chunk;
+        pl.row_nchunks = (int)((L + c.row_chunk - 1) / c.row_chunk);
+        pl.row_wgs = (pl.row_nchunks + NW - 1) / NW;
     };
-    const long long slots = 256LL * (16 / NW);
-    int nseg = 1;
     {
-        double best = 1e300;
-        for (int n = 1; n <= 64; ++n) {
-            int sg = (H + n - 1) / n;
-            sg = ((sg + 15) / 16) * 16;
-            if (n > 1 && sg < 32) break;
-            const int nn = (H + sg - 1) / sg;
-            const long long wgs = (long long)B * (2LL * pl.col_tiles * nn + 2LL * row_wgs_for(nn, sg));
-            const long long rounds = (wgs + slots - 1) / slots;
-            const double cost = (double)rounds * (sg / 16 + 0.7);
-            if (cost < best * 0.98) { best = cost; nseg = nn; }
+        static std::mutex mu;
+        static std::vector<std::pair<std::array<int, 6>, Cand>> cache;
+        const std::array<int, 6> key = {B, D, H, W, pl.NP, NW};
+        std::lock_guard<std::mutex> lk(mu);
+        const Cand* hit = nullptr;
+        for (const auto& e : cache) if (e.first == key) { hit = &e.second; break; }
+        if (hit) fill(*hit);
+        else {
+            double best = 1e300; Cand bc{((H + 15) / 16) * 16, 1, 32};
+            int last_seg = -1;
+            for (int n = 1; n <= 64; ++n) {
+                int sg = (H + n - 1) / n;
+                sg = ((sg + 15) / 16) * 16;
+                if (n > 1 && sg < 32) break;
+                if (sg == last_seg) continue;
+                last_seg = sg;
+                const int nn = (H + sg - 1) / sg;
+                int last_chunk = -1;
+                for (long long ct = RT < 128 ? RT : 128; ct >= 2; --ct) {      // tiles per row chunk
+                    const long long m = (RT + ct - 1) / ct;                    // row workgroups per direction
+                    long long c = (L + m * NW - 1) / (m * NW);
+                    c = ((c + 15) / 16) * 16;
+                    if (c < 32) c = 32;
+                    if ((int)c == last_chunk) continue;
+                    last_chunk = (int)c;
+                    const Cand cand{sg, nn, (int)c};
+                    fill(cand);
+                    const double t = core_makespan(pl, B, H, best);
+                    if (t < best * 0.995) { best = t; bc = cand; }
+                }
+            }
+            fill(bc);
+            if (cache.size() < 256) cache.emplace_back(key, bc);
         }
     }
-    int seg = (H + nseg - 1) / nseg;
-    seg = ((seg + 15) / 16) * 16;
-    pl.col_seg = seg;
-    pl.col_nseg = (H + seg - 1) / seg;
-    pl.col_nchunks = (long long)W * pl.col_nseg;
-    pl.col_wgs = ((pl.col_tiles * pl.col_nseg + 7) / 8) * 8;
-    // row directions: WM_CORE_ROW_SPLIT x as many chunks as the column directions have.  Shorter row workgroups behind
-    // the (long) column workgroups were tried to level the launch's tail: with 2x / 4x the row workgroups still arrive
-    // in whole rounds of 256, the launch time did not move and the carry grew - 1x (same per-wave work) is kept.
-#ifndef WM_CORE_ROW_SPLIT
-#define WM_CORE_ROW_SPLIT 1
-#endif
-    long long want = (long long)WM_CORE_ROW_SPLIT * pl.col_tiles * NW * pl.col_nseg;
-    long long cl = (L + want - 1) / want;
-    cl = ((cl + 15) / 16) * 16;
-    if (cl < 32) cl = 32;
-    pl.row_chunk = (int)cl;
-    pl.row_nchunks = (int)((L + cl - 1) / cl);
-    pl.row_wgs = (pl.row_nchunks + NW - 1) / NW;
     pl.max_chunks = pl.col_nchunks > pl.row_nchunks ? pl.col_nchunks : pl.row_nchunks;
     if ((long long)B * (2LL * pl.row_wgs + 2LL * pl.col_wgs) > 0x7fffffffLL) return WM_EUNSUPPORTED;
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     pl.half_bytes = up((size_t)pl.max_chunks * B * D * pl.NP * sizeof(float));
     pl.ytmp_bytes = merged ? up((size_t)B * D * L * sizeof(float)) : 0;
-    pl.total = 8 * pl.half_bytes + 3 * pl.ytmp_bytes;
+    pl.prep_bytes = up((size_t)4 * (pl.NP == 16 ? CoreCfg<16>::PREP : CoreCfg<32>::PREP) * sizeof(float));
+    pl.total = 8 * pl.half_bytes + 3 * pl.ytmp_bytes + pl.prep_bytes;
     return WM_OK;
 }
 
 template <int NP, int NW, bool RHI, typename TP>
-static int core_launch(const CoreArgs& a, const CorePlan& pl, hipStream_t st) {
+static int core_launch(const CoreArgs& a, const CorePlan& pl, bool do_prep, hipStream_t st) {
     constexpr int lds = core_lds_bytes<NP, NW>();
     // > 64 KB of dynamic LDS is an opt-in per function AND per device
     static bool configured[64] = {};
@@ -709,6 +784,11 @@ static int core_launch(const CoreArgs& a, const CorePlan& pl, hipStream_t st) {
     }
     const dim3 grid((unsigned)(a.B * (2 * pl.row_wgs + 2 * pl.col_wgs))), block(64 * NW);
     const bool split = pl.row_nchunks > 1 || pl.col_nchunks > 1;
+    if (do_prep) {   // parameters -> bf16 weight fragments, A * log2(e), per-channel constants (four small blocks)
+        ProfScope ps(10, st);
+        hipLaunchKernelGGL((ss2d_core_prep_kernel<NP>), dim3(4), dim3(256), 0, st, a.Wx, a.Wdt, a.dtb, a.A_logs, a.Ds,
+                           const_cast<float*>(a.prep), a.D, a.N, a.R);
+    }
     if (split) {
         {
             ProfScope ps(10, st);
@@ -746,10 +826,45 @@ size_t wm_ss2d_core_fwd_workspace_bytes(int B, int D, int H, int W, int N, int R
     return pl.total;
 }
 
+size_t wm_ss2d_core_prep_bytes(int N) {
+    if (N <= 0 || N > 32) return 0;
+    return (size_t)4 * (N <= 16 ? CoreCfg<16>::PREP : CoreCfg<32>::PREP) * sizeof(float);
+}
+
+int wm_ss2d_core_prep(const float* x_proj_weight, const float* dt_projs_weight, const float* dt_projs_bias,
+                      const float* A_logs, const float* Ds, void* prepared, int D, int N, int R, void* stream) {
+    if (D <= 0 || N <= 0 || R <= 0) return WM_EINVAL;
+    if (N > 32 || R > 4 || D > 64) return WM_EUNSUPPORTED;
+    if (!x_proj_weight || !dt_projs_weight || !dt_projs_bias || !A_logs || !Ds || !prepared) return WM_ENULL;
+    if (!aligned16(prepared)) return WM_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 16)
+        hipLaunchKernelGGL((ss2d_core_prep_kernel<16>), dim3(4), dim3(256), 0, st, x_proj_weight, dt_projs_weight,
+                           dt_projs_bias, A_logs, Ds, (float*)prepared, D, N, R);
+    else
+        hipLaunchKernelGGL((ss2d_core_prep_kernel<32>), dim3(4), dim3(256), 0, st, x_proj_weight, dt_projs_weight,
+                           dt_projs_bias, A_logs, Ds, (float*)prepared, D, N, R);
+    return launch_status();
+}
+
+int wm_ss2d_core_plan(int B, int D, int H, int W, int N, int R, int* out10) {
+    if (!out10) return WM_ENULL;
+    if (!core_v2_shape(W)) return WM_EUNSUPPORTED;
+    CorePlan pl;
+    const int rc = core_plan(pl, B, D, H, W, N, R, 0);
+    if (rc) return rc;
+    out10[0] = pl.NW; out10[1] = pl.col_seg; out10[2] = pl.col_nseg; out10[3] = pl.col_tiles; out10[4] = pl.col_wgs;
+    out10[5] = pl.row_chunk; out10[6] = pl.row_nchunks; out10[7] = pl.row_wgs;
+    out10[8] = B * (2 * pl.row_wgs + 2 * pl.col_wgs);
+    out10[9] = (int)(100.0 * core_makespan(pl, B, H, 1e300));
+    return WM_OK;
+}
+
 int wm_ss2d_core_fwd(const void* x, const float* x_proj_weight, const float* dt_projs_weight,
                      const float* dt_projs_bias, const float* A_logs, const float* Ds, void* y_row_fwd,
                      void* y_row_rev, void* y_col_fwd, void* y_col_rev, int merged, void* workspace,
-                     size_t workspace_bytes, int B, int D, int H, int W, int N, int R, int plane_dtype, void* stream) {
+                     size_t workspace_bytes, const void* prepared, int B, int D, int H, int W, int N, int R, int plane_dtype,
+                     void* stream) {
     if (B == 0 || D == 0 || H == 0 || W == 0) return (B < 0 || D < 0 || H < 0 || W < 0) ? WM_EINVAL : WM_OK;
     if (plane_dtype != WM_F32 && plane_dtype != WM_BF16) return WM_EUNSUPPORTED;
     if (!core_v2_shape(W)) {
@@ -776,6 +891,8 @@ int wm_ss2d_core_fwd(const void* x, const float* x_proj_weight, const float* dt_
         a.wsH[k] = (float*)(w + (size_t)(2 * k + 1) * pl.half_bytes);
     }
     char* yt = w + 8 * pl.half_bytes;
+    a.prep = prepared ? (const float*)prepared : (const float*)(yt + 3 * pl.ytmp_bytes);
+    if (prepared && !aligned16(prepared)) return WM_EALIGN;
     // direction k: 0 row forward, 1 column forward, 2 row reversed, 3 column reversed (the reference's xs order, :451-452)
     a.y[0] = y_row_fwd;
     a.y[1] = merged ? (void*)yt : y_col_fwd;
@@ -800,8 +917,9 @@ int wm_ss2d_core_fwd(const void* x, const float* x_proj_weight, const float* dt_
 #endif
 #define WM_CORE_GO(TP)                                                                                                        \
     do {                                                                                                                      \
-        if (pl.NP == 16) rc = R > 2 ? core_launch<16, WM_CORE_NW, true, TP>(a, pl, st) : core_launch<16, WM_CORE_NW, false, TP>(a, pl, st); \
-        else rc = R > 2 ? core_launch<32, 8, true, TP>(a, pl, st) : core_launch<32, 8, false, TP>(a, pl, st);                  \
+        const bool dp = prepared == nullptr;                                                                                  \
+        if (pl.NP == 16) rc = R > 2 ? core_launch<16, WM_CORE_NW, true, TP>(a, pl, dp, st) : core_launch<16, WM_CORE_NW, false, TP>(a, pl, dp, st); \
+        else rc = R > 2 ? core_launch<32, 8, true, TP>(a, pl, dp, st) : core_launch<32, 8, false, TP>(a, pl, dp, st);          \
     } while (0)
     if (plane_dtype == WM_F32) WM_CORE_GO(float); else WM_CORE_GO(bf16_t);
 #undef WM_CORE_GO
@@ -822,42 +940,45 @@ int wm_ss2d_core_fwd(const void* x, const float* x_proj_weight, const float* dt_
 }  // extern "C"
 namespace wm {
 struct CoreBwdPlan {
-    BwdPlan scan; long long L; int CP;
+    BwdPlan scan; long long L; int CP, NP, RS, ndir;      // RS: record stride, ndir: directions per record set (4 / 2)
     size_t rec_bytes, gpl_bytes, map_bytes, part_bytes, scan_bytes, total;
 };
 static int core_bwd_plan(CoreBwdPlan& pl, int B, int D, int H, int W, int N, int R) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || N <= 0 || R <= 0) return WM_EINVAL;
-    if (N > 16 || R > kRecPad || D > 64) return WM_EUNSUPPORTED;
+    if (N > 32 || R > kRecPad || D > 64) return WM_EUNSUPPORTED;
     pl.L = (long long)H * W;
     if (pl.L > 0x7fffffffLL) return WM_EUNSUPPORTED;
     int rc = bwd_plan(pl.scan, B, D, (int)pl.L, N, 1);
     if (rc) return rc;
     pl.CP = R + 2 * N;
+    pl.NP = N <= 16 ? 16 : 32;
+    pl.RS = pl.NP == 16 ? kRS : kRS32;
+    pl.ndir = pl.NP == 16 ? 4 : 2;                                // d_state 32: records of the layout's two directions only
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-    pl.rec_bytes = up((size_t)B * 4 * pl.L * kRS * sizeof(float));
+    pl.rec_bytes = up((size_t)B * pl.ndir * pl.L * pl.RS * sizeof(float));
     pl.gpl_bytes = up((size_t)B * 2 * pl.CP * pl.L * sizeof(float));
     pl.map_bytes = up((size_t)B * D * pl.L * sizeof(float));
-    pl.part_bytes = up((size_t)pl.scan.nchunks * B * D * (16 + kPartPadFused) * sizeof(float));
+    pl.part_bytes = up((size_t)pl.scan.nchunks * B * D * (pl.NP + kPartPadFused) * sizeof(float));
     pl.scan_bytes = up(4 * pl.scan.arr_bytes + pl.scan.seg_bytes);
     pl.total = pl.rec_bytes + pl.gpl_bytes + 4 * pl.map_bytes + pl.scan_bytes + pl.part_bytes;
     return WM_OK;
 }
 
 // one direction of one layout: chunked adjoint scan with fused operands, then the parameter-gradient reduction
-template <bool VEC, int MODE>
+template <int NP, bool VEC, int MODE>
 static void core_bwd_dir(ScanBwdArgs a, const CoreBwdPlan& pl, float* seg, const float* A_logs_k, float* dA_logs_k,
                          float* dD_k, float* dbias_k, float* dWdt_k, hipStream_t st) {
     const dim3 grid((unsigned)pl.scan.nchunks, (unsigned)pl.scan.rows), block(64);
     if (pl.scan.nchunks > 1) {
-        hipLaunchKernelGGL((selscan_bwd_reduce_kernel<16, VEC, MODE>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((selscan_bwd_reduce_kernel<NP, VEC, MODE>), grid, block, 0, st, a);
         launch_carry(a.wsP, a.wsH, seg, pl.scan.chains, pl.scan.nchunks, st);
         launch_carry(a.wsPr, a.wsG, seg, pl.scan.chains, pl.scan.nchunks, st);
     }
-    hipLaunchKernelGGL((selscan_bwd_chunk_kernel<16, VEC, MODE>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((selscan_bwd_chunk_kernel<NP, VEC, MODE>), grid, block, 0, st, a);
     const int ysplit = pl.scan.nchunks >= 2048 ? 16 : (pl.scan.nchunks >= 256 ? 4 : 1);
     hipLaunchKernelGGL(selscan_bwd_finish_kernel, dim3((unsigned)a.dim, (unsigned)ysplit), dim3(256), 0, st,
-                       (const float*)a.part, dA_logs_k, dD_k, dbias_k, a.batch, a.dim, a.N, 16 + kPartPadFused,
-                       pl.scan.nchunks, A_logs_k, dWdt_k, a.R, 16);
+                       (const float*)a.part, dA_logs_k, dD_k, dbias_k, a.batch, a.dim, a.N, NP + kPartPadFused,
+                       pl.scan.nchunks, A_logs_k, dWdt_k, a.R, NP);
 }
 }  // namespace wm
 extern "C" {
@@ -929,7 +1050,11 @@ int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt
             long long waves = (long long)B * groups;
             int blocks = (int)((waves + kProjWaves - 1) / kProjWaves);
             if (blocks > 256 * 2) blocks = 256 * 2;
-            hipLaunchKernelGGL(ss2d_proj_kernel, dim3((unsigned)blocks), dim3(64 * kProjWaves), 0, st, pa, groups);
+            if (pl.NP == 16)
+                hipLaunchKernelGGL(ss2d_proj_kernel, dim3((unsigned)blocks), dim3(64 * kProjWaves), 0, st, pa, groups);
+            else
+                hipLaunchKernelGGL(ss2d_proj32_kernel, dim3((unsigned)blocks), dim3(64 * kProjWaves), 0, st, pa, groups,
+                                   layout ? 1 : 0, layout ? 3 : 2);
         }
         for (int kk = 0; kk < 2; ++kk) {
             const int k = layout ? (kk ? 3 : 1) : (kk ? 2 : 0);
@@ -940,30 +1065,43 @@ int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt
             a.wsP = wsP; a.wsH = wsH; a.wsPr = wsPr; a.wsG = wsG; a.part = part;
             a.batch = B; a.dim = D; a.L = (int)L; a.N = N; a.G = 1; a.dpg = D; a.wpg = 1; a.nchunks = pl.scan.nchunks;
             a.softplus = 1; a.atomic_bc = 0;
-            a.rec = rec + (size_t)k * L * kRS; a.rec_bstride = 4 * L * kRS;
+            // records: (B, 4, L, 36) indexed by direction k, or (B, 2, L, 68) indexed by the layout's pair index kk
+            a.rec = rec + (size_t)(pl.NP == 16 ? k : kk) * L * pl.RS; a.rec_bstride = (long long)pl.ndir * L * pl.RS;
             a.Wdt = dt_projs_weight + (size_t)k * D * R; a.R = R;
             a.dplanes = gpl + (size_t)kk * CP * L; a.dpl_bstride = 2LL * CP * L;
             const bool vec = (L % 4 == 0) && aligned16(xl) && aligned16(dyl[kk]) && aligned16(dxl) && aligned16(gpl);
             float* dA_k = dA_logs + (size_t)k * D * N; float* dD_k = dDs + (size_t)k * D;
             float* db_k = ddt_projs_bias + (size_t)k * D; float* dW_k = ddt_projs_weight + (size_t)k * D * R;
-            if (kk == 0) { if (vec) core_bwd_dir<true, 1>(a, pl, seg, a.A, dA_k, dD_k, db_k, dW_k, st);
-                           else core_bwd_dir<false, 1>(a, pl, seg, a.A, dA_k, dD_k, db_k, dW_k, st); }
-            else         { if (vec) core_bwd_dir<true, 2>(a, pl, seg, a.A, dA_k, dD_k, db_k, dW_k, st);
-                           else core_bwd_dir<false, 2>(a, pl, seg, a.A, dA_k, dD_k, db_k, dW_k, st); }
+#define WM_BWD_DIR(NPV)                                                                                          \
+            do {                                                                                                 \
+                if (kk == 0) { if (vec) core_bwd_dir<NPV, true, 1>(a, pl, seg, a.A, dA_k, dD_k, db_k, dW_k, st);   \
+                               else core_bwd_dir<NPV, false, 1>(a, pl, seg, a.A, dA_k, dD_k, db_k, dW_k, st); }    \
+                else         { if (vec) core_bwd_dir<NPV, true, 2>(a, pl, seg, a.A, dA_k, dD_k, db_k, dW_k, st);   \
+                               else core_bwd_dir<NPV, false, 2>(a, pl, seg, a.A, dA_k, dD_k, db_k, dW_k, st); }    \
+            } while (0)
+            if (pl.NP == 16) WM_BWD_DIR(16); else WM_BWD_DIR(32);
+#undef WM_BWD_DIR
         }
         ProjBwdArgs g;
         g.g = gpl; g.x = xl; g.dx = dxl; g.B = B; g.D = D; g.CP = CP; g.L = L;
         const int k0 = layout ? 1 : 0, k1 = layout ? 3 : 2;
         g.Wx0 = x_proj_weight + (size_t)k0 * CP * D; g.Wx1 = x_proj_weight + (size_t)k1 * CP * D;
         g.dWx0 = dx_proj_weight + (size_t)k0 * CP * D; g.dWx1 = dx_proj_weight + (size_t)k1 * CP * D;
-        hipLaunchKernelGGL(projbwd_dx_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)B), dim3(256), 0, st, g);
+        if (pl.NP == 16)
+            hipLaunchKernelGGL(projbwd_dx_kernel<36>, dim3((unsigned)((L + 255) / 256), (unsigned)B), dim3(256), 0, st, g);
+        else
+            hipLaunchKernelGGL(projbwd_dx_kernel<68>, dim3((unsigned)((L + 255) / 256), (unsigned)B), dim3(256), 0, st, g);
         long long waves = (L + 255) / 256;                                  // >= 256 positions per wave
         if (waves > 4096) waves = 4096;
         waves = ((waves + kPgWaves - 1) / kPgWaves) * kPgWaves;
         long long slice = (L + waves - 1) / waves;
         slice = ((slice + 15) / 16) * 16;
-        hipLaunchKernelGGL(projgrad_kernel, dim3((unsigned)(waves / kPgWaves), (unsigned)B, 2), dim3(64 * kPgWaves), 0, st,
-                           g, slice);
+        if (pl.NP == 16)
+            hipLaunchKernelGGL(projgrad_kernel<3>, dim3((unsigned)(waves / kPgWaves), (unsigned)B, 2), dim3(64 * kPgWaves), 0,
+                               st, g, slice);
+        else
+            hipLaunchKernelGGL(projgrad_kernel<5>, dim3((unsigned)(waves / kPgWaves), (unsigned)B, 2), dim3(64 * kPgWaves), 0,
+                               st, g, slice);
         if (layout) {
             const dim3 tg((unsigned)((H + 31) / 32), (unsigned)((W + 31) / 32), (unsigned)(B * D)), tb(32, 8);
             hipLaunchKernelGGL(transpose_planes_kernel, tg, tb, 0, st, (const float*)dxT, dx, W, H, 1);   // dx += (dx^T)^T
@@ -1065,6 +1203,33 @@ int wm_lfss_out_fwd(const void* fc_, const float* tok1, const float* conv3_weigh
         return launch_status();
     }
     WM_LFSS_DISPATCH(lfss_out_kernel, fc, tok1, conv3_weight, conv3_bias, skip_scale2, out, out_nchw, B, (long long)L);
+}
+
+int wm_lfss_out_conv_fwd(const void* f_, const float* conv2_weight, const float* conv2_bias, const float* tok1,
+                         const float* conv3_weight, const float* conv3_bias, const float* skip_scale2, float* out,
+                         int out_nchw, int B, int H, int W, int C, int plane_dtype, void* stream) {
+    if (B < 0 || H < 0 || W < 0) return WM_EINVAL;
+    if (C != 32 || W % 32 != 0) return WM_EUNSUPPORTED;          // callers fall back to wm_dwconv3x3_fwd + wm_lfss_out_fwd
+    if (plane_dtype != WM_F32 && plane_dtype != WM_BF16) return WM_EUNSUPPORTED;
+    const long long L = (long long)H * W;
+    if (B == 0 || L == 0) return WM_OK;
+    if (!f_ || !conv2_weight || !tok1 || !conv3_weight || !conv3_bias || !skip_scale2 || !out) return WM_ENULL;
+    if (!aligned16(tok1) || (!out_nchw && !aligned16(out))) return WM_EALIGN;
+    const int ngl = (int)((L + 63) / 64);
+    const long long ngroups = (long long)B * ngl;
+    const int gpw = lfss_groups_per_wave(ngroups, 2048);
+    const long long waves = (ngroups + gpw - 1) / gpw;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(5, st);
+    if (plane_dtype == WM_F32)
+        hipLaunchKernelGGL(lfss_out_conv_mfma_kernel<float>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, (const float*)f_,
+                           conv2_weight, conv2_bias, tok1, conv3_weight, conv3_bias, skip_scale2, out, out_nchw, B, H, W, ngl,
+                           ngroups, gpw);
+    else
+        hipLaunchKernelGGL(lfss_out_conv_mfma_kernel<bf16_t>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
+                           (const bf16_t*)f_, conv2_weight, conv2_bias, tok1, conv3_weight, conv3_bias, skip_scale2, out, out_nchw,
+                           B, H, W, ngl, ngroups, gpw);
+    return launch_status();
 }
 
 int wm_layernorm2d_fwd(const float* x, const float* weight, const float* bias, float eps, float* y, int B,
@@ -1419,7 +1584,8 @@ static int conv_select_mode() {
     }
     return m;
 }
-static bool conv_ws_enabled(const wm::Conv2dArgs& a, int B, bool gated) {
+// th: tile rows of the launch that would run (2 x row tiles per workgroup)
+static bool conv_ws_enabled(const wm::Conv2dArgs& a, int B, int th) {
     const int mode = conv_select_mode();
     if (mode == 1) return false;
     // 32-bit byte offsets inside one batch element of every tensor; gather indices in two registers
@@ -1428,7 +1594,6 @@ static bool conv_ws_enabled(const wm::Conv2dArgs& a, int B, bool gated) {
     if (a.gate && a.res) return false;
     if (mode == 2) return true;
     if ((a.gate || a.res) && a.mtot > 1) return false;
-    const int th = gated ? 2 * WM_CONV_WS_RWG : 8;          // tile rows of the launch that would run
     const long long ntiles = (long long)B * ((a.W + wm::kWsTW - 1) / wm::kWsTW) * ((a.H + th - 1) / th);
     return ntiles >= 768;
 }
@@ -1488,7 +1653,7 @@ int wm_conv2d_fwd(const float* xa, const float* xb, const int* xb_index, const v
 #endif
             // 32 output channels: 12-row tiles (49 KB of LDS: three workgroups per compute unit, staging slots 93 % used)
             // beat 16-row tiles (two workgroups, 80 %) by 4-13 %; 64 channels keep 16 rows (two accumulator sets)
-            if (conv_ws_enabled(a, B, false)) {
+            if (conv_ws_enabled(a, B, 8)) {
                 if (gate || residual) { rc = conv2d_ws_launch<WM_CONV_WS_RW1, 1, false, true>(a, B, st); mb += 1; }
                 else if (left >= 2) { rc = conv2d_ws_launch<WM_CONV_WS_RW2, 2>(a, B, st); mb += 2; }
                 else { rc = conv2d_ws_launch<WM_CONV_WS_RW1, 1, false, false, WM_CONV_WS_NPW1>(a, B, st); mb += 1; }
@@ -1527,8 +1692,9 @@ int wm_conv2d_gated_fwd(const float* xa, const float* xb, const int* xb_index, c
         // two 32-channel x 16-row launches at UHD level 1, 64 -> 64); a last odd row tile takes the 16-row form
         a.mbase = mb;
         int rc;
-        if (conv_ws_enabled(a, B, true)) {
-            if (a.mtot - mb >= 2) { rc = conv2d_ws_launch<WM_CONV_WS_RWG, 2, true>(a, B, st); mb += 2; }
+        const bool two = a.mtot - mb >= 2;                   // an odd tail runs one 32-channel tile on 8-row tiles
+        if (conv_ws_enabled(a, B, two ? 2 * WM_CONV_WS_RWG : 8)) {
+            if (two) { rc = conv2d_ws_launch<WM_CONV_WS_RWG, 2, true>(a, B, st); mb += 2; }
             else { rc = conv2d_ws_launch<4, 1, true>(a, B, st); mb += 1; }
         } else if (a.mtot - mb >= 2) { rc = conv2d_launch<3, 2, 2, true>(a, B, st); mb += 2; }
         else { rc = conv2d_launch<3, 4, 1, true>(a, B, st); mb += 1; }

@@ -12,6 +12,8 @@ Every op is a torch.autograd.Function over the C ABI of libwavemamba_hip.so (han
 gfx950).  PyTorch only supplies device memory, the current stream and autograd plumbing.  There is
 NO CPU / eager fallback: a non-CUDA tensor or a missing library raises.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -297,17 +299,20 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
 # ------------------------------------------------------------------------------------------------
 # fused SS2D four-direction core (forward / inference)
 # ------------------------------------------------------------------------------------------------
-def ss2d_core_supported(d_inner, d_state, dt_rank, width=None):
+def ss2d_core_supported(d_inner, d_state, dt_rank, width=None, height=None):
     """Shapes the fused HIP core covers (else: direction glue + selective_scan_fn).  d_state in (16, 32] needs a map
-    width that is a multiple of 4 (pass `width` to check it)."""
+    width that is a multiple of 4 (pass `width` to check it); with `height` too, maps beyond the kernels' 32-bit
+    element offsets (d_inner * H * W >= 2^31, wavemamba_hip.hip: core_plan) are refused here instead of at the call."""
     if d_inner > 64 or dt_rank > 4 or d_state > 32:
+        return False
+    if width is not None and height is not None and width % 4 == 0 and d_inner * width * height > 2 ** 31 - 1:
         return False
     return d_state <= 16 or width is None or width % 4 == 0
 
 
 def ss2d_core_bwd_supported(d_inner, d_state, dt_rank):
-    """Shapes wm_ss2d_core_bwd covers (training)."""
-    return d_inner <= 64 and d_state <= 16 and dt_rank <= 4
+    """Shapes wm_ss2d_core_bwd covers (training): d_state <= 32 (BASELINE config 5's block included)."""
+    return d_inner <= 64 and d_state <= 32 and dt_rank <= 4
 
 
 def _ss2d_core_shapes(x, x_proj_weight, dt_projs_weight, A_logs):
@@ -316,13 +321,49 @@ def _ss2d_core_shapes(x, x_proj_weight, dt_projs_weight, A_logs):
     R, N = dt_projs_weight.shape[2], A_logs.shape[1]
     if K != 4 or D2 != D or C != R + 2 * N or dt_projs_weight.shape != (4, D, R) or A_logs.shape[0] != 4 * D:
         raise RuntimeError("ss2d_core: inconsistent parameter shapes")
-    if not ss2d_core_supported(D, N, R, W):
+    if not ss2d_core_supported(D, N, R, W, H):
         raise NotImplementedError(f"ss2d_core: d_inner={D}, d_state={N}, dt_rank={R} outside the fused kernel's range")
     return B, D, H, W, N, R
 
 
-def _ss2d_core_fwd(f, merged):
-    """f[0] = x (fp32 or bf16 planes: the outputs take the same storage type), f[1:] fp32 parameters."""
+_CORE_PREP_CACHE = {}   # id(x_proj_weight) -> (weakrefs, data_ptrs, versions, prepared buffer, done event, stream)
+
+
+def _ss2d_core_prepared(params):
+    """The prepared copy (wm_ss2d_core_prep: bf16-split x_proj fragments, A * log2(e), per-channel constants) of the five
+    SS2D parameters `params` = (x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds), kept per module while the
+    parameters are unchanged (`_version`, storage) - inference runs the core 14 times per image with static parameters.
+    Returns None (the call prepares for itself) for parameters that require grad (training updates them every step),
+    under graph capture, and for temporaries."""
+    import weakref
+    if any((not isinstance(p, torch.nn.Parameter)) or p.requires_grad and torch.is_grad_enabled() for p in params) \
+            or torch.cuda.is_current_stream_capturing():
+        return None
+    key = id(params[0])
+    cur = torch.cuda.current_stream(params[0].device)
+    sig = tuple((p.data_ptr(), p._version, p.dtype) for p in params)
+    ent = _CORE_PREP_CACHE.get(key)
+    if ent is not None and all(r() is p for r, p in zip(ent[0], params)) and ent[1] == sig:
+        if ent[4] != cur.cuda_stream:
+            cur.wait_event(ent[3])
+            ent[2].record_stream(cur)
+        return ent[2]
+    lib = _lib.load()
+    f = [p.detach().contiguous().float() for p in params]
+    D, R, N = f[1].shape[1], f[1].shape[2], f[3].shape[1]
+    buf = torch.empty(lib.wm_ss2d_core_prep_bytes(N), dtype=torch.uint8, device=f[0].device)
+    with torch.cuda.device(f[0].device):
+        check(lib.wm_ss2d_core_prep(*[_ptr(t) for t in f], _ptr(buf), D, N, R, _stream()), "wm_ss2d_core_prep")
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    _CORE_PREP_CACHE[key] = ([weakref.ref(p) for p in params], sig, buf, ev, cur.cuda_stream)
+    weakref.finalize(params[0], _CORE_PREP_CACHE.pop, key, None)
+    return buf
+
+
+def _ss2d_core_fwd(f, merged, prepared=None):
+    """f[0] = x (fp32 or bf16 planes: the outputs take the same storage type), f[1:] fp32 parameters; `prepared`: the
+    buffer of _ss2d_core_prepared for these parameters, or None."""
     lib = _lib.load()
     x = f[0]
     B, D, H, W, N, R = _ss2d_core_shapes(x, f[1], f[2], f[4])
@@ -336,6 +377,7 @@ def _ss2d_core_fwd(f, merged):
     ptrs = [_ptr(o) for o in outs] + [None] * (4 - len(outs))
     with torch.cuda.device(x.device):
         check(lib.wm_ss2d_core_fwd(*[_ptr(t) for t in f], *ptrs, int(bool(merged)), _ptr(ws), ws_bytes,
+                                   None if prepared is None else _ptr(prepared),
                                    B, D, H, W, N, R, _dtype_code(x, "ss2d_core"), _stream()), "wm_ss2d_core_fwd")
     return outs
 
@@ -388,20 +430,24 @@ def ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, merg
     xin = x.detach().contiguous()
     if xin.dtype != torch.bfloat16:                # bf16 planes stay bf16 (outputs too); anything else computes in fp32
         xin = xin.float()
-    outs = _ss2d_core_fwd([xin] + [t.detach().contiguous().float() for t in args[1:]], merged)
+    outs = _ss2d_core_fwd([xin] + [t.detach().contiguous().float() for t in args[1:]], merged,
+                          _ss2d_core_prepared(args[1:]))
     return outs[0] if merged else tuple(outs)
 
 
 # ------------------------------------------------------------------------------------------------
 # LFSSBlock forward, fused (inference): lfss_in -> dwconv+SiLU -> ss2d core -> lfss_mid -> dwconv -> lfss_out
 # ------------------------------------------------------------------------------------------------
-def lfss_block_supported(C, d_inner, d_state, dt_rank, ffn_hidden, width=None):
+def lfss_block_supported(C, d_inner, d_state, dt_rank, ffn_hidden, width=None, height=None):
     return (C in (8, 16, 32) and d_inner == 2 * C and ffn_hidden == 2 * C
-            and ss2d_core_supported(d_inner, d_state, dt_rank, width))
+            and ss2d_core_supported(d_inner, d_state, dt_rank, width, height))
 
 
 def _w(t):
     return t.detach().contiguous().float()
+
+
+_FUSE_OUT_CONV = True      # tests / tools: False takes wm_dwconv3x3_fwd + wm_lfss_out_fwd (bit-identical on fp32 planes)
 
 
 def lfss_block_forward(tok, x_size, blk, tok_nchw=False, out_nchw=False):
@@ -419,7 +465,8 @@ def lfss_block_forward(tok, x_size, blk, tok_nchw=False, out_nchw=False):
     tok = tok.contiguous().float()
     dev = tok.device
     st = _stream()
-    pd = _PLANE_DTYPE if C == 32 else torch.float32           # bf16 planes: the C = 32 kernels
+    # bf16 planes: the C = 32 kernels on maps the second-generation core serves (W % 4 == 0); else fp32 planes
+    pd = _PLANE_DTYPE if (C == 32 and W % 4 == 0) else torch.float32
     code = WM_F32 if pd == torch.float32 else WM_BF16
     x = torch.empty((B, D, H, W), dtype=pd, device=dev)
     z = torch.empty((B, D, L), dtype=pd, device=dev)
@@ -429,8 +476,8 @@ def lfss_block_forward(tok, x_size, blk, tok_nchw=False, out_nchw=False):
               "wm_lfss_in_fwd")
     xc = dwconv3x3(x, ss.conv2d.weight, ss.conv2d.bias, "silu")
     # the four directions' outputs stay separate (one (4, B, D, L) allocation); lfss_mid adds them as it loads (:490)
-    y4 = _ss2d_core_fwd([xc] + [_w(t) for t in (ss.x_proj_weight, ss.dt_projs_weight, ss.dt_projs_bias, ss.A_logs, ss.Ds)],
-                        merged=False)
+    core_params = (ss.x_proj_weight, ss.dt_projs_weight, ss.dt_projs_bias, ss.A_logs, ss.Ds)
+    y4 = _ss2d_core_fwd([xc] + [_w(t) for t in core_params], merged=False, prepared=_ss2d_core_prepared(core_params))
     tok1 = torch.empty((B, L, C), dtype=torch.float32, device=dev)
     f = torch.empty((B, D, H, W), dtype=pd, device=dev)
     with torch.cuda.device(dev):
@@ -439,8 +486,16 @@ def lfss_block_forward(tok, x_size, blk, tok_nchw=False, out_nchw=False):
                                   _ptr(_w(blk.skip_scale)), _ptr(_w(blk.ln_2.weight)), _ptr(_w(blk.ln_2.bias)),
                                   float(blk.ln_2.eps), _ptr(_w(ff.conv1.weight)), _ptr(_w(ff.conv1.bias)),
                                   _ptr(tok1), _ptr(f), B, L, C, code, st), "wm_lfss_mid_fwd")
-    fc = dwconv3x3(f, ff.conv2.weight, ff.conv2.bias, "none")
     out = torch.empty((B, C, H, W) if out_nchw else (B, L, C), dtype=torch.float32, device=dev)
+    if C == 32 and W % 32 == 0 and _FUSE_OUT_CONV:
+        # the ffn's depth-wise 3x3 inside the closing kernel: fc (conv2's output) never reaches HBM
+        with torch.cuda.device(dev):
+            check(lib.wm_lfss_out_conv_fwd(_ptr(f), _ptr(_w(ff.conv2.weight)),
+                                           None if ff.conv2.bias is None else _ptr(_w(ff.conv2.bias)), _ptr(tok1),
+                                           _ptr(_w(ff.conv3.weight)), _ptr(_w(ff.conv3.bias)), _ptr(_w(blk.skip_scale2)),
+                                           _ptr(out), int(out_nchw), B, H, W, C, code, st), "wm_lfss_out_conv_fwd")
+        return out
+    fc = dwconv3x3(f, ff.conv2.weight, ff.conv2.bias, "none")
     with torch.cuda.device(dev):
         check(lib.wm_lfss_out_fwd(_ptr(fc), _ptr(tok1), _ptr(_w(ff.conv3.weight)), _ptr(_w(ff.conv3.bias)),
                                   _ptr(_w(blk.skip_scale2)), _ptr(out), int(out_nchw), B, L, C, code, st),
@@ -729,6 +784,7 @@ def conv2d_cache_clear():
     version counter, so code that updates weights that way must call this (WaveMamba.train() / .eval() / ._apply() and
     trainer.load_network do)."""
     _WFRAG_CACHE.clear()
+    _CORE_PREP_CACHE.clear()                 # (the SS2D core's prepared parameters: same validation, same caveat)
 
 
 def _conv2d_wfrag(weight, cache=True):
@@ -743,8 +799,15 @@ def _conv2d_wfrag(weight, cache=True):
     ent = _WFRAG_CACHE.get(key) if cache else None
     if ent is not None and ent[0]() is weight and ent[1] == weight.data_ptr() and ent[2] == weight._version:
         if ent[5] != cur.cuda_stream:
-            cur.wait_event(ent[4])
-            ent[3].record_stream(cur)
+            if torch.cuda.is_current_stream_capturing():
+                # an event recorded outside the capture cannot be waited for inside it: the cache must be warm (one
+                # eager forward, synchronised) before a graph is captured - then the fragments are simply there
+                if not ent[4].query():
+                    raise RuntimeError("conv2d: weight fragments still being prepared on another stream during graph "
+                                       "capture - run one eager forward and synchronize before capturing")
+            else:
+                cur.wait_event(ent[4])
+                ent[3].record_stream(cur)
         return ent[3]
     lib = _lib.load()
     cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
@@ -752,6 +815,8 @@ def _conv2d_wfrag(weight, cache=True):
     with torch.cuda.device(weight.device):
         check(lib.wm_conv2d_prep(_ptr(weight.detach().contiguous()), _ptr(frag), cout, cin, ks, _stream()),
               "wm_conv2d_prep")
+    if cache and torch.cuda.is_current_stream_capturing():
+        return frag                                   # prepared inside the capture: part of the graph, not of the cache
     if cache:
         ev = torch.cuda.Event()
         ev.record(cur)
@@ -915,9 +980,33 @@ class _Conv2dTrain(torch.autograd.Function):
         return gx, gw, gb
 
 
+# Training convolutions.  The split-bf16 matrix-core kernel carries 16 significant bits per operand (3-4e-6 relative on an
+# output): right for inference (the contract's bar is 1e-4 on outputs), but in the training step those 3e-6 on the
+# activations become ~1e-4 on the parameter gradients of the deepest block, whose 8 x 8 maps make every gradient a short
+# cancelling sum - measured against the float64 evaluation of the reference (tools/grad_localize.py): prediction 2.8e-6 /
+# worst gradient tensor 1.1e-4 with it, 7.7e-8 / 1.4e-5 with fp32 convolutions (the reference's own fp32: 9.7e-8 / 6e-6).
+# So autograd takes ATen's fp32 convolutions (MIOpen) unless the fast mode is asked for.
+_TRAIN_CONV_BF16X3 = os.environ.get("WM_TRAIN_CONV_BF16X3", "0") == "1"
+
+
+def set_train_conv_bf16x3(on):
+    """True: forward and input gradient of the dense convolutions on the split-bf16 matrix-core kernel in training too
+    (8 ms of a 110-ms step at 8 x 512 x 512 faster, parameter gradients to ~1e-4 instead of ~1e-5).  Returns the old value."""
+    global _TRAIN_CONV_BF16X3
+    prev, _TRAIN_CONV_BF16X3 = _TRAIN_CONV_BF16X3, bool(on)
+    return prev
+
+
+def conv2d_train_enabled():
+    return _TRAIN_CONV_BF16X3
+
+
 def conv2d_train(x, weight, bias=None):
-    """F.conv2d(x, weight, bias, stride=1, padding=ks // 2) with autograd (see _Conv2dTrain)."""
+    """F.conv2d(x, weight, bias, stride=1, padding=ks // 2) with autograd: ATen's fp32 convolution, or - fast mode,
+    set_train_conv_bf16x3(True) - the split-bf16 matrix-core kernel for forward and input gradient (_Conv2dTrain)."""
     _require_cuda("conv2d_train", x, weight, bias)
+    if not _TRAIN_CONV_BF16X3:
+        return F.conv2d(x.float(), weight, bias, stride=1, padding=weight.shape[2] // 2)
     return _Conv2dTrain.apply(x.contiguous().float(), weight, bias)
 
 
