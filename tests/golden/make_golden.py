@@ -173,7 +173,8 @@ def main():
 
     out = {}
     for tag, (dm, ds, hh_, ww_) in {"s16": (32, 16, 8, 12), "sq16": (32, 16, 8, 8),
-                                    "s32": (32, 32, 6, 10), "d8": (8, 16, 5, 7)}.items():
+                                    "s32": (32, 32, 6, 10), "d8": (8, 16, 5, 7),
+                                    "c32": (32, 32, 8, 12)}.items():      # d_state 32 on a map the fused core serves (W % 4 == 0)
         torch.manual_seed(0)
         ss = arch.SS2D(d_model=dm, d_state=ds, expand=2.0)
         ss.selective_scan = spy

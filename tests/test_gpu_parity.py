@@ -382,7 +382,7 @@ def test_training_step_per_parameter_gradients_on_gpu():
 # ------------------------------------------------------------------------------------------------
 # fused SS2D four-direction core (reference SS2D.forward_core, :446-478)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tag", ["s16", "sq16", "s32", "d8"])
+@pytest.mark.parametrize("tag", ["s16", "sq16", "c32", "d8"])       # c32: d_state 32 on an 8 x 12 map (W % 4 == 0)
 def test_ss2d_core_golden(golden, tag):
     g = golden("scan")          # captured from the reference's real forward_core
     args = cu(g[f"{tag}_core_x"], g[f"{tag}_x_proj_weight"], g[f"{tag}_dt_projs_weight"],
@@ -496,7 +496,7 @@ def test_lfss_block_config5_full_size():
         again = blk(x, [2048, 2048])
         assert torch.equal(fused, again)
         saved = (arch.LFSSBlock._fused_ok, arch.SS2D._fused_ok)
-        arch.LFSSBlock._fused_ok = lambda self, t, width=None: False
+        arch.LFSSBlock._fused_ok = lambda self, t, width=None, height=None: False
         arch.SS2D._fused_ok = lambda self, t: False
         try:
             ref = blk(x, [2048, 2048])
@@ -638,7 +638,7 @@ def test_lfss_block_fused_vs_module_path(C, H, W):
         x = torch.randn(2, H * W, C, device=DEV)
         fused = blk(x, [H, W])
         saved = arch.LFSSBlock._fused_ok
-        arch.LFSSBlock._fused_ok = lambda self, t, width=None: False
+        arch.LFSSBlock._fused_ok = lambda self, t, width=None, height=None: False
         try:
             ref = blk(x, [H, W])
         finally:
@@ -1174,7 +1174,7 @@ def assert_vs_truth(got, ref, truth, what):
 # ------------------------------------------------------------------------------------------------
 # fused SS2D core backward (wm_ss2d_core_bwd) against the reference's autograd of forward_core
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tag", ["s16", "sq16", "s32", "d8"])       # s32: d_state 32 (BASELINE config 5's block)
+@pytest.mark.parametrize("tag", ["s16", "sq16", "c32", "d8"])       # c32: d_state 32 (BASELINE config 5's block)
 def test_ss2d_core_backward_golden(golden, tag):
     """Gradients of the reference's real SS2D.forward_core (tests/golden/make_golden.py) for four random dys: within
     1e-4 of the reference's fp32 autograd, or - the parameter gradients are sums over every position - judged with it
@@ -1192,7 +1192,7 @@ def test_ss2d_core_backward_golden(golden, tag):
 
 
 @pytest.mark.parametrize("B,D,H,W,N,R", [(1, 64, 12, 20, 16, 2), (2, 32, 7, 9, 16, 2), (1, 16, 33, 5, 8, 1),
-                                         (1, 64, 40, 48, 16, 4), (1, 64, 24, 20, 32, 2), (2, 64, 9, 7, 24, 3)])
+                                         (1, 64, 40, 48, 16, 4), (1, 64, 24, 20, 32, 2), (2, 64, 9, 8, 24, 3)])
 @pytest.mark.parametrize("merged", [True, False])
 def test_ss2d_core_backward_vs_unfused_autograd(B, D, H, W, N, R, merged):
     """Fused backward against PyTorch autograd through the direction glue + the HIP op-boundary scan (itself checked

@@ -38,7 +38,7 @@ for sub in ("fetch", "write", "sq1", "sq2"):
     for r in rows(sub):
         k = r["Kernel_Name"]
         cls = "reduce" if "ss2d_core_kernel<16, 16, 1" in k else "scan" if "ss2d_core_kernel<16, 16, 3" in k else \
-              "carry" if "selscan_carry_kernel" in k else None
+              "carry" if "selscan_carry_kernel" in k else "prep" if "ss2d_core_prep_kernel" in k else None
         if cls:
             disp[cls][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
 acc = defaultdict(lambda: defaultdict(list))          # (kernel class, level) -> counter -> values
@@ -54,7 +54,7 @@ for lvl in (1, 2, 3):
     H, W = 2176 >> lvl, 3840 >> lvl
     e = {"H": H, "W": W, "positions": H * W}
     tot = 0.0
-    for cls in ("reduce", "scan", "carry"):
+    for cls in ("reduce", "scan", "carry", "prep"):
         c = acc.get((cls, lvl), {})
         fb, wb = mean(c.get("FETCH_SIZE", [])) * 1024 * fetch_k, mean(c.get("WRITE_SIZE", [])) * 1024 * write_k
         e[cls] = {"fetch_bytes": fb, "write_bytes": wb}
@@ -71,7 +71,13 @@ for lvl in (1, 2, 3):
             e[cls]["mfma_busy_frac"] = mean(c.get("SQ_VALU_MFMA_BUSY_CYCLES", [])) / 1024 / gui
             e[cls]["lds_busy_frac"] = mean(c.get("SQ_LDS_IDX_ACTIVE", [])) / 256 / gui
     levels[str(lvl)] = e
+sys.path.insert(0, root)
+import wave_mamba_amd as wm                         # the library the counters were collected on (same tree, same build)
+kernels = sorted({r["Kernel_Name"].split("(")[0] for sub in ("fetch", "write") for r in rows(sub)
+                  if "ss2d_core" in r["Kernel_Name"] or "selscan_carry" in r["Kernel_Name"]})
 res = {
+    "build_id": wm._lib.build_id(),
+    "kernels": kernels,
     "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_core.sh); counter value x 1024 x the "
               "calibration factor below (true / reported bytes of copies of known size in tools/microbench, same session)",
     "calibration": {"true_over_reported": cal, "applied": {"fetch": fetch_k, "write": write_k},

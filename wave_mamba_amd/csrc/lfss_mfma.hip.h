@@ -402,60 +402,79 @@ __global__ __launch_bounds__(256, 2) void lfss_out_mfma_kernel(const TP* __restr
 
 // ---- lfss_out with the gated ffn's depth-wise 3x3 folded in: f (B, D, H, W), tok1 -> tok2 -------------------------
 // SURVEY.md 8f rank 2 / reference :226-230: fc = dwconv3x3(f) + bias;  gelu(fc[:C]) * fc[C:] -> conv3 -> * skip.  The
-// unfused pair wrote fc (256 B per position) and read it back in the next launch.  A depth-wise tap needs no other
-// channel, so the nine taps of the 32 channels a lane owns are simply loaded (the eight neighbours sit in the same or
-// adjacent 128-byte lines: first-level cache hits; 288 dword loads per lane and 32-position tile against 1,024 cycles
-// of fp32 MFMA) and reduced in the depth-wise kernel's own order (bias, then the taps row by row), so fused and unfused
-// results are bit-identical.  Needs W % 32 == 0: a 32-position tile then lies inside one image row, row validity is
-// wave-uniform, and only the first / last tile of a row has a lane with a missing column neighbour.
+// unfused pair wrote fc (256 B per position) and read it back in the next launch.  Here a wave takes 64 consecutive
+// positions, one per lane: a depth-wise tap needs no other channel, so the lane loads the nine taps of each of its 64
+// channel values itself - 256-byte coalesced runs per (channel, row, column shift), the shifted copies are first-level
+// cache hits - and reduces them in the depth-wise kernel's own order (bias, then the taps row by row).  The 32 products
+// gelu(gate) * value go to a per-wave LDS tile [channel][position], from which the two 32-position MFMA tiles read their
+// B operands in lfss_out's K order: fused and unfused results are BIT-IDENTICAL on fp32 planes.
+// Groups in which no lane sits in the first or last image column take the unmasked path; zero padding above / below the
+// image comes from the buffer range check.
+// One plane (channel) of f as a raw buffer (a descriptor per channel: four SGPRs from scalar arithmetic): a 32-bit lane
+// offset + immediate column shift per load, and the range check (offset >= plane bytes -> 0; a negative offset wraps to a
+// huge one) supplies the zero padding ABOVE the first and BELOW the last image row for free.  (The scalar offset operand
+// takes part in the range check on gfx950 - one descriptor over all planes + a per-channel soffset read zeros.)
+template <typename TP> __device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, int voff);
+template <> __device__ __forceinline__ float buf_ld<float>(__amdgpu_buffer_rsrc_t r, int voff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
+template <> __device__ __forceinline__ float buf_ld<bf16_t>(__amdgpu_buffer_rsrc_t r, int voff) {
+    return __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, voff, 0, 0) << 16);
+}
+
+// EDGE: some lane of the group sits in the first or last image column (its left / right taps are zero padding, not the
+// neighbouring row's end).  Rows need no care (range check above).
 template <bool EDGE, typename TP>
-__device__ __forceinline__ void dwconv_gate_tile(const TP* __restrict__ fb /* + b D L */, const float* __restrict__ s_cw,
-                                                 long long L, int W, long long pq /* row W + w0 + n, clamped */, int h,
-                                                 bool up, bool down, bool left, bool right, float (&g)[16]) {
-    // channel of register i: gate 8 (i >> 2) + (i & 3) + 4 h, value = that + 32
+__device__ __forceinline__ void dwconv_gate_positions(const TP* __restrict__ fb /* + b D L */, const float* __restrict__ s_cw,
+                                                      long long L, int W, long long p /* the lane's position, < L */,
+                                                      float* __restrict__ sg /* the wave's [32 channels][64 positions] + lane */) {
+    constexpr int E = (int)sizeof(TP);
+    bool ml = true, mr = true;
+    if constexpr (EDGE) {
+        const int col = (int)(p % W);
+        ml = col > 0; mr = col < W - 1;
+    }
+    int off[3];
 #pragma unroll
-    for (int i0 = 0; i0 < 16; i0 += 4) {
-        float tp[2][4][9];
+    for (int dr = 0; dr < 3; ++dr) off[dr] = (int)((p + (long long)(dr - 1) * W) * E);
+    // A ROLLED loop over groups of four channel pairs (72 loads in flight): unrolled, the compiler hoists all 576 loads of
+    // the lane above their first use and spills a thousand registers.
+#pragma unroll 1
+    for (int c0 = 0; c0 < 32; c0 += 4) {
+        float t[4][2][9];
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                const int i = i0 + ii;
-                const TP* cp = fb + (long long)(8 * (i >> 2) + (i & 3) + 4 * h + 32 * v) * L + pq;
+            for (int v = 0; v < 2; ++v) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(               // wave-uniform
+                    const_cast<TP*>(fb + (long long)(c0 + cc + 32 * v) * L), 0, (int)(L * E), 0x00020000);
 #pragma unroll
-                for (int dr = 0; dr < 3; ++dr)
-#pragma unroll
-                    for (int dc = 0; dc < 3; ++dc) {
-                        if constexpr (EDGE) {
-                            const bool ok = (dr != 0 || up) && (dr != 2 || down) && (dc != 0 || left) && (dc != 2 || right);
-                            tp[v][ii][3 * dr + dc] = ok ? ld1(cp + (long long)(dr - 1) * W + (dc - 1)) : 0.0f;
-                        } else {
-                            tp[v][ii][3 * dr + dc] = ld1(cp + (long long)(dr - 1) * W + (dc - 1));
-                        }
-                    }
+                for (int dr = 0; dr < 3; ++dr) {
+                    const float a = buf_ld<TP>(rs, off[dr] - E), b = buf_ld<TP>(rs, off[dr]), e = buf_ld<TP>(rs, off[dr] + E);
+                    t[cc][v][3 * dr] = (!EDGE || ml) ? a : 0.0f; t[cc][v][3 * dr + 1] = b; t[cc][v][3 * dr + 2] = (!EDGE || mr) ? e : 0.0f;
+                }
             }
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int i = i0 + ii;
+        for (int cc = 0; cc < 4; ++cc) {
             float fc[2];
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
-                const float* wk = s_cw + (8 * (i >> 2) + (i & 3) + 4 * h + 32 * v) * 12;      // [9 taps | bias | 0 0]
+                const float* wk = s_cw + (c0 + cc + 32 * v) * 12;                                    // [9 taps | bias | 0 0]
                 const float4 w0 = *reinterpret_cast<const float4*>(wk), w1 = *reinterpret_cast<const float4*>(wk + 4),
                              w2 = *reinterpret_cast<const float4*>(wk + 8);
-                float acc = w2.y;
-                acc = fmaf(w0.x, tp[v][ii][0], acc); acc = fmaf(w0.y, tp[v][ii][1], acc); acc = fmaf(w0.z, tp[v][ii][2], acc);
-                acc = fmaf(w0.w, tp[v][ii][3], acc); acc = fmaf(w1.x, tp[v][ii][4], acc); acc = fmaf(w1.y, tp[v][ii][5], acc);
-                acc = fmaf(w1.z, tp[v][ii][6], acc); acc = fmaf(w1.w, tp[v][ii][7], acc); acc = fmaf(w2.x, tp[v][ii][8], acc);
-                fc[v] = acc;
+                float a = w2.y;                                      // the depth-wise kernel's order: bias, then taps row by row
+                a = fmaf(w0.x, t[cc][v][0], a); a = fmaf(w0.y, t[cc][v][1], a); a = fmaf(w0.z, t[cc][v][2], a);
+                a = fmaf(w0.w, t[cc][v][3], a); a = fmaf(w1.x, t[cc][v][4], a); a = fmaf(w1.y, t[cc][v][5], a);
+                a = fmaf(w1.z, t[cc][v][6], a); a = fmaf(w1.w, t[cc][v][7], a); a = fmaf(w2.x, t[cc][v][8], a);
+                fc[v] = a;
             }
-            g[i] = gelu_erf(fc[0]) * fc[1];
+            sg[(c0 + cc) * 64] = gelu_erf(fc[0]) * fc[1];
         }
     }
 }
 
 template <typename TP = float>
-__global__ __launch_bounds__(256, 2) void lfss_out_conv_mfma_kernel(
+__global__ __launch_bounds__(256, 4) void lfss_out_conv_mfma_kernel(
     const TP* __restrict__ f, const float* __restrict__ cw /*(D, 3, 3)*/, const float* __restrict__ cbias /*(D) or null*/,
     const float* __restrict__ tok1, const float* __restrict__ W3 /*(C, C)*/, const float* __restrict__ b3,
     const float* __restrict__ skip2, float* __restrict__ out, int out_nchw, int B, int H, int W, int ngl, long long ngroups,
@@ -463,56 +482,70 @@ __global__ __launch_bounds__(256, 2) void lfss_out_conv_mfma_kernel(
     constexpr int C = 32, D = 64;
     __shared__ __attribute__((aligned(16))) float s_b3[C];
     __shared__ __attribute__((aligned(16))) float s_skip[C];
-    __shared__ __attribute__((aligned(16))) float s_cw[D * 12];
+    __shared__ __attribute__((aligned(16))) float s_A3[(C / 2) * 64];            // 16 A operands x 64 lanes, fetch order
+    __shared__ __attribute__((aligned(16))) float s_cw[D * 12];                  // [channel][9 taps | bias | 0 0]
+    __shared__ __attribute__((aligned(16))) float s_g[4 * C * 64];               // per wave: gelu(gate) * value, [channel][position]
     const long long L = (long long)H * W;
     const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x < C) { s_b3[threadIdx.x] = b3[threadIdx.x]; s_skip[threadIdx.x] = skip2[threadIdx.x]; }
+    for (int e = threadIdx.x; e < (C / 2) * 64; e += 256) {
+        const int j = e >> 6, l = e & 63;
+        s_A3[aop_slot(j, l)] = W3[(l & 31) * C + acc_chan(j, l >> 5)];    // lfss_out's K order: bit-identical sums
+    }
     for (int e = threadIdx.x; e < D * 12; e += 256) {
         const int c = e / 12, q = e - 12 * c;
         s_cw[e] = q < 9 ? cw[c * 9 + q] : (q == 9 && cbias ? cbias[c] : 0.0f);
     }
-    float A[C / 2];
-#pragma unroll
-    for (int j = 0; j < C / 2; ++j) A[j] = W3[n * C + (j & 3) + 8 * (j >> 2) + 4 * h];
     __syncthreads();
-    float sk[16];
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-        const float4 s4 = *reinterpret_cast<const float4*>(&s_skip[8 * gq + 4 * h]);
-        sk[4 * gq] = s4.x; sk[4 * gq + 1] = s4.y; sk[4 * gq + 2] = s4.z; sk[4 * gq + 3] = s4.w;
-    }
     const long long g0 = (long long)blockIdx.x * 4 * gpw + wv;     // the block's waves walk adjacent groups together
     for (int gi = 0; gi < gpw; ++gi) {
         const long long g = g0 + 4 * gi;
         if (g >= ngroups) break;
         const long long b = g / ngl;
         const long long p0 = (g - b * ngl) * 64;
-#pragma unroll 1
+        const long long pc = min(p0 + lane, L - 1);
+        const int row0 = (int)(p0 / W), col0 = (int)(p0 - (long long)row0 * W);                   // wave-uniform
+        const bool edge = col0 == 0 || col0 + 64 >= W;               // a lane in the first / last column (or two rows in the group)
+        (void)row0;
+        float* sg = s_g + wv * (C * 64);
+        const TP* fb = f + b * D * L;
+        __builtin_amdgcn_wave_barrier();                             // the previous group's operand reads are done (in-order LDS)
+        if (edge) dwconv_gate_positions<true, TP>(fb, s_cw, L, W, pc, sg + lane);
+        else dwconv_gate_positions<false, TP>(fb, s_cw, L, W, pc, sg + lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        lfss_v16f acc[2];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const float4 bb = *reinterpret_cast<const float4*>(&s_b3[8 * gq + 4 * h]);
+            acc[0][4 * gq] = bb.x; acc[0][4 * gq + 1] = bb.y; acc[0][4 * gq + 2] = bb.z; acc[0][4 * gq + 3] = bb.w;
+        }
+        acc[1] = acc[0];
+#pragma unroll
+        for (int j4 = 0; j4 < C / 8; ++j4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&s_A3[(j4 * 64 + lane) * 4]);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {            // K-step j = channels acc_chan(j, h); tile 0 = positions n, tile 1 = 32 + n
+                const int ch = acc_chan(4 * j4 + jj, h);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], sg[ch * 64 + n], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], sg[ch * 64 + 32 + n], acc[1], 0, 0, 0);
+            }
+        }
+#pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const long long pt = p0 + 32 * t;                       // first position of the tile (wave-uniform)
-            if (pt >= L) break;                                     // (L % 64 == 32: the last group has one tile)
-            const int row = (int)(pt / W), w0 = (int)(pt - (long long)row * W);
-            const long long pos = pt + n;
-            const bool up = row > 0, down = row < H - 1;
-            const bool edge = !up || !down || w0 == 0 || w0 + 32 == W;               // wave-uniform
-            float gt[16], tk[16];
-            const TP* fb = f + b * D * L;
-            if (edge) dwconv_gate_tile<true, TP>(fb, s_cw, L, W, pos, h, up, down, w0 + n > 0, w0 + n < W - 1, gt);
-            else dwconv_gate_tile<false, TP>(fb, s_cw, L, W, pos, h, true, true, true, true, gt);
-            load_tile32(tok1, false, b, pos, L, h, tk);
-            lfss_v16f acc;
+            const long long pos = p0 + 32 * t + n;
+            float tk[16], o[16];
+            load_tile32(tok1, false, b, min(pos, L - 1), L, h, tk);
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const float4 bb = *reinterpret_cast<const float4*>(&s_b3[8 * gq + 4 * h]);
-                acc[4 * gq] = bb.x; acc[4 * gq + 1] = bb.y; acc[4 * gq + 2] = bb.z; acc[4 * gq + 3] = bb.w;
+                const float4 s4 = *reinterpret_cast<const float4*>(&s_skip[8 * gq + 4 * h]);
+                o[4 * gq] = fmaf(tk[4 * gq], s4.x, acc[t][4 * gq]); o[4 * gq + 1] = fmaf(tk[4 * gq + 1], s4.y, acc[t][4 * gq + 1]);
+                o[4 * gq + 2] = fmaf(tk[4 * gq + 2], s4.z, acc[t][4 * gq + 2]); o[4 * gq + 3] = fmaf(tk[4 * gq + 3], s4.w, acc[t][4 * gq + 3]);
             }
-#pragma unroll
-            for (int j = 0; j < C / 2; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[j], gt[j], acc, 0, 0, 0);
-            float o[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o[i] = fmaf(tk[i], sk[i], acc[i]);
-            store_tile32(out, out_nchw != 0, b, pos, L, h, o);
+            if (pos < L) store_tile32(out, out_nchw != 0, b, pos, L, h, o);
         }
     }
 }
