@@ -226,9 +226,6 @@ int wm_dwconv3x3_wgrad(const float* x, const float* gy, float* dW, float* db, in
 int wm_layernorm2d_bwd(const float* x, const float* weight, const float* gy, float eps, float* gx,
                        float* dweight, float* dbias, int B, int64_t L, int C, void* stream);
 
-/* Pixel-attention gate of PAConv (HFE branch): out = a * sigmoid(b), n fp32 elements (n % 4 == 0),
- * wavemamba_arch.py:694-697 (`torch.mul(self.k3(x), self.sigmoid(self.k2(x)))`).  Forward only. */
-int wm_mul_sigmoid_fwd(const float* a, const float* b, float* out, int64_t n, void* stream);
 
 /* Dense 3x3 (stride 1, zero padding 1) and 1x1 convolutions, NCHW fp32, with the element-wise neighbours they
  * have in the HFE branch fused (wavemamba_arch.py: PAConv k2/k3/k4 :690-697 on

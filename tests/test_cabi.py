@@ -65,3 +65,30 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libwavemamba_hip.so")
     with pytest.raises(_lib.WaveMambaHipError):
         _lib.load()
+
+
+def test_core_work_split_is_consistent():
+    """wm_ss2d_core_plan (host-only): the work split wm_ss2d_core_fwd uses covers the map exactly once in every direction,
+    is the same on every call (the search result is cached per shape), and the UHD level-1 launch is not the 480 equal
+    workgroups of round 2 (two dispatch rounds, the second 7/8 full) but column workgroups + shorter row workgroups."""
+    import ctypes
+    from wave_mamba_amd import _lib
+    lib = _lib.load()
+    out = (ctypes.c_int * 10)()
+    for (B, H, W, N) in [(1, 1088, 1920, 16), (1, 544, 960, 16), (1, 272, 480, 16), (1, 2048, 2048, 32), (8, 256, 256, 16),
+                         (2, 24, 40, 16), (1, 8, 12, 16), (1, 33, 72, 32), (1, 16, 2048, 16), (1, 8192, 16, 16)]:
+        assert lib.wm_ss2d_core_plan(B, 64, H, W, N, 2, out) == 0
+        nw, seg, nseg, ctiles, cwgs, rchunk, rnchunks, rwgs, grid, span = list(out)
+        L = H * W
+        assert nw == (16 if N <= 16 else 8)
+        assert seg % 16 == 0 and seg * nseg >= H and seg * (nseg - 1) < H            # column segments tile the rows
+        assert ctiles * nw >= W and (ctiles - 1) * nw < W and cwgs >= ctiles * nseg and cwgs % 8 == 0
+        assert rchunk % 16 == 0 and rchunk * rnchunks >= L and rchunk * (rnchunks - 1) < L
+        assert rwgs * nw >= rnchunks and grid == B * (2 * rwgs + 2 * cwgs) and span > 0
+        again = (ctypes.c_int * 10)()
+        assert lib.wm_ss2d_core_plan(B, 64, H, W, N, 2, again) == 0 and list(again) == list(out)
+    assert lib.wm_ss2d_core_plan(1, 64, 1088, 1920, 16, 2, out) == 0
+    assert out[2] == 1 and out[5] // 16 < 1088 // 16            # one segment per column; row chunks shorter than a column
+    assert lib.wm_ss2d_core_plan(1, 64, 10, 14, 16, 2, out) == -5      # W % 4 != 0: first-generation kernels, no plan
+    assert lib.wm_ss2d_core_plan(1, 64, 8, 8, 64, 2, out) == -5        # N > 32
+    assert lib.wm_ss2d_core_prep_bytes(16) > 0 and lib.wm_ss2d_core_prep_bytes(33) == 0

@@ -1,0 +1,10 @@
+#!/bin/bash
+# round-3 GPU job 10: the evidence for profiles/r03 on the shipped binary: rocprofv3 kernel stats of the bench command,
+# per-step breakdowns (multi-stream and single-stream), PMC traffic / busy fractions of the core
+cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r03prof; mkdir -p $O
+python -c "import wave_mamba_amd as wm; print('build_id', wm._lib.build_id())" > $O/build_id.txt 2>&1
+bash tools/profile_bench.sh $O/multi > $O/profile_multi.log 2>&1
+WM_TWO_STREAMS=0 bash tools/profile_bench.sh $O/single > $O/profile_single.log 2>&1
+bash tools/pmc_core.sh $O/pmc_core > $O/pmc_core.log 2>&1
+python tools/pmc_traffic.py $O/pmc_core $O/pmc_traffic.json > $O/pmc_traffic.log 2>&1
+cat $O/build_id.txt; cat $O/pmc_traffic.log; head -12 $O/multi/bench_rocprofv3_kernel_stats.csv; head -20 $O/single/bench_per_step_kernel_breakdown.txt; ls -la $O $O/multi $O/single | head -40

@@ -43,7 +43,6 @@ SIGNATURES = {
     "wm_layernorm2d_fwd": (_i, [_p, _p, _p, _c.c_float, _p, _i, _i64, _i, _p]),
     "wm_gram_workspace_bytes": (_sz, [_i, _i, _i64]),
     "wm_gram_fwd": (_i, [_p] * 6 + [_sz, _i, _i, _i64, _p]),
-    "wm_mul_sigmoid_fwd": (_i, [_p, _p, _p, _i64, _p]),
     "wm_dwconv3x3_wgrad": (_i, [_p] * 4 + [_i] * 4 + [_p]),
     "wm_layernorm2d_bwd": (_i, [_p, _p, _p, _c.c_float, _p, _p, _p, _i, _i64, _i, _p]),
     "wm_dwconv3x3_fwd": (_i, [_p] * 4 + [_i] * 6 + [_p]),

@@ -188,15 +188,6 @@ __global__ __launch_bounds__(256) void layernorm2d_kernel(const float* __restric
     for (int c = 0; c < C; ++c) y[(bb * C + c) * L + p] = fmaf(w[c], (v[c] - mean) * rstd, b[c]);
 }
 
-// ---- pixel-attention gate of PAConv: out = a * sigmoid(b) (reference :694-697), 16-byte accesses ----------
-__global__ __launch_bounds__(256) void mul_sigmoid_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
-                                                          float4* __restrict__ out, long long n4) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-        const float4 x = a[i], g = b[i];
-        out[i] = make_float4(x.x / (1.0f + expf(-g.x)), x.y / (1.0f + expf(-g.y)), x.z / (1.0f + expf(-g.z)),
-                             x.w / (1.0f + expf(-g.w)));
-    }
-}
 
 }  // namespace wm
 

@@ -96,6 +96,7 @@ struct CoreArgs {
     float* wsH[4];
     int B, D, H, W, L, N, R;
     int row_chunk, row_nchunks, row_wgs;        // steps per row chunk (multiple of 16), chunks, workgroups per direction
+    int row_cpw;                                // row chunks per workgroup (handed to its waves on demand)
     unsigned long long* stamps;                 // WM_CORE_STAMP builds: [workgroup][wave][12] cycle totals / stamps, else unused
     int dirmask;                                // bit k set: direction k runs (tools: time one direction alone)
     const float* prep;                          // ss2d_core_prep_kernel's output: 4 x CoreCfg<NP>::PREP floats
@@ -123,7 +124,7 @@ template <int NP> struct CoreCfg {
     static constexpr int PREP = P_LC + 6 * 64;
 };
 template <int NP, int NW> constexpr int core_lds_bytes() {
-    return (CoreCfg<NP>::WF + NW * CoreCfg<NP>::XT + NW * 16 * CoreCfg<NP>::RS) * 4;
+    return (CoreCfg<NP>::WF + NW * CoreCfg<NP>::XT + NW * 16 * CoreCfg<NP>::RS + 4 /* row-chunk counter */) * 4;
 }
 
 typedef __bf16 core_bf2 __attribute__((ext_vector_type(2)));
@@ -264,18 +265,41 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
     const float bias = prep[Cfg::P_LC + 4 * 64 + lane];
     const float Dd = prep[Cfg::P_LC + 5 * 64 + lane];
 
-    // ---- the wave's sequence chunk
+    // ---- the wave's sequence chunk(s)
+    // Column mode: one chunk per wave - the NW waves of the workgroup own NW adjacent columns and move in step (barriers).
+    // Row mode: the workgroup owns `row_cpw` consecutive chunks and its waves TAKE them one at a time from a counter in
+    // LDS (summary slots are indexed by chunk, so which wave ran a chunk changes nothing: results stay bit-reproducible).
+    // The free-running waves of a SIMD drift apart (the oldest wave wins the issue arbitration): in the UHD level-1
+    // chunk-scan launch the waves of a row workgroup finished between 370 and 857 us (tools/core_stamps.py).  Handing
+    // out several shorter chunks per wave evens that out (566 - 918 us) but does not shorten the launch - the host plans
+    // one chunk per wave (core_plan: WM_CORE_ROW_SPLIT).
+    int* s_next = reinterpret_cast<int*>(s_rec + NW * 16 * RS);
+    if (!COL && tid == 0) *s_next = 0;
+    __syncthreads();                                     // weight fragments (and the counter) visible
+
+    using IO = CoreIO<TP>;
+    const TP* xb = static_cast<const TP*>(p.x) + (long long)b * D * L;
+    TP* yb = (PHASE == 3) ? static_cast<TP*>(p.y[k]) + (long long)b * D * L : nullptr;
+    float* sx = s_x + wv * XT;                           // the wave's x / y tile  [64][ROW]
+    float* srec = s_rec + wv * (16 * RS);                // the wave's record tile [16][RS]
+    const int trow = lane >> 2, tq = lane & 3;
+
+    for (int rep = 0;; ++rep) {
     int t_begin, t_end;            // scan steps [t_begin, t_end) of the wave's line (row mode: l; column mode: tau)
     long long chunk;               // summary slot, in scan order
     bool active;                   // the wave has a sequence at all
     int wlo = 0;                   // column mode: first image column of the workgroup's tile
     if (!COL) {
-        const int c = wg * NW + wv;
-        active = c < p.row_nchunks;
+        int c = 0;
+        if (lane == 0) c = atomicAdd(s_next, 1);
+        c = __builtin_amdgcn_readfirstlane(c) + wg * p.row_cpw;
+        if (c >= min((wg + 1) * p.row_cpw, p.row_nchunks)) break;
+        active = true;
         chunk = c;
         t_begin = c * p.row_chunk;
         t_end = (int)min(L, (long long)t_begin + p.row_chunk);
     } else {
+        if (rep > 0) break;
         const int ct = wg % p.col_tiles, sg = wg / p.col_tiles;
         const int omega = ct * NW + wv;                  // column in scan order
         active = omega < W;
@@ -285,9 +309,6 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
         wlo = REV ? W - NW - ct * NW : ct * NW;
     }
     const int ntiles = (t_end - t_begin + 15) >> 4;
-
-    __syncthreads();                                     // weight fragments visible
-    if (!COL && !active) return;                         // row mode has no workgroup barrier below
 
     v2f h[NP / 2];
     const long long wsrow = ((chunk * p.B + b) * D + d) * NP;
@@ -303,16 +324,9 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
     }
     float sum_dt = 0.0f;
 
-    using IO = CoreIO<TP>;
-    const TP* xb = static_cast<const TP*>(p.x) + (long long)b * D * L;
-    TP* yb = (PHASE == 3) ? static_cast<TP*>(p.y[k]) + (long long)b * D * L : nullptr;
-    float* sx = s_x + wv * XT;                           // the wave's x / y tile  [64][ROW]
-    float* srec = s_rec + wv * (16 * RS);                // the wave's record tile [16][RS]
-
     // tile ti covers steps t0 .. t0+15 of the line; in memory that is positions / rows lo .. lo+15 ascending, and
     // step tt sits at tile column tt (forward) or 15 - tt (reversed).  Valid tile columns: [v_lo, v_hi).
     typename IO::raw xp[4];                              // the next tile, in flight (raw bits: converted when staged)
-    const int trow = lane >> 2, tq = lane & 3;
     // Loads are UNCONDITIONAL with clamped offsets (an `ok ? load : 0` compiles to a branch around the load plus
     // register copies behind it, i.e. a wait for the load right where it was issued); invalid elements are zeroed when
     // the tile is staged, one tile later.  Per thread and float4 i: element offset = tbase[i] + ti * tdelta (D * L < 2^31,
@@ -616,6 +630,8 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
             *reinterpret_cast<float4*>(p.wsP[k] + wsrow + 4 * q) = make_float4(p0.x, p0.y, p1.x, p1.y);
         }
     }
+    if (!COL) core_lds_fence();                          // the wave's tiles are its own: nothing of this chunk is pending
+    }                                                    // next chunk (row mode)
 }
 
 #undef WM_A2

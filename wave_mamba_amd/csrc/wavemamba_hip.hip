@@ -617,7 +617,7 @@ namespace wm {
 // ------------------------------------------------------------------------------------------------
 struct CorePlan {
     int NP, NW;
-    int row_chunk, row_nchunks, row_wgs;
+    int row_chunk, row_nchunks, row_wgs, row_cpw;
     int col_seg, col_nseg, col_tiles, col_wgs;
     long long col_nchunks, max_chunks;
     size_t half_bytes, ytmp_bytes, prep_bytes, total;   // one P (or H) array of one direction; merged-mode y buffers;
@@ -648,7 +648,8 @@ static double core_makespan(const CorePlan& pl, int B, int H, double bound) {
     for (int x = 0; x < 8; ++x) for (int i = 0; i < slots; ++i) freeat[x][i] = 0.0;
     const long long per_b = 2LL * pl.row_wgs + 2LL * pl.col_wgs;
     const long long total = (long long)B * per_b;
-    const int row_tiles = pl.row_chunk / 16;
+    // a row workgroup's waves share its row_cpw chunks: tile rounds = chunks x tiles per chunk / waves
+    const int row_tiles = (pl.row_cpw * (pl.row_chunk / 16) + pl.NW - 1) / pl.NW;
     double span = 0.0;
     {   // lower bound: all work spread evenly
         double work = 0.0;
@@ -671,7 +672,7 @@ static double core_makespan(const CorePlan& pl, int B, int H, double bound) {
             cost = ((rows + 15) / 16) * kColTile + kWgStart;
         } else {
             const long long wg = (r - 2LL * pl.col_wgs) >> 1;
-            long long c0 = wg * pl.NW;                                        // first chunk of the workgroup
+            long long c0 = wg * pl.row_cpw;                                   // first chunk of the workgroup
             if (c0 >= pl.row_nchunks) continue;
             cost = row_tiles + kWgStart;                                       // (the very last chunk may be shorter)
         }
@@ -707,6 +708,15 @@ static int core_plan(CorePlan& pl, int B, int D, int H, int W, int N, int R, int
     // costs (core_makespan) and the shortest launch wins, e.g. level 1: 240 column workgroups of 68 tiles + 272 row
     // workgroups of 60.  Plans are cached per shape (the search replays ~10^5 workgroups).
     const long long RT = (L / 16 + NW - 1) / NW;                    // row workgroup-tiles per direction (L % 16 == 0: W % 4, H ...)
+    // Row workgroups hand their chunks to their waves on demand (ss2d_core.hip.h), kRowSplit chunks per wave.  Measured
+    // (gpurun_out r3h, UHD levels 1 / 2 / 3, ms per call): 1 chunk per wave 3.564 / 1.034 / 0.323, 2: 3.541 / 1.046 /
+    // 0.339, 3: 3.498 / 1.081 / 0.344, 4: 3.584 / 1.062 / 0.366 - shorter chunks do even out the waves' lifetimes (566-918 us
+    // instead of 370-857 at level 1) but the launch does not get shorter (the remaining waves of a SIMD were using the
+    // issue slots of the finished ones) and the carry pays for the extra chunks: 1.
+#ifndef WM_CORE_ROW_SPLIT
+#define WM_CORE_ROW_SPLIT 1
+#endif
+    constexpr int kRowSplit = WM_CORE_ROW_SPLIT;
     struct Cand { int seg, nseg, row_chunk; };
     auto fill = [&](const Cand& c) {
         pl.col_seg = c.seg; pl.col_nseg = c.nseg;
@@ -714,7 +724,8 @@ static int core_plan(CorePlan& pl, int B, int D, int H, int W, int N, int R, int
         pl.col_wgs = ((pl.col_tiles * pl.col_nseg + 7) / 8) * 8;
         pl.row_chunk = c.row_chunk;
         pl.row_nchunks = (int)((L + c.row_chunk - 1) / c.row_chunk);
-        pl.row_wgs = (pl.row_nchunks + NW - 1) / NW;
+        pl.row_cpw = NW * kRowSplit;
+        pl.row_wgs = (pl.row_nchunks + pl.row_cpw - 1) / pl.row_cpw;
     };
     {
         static std::mutex mu;
@@ -735,9 +746,9 @@ static int core_plan(CorePlan& pl, int B, int D, int H, int W, int N, int R, int
                 last_seg = sg;
                 const int nn = (H + sg - 1) / sg;
                 int last_chunk = -1;
-                for (long long ct = RT < 128 ? RT : 128; ct >= 2; --ct) {      // tiles per row chunk
+                for (long long ct = RT < 128 ? RT : 128; ct >= 2; --ct) {      // tile rounds per row workgroup
                     const long long m = (RT + ct - 1) / ct;                    // row workgroups per direction
-                    long long c = (L + m * NW - 1) / (m * NW);
+                    long long c = (L + m * NW * kRowSplit - 1) / (m * NW * kRowSplit);
                     c = ((c + 15) / 16) * 16;
                     if (c < 32) c = 32;
                     if ((int)c == last_chunk) continue;
@@ -854,7 +865,7 @@ int wm_ss2d_core_plan(int B, int D, int H, int W, int N, int R, int* out10) {
     const int rc = core_plan(pl, B, D, H, W, N, R, 0);
     if (rc) return rc;
     out10[0] = pl.NW; out10[1] = pl.col_seg; out10[2] = pl.col_nseg; out10[3] = pl.col_tiles; out10[4] = pl.col_wgs;
-    out10[5] = pl.row_chunk; out10[6] = pl.row_nchunks; out10[7] = pl.row_wgs;
+    out10[5] = pl.row_chunk; out10[6] = pl.row_nchunks; out10[7] = pl.row_wgs;      // (row_wgs x 2 NW chunks, taken on demand)
     out10[8] = B * (2 * pl.row_wgs + 2 * pl.col_wgs);
     out10[9] = (int)(100.0 * core_makespan(pl, B, H, 1e300));
     return WM_OK;
@@ -899,7 +910,7 @@ int wm_ss2d_core_fwd(const void* x, const float* x_proj_weight, const float* dt_
     a.y[2] = merged ? (void*)(yt + pl.ytmp_bytes) : y_row_rev;
     a.y[3] = merged ? (void*)(yt + 2 * pl.ytmp_bytes) : y_col_rev;
     a.B = B; a.D = D; a.H = H; a.W = W; a.L = H * W; a.N = N; a.R = R;
-    a.row_chunk = pl.row_chunk; a.row_nchunks = pl.row_nchunks; a.row_wgs = pl.row_wgs;
+    a.row_chunk = pl.row_chunk; a.row_nchunks = pl.row_nchunks; a.row_wgs = pl.row_wgs; a.row_cpw = pl.row_cpw;
     a.stamps = nullptr;
 #if WM_CORE_STAMP
     {   // diagnostics build: WM_CORE_STAMPS=<device pointer, decimal> receives [workgroups][waves][8] cycle totals of the scan launch
@@ -1294,19 +1305,6 @@ int wm_gram_fwd(const float* X, const float* Y, float* G, float* nx, float* ny, 
     return launch_status();
 }
 
-int wm_mul_sigmoid_fwd(const float* a, const float* b, float* out, int64_t n, void* stream) {
-    if (n < 0) return WM_EINVAL;
-    if (n == 0) return WM_OK;
-    if (!a || !b || !out) return WM_ENULL;
-    if (n % 4 != 0) return WM_EUNSUPPORTED;
-    if (!aligned16(a) || !aligned16(b) || !aligned16(out)) return WM_EALIGN;
-    const long long n4 = n / 4;
-    long long blocks = (n4 + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(mul_sigmoid_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)a,
-                       (const float4*)b, (float4*)out, n4);
-    return launch_status();
-}
 
 int wm_dwconv3x3_wgrad(const float* x, const float* gy, float* dW, float* db, int B, int C, int H, int W,
                        void* stream) {

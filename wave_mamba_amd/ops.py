@@ -654,19 +654,6 @@ class _NoCtx:
         pass
 
 
-def mul_sigmoid(a, b):
-    """a * sigmoid(b) in one pass (PAConv gate, reference :694-697); fp32, same shape, forward only."""
-    lib = _lib.load()
-    _require_cuda("mul_sigmoid", a, b)
-    if a.shape != b.shape or a.dtype != torch.float32 or b.dtype != torch.float32 or a.numel() % 4:
-        raise NotImplementedError("mul_sigmoid: two fp32 tensors of equal shape, numel % 4 == 0")
-    a, b = a.contiguous(), b.contiguous()
-    out = torch.empty_like(a)
-    with torch.cuda.device(a.device):
-        check(lib.wm_mul_sigmoid_fwd(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "wm_mul_sigmoid_fwd")
-    return out
-
-
 # ------------------------------------------------------------------------------------------------
 # depth-wise 3x3 convolution (+ bias, + SiLU) - inference path of SS2D.conv2d / ffn.conv2
 # ------------------------------------------------------------------------------------------------
