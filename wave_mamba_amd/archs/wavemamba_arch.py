@@ -714,14 +714,23 @@ _SIDE_STREAMS = {}
 def _side_streams(x, n):
     """The side streams of the inference forward, per (device, the stream the forward is issued on): forwards in flight
     on different main streams (multi-stream serving, bench.py's concurrent leg) must not share side streams, or each
-    one's join would also wait for the others' high-frequency work.  ((None,) * n off a GPU.)"""
+    one's join would also wait for the others' high-frequency work.  Under HIP-graph capture no stream may be created
+    (the capture would be invalidated): a per-device set reserved for captures is made together with the first ordinary
+    one.  ((None,) * n off a GPU.)"""
     if not x.is_cuda:
         return (None,) * n
     dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
-    key = (dev, torch.cuda.current_stream(x.device).cuda_stream)
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (dev, "capture" if capturing else torch.cuda.current_stream(x.device).cuda_stream)
     sts = _SIDE_STREAMS.get(key)
     if sts is None or len(sts) < n:
+        if capturing:
+            raise RuntimeError("WaveMamba: run one eager forward on this device before capturing it into a graph "
+                               "(the side streams of a capture are created outside of it)")
         sts = _SIDE_STREAMS[key] = tuple(torch.cuda.Stream(device=x.device) for _ in range(n))
+        cap = _SIDE_STREAMS.get((dev, "capture"))
+        if cap is None or len(cap) < n:
+            _SIDE_STREAMS[(dev, "capture")] = tuple(torch.cuda.Stream(device=x.device) for _ in range(n))
     return sts[:n]
 
 

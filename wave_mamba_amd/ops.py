@@ -336,18 +336,19 @@ def _ss2d_core_prepared(params):
     Returns None (the call prepares for itself) for parameters that require grad (training updates them every step),
     under graph capture, and for temporaries."""
     import weakref
-    if any((not isinstance(p, torch.nn.Parameter)) or p.requires_grad and torch.is_grad_enabled() for p in params) \
-            or torch.cuda.is_current_stream_capturing():
+    if any((not isinstance(p, torch.nn.Parameter)) or p.requires_grad and torch.is_grad_enabled() for p in params):
         return None
     key = id(params[0])
     cur = torch.cuda.current_stream(params[0].device)
     sig = tuple((p.data_ptr(), p._version, p.dtype) for p in params)
     ent = _CORE_PREP_CACHE.get(key)
     if ent is not None and all(r() is p for r, p in zip(ent[0], params)) and ent[1] == sig:
-        if ent[4] != cur.cuda_stream:
+        if ent[4] != cur.cuda_stream and not torch.cuda.is_current_stream_capturing():
             cur.wait_event(ent[3])
             ent[2].record_stream(cur)
         return ent[2]
+    if torch.cuda.is_current_stream_capturing():
+        return None                                  # cold cache under capture: the call prepares for itself, inside the graph
     lib = _lib.load()
     f = [p.detach().contiguous().float() for p in params]
     D, R, N = f[1].shape[1], f[1].shape[2], f[3].shape[1]
@@ -787,11 +788,9 @@ def _conv2d_wfrag(weight, cache=True):
     if ent is not None and ent[0]() is weight and ent[1] == weight.data_ptr() and ent[2] == weight._version:
         if ent[5] != cur.cuda_stream:
             if torch.cuda.is_current_stream_capturing():
-                # an event recorded outside the capture cannot be waited for inside it: the cache must be warm (one
-                # eager forward, synchronised) before a graph is captured - then the fragments are simply there
-                if not ent[4].query():
-                    raise RuntimeError("conv2d: weight fragments still being prepared on another stream during graph "
-                                       "capture - run one eager forward and synchronize before capturing")
+                # an event recorded outside the capture can be neither waited for nor queried inside it: the cache must
+                # be warm (one eager forward, synchronised) before a graph is captured - then the fragments are simply there
+                pass
             else:
                 cur.wait_event(ent[4])
                 ent[3].record_stream(cur)
