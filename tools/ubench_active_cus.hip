@@ -12,7 +12,7 @@ __device__ __forceinline__ v2f ex2(v2f x) { return (v2f){__builtin_amdgcn_exp2f(
 template <int MODE>   // 0: scan step (exp + packed), 1: packed operations only, 2: exponentials only
 __global__ __launch_bounds__(1024) void loop(float* out, unsigned long long* clk, int steps) {
     extern __shared__ float s_rec[];                      // 64 steps of [dt_r(4) | B(16) | C(16)]
-    for (int i = threadIdx.x; i < 64 * 36; i += 1024) s_rec[i] = 0.001f * (i % 37) - 0.01f;
+    for (int i = threadIdx.x; i < 64 * 36; i += blockDim.x) s_rec[i] = 0.001f * (i % 37) - 0.01f;
     __syncthreads();
     const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
     v2f A2[8], h[8];
@@ -70,10 +70,27 @@ template <int MODE> void run(const char* name, float* d, unsigned long long* dc,
     }
 }
 
+// waves per SIMD: the same loop with 4, 8, 12, 16 waves per workgroup (1 - 4 per SIMD), 256 workgroups
+void occupancy(float* d, unsigned long long* dc, int steps) {
+    hipFuncSetAttribute((const void*)loop<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    printf("scan step, 256 workgroups, waves per workgroup (one workgroup per compute unit):\n  waves   ms/launch   state-steps/ns\n");
+    for (int w : {4, 8, 12, 16}) {
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipLaunchKernelGGL(loop<0>, dim3(256), dim3(64 * w), 100 * 1024, 0, d, dc, steps);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(loop<0>, dim3(256), dim3(64 * w), 100 * 1024, 0, d, dc, steps);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+        printf("  %5d    %8.3f    %10.2f\n", w, ms, 256.0 * 64 * w * 16.0 * steps / (ms * 1e6));
+    }
+}
+
 int main() {
     float* d; unsigned long long* dc;
     hipMalloc(&d, 512 * 1024 * sizeof(float)); hipMalloc(&dc, 1024 * sizeof(unsigned long long));
     const int steps = 20000;
+    occupancy(d, dc, steps);
     run<0>("scan step (16 v_exp_f32 + 32 packed fp32)", d, dc, steps);
     run<1>("packed fp32 only", d, dc, steps);
     run<2>("v_exp_f32 + 1 packed add", d, dc, steps);

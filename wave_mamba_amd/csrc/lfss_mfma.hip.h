@@ -431,7 +431,7 @@ __device__ __forceinline__ void dwconv_gate_positions(const TP* __restrict__ fb 
     constexpr int E = (int)sizeof(TP);
     bool ml = true, mr = true;
     if constexpr (EDGE) {
-        const int col = (int)(p % W);
+        const int col = (int)((unsigned)p % (unsigned)W);            // p < L < 2^31
         ml = col > 0; mr = col < W - 1;
     }
     int off[3];
@@ -505,9 +505,8 @@ __global__ __launch_bounds__(256, 4) void lfss_out_conv_mfma_kernel(
         const long long b = g / ngl;
         const long long p0 = (g - b * ngl) * 64;
         const long long pc = min(p0 + lane, L - 1);
-        const int row0 = (int)(p0 / W), col0 = (int)(p0 - (long long)row0 * W);                   // wave-uniform
+        const int col0 = (int)((unsigned)p0 % (unsigned)W);          // wave-uniform; p0 < L < 2^31
         const bool edge = col0 == 0 || col0 + 64 >= W;               // a lane in the first / last column (or two rows in the group)
-        (void)row0;
         float* sg = s_g + wv * (C * 64);
         const TP* fb = f + b * D * L;
         __builtin_amdgcn_wave_barrier();                             // the previous group's operand reads are done (in-order LDS)

@@ -1224,6 +1224,7 @@ int wm_lfss_out_conv_fwd(const void* f_, const float* conv2_weight, const float*
     if (plane_dtype != WM_F32 && plane_dtype != WM_BF16) return WM_EUNSUPPORTED;
     const long long L = (long long)H * W;
     if (B == 0 || L == 0) return WM_OK;
+    if (L > 0x1fffffffLL) return WM_EUNSUPPORTED;                // 32-bit byte offsets inside one channel plane
     if (!f_ || !conv2_weight || !tok1 || !conv3_weight || !conv3_bias || !skip_scale2 || !out) return WM_ENULL;
     if (!aligned16(tok1) || (!out_nchw && !aligned16(out))) return WM_EALIGN;
     const int ngl = (int)((L + 63) / 64);

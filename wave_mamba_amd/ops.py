@@ -357,8 +357,9 @@ def _ss2d_core_prepared(params):
         check(lib.wm_ss2d_core_prep(*[_ptr(t) for t in f], _ptr(buf), D, N, R, _stream()), "wm_ss2d_core_prep")
     ev = torch.cuda.Event()
     ev.record(cur)
+    if key not in _CORE_PREP_CACHE:                  # one finalizer per parameter object, not one per rebuild
+        weakref.finalize(params[0], _CORE_PREP_CACHE.pop, key, None)
     _CORE_PREP_CACHE[key] = ([weakref.ref(p) for p in params], sig, buf, ev, cur.cuda_stream)
-    weakref.finalize(params[0], _CORE_PREP_CACHE.pop, key, None)
     return buf
 
 
