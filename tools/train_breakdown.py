@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Per-kernel GPU time of one steady-state training step (BASELINE config 3 on one GPU: batch 8 x 3 x 512 x 512), from
+torch.profiler.   python tools/train_breakdown.py [--steps 3]"""
+import argparse, os, sys, collections
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import wave_mamba_amd as wm
+import bench
+ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=3); args = ap.parse_args()
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+net = wm.WaveMamba(**bench.SHIPPED).train().to(dev)
+opt = wm.trainer.make_optimizer(net)
+g = torch.Generator().manual_seed(1234)
+lq, gt = torch.rand(8, 3, 512, 512, generator=g).to(dev), torch.rand(8, 3, 512, 512, generator=g).to(dev)
+for _ in range(3):
+    wm.trainer.train_step(net, opt, lq, gt)
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CUDA]) as prof:
+    for _ in range(args.steps):
+        wm.trainer.train_step(net, opt, lq, gt)
+    torch.cuda.synchronize()
+agg = collections.defaultdict(lambda: [0, 0.0])
+for e in prof.events():
+    if e.device_type == torch.autograd.DeviceType.CUDA:
+        k = e.name.split("(")[0][:110]
+        agg[k][0] += 1; agg[k][1] += e.device_time
+tot = sum(v[1] for v in agg.values())
+print(f"GPU kernel time per step: {tot / args.steps / 1e3:.2f} ms in {sum(v[0] for v in agg.values()) / args.steps:.0f} kernels")
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+    print(f"{v[0] / args.steps:7.1f} {v[1] / args.steps / 1e3:8.3f} ms  {k}")
