@@ -301,6 +301,24 @@ int wm_linear_wgrad(const float* gy, const float* x, float* dW, int64_t T, int O
 /* sums (C) = sum over batch and plane of x (B, C, H, W): the bias gradient of a convolution (training). */
 int wm_plane_sums(const float* x, float* sums, int B, int C, int H, int W, void* stream);
 
+/* --------------------------------------------------------------------------------------------
+ * Element-wise gates and scaled skips of the LFSSBlock TRAINING path, forward and backward:
+ *   wm_gate_fwd:      out = act(a) * b          act 1 = SiLU  (SS2D: y * F.silu(z),           wavemamba_arch.py:493)
+ *                                               act 2 = GELU  (ffn:  F.gelu(x1) * x2, erf form, :228-229)
+ *   wm_gate_bwd:      ga = g * b * act'(a),  gb = g * act(a)
+ *   wm_scale_add_fwd: out = x * scale[c] + o    (LFSSBlock: input * skip_scale + ..., x * skip_scale2 + ..., :525-526)
+ *   wm_scale_add_bwd: gx = g * scale[c],  gscale[c] = sum_{b, p} g * x   (zeroed here, accumulated with one atomic per block)
+ * Gate operands are (B, per_b) fp32 with batch strides in elements, so the two halves of a channel chunk are passed as
+ * views; scale_add operands are dense (B, C, L).  16-byte accesses when sizes / strides / pointers allow, scalar otherwise.
+ */
+int wm_gate_fwd(const float* a, const float* b, float* out, int act, int B, int64_t per_b, int64_t stride_a, int64_t stride_b,
+                int64_t stride_out, void* stream);
+int wm_gate_bwd(const float* a, const float* b, const float* g, float* ga, float* gb, int act, int B, int64_t per_b,
+                int64_t stride_a, int64_t stride_b, int64_t stride_g, int64_t stride_ga, int64_t stride_gb, void* stream);
+int wm_scale_add_fwd(const float* x, const float* scale, const float* o, float* out, int B, int C, int64_t L, void* stream);
+int wm_scale_add_bwd(const float* g, const float* x, const float* scale, float* gx, float* gscale, int B, int C, int64_t L,
+                     void* stream);
+
 /* Small-tensor steps of the HFE branch as single kernels (csrc/hfe.hip.h).  Forward only.
  *   wm_match_index   channel matching with every channel kept (wavemamba_arch.py:659-666, match_factor = 1):
  *                    index[b, c] = argmin_j (nx[b, c] + ny[b, j] - 2 G[b, c, j]) from wm_gram_fwd's outputs; (B, C) int32.

@@ -1626,3 +1626,47 @@ def test_training_step_at_config3_size():
     opt.step()
     moved = sum(int(not torch.equal(a, b.detach())) for a, b in zip(before, net.parameters()))
     assert moved == len(before)
+
+
+# ------------------------------------------------------------------------------------------------
+# gates and scaled skips of the LFSSBlock training path (wm_gate_*, wm_scale_add_*): forward + backward vs fp64 autograd
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 64, 16, 24), (1, 16, 5, 7), (3, 8, 9, 9)])
+@pytest.mark.parametrize("act", ["silu", "gelu"])
+def test_gate_and_glu_gate_vs_fp64_autograd(shape, act):
+    B, C, H, W = shape
+    gg = gen(C * H + W)
+    a, b, g = (torch.randn(B, C, H, W, generator=gg) * 2 for _ in range(3))
+    f = F.silu if act == "silu" else F.gelu
+    a64, b64 = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = f(a64) * b64
+    ra, rb = torch.autograd.grad(ref, (a64, b64), g.double())
+    ad, bd = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    out = wm.ops.gate_act(ad, bd, act)
+    ga, gb = torch.autograd.grad(out, (ad, bd), g.to(DEV))
+    assert_close(out.detach(), ref.detach().float(), 2e-6, f"{act} gate")
+    assert_close(ga, ra.float(), 2e-6, f"{act} gate d/da"); assert_close(gb, rb.float(), 2e-6, f"{act} gate d/db")
+    # chunked form: one (B, 2C, H, W) tensor in, one gradient tensor out; operands may also be channel-chunk views
+    t = torch.cat([a, b], 1).to(DEV).requires_grad_(True)
+    out2 = wm.ops.glu_gate(t, act)
+    (gt,) = torch.autograd.grad(out2, t, g.to(DEV))
+    assert torch.equal(out2, out) and torch.equal(gt[:, :C], ga) and torch.equal(gt[:, C:], gb)
+    v1, v2 = t.detach().chunk(2, dim=1)
+    assert torch.equal(wm.ops.gate_act(v1, v2, act), out)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 16, 24), (1, 8, 5, 7), (8, 32, 64, 64)])
+def test_scale_add_vs_fp64_autograd(shape):
+    B, C, H, W = shape
+    gg = gen(B * 100 + W)
+    x, o, g = (torch.randn(B, C, H, W, generator=gg) for _ in range(3))
+    s = torch.randn(C, generator=gg) * 0.3 + 1
+    x64, s64, o64 = (t.double().requires_grad_(True) for t in (x, s, o))
+    ref = x64 * s64.view(1, -1, 1, 1) + o64
+    rx, rs, ro = torch.autograd.grad(ref, (x64, s64, o64), g.double())
+    xd, sd, od = (t.to(DEV).requires_grad_(True) for t in (x, s, o))
+    out = wm.ops.scale_add(xd, sd, od)
+    gx, gs, go = torch.autograd.grad(out, (xd, sd, od), g.to(DEV))
+    assert_close(out.detach(), ref.detach().float(), 1e-6, "scale_add")
+    assert_close(gx, rx.float(), 1e-6, "scale_add d/dx"); assert_close(go, ro.float(), 1e-6, "scale_add d/do")
+    assert_close(gs, rs.float(), 2e-5, "scale_add d/dscale")       # a sum of B H W products of both signs, fp32 accumulation

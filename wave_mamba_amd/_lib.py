@@ -52,6 +52,10 @@ SIGNATURES = {
     "wm_image_post_u8": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "wm_linear_wgrad": (_i, [_p, _p, _p, _i64, _i, _i, _p]),
     "wm_plane_sums": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "wm_gate_fwd": (_i, [_p] * 3 + [_i, _i] + [_i64] * 4 + [_p]),
+    "wm_gate_bwd": (_i, [_p] * 5 + [_i, _i] + [_i64] * 6 + [_p]),
+    "wm_scale_add_fwd": (_i, [_p] * 4 + [_i, _i, _i64, _p]),
+    "wm_scale_add_bwd": (_i, [_p] * 5 + [_i, _i, _i64, _p]),
     "wm_match_index": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "wm_attn_fold": (_i, [_p] * 6 + [_i, _i, _i, _p]),
     "wm_skff_workspace_bytes": (_sz, [_i, _i]),

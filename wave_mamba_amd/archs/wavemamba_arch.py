@@ -143,7 +143,11 @@ class ffn(nn.Module):
         self.conv3 = nn.Conv2d(hidden // 2, num_feat, kernel_size=1)
 
     def forward(self, x):
-        gate, value = _dwconv(self.conv2, _conv(self.conv1, x)).chunk(2, dim=1)
+        t = _dwconv(self.conv2, _conv(self.conv1, x))
+        ops = _OpsBackend.impl
+        if torch.is_grad_enabled() and t.requires_grad and t.is_cuda and t.dtype == torch.float32 and hasattr(ops, "glu_gate"):
+            return _conv(self.conv3, ops.glu_gate(t, "gelu"))          # training: chunk + gate, one launch each way
+        gate, value = t.chunk(2, dim=1)
         return _conv(self.conv3, F.gelu(gate) * value)
 
 
@@ -343,10 +347,16 @@ class LFSSBlock(nn.Module):
         xs = F.silu(ops.dwconv3x3_train(xs, ss.conv2d.weight, ss.conv2d.bias))
         y = ops.ss2d_core(xs, ss.x_proj_weight, ss.dt_projs_weight, ss.dt_projs_bias, ss.A_logs, ss.Ds, merged=True)
         y = ops.layernorm2d_train(y.view_as(xs), ss.out_norm.weight, ss.out_norm.bias, ss.out_norm.eps)
-        o = ops.conv2d_train(y * F.silu(z), ss.out_proj.weight.view(C, D, 1, 1))
-        t = x * self.skip_scale.view(1, -1, 1, 1) + o
+        fused = hasattr(ops, "gate_act") and hasattr(ops, "scale_add")           # gates / skips: one HIP launch each way
+        gated = ops.gate_act(z, y, "silu") if fused and ops.gate_supported(z, y) else y * F.silu(z)
+        o = ops.conv2d_train(gated, ss.out_proj.weight.view(C, D, 1, 1))
+        if not fused:
+            t = x * self.skip_scale.view(1, -1, 1, 1) + o
+            u = ops.layernorm2d_train(t, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
+            return t * self.skip_scale2.view(1, -1, 1, 1) + self.conv_blk(u)
+        t = ops.scale_add(x, self.skip_scale, o)
         u = ops.layernorm2d_train(t, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
-        return t * self.skip_scale2.view(1, -1, 1, 1) + self.conv_blk(u)
+        return ops.scale_add(t, self.skip_scale2, self.conv_blk(u))
 
     def forward(self, input, x_size):
         B, L, C = input.shape

@@ -24,6 +24,7 @@
 #include "hfe.hip.h"
 #include "ss2d_bwd.hip.h"
 #include "imageio.hip.h"
+#include "gates.hip.h"
 
 namespace wm {
 
@@ -1459,6 +1460,75 @@ int wm_plane_sums(const float* x, float* sums, int B, int C, int H, int W, void*
     if (bpp > cap) bpp = cap;
     if (bpp < 1) bpp = 1;
     hipLaunchKernelGGL(plane_sums_kernel, dim3((unsigned)bpp, (unsigned)planes), dim3(256), 0, st, x, sums, C, HW, vec);
+    return launch_status();
+}
+
+// act: 1 = SiLU, 2 = GELU (erf).  a / b / out (and g / ga / gb) are (B, per_b) with batch strides in elements.
+int wm_gate_fwd(const float* a, const float* b, float* out, int act, int B, int64_t per_b, int64_t stride_a, int64_t stride_b,
+                int64_t stride_out, void* stream) {
+    if (B < 0 || per_b < 0) return WM_EINVAL;
+    if (act != 1 && act != 2) return WM_EUNSUPPORTED;
+    if (B == 0 || per_b == 0) return WM_OK;
+    if (!a || !b || !out) return WM_ENULL;
+    if (B > 65535) return WM_EUNSUPPORTED;
+    GateArgs p{a, b, nullptr, out, nullptr, nullptr, per_b, stride_a, stride_b, 0, stride_out, 0, 0};
+    const bool vec = per_b % 4 == 0 && stride_a % 4 == 0 && stride_b % 4 == 0 && stride_out % 4 == 0 && aligned16(a) &&
+                     aligned16(b) && aligned16(out);
+    const dim3 grid((unsigned)((per_b + 1023) / 1024), (unsigned)B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define WM_GATE(ACT) do { if (vec) hipLaunchKernelGGL((gate_kernel<ACT, false, true>), grid, block, 0, st, p);          \
+                          else hipLaunchKernelGGL((gate_kernel<ACT, false, false>), grid, block, 0, st, p); } while (0)
+    if (act == 1) WM_GATE(1); else WM_GATE(2);
+#undef WM_GATE
+    return launch_status();
+}
+
+int wm_gate_bwd(const float* a, const float* b, const float* g, float* ga, float* gb, int act, int B, int64_t per_b,
+                int64_t stride_a, int64_t stride_b, int64_t stride_g, int64_t stride_ga, int64_t stride_gb, void* stream) {
+    if (B < 0 || per_b < 0) return WM_EINVAL;
+    if (act != 1 && act != 2) return WM_EUNSUPPORTED;
+    if (B == 0 || per_b == 0) return WM_OK;
+    if (!a || !b || !g || !ga || !gb) return WM_ENULL;
+    if (B > 65535) return WM_EUNSUPPORTED;
+    GateArgs p{a, b, g, nullptr, ga, gb, per_b, stride_a, stride_b, stride_g, 0, stride_ga, stride_gb};
+    const bool vec = per_b % 4 == 0 && stride_a % 4 == 0 && stride_b % 4 == 0 && stride_g % 4 == 0 && stride_ga % 4 == 0 &&
+                     stride_gb % 4 == 0 && aligned16(a) && aligned16(b) && aligned16(g) && aligned16(ga) && aligned16(gb);
+    const dim3 grid((unsigned)((per_b + 1023) / 1024), (unsigned)B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define WM_GATE(ACT) do { if (vec) hipLaunchKernelGGL((gate_kernel<ACT, true, true>), grid, block, 0, st, p);           \
+                          else hipLaunchKernelGGL((gate_kernel<ACT, true, false>), grid, block, 0, st, p); } while (0)
+    if (act == 1) WM_GATE(1); else WM_GATE(2);
+#undef WM_GATE
+    return launch_status();
+}
+
+int wm_scale_add_fwd(const float* x, const float* scale, const float* o, float* out, int B, int C, int64_t L, void* stream) {
+    if (B < 0 || C < 0 || L < 0) return WM_EINVAL;
+    if (B == 0 || C == 0 || L == 0) return WM_OK;
+    if (!x || !scale || !o || !out) return WM_ENULL;
+    if ((long long)B * C > 65535) return WM_EUNSUPPORTED;
+    const bool vec = L % 4 == 0 && aligned16(x) && aligned16(o) && aligned16(out);
+    const dim3 grid((unsigned)((L + 1023) / 1024), (unsigned)(B * C)), block(256);
+    if (vec) hipLaunchKernelGGL(scale_add_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, x, scale, o, out, C, (long long)L);
+    else hipLaunchKernelGGL(scale_add_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, x, scale, o, out, C, (long long)L);
+    return launch_status();
+}
+
+int wm_scale_add_bwd(const float* g, const float* x, const float* scale, float* gx, float* gscale, int B, int C, int64_t L,
+                     void* stream) {
+    if (B < 0 || C < 0 || L < 0) return WM_EINVAL;
+    if (C == 0) return WM_OK;
+    if (!gscale) return WM_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(gscale, 0, (size_t)C * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    if (B == 0 || L == 0) return WM_OK;
+    if (!g || !x || !scale || !gx) return WM_ENULL;
+    if ((long long)B * C > 65535) return WM_EUNSUPPORTED;
+    const bool vec = L % 4 == 0 && aligned16(g) && aligned16(x) && aligned16(gx);
+    const dim3 grid((unsigned)((L + 1023) / 1024), (unsigned)(B * C)), block(256);
+    if (vec) hipLaunchKernelGGL(scale_add_bwd_kernel<true>, grid, block, 0, st, g, x, scale, gx, gscale, C, (long long)L);
+    else hipLaunchKernelGGL(scale_add_bwd_kernel<false>, grid, block, 0, st, g, x, scale, gx, gscale, C, (long long)L);
     return launch_status();
 }
 

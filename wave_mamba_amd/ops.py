@@ -657,6 +657,143 @@ class _NoCtx:
 
 
 # ------------------------------------------------------------------------------------------------
+# element-wise gates and scaled skips of the LFSSBlock training path (forward + backward in HIP)
+# ------------------------------------------------------------------------------------------------
+_ACTS = {"silu": 1, "gelu": 2}
+
+
+def _batch_strided(t):
+    """(B, ...) tensor whose batch items are dense: -> batch stride in elements, or None."""
+    if t.dim() < 2 or t.dtype != torch.float32:
+        return None
+    inner = t[0]
+    return t.stride(0) if inner.is_contiguous() else None
+
+
+class _Gate(torch.autograd.Function):
+    """out = act(a) * b (wm_gate_fwd / wm_gate_bwd): SS2D's `y * F.silu(z)` (reference :493) and the ffn's
+    `F.gelu(x1) * x2` (:228-229).  a, b: (B, C, H, W) fp32, each dense per batch item (channel-chunk views are fine)."""
+
+    @staticmethod
+    def forward(ctx, a, b, act):
+        lib = _lib.load()
+        B, per_b = a.shape[0], a[0].numel()
+        out = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            check(lib.wm_gate_fwd(_ptr(a), _ptr(b), _ptr(out), act, B, per_b, a.stride(0), b.stride(0), out.stride(0) if B else 0,
+                                  _stream()), "wm_gate_fwd")
+        ctx.save_for_backward(a, b)
+        ctx.act = act
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        a, b = ctx.saved_tensors
+        g = g.contiguous().float()
+        B, per_b = a.shape[0], a[0].numel()
+        ga, gb = torch.empty_like(g), torch.empty_like(g)
+        with torch.cuda.device(a.device):
+            check(lib.wm_gate_bwd(_ptr(a), _ptr(b), _ptr(g), _ptr(ga), _ptr(gb), ctx.act, B, per_b, a.stride(0), b.stride(0),
+                                  g.stride(0) if B else 0, ga.stride(0) if B else 0, gb.stride(0) if B else 0, _stream()),
+                  "wm_gate_bwd")
+        return ga, gb, None
+
+
+class _GluGate(torch.autograd.Function):
+    """out = act(t[:, :C]) * t[:, C:] for t (B, 2C, H, W): the gated ffn's chunk + gate as one node, so that the backward
+    writes ONE gradient tensor in t's layout (autograd's backward of a chunk would concatenate two)."""
+
+    @staticmethod
+    def forward(ctx, t, act):
+        lib = _lib.load()
+        t = t.contiguous().float()
+        B, C2 = t.shape[:2]
+        C = C2 // 2
+        per_b = C * t[0, 0].numel()
+        out = torch.empty((B, C) + tuple(t.shape[2:]), dtype=torch.float32, device=t.device)
+        with torch.cuda.device(t.device):
+            check(lib.wm_gate_fwd(_ptr(t), t.data_ptr() + 4 * per_b, _ptr(out), act, B, per_b, 2 * per_b, 2 * per_b, per_b,
+                                  _stream()), "wm_gate_fwd")
+        ctx.save_for_backward(t)
+        ctx.act = act
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (t,) = ctx.saved_tensors
+        g = g.contiguous().float()
+        B, per_b = t.shape[0], g[0].numel()
+        gt = torch.empty_like(t)
+        with torch.cuda.device(t.device):
+            check(lib.wm_gate_bwd(_ptr(t), t.data_ptr() + 4 * per_b, _ptr(g), _ptr(gt), gt.data_ptr() + 4 * per_b, ctx.act, B,
+                                  per_b, 2 * per_b, 2 * per_b, per_b, 2 * per_b, 2 * per_b, _stream()), "wm_gate_bwd")
+        return gt, None
+
+
+def glu_gate(t, act):
+    """act(t[:, :C]) * t[:, C:] for a (B, 2C, H, W) fp32 tensor, act in {"silu", "gelu"}, differentiable (_GluGate)."""
+    _lib.load()
+    _require_cuda("glu_gate", t)
+    if t.dim() != 4 or t.shape[1] % 2 or t.shape[0] > 65535:
+        raise NotImplementedError("glu_gate: a (B, 2C, H, W) tensor")
+    return _GluGate.apply(t, _ACTS[act])
+
+
+def gate_supported(a, b):
+    return (a.is_cuda and b.is_cuda and a.shape == b.shape and a.dim() == 4 and _batch_strided(a) is not None
+            and _batch_strided(b) is not None and a.shape[0] <= 65535)
+
+
+def gate_act(a, b, act):
+    """act(a) * b with act in {"silu", "gelu"} (exact erf GELU), differentiable; see _Gate."""
+    _lib.load()
+    _require_cuda("gate_act", a, b)
+    if not gate_supported(a, b):
+        raise NotImplementedError("gate_act: two fp32 (B, C, H, W) tensors, dense per batch item")
+    return _Gate.apply(a, b, _ACTS[act])
+
+
+class _ScaleAdd(torch.autograd.Function):
+    """out = x * scale[c] + o over (B, C, H, W) (wm_scale_add_fwd / _bwd): LFSSBlock's scaled skips (reference :525-526)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, o):
+        lib = _lib.load()
+        x, o, sc = x.contiguous().float(), o.contiguous().float(), scale.detach().contiguous().float()
+        B, C = x.shape[:2]
+        L = x[0, 0].numel()
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            check(lib.wm_scale_add_fwd(_ptr(x), _ptr(sc), _ptr(o), _ptr(out), B, C, L, _stream()), "wm_scale_add_fwd")
+        ctx.save_for_backward(x, sc)
+        ctx.scale_shape = scale.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, sc = ctx.saved_tensors
+        g = g.contiguous().float()
+        B, C = x.shape[:2]
+        L = x[0, 0].numel()
+        gx, gs = torch.empty_like(x), torch.empty(C, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib.wm_scale_add_bwd(_ptr(g), _ptr(x), _ptr(sc), _ptr(gx), _ptr(gs), B, C, L, _stream()), "wm_scale_add_bwd")
+        return gx, gs.view(ctx.scale_shape), g
+
+
+def scale_add(x, scale, o):
+    """x * scale.view(1, C, 1, 1) + o for (B, C, H, W) fp32 tensors and a C-element scale, differentiable."""
+    _lib.load()
+    _require_cuda("scale_add", x, scale, o)
+    if x.dim() != 4 or x.shape != o.shape or scale.numel() != x.shape[1] or x.shape[0] * x.shape[1] > 65535:
+        raise NotImplementedError("scale_add: (B, C, H, W) operands with B C <= 65535 and a C-element scale")
+    return _ScaleAdd.apply(x, scale, o)
+
+
+# ------------------------------------------------------------------------------------------------
 # depth-wise 3x3 convolution (+ bias, + SiLU) - inference path of SS2D.conv2d / ffn.conv2
 # ------------------------------------------------------------------------------------------------
 def dwconv3x3(x, weight, bias=None, act="none"):
