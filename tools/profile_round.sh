@@ -1,7 +1,8 @@
 #!/bin/bash
-# round-3 GPU job 10: the evidence for profiles/r03 on the shipped binary: rocprofv3 kernel stats of the bench command,
-# per-step breakdowns (multi-stream and single-stream), PMC traffic / busy fractions of the core
-cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r03prof; mkdir -p $O
+# The per-round evidence on the shipped binary (run on the GPU box: gpurun -- bash tools/profile_round.sh): rocprofv3 kernel
+# stats of the bench command, per-step breakdowns (multi-stream and single-stream), PMC traffic / busy fractions of the core.
+# Output under gpurun_out/prof_round/; copy what is to be kept into profiles/rNN/ and profiles/pmc_traffic.json.
+cd "${GRAFT_REPO_ROOT:-.}"; O=gpurun_out/prof_round; mkdir -p $O
 python -c "import wave_mamba_amd as wm; print('build_id', wm._lib.build_id())" > $O/build_id.txt 2>&1
 bash tools/profile_bench.sh $O/multi > $O/profile_multi.log 2>&1
 WM_TWO_STREAMS=0 bash tools/profile_bench.sh $O/single > $O/profile_single.log 2>&1
