@@ -40,6 +40,7 @@ struct ScanBwdArgs {
     float *wsPr, *wsG;             // adjoint summaries   [nchunks-1-chunk][chain]
     float *part;                   // [chunk][batch*dim][NP + kPartPad]
     int batch, dim, L, N, G, dpg, wpg, nchunks, softplus, atomic_bc;
+    int cpb;                       // chunks per block: a block walks cpb consecutive 16-step chunks (one prologue, fewer launches of tiny workgroups)
     // fused SS2D-core backward (MODE 1 forward time, MODE 2 reversed time; ss2d_bwd.hip.h): u = x and dy are
     // (batch, dim, L) planes of the scan layout, `A` holds A_logs, delta / B / C come from the record tile
     const float* rec;              // records of this direction, batch stride rec_bstride floats
@@ -226,14 +227,16 @@ __global__ __launch_bounds__(64) void selscan_bwd_reduce_kernel(ScanBwdArgs p) {
     __shared__ __attribute__((aligned(16))) float s_u[64 * kBRow], s_d[64 * kBRow], s_dy[64 * kBRow];
     __shared__ __attribute__((aligned(16))) float s_B[kBT * NP], s_C[kBT * NP];
     __shared__ __attribute__((aligned(16))) float s_dtr[MODE == 0 ? 4 : kBT * 4];
-    const int lane = threadIdx.x, chunk = blockIdx.x;
+    const int lane = threadIdx.x;
     const BwdTileIdx ix = bwd_decode(p, blockIdx.y, lane);
     const long long L = p.L;
-    const int t0 = chunk * kBT, t_end = min(p.L, t0 + kBT), tl = t_end - t0;
-
     v2f A2[NP / 2];
     bwd_load_A<NP, MODE>(p, ix.d, A2);
     const float bias = p.bias ? p.bias[ix.d] : 0.0f;
+    const int c_first = blockIdx.x * p.cpb, c_end = min(p.nchunks, c_first + p.cpb);
+    for (int chunk = c_first; chunk < c_end; ++chunk) {
+    if (chunk != c_first) __syncthreads();               // the previous chunk's tiles are consumed
+    const int t0 = chunk * kBT, t_end = min(p.L, t0 + kBT), tl = t_end - t0;
     if constexpr (MODE == 0) {
         const long long rowbase = ((long long)ix.b * p.dim + ix.ch0) * L;
         const long long bcbase = ((long long)ix.b * p.G + ix.g) * p.N * L;
@@ -293,6 +296,7 @@ __global__ __launch_bounds__(64) void selscan_bwd_reduce_kernel(ScanBwdArgs p) {
             *reinterpret_cast<float4*>(p.wsG + m + 4 * q) = make_float4(gl[2 * q].x, gl[2 * q].y, gl[2 * q + 1].x, gl[2 * q + 1].y);
         }
     }
+    }                                                    // next chunk of the block
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -306,17 +310,19 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
     __shared__ __attribute__((aligned(16))) float s_hs[NSUB * NP * 64];       // state at the start of each sub-tile
     __shared__ __attribute__((aligned(16))) float s_red[(2 * NP + (MODE == 0 ? 0 : 4)) * kBRow];   // dB, dC (, d dt_r) rows, [value][step]
     __shared__ __attribute__((aligned(16))) float s_dtr[MODE == 0 ? 4 : kBT * 4];
-    const int lane = threadIdx.x, chunk = blockIdx.x;
+    const int lane = threadIdx.x;
     const BwdTileIdx ix = bwd_decode(p, blockIdx.y, lane);
     const long long L = p.L;
-    const int t0 = chunk * kBT, t_end = min(p.L, t0 + kBT), tl = t_end - t0;
-
     v2f A2[NP / 2];
     bwd_load_A<NP, MODE>(p, ix.d, A2);
     const float bias = p.bias ? p.bias[ix.d] : 0.0f;
     const float Dd = p.D ? p.D[ix.d] : 0.0f;
     const long long rowbase = ((long long)ix.b * p.dim + ix.ch0) * L;
     const long long bcbase = ((long long)ix.b * p.G + ix.g) * p.N * L;
+    const int c_first = blockIdx.x * p.cpb, c_end = min(p.nchunks, c_first + p.cpb);
+    for (int chunk = c_first; chunk < c_end; ++chunk) {
+    if (chunk != c_first) __syncthreads();               // the previous chunk's tiles are consumed
+    const int t0 = chunk * kBT, t_end = min(p.L, t0 + kBT), tl = t_end - t0;
     if constexpr (MODE == 0) {
         bwd_load_rows<VEC>(p.u + rowbase, L, t0, t_end, ix.nch, lane, s_u);
         bwd_load_rows<VEC>(p.delta + rowbase, L, t0, t_end, ix.nch, lane, s_d);
@@ -602,6 +608,7 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
         *reinterpret_cast<float4*>(pr + NP + 4) = make_float4(dwp[2], dwp[3], 0.f, 0.f);
     }
     }
+    }                                                    // next chunk of the block
 }
 
 // dA (dim, N), dD (dim), dbias (dim) = sums of the per-chunk partials over chunks and batch.

@@ -438,10 +438,19 @@ static int bwd_plan(BwdPlan& pl, int batch, int dim, int L, int N, int G) {
     return WM_OK;
 }
 
+// chunks per block of the two backward kernels: enough blocks to fill the chip several times over, at most 8 chunks each
+static int bwd_chunks_per_block(const BwdPlan& pl) {
+    const long long blocks1 = (long long)pl.nchunks * pl.rows;
+    int cpb = (int)(blocks1 / (256LL * 32));
+    return cpb < 1 ? 1 : (cpb > 8 ? 8 : cpb);
+}
+
 template <int NP, bool VEC>
-static int bwd_launch(const ScanBwdArgs& a, const BwdPlan& pl, float* seg, float* dA, float* dD, float* dbias,
+static int bwd_launch(const ScanBwdArgs& a0, const BwdPlan& pl, float* seg, float* dA, float* dD, float* dbias,
                       hipStream_t st) {
-    const dim3 grid((unsigned)pl.nchunks, (unsigned)pl.rows), block(64);
+    ScanBwdArgs a = a0;
+    a.cpb = bwd_chunks_per_block(pl);
+    const dim3 grid((unsigned)((pl.nchunks + a.cpb - 1) / a.cpb), (unsigned)pl.rows), block(64);
     ProfScope ps(12, st);
     if (pl.nchunks > 1) {
         hipLaunchKernelGGL((selscan_bwd_reduce_kernel<NP, VEC, 0>), grid, block, 0, st, a);
@@ -980,7 +989,8 @@ static int core_bwd_plan(CoreBwdPlan& pl, int B, int D, int H, int W, int N, int
 template <int NP, bool VEC, int MODE>
 static void core_bwd_dir(ScanBwdArgs a, const CoreBwdPlan& pl, float* seg, const float* A_logs_k, float* dA_logs_k,
                          float* dD_k, float* dbias_k, float* dWdt_k, hipStream_t st) {
-    const dim3 grid((unsigned)pl.scan.nchunks, (unsigned)pl.scan.rows), block(64);
+    a.cpb = bwd_chunks_per_block(pl.scan);
+    const dim3 grid((unsigned)((pl.scan.nchunks + a.cpb - 1) / a.cpb), (unsigned)pl.scan.rows), block(64);
     if (pl.scan.nchunks > 1) {
         hipLaunchKernelGGL((selscan_bwd_reduce_kernel<NP, VEC, MODE>), grid, block, 0, st, a);
         launch_carry(a.wsP, a.wsH, seg, pl.scan.chains, pl.scan.nchunks, st);
