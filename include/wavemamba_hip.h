@@ -123,8 +123,9 @@ int wm_selscan_bwd(const float* u, const float* delta, const float* A, const flo
  *     transposed back).  merged != 0: only y_row_fwd is written and holds the SUM of the four
  *     (what SS2D.forward computes next, :490, added in the reference's order); the other three
  *     pointers may be NULL.  wm_lfss_mid_fwd can add the four un-merged outputs while it reads them.
- *   Supported: N <= 32, R <= 4, D <= 64 (else WM_EUNSUPPORTED: use wm_selscan_fwd); N > 16 needs W % 4 == 0.
- *   x and the y buffers must be 16-byte aligned when W % 4 == 0 (WM_EALIGN).
+ *   Supported: N <= 32, R <= 4, D <= 64, D * H * W < 2^31 (else WM_EUNSUPPORTED: use wm_selscan_fwd); any H, W.
+ *   W % 4 == 0 with 16-byte aligned x / y buffers: 16-byte tile accesses; otherwise (odd widths, fp32 planes only)
+ *   the same kernels with element-wise tile accesses, slower per position.
  *   The workspace size depends on `merged` (three temporary y buffers).
  */
 size_t wm_ss2d_core_fwd_workspace_bytes(int B, int D, int H, int W, int N, int R, int merged);
@@ -132,11 +133,11 @@ size_t wm_ss2d_core_fwd_workspace_bytes(int B, int D, int H, int W, int N, int R
  *   out[0..9] = waves per workgroup, rows per column segment, segments per column, column tiles, column workgroup slots
  *   per direction, steps per row chunk, row chunks, row workgroups per direction, workgroups per launch, estimated
  *   launch length in row-tile times x 100 under the dispatch model (wavemamba_hip.hip: core_makespan).
- *   W % 4 != 0 (first-generation kernels): WM_EUNSUPPORTED.
  */
 int wm_ss2d_core_plan(int B, int D, int H, int W, int N, int R, int* out10);
 /*   plane_dtype: storage type of x and of the y buffers, WM_F32 or WM_BF16 (bf16-storage mode: bf16 planes between
- *   the kernels, fp32 tiles / projection / state inside; needs W % 4 == 0).
+ *   the kernels, fp32 tiles / projection / state inside; needs W % 4 == 0 and 16-byte aligned planes: WM_EUNSUPPORTED /
+ *   WM_EALIGN otherwise).
  */
 /*   prepared: NULL, or the buffer wm_ss2d_core_prep filled from THESE parameters (wm_ss2d_core_prep_bytes(N) bytes,
  *   16-byte aligned): the bf16-split x_proj weight fragments, A * log2(e) and the per-channel constants the kernels
@@ -342,9 +343,9 @@ int wm_skff_fwd(const float* x0, const float* x1, const float* x2, const float* 
  * class).  Disabled by default; when disabled the library records nothing.
  *   kernel ids: 0 haar analysis (dwt fwd / iwt bwd), 1 haar synthesis (iwt fwd / dwt bwd),
  *               2 scan chunk-reduce, 3 scan carry, 4 scan chunk-scan (drop-in op), 5 lfss glue (in/mid/out),
- *               6 ss2d projection (first-generation core / backward), 7 depth-wise conv, 8 ss2d core chunk-scan
- *               (+ the merged-output sum), 9 first-generation core chunk-scan (W % 4 != 0 only), 10 ss2d core
- *               chunk-reduce, 11 first-generation chunk-reduce, 12 selective-scan backward (all phases),
+ *               6 ss2d projection records (core backward), 7 depth-wise conv, 8 ss2d core chunk-scan
+ *               (+ the merged-output sum), 9 unused (the first-generation core's chunk-scan until round 3), 10 ss2d core
+ *               chunk-reduce (+ the parameter prep), 11 unused, 12 selective-scan backward (all phases),
  *               13 dense 3x3 convolution, 14 1x1 convolution, 15 SKFF (all three kernels)
  * wm_prof_enable(mask): bit k of `mask` switches recording for kernel id k (0 = off, ~0u = every class);
  * a non-zero mask also clears what was recorded before.  Two hipEventRecord calls cost ~10 us of stream

@@ -76,7 +76,8 @@ def test_core_work_split_is_consistent():
     lib = _lib.load()
     out = (ctypes.c_int * 10)()
     for (B, H, W, N) in [(1, 1088, 1920, 16), (1, 544, 960, 16), (1, 272, 480, 16), (1, 2048, 2048, 32), (8, 256, 256, 16),
-                         (2, 24, 40, 16), (1, 8, 12, 16), (1, 33, 72, 32), (1, 16, 2048, 16), (1, 8192, 16, 16)]:
+                         (2, 24, 40, 16), (1, 8, 12, 16), (1, 33, 72, 32), (1, 16, 2048, 16), (1, 8192, 16, 16),
+                         (1, 10, 14, 16), (1, 9, 7, 32), (2, 33, 71, 16), (1, 1, 1, 16)]:      # odd widths: same plan, element-wise tiles
         assert lib.wm_ss2d_core_plan(B, 64, H, W, N, 2, out) == 0
         nw, seg, nseg, ctiles, cwgs, rchunk, rnchunks, rwgs, grid, span = list(out)
         L = H * W
@@ -89,6 +90,5 @@ def test_core_work_split_is_consistent():
         assert lib.wm_ss2d_core_plan(B, 64, H, W, N, 2, again) == 0 and list(again) == list(out)
     assert lib.wm_ss2d_core_plan(1, 64, 1088, 1920, 16, 2, out) == 0
     assert out[2] == 1 and out[5] // 16 < 1088 // 16            # one segment per column; row chunks shorter than a column
-    assert lib.wm_ss2d_core_plan(1, 64, 10, 14, 16, 2, out) == -5      # W % 4 != 0: first-generation kernels, no plan
     assert lib.wm_ss2d_core_plan(1, 64, 8, 8, 64, 2, out) == -5        # N > 32
     assert lib.wm_ss2d_core_prep_bytes(16) > 0 and lib.wm_ss2d_core_prep_bytes(33) == 0

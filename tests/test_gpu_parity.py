@@ -419,6 +419,14 @@ def random_core_case(B, D, H, W, N, R, seed):
     (2, 64, 33, 72, 32, 4),      # d_state 32, dt_rank 4, odd H, batch 2
     (1, 64, 50, 52, 16, 4),      # dt_rank 4 at d_state 16; W % 16 != 0, H % 16 != 0
     (1, 32, 272, 480, 16, 1),    # UHD level-3 map at wf = 16: column segments
+    (1, 64, 9, 7, 32, 2),        # d_state 32 on an odd map (element-wise tile accesses; the first-generation kernels
+                                 # that served odd widths until round 3 stopped at d_state 16)
+    (2, 64, 33, 71, 16, 2),      # odd width, several column tiles and row chunks, batch 2 (odd plane offsets)
+    (1, 40, 37, 130, 32, 3),     # W % 4 == 2, d_state 32, dt_rank 3, D < 64
+    (1, 64, 65, 33, 16, 2),      # L odd, several row chunks: reversed row tiles start before the plane
+    (1, 8, 1, 1, 16, 1),         # a single position
+    (1, 64, 1, 37, 16, 2),       # a single row / a single column
+    (1, 64, 37, 1, 16, 2),
 ])
 def test_ss2d_core_vs_oracle(B, D, H, W, N, R):
     case = random_core_case(B, D, H, W, N, R, seed=H * 100 + W)
@@ -427,6 +435,20 @@ def test_ss2d_core_vs_oracle(B, D, H, W, N, R):
     for i, (a, b) in enumerate(zip(got, want)):
         assert_close(a, b, TOL, f"core y{i}")
     assert_close(wm.ops.ss2d_core(*cu(*case), merged=True), sum(want), TOL, "merged")
+
+
+def test_ss2d_core_unaligned_planes():
+    """x at a 4-byte-aligned address that is not 16-byte aligned (a view into a larger buffer): the core takes its
+    element-wise tile accesses instead of refusing the call; same results as from an aligned copy."""
+    case = random_core_case(1, 64, 24, 40, 16, 2, seed=5)
+    dev = cu(*case)
+    big = torch.empty(dev[0].numel() + 1, device=DEV)
+    xv = big[1:].view_as(dev[0]); xv.copy_(dev[0])
+    assert xv.data_ptr() % 16 == 4 and xv.is_contiguous()
+    want = wm.ops.ss2d_core(*dev)
+    got = wm.ops.ss2d_core(xv, *dev[1:])
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), f"y{i}: element-wise and 16-byte tile accesses differ"
 
 
 def core_vs_unfused_and_oracle_subset(H, W, N, seed, channels, what):
@@ -576,9 +598,9 @@ def test_core_abi_error_codes_from_real_calls():
     p = lambda t: t.data_ptr()
     yp = [p(ys[i]) for i in range(4)]
 
-    def call(xp=p(x), wsp=p(ws), wsb=need, y0=yp[0], n=N, h=H, prep=None):
+    def call(xp=p(x), wsp=p(ws), wsb=need, y0=yp[0], n=N, h=H, prep=None, pd=0):
         return lib.wm_ss2d_core_fwd(xp, p(Wx), p(Wdt), p(bias), p(A_logs), p(Ds), y0, yp[1], yp[2], yp[3], 0, wsp, wsb,
-                                    prep, B, D, h, W, n, R, 0, torch.cuda.current_stream().cuda_stream)
+                                    prep, B, D, h, W, n, R, pd, torch.cuda.current_stream().cuda_stream)
     assert call() == 0
     # the prepared-parameters form gives the same bits as the self-preparing call
     y_self = ys.clone()
@@ -591,7 +613,8 @@ def test_core_abi_error_codes_from_real_calls():
     assert lib.wm_ss2d_core_prep_bytes(64) == 0
     assert call(wsb=need - 1) == -4                       # WM_EWORKSPACE
     assert call(wsp=p(ws) + 4) == -3                      # WM_EALIGN (workspace)
-    assert call(xp=p(x) + 4) == -3                        # WM_EALIGN (x: 16-byte tile loads)
+    assert call(xp=p(x) + 2) == -3                        # WM_EALIGN (x not even element-aligned; + 4 would run: element-wise tiles)
+    assert call(xp=p(x) + 4, pd=1) == -3                  # WM_EALIGN (bf16 planes exist with 16-byte tile accesses only)
     assert call(y0=None) == -2                            # WM_ENULL
     assert call(n=64) == -5                               # WM_EUNSUPPORTED
     assert call(h=-1) == -1                               # WM_EINVAL
@@ -735,8 +758,8 @@ def test_lfss_glue_kernels_c32_vs_fp64(B, L, nchw):
 
 def test_lfss_block_d_state_32_on_the_fused_core():
     """BASELINE config 5 flavour: LFSSBlock(32, d_state=32) takes the fused HIP block path (N = 32 instantiation of
-    the SS2D core).  Checked against the same block on the CPU oracle backend; with a width that is not a multiple of
-    4 the block falls back to the direction glue + the drop-in selective_scan_fn (N = 32 kernels), same check."""
+    the SS2D core).  Checked against the same block on the CPU oracle backend; a width that is not a multiple of 4
+    takes the same fused path (element-wise tile accesses), same check."""
     torch.manual_seed(5)
     blk = arch.LFSSBlock(32, d_state=32, expand=2.0).eval()
     for (H, W) in ((48, 40), (20, 30)):
@@ -749,7 +772,7 @@ def test_lfss_block_d_state_32_on_the_fused_core():
             oracle_backend.set_ops_backend(prev)
         blk = blk.to(DEV)
         with torch.no_grad():
-            assert blk._fused_ok(x.to(DEV), W) == (W % 4 == 0)
+            assert blk._fused_ok(x.to(DEV), W, H)
             got = blk(x.to(DEV), [H, W])
         assert_close(got, want, TOL, f"LFSSBlock d_state=32 {H}x{W}")
 

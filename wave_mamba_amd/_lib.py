@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("WAVEMAMBA_HIP_LIB") or os.path.join(HERE, "libwavemam
 
 WM_F32, WM_BF16 = 0, 1
 WM_PROF_NKERNELS = 16
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _c = ctypes
 _p, _i, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t

@@ -1,30 +1,16 @@
-// ss2d.hip.h - fused SS2D four-direction scan core for gfx950 (MI355X).
+// ss2d.hip.h - projection records of the SS2D core for gfx950 (MI355X): the forward half of the core's BACKWARD.
 //
-// Replaces SS2D.forward_core (/root/reference/basicsr/archs/wavemamba_arch.py:446-478):
-//   xs = [x row-major | x column-major | their flips]                         (:451-452)
+// SS2D.forward_core (/root/reference/basicsr/archs/wavemamba_arch.py:446-478) computes per direction k and position
 //   x_dbl[k] = x_proj_weight[k] . xs[k]  -> split (dt_r | B | C)              (:453-454)
-//   dts[k]   = dt_projs_weight[k] . dt_r                                      (:455)
-//   y[k]     = selective_scan(xs[k], dts[k], -exp(A_logs), B, C, Ds, bias, softplus)   (:465-471)
-//   flips / transposes back to row-major                                      (:474-478)
-// without materialising xs / x_dbl / dts / flips / transposes (9.5 GB of intermediates per
-// LFSSBlock at UHD level 1 in the reference).  Three kernel families:
-//
-//  1. ss2d_proj_kernel - the only GEMM-shaped piece: per position a (4 x (R+2N)) x D_in mat-vec,
-//     i.e. an (136 x 64) x (64 x L) GEMM at the shipped config.  fp32-input MFMA
-//     (v_mfma_f32_16x16x4_f32, exact fp32 = an fmaf chain): A = the stacked weights, kept in VGPRs
-//     for the whole kernel (9 row-tiles x 16 K-steps), B = x read straight from NCHW in fragment
-//     layout (16 lanes x 8 B = one 128-B line per channel row), D = per-position records
-//         rec[b][k][p] = [dt_r(4) | B(16) | C(16)]   (p = row-major position, 144 B, 16-B aligned)
-//     written as 16-byte pieces.  Every direction's record lives at the ROW-MAJOR position, so no
-//     direction ever needs a transposed copy.
-//  2. ss2d_row_kernel (k = 0, 2) - lane = channel, time = row-major l (reversed for k = 2): the
-//     chunked scan of selscan.hip.h with u read from x, dt rebuilt in-register from dt_r
-//     (R FMAs + softplus per step) and B/C taken from the record tile (plain linear LDS copy).
-//  3. ss2d_col_kernel (k = 1, 3) - lanes = 64 adjacent COLUMNS, time = row h (reversed for k = 3):
-//     u loads and y stores are coalesced straight in NCHW, every lane scans its own column segment;
-//     a workgroup (4 waves x 2 channels) shares the record rows through LDS; A / dt weights of a
-//     wave's channels are wave-uniform (SGPR operands of the packed ops).
-//  All three write y in row-major (B, D, L), optionally accumulating (y1+y2+y3+y4 of :490).
+// The forward (ss2d_core.hip.h) keeps these records in LDS and never writes them; the backward re-runs the projection
+// and stores them, because every backward kernel reads them several times:
+//     rec[b][k][p] = [dt_r(4) | B(N) | C(N)]   (p = ROW-MAJOR position for every direction: no transposed copies)
+//  - ss2d_proj_kernel   (N <= 16): all four directions in one pass, 36-float records, fp32-input MFMA
+//    (v_mfma_f32_16x16x4_f32, exact fp32 = an fmaf chain): A = the stacked weights, B = x read straight from NCHW in
+//    fragment layout (16 lanes x 8 B = one 128-B line per channel row), D = records written as 16-byte pieces;
+//  - ss2d_proj32_kernel (N <= 32): one direction pair per pass, 68-float records.
+// (The first-generation forward - separate row / column scan kernels reading these records from HBM - lived here until
+// round 3; the second-generation core now takes every shape, odd widths included.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -256,463 +242,6 @@ __global__ __launch_bounds__(64 * kProjWaves, 2) void ss2d_proj32_kernel(Ss2dArg
 #pragma unroll
                     for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(rk + kRecPad + 4 * g4 + 16 * q) = acc[1 + 4 * pi + q][i];
                 }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// 2. row-major directions (k = 0 forward, k = 2 reversed): lane = channel
-// ------------------------------------------------------------------------------------------------
-template <int PHASE, bool REV, bool VEC>
-__global__ __launch_bounds__(64) void ss2d_row_kernel(Ss2dArgs p) {
-    constexpr int NP = 16;
-    constexpr int T = 16;                            // steps per tile
-    constexpr int ROW = 20;                          // padded LDS row of the u tile
-    constexpr int NREC4 = (T * kRS / 4 + 63) / 64;   // float4 per lane of a record tile (144 -> 3)
-    __shared__ __attribute__((aligned(16))) float s_u[64 * ROW];
-    __shared__ __attribute__((aligned(16))) float s_rec[T * kRS];
-
-    const int lane = threadIdx.x;
-    const int chunk = blockIdx.x, b = blockIdx.y, k = p.k;
-    const bool live = lane < p.D;
-    const int d = live ? lane : 0;
-    const int kd = k * p.D + d;
-    const long long L = p.L;
-    const int t_begin = chunk * p.chunk_len;
-    const int t_end = min(p.L, t_begin + p.chunk_len);
-
-    // parameter loads first, unconditional with clamped indices (see the column kernel)
-    v2f A2[NP / 2];
-    float araw[NP], wdt[kRecPad];
-#pragma unroll
-    for (int n = 0; n < NP; ++n) araw[n] = p.A_logs[(long long)kd * p.N + min(n, p.N - 1)];
-#pragma unroll
-    for (int r = 0; r < kRecPad; ++r) wdt[r] = p.Wdt[(long long)kd * p.R + min(r, p.R - 1)];
-    const float bias = p.dtb[kd];
-    const float Dd = p.Ds[kd];
-#pragma unroll
-    for (int n = 0; n < NP; ++n) {
-        const float a = (n < p.N) ? -expf(araw[n]) * 1.4426950408889634f : 0.0f;
-        if (n & 1) A2[n / 2].y = a; else A2[n / 2].x = a;
-    }
-#pragma unroll
-    for (int r = 0; r < kRecPad; ++r) wdt[r] = (r < p.R) ? wdt[r] : 0.0f;
-
-    v2f h[NP / 2];
-    const long long wsrow = ((long long)chunk * p.B * p.D + (long long)b * p.D + d) * NP;
-    if (PHASE == 3 && chunk > 0) {
-#pragma unroll
-        for (int q = 0; q < NP / 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4*>(p.wsH + wsrow + 4 * q);
-            h[2 * q] = (v2f){v.x, v.y}; h[2 * q + 1] = (v2f){v.z, v.w};
-        }
-    } else {
-#pragma unroll
-        for (int n = 0; n < NP / 2; ++n) h[n] = splat(0.0f);
-    }
-    float sum_dt = 0.0f;
-
-    const float* xb = p.x + (long long)b * p.D * L;
-    const float* recb = p.rec + ((long long)b * 4 + k) * L * kRS;
-    float* yb = (PHASE == 3) ? p.y + (long long)b * p.D * L : nullptr;
-
-    float4 ru[4], rr[NREC4], ry[4];                 // ry: previous directions' y (accumulate mode)
-    const int trow = lane >> 2, tq = lane & 3;
-
-    // tile at step t0 covers positions plo .. plo+15 (column c <-> position plo + c);
-    // step tt uses column tt (forward) or 15 - tt (reversed)
-    auto tile_lo = [&](int t0) -> long long { return REV ? (L - 16 - t0) : (long long)t0; };
-
-    auto fetch = [&](int t0) {
-        const long long plo = tile_lo(t0);
-        const int tl = min(T, t_end - t0);
-        const int c_lo = REV ? T - tl : 0, c_hi = REV ? T : tl;          // valid columns [c_lo, c_hi)
-        const int c = 4 * tq;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 16 * i + trow;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < p.D) {
-                const float* q = xb + (long long)r * L + plo + c;
-                if constexpr (VEC) {
-                    if (c >= c_lo && c < c_hi) v = *reinterpret_cast<const float4*>(q);
-                } else {
-                    if (c + 0 >= c_lo && c + 0 < c_hi) v.x = q[0];
-                    if (c + 1 >= c_lo && c + 1 < c_hi) v.y = q[1];
-                    if (c + 2 >= c_lo && c + 2 < c_hi) v.z = q[2];
-                    if (c + 3 >= c_lo && c + 3 < c_hi) v.w = q[3];
-                }
-            }
-            ru[i] = v;
-            if (PHASE == 3) {
-                float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.accumulate && r < p.D) {
-                    const float* q = yb + (long long)r * L + plo + c;
-                    if constexpr (VEC) {
-                        if (c >= c_lo && c < c_hi) e = *reinterpret_cast<const float4*>(q);
-                    } else {
-                        if (c + 0 >= c_lo && c + 0 < c_hi) e.x = q[0];
-                        if (c + 1 >= c_lo && c + 1 < c_hi) e.y = q[1];
-                        if (c + 2 >= c_lo && c + 2 < c_hi) e.z = q[2];
-                        if (c + 3 >= c_lo && c + 3 < c_hi) e.w = q[3];
-                    }
-                }
-                ry[i] = e;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NREC4; ++j) {
-            const int f = lane + 64 * j;                       // float4 index inside the record tile
-            const int col = (4 * f) / kRS;
-            rr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            const bool used = PHASE == 3 || (4 * f - col * kRS) < kRecPad + NP;    // reduce phase: no C
-            if (f < T * kRS / 4 && col >= c_lo && col < c_hi && used)
-                rr[j] = *reinterpret_cast<const float4*>(recb + plo * kRS + 4 * f);
-        }
-    };
-    float4 yold[4];
-    auto stage = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4*>(&s_u[(16 * i + trow) * ROW + 4 * tq]) = ru[i];
-            if (PHASE == 3) yold[i] = ry[i];
-        }
-#pragma unroll
-        for (int j = 0; j < NREC4; ++j) {
-            const int f = lane + 64 * j;
-            if (f < T * kRS / 4) *reinterpret_cast<float4*>(&s_rec[4 * f]) = rr[j];
-        }
-    };
-
-    fetch(t_begin);
-    for (int t0 = t_begin; t0 < t_end; t0 += T) {
-        stage();
-        __syncthreads();
-        if (t0 + T < t_end) fetch(t0 + T);
-        const int tl = min(T, t_end - t0);
-
-#pragma unroll
-        for (int q = 0; q < T / 4; ++q) {
-            if (4 * q < tl) {
-                const int cq = REV ? 3 - q : q;                          // column quad of this step quad
-                const float4 u4 = *reinterpret_cast<const float4*>(&s_u[lane * ROW + 4 * cq]);
-                const float uu[4] = {REV ? u4.w : u4.x, REV ? u4.z : u4.y, REV ? u4.y : u4.z, REV ? u4.x : u4.w};
-                float dts[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int col = REV ? 15 - (4 * q + j) : 4 * q + j;
-                    const float4 dr = *reinterpret_cast<const float4*>(&s_rec[col * kRS]);
-                    dts[j] = fmaf(wdt[1], dr.y, fmaf(wdt[0], dr.x, bias));
-                    if (p.R > 2) dts[j] = fmaf(wdt[3], dr.w, fmaf(wdt[2], dr.z, dts[j]));               // uniform
-                }
-                const v2f sa = softplus2((v2f){dts[0], dts[1]}), sb = softplus2((v2f){dts[2], dts[3]});
-                dts[0] = sa.x; dts[1] = sa.y; dts[2] = sb.x; dts[3] = sb.y;
-                float yy[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int tt = 4 * q + j;
-                    if (tt < tl) {
-                        const int col = REV ? 15 - tt : tt;
-                        const float dt = dts[j], ut = uu[j];
-                        const v2f dt2 = splat(dt), du2 = splat(dt * ut);
-                        if (PHASE == 1) sum_dt += dt;
-                        v2f y2 = splat(0.0f);
-                        const float* rc = &s_rec[col * kRS + kRecPad];
-#pragma unroll
-                        for (int r = 0; r < NP / 4; ++r) {
-                            const float4 bv = *reinterpret_cast<const float4*>(rc + 4 * r);
-                            const v2f a0 = exp2_2(dt2 * A2[2 * r]);
-                            const v2f a1 = exp2_2(dt2 * A2[2 * r + 1]);
-                            h[2 * r] = a0 * h[2 * r] + du2 * (v2f){bv.x, bv.y};
-                            h[2 * r + 1] = a1 * h[2 * r + 1] + du2 * (v2f){bv.z, bv.w};
-                            if (PHASE == 3) {
-                                const float4 cv = *reinterpret_cast<const float4*>(rc + NP + 4 * r);
-                                y2 = (v2f){cv.x, cv.y} * h[2 * r] + y2;
-                                y2 = (v2f){cv.z, cv.w} * h[2 * r + 1] + y2;
-                            }
-                        }
-                        if (PHASE == 3) yy[j] = fmaf(Dd, ut, y2.x + y2.y);
-                    }
-                }
-                if (PHASE == 3)
-                    *reinterpret_cast<float4*>(&s_u[lane * ROW + 4 * cq]) =
-                        REV ? make_float4(yy[3], yy[2], yy[1], yy[0]) : make_float4(yy[0], yy[1], yy[2], yy[3]);
-            }
-        }
-        __syncthreads();
-        if (PHASE == 3) {
-            const long long plo = tile_lo(t0);
-            const int c_lo = REV ? T - tl : 0, c_hi = REV ? T : tl;
-            const int c = 4 * tq;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 16 * i + trow;
-                if (r < p.D) {
-                    const float4 v = *reinterpret_cast<const float4*>(&s_u[r * ROW + c]);
-                    float* o = yb + (long long)r * L + plo + c;
-                    const float4 e = yold[i];
-                    if constexpr (VEC) {
-                        if (c >= c_lo && c < c_hi)
-                            *reinterpret_cast<float4*>(o) = make_float4(v.x + e.x, v.y + e.y, v.z + e.z, v.w + e.w);
-                    } else {
-                        const float vv[4] = {v.x + e.x, v.y + e.y, v.z + e.z, v.w + e.w};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (c + j >= c_lo && c + j < c_hi) o[j] = vv[j];
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-
-    if (PHASE == 1 && live) {
-#pragma unroll
-        for (int q = 0; q < NP / 4; ++q) {
-            *reinterpret_cast<float4*>(p.wsH + wsrow + 4 * q) =
-                make_float4(h[2 * q].x, h[2 * q].y, h[2 * q + 1].x, h[2 * q + 1].y);
-            const v2f p0 = exp2_2(splat(sum_dt) * A2[2 * q]), p1 = exp2_2(splat(sum_dt) * A2[2 * q + 1]);
-            *reinterpret_cast<float4*>(p.wsP + wsrow + 4 * q) = make_float4(p0.x, p0.y, p1.x, p1.y);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// 3. column-major directions (k = 1 forward, k = 3 reversed): lanes = 64 adjacent columns
-//    scan order l = w*H + h: time tau = h (k=1) or H-1-h (k=3); column order omega = w or W-1-w;
-//    chunk = (omega, segment of tau), chunk index = omega * nseg + seg.
-// ------------------------------------------------------------------------------------------------
-#ifndef WM_COLT
-#define WM_COLT 4
-#endif
-#ifndef WM_COLWAVES
-#define WM_COLWAVES 4
-#endif
-#ifndef WM_COL_LB
-#define WM_COL_LB 1
-#endif
-#ifndef WM_COL_SLOTS
-#define WM_COL_SLOTS 512     // resident column-scan workgroups: 256 compute units x 2
-#endif
-constexpr int kColT = WM_COLT;  // record rows per LDS batch
-constexpr int kColCH = 2;       // channels per wave
-constexpr int kColWaves = WM_COLWAVES;   // waves per workgroup -> 2 * kColWaves channels per workgroup
-
-// LDS image of a record row batch: kColT rows x 64 columns x RSL floats.  The chunk-scan phase keeps whole records
-// (36 floats); the chunk-reduce phase never reads C and keeps only [dt_r | B] (20 floats).  Both strides are
-// conflict-free for the 16-byte B/C reads (every 16-lane group of ds_read_b128 lands on 64 distinct banks).
-template <int PHASE> struct ColRec { static constexpr int RSL = PHASE == 3 ? kRS : kRecPad + 16; };
-template <int PHASE> constexpr int col_lds_bytes() { return 2 * kColT * 64 * ColRec<PHASE>::RSL * 4; }
-
-template <int PHASE, bool REV>
-__global__ __launch_bounds__(64 * kColWaves, WM_COL_LB) void ss2d_col_kernel(Ss2dArgs p) {
-    constexpr int NP = 16;
-    constexpr int RSL = ColRec<PHASE>::RSL;          // floats per record in LDS
-    constexpr int CH4 = RSL / 4;                     // 16-byte pieces per record (9 or 5)
-    constexpr int BUF = kColT * 64 * RSL;            // floats per buffer
-    extern __shared__ __attribute__((aligned(16))) float s_col[];           // 2 buffers
-
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int k = p.k;
-    // XCD-aware block order.  The `cgroups` workgroups that scan different channels of the SAME
-    // (column tile, segment, batch) read the same record rows; workgroup q is dispatched to XCD q % 8,
-    // so give those workgroups consecutive slots of one XCD: its private L2 then serves the re-reads.
-    const int cgroups = (p.D + kColCH * kColWaves - 1) / (kColCH * kColWaves);
-    const int coltiles = (p.W + 63) / 64;
-    const int ntiles = coltiles * p.nseg * p.B;
-    const int q = blockIdx.x, xcd = q & 7, m = q >> 3;
-    const int tile = (m / cgroups) * 8 + xcd;
-    if (tile >= ntiles) return;
-    const int w0 = (tile % coltiles) * 64;
-    const int seg = (tile / coltiles) % p.nseg;
-    const int b = tile / (coltiles * p.nseg);
-    const int d0 = (m % cgroups) * (kColCH * kColWaves) + wv * kColCH;            // wave-uniform
-    const int w = w0 + lane;
-    const bool colok = w < p.W;
-    const int H = p.H, W = p.W;
-    const long long L = p.L;
-    const int tau_begin = seg * p.chunk_len;
-    const int tau_end = min(H, tau_begin + p.chunk_len);
-
-    // wave-uniform per-channel constants (scalar registers)
-    v2f A2[kColCH][NP / 2];
-    float wdt[kColCH][kRecPad], bias[kColCH], Dd[kColCH];
-    bool chok[kColCH];
-    // All parameter loads first, unconditional with clamped indices (a `n < N ? load : 0` select compiles to a branch
-    // around each load followed by its own wait: 32 serialised round trips before the first scan step).
-    float araw[kColCH][NP];
-#pragma unroll
-    for (int c = 0; c < kColCH; ++c) {
-        const int d = d0 + c;
-        chok[c] = d < p.D;
-        const int kd = k * p.D + (chok[c] ? d : 0);
-#pragma unroll
-        for (int n = 0; n < NP; ++n) araw[c][n] = p.A_logs[(long long)kd * p.N + min(n, p.N - 1)];
-#pragma unroll
-        for (int r = 0; r < kRecPad; ++r) wdt[c][r] = p.Wdt[(long long)kd * p.R + min(r, p.R - 1)];
-        bias[c] = p.dtb[kd];
-        Dd[c] = p.Ds[kd];
-    }
-#pragma unroll
-    for (int c = 0; c < kColCH; ++c) {
-#pragma unroll
-        for (int n = 0; n < NP; ++n) {
-            float a = (n < p.N) ? -expf(araw[c][n]) * 1.4426950408889634f : 0.0f;
-            // wave-uniform, but v_pk_mul_f32 cannot take an SGPR pair: pin the value in a VGPR once
-            // (otherwise the compiler re-copies SGPR -> VGPR at every use, 16 v_mov per step)
-            asm volatile("" : "+v"(a));
-            if (n & 1) A2[c][n / 2].y = a; else A2[c][n / 2].x = a;
-        }
-#pragma unroll
-        for (int r = 0; r < kRecPad; ++r) wdt[c][r] = (r < p.R) ? wdt[c][r] : 0.0f;
-    }
-
-    const int omega = REV ? W - 1 - w : w;
-    const long long chunk = (long long)omega * p.nseg + seg;
-    v2f h[kColCH][NP / 2];
-    float sum_dt[kColCH];
-#pragma unroll
-    for (int c = 0; c < kColCH; ++c) {
-        sum_dt[c] = 0.0f;
-        const long long wsrow = (chunk * p.B * p.D + (long long)b * p.D + d0 + c) * NP;
-        if (PHASE == 3 && colok && chok[c] && chunk > 0) {
-#pragma unroll
-            for (int q = 0; q < NP / 4; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(p.wsH + wsrow + 4 * q);
-                h[c][2 * q] = (v2f){v.x, v.y}; h[c][2 * q + 1] = (v2f){v.z, v.w};
-            }
-        } else {
-#pragma unroll
-            for (int n = 0; n < NP / 2; ++n) h[c][n] = splat(0.0f);
-        }
-    }
-
-    const float* recb = p.rec + ((long long)b * 4 + k) * L * kRS;
-    float ur[kColCH][kColT];
-    float yr[kColCH][kColT];        // previous directions' y (accumulate mode), fetched with u
-
-    auto row_of = [&](int tau) { return REV ? H - 1 - tau : tau; };
-    // u / y: unconditional loads with clamped addresses (a lane outside the map re-reads column W-1, a row past the
-    // segment re-reads its last row; neither is ever used or stored): all 64-bit address arithmetic is done once
-    // here, a fetch adds one wave-uniform row offset to per-lane bases.
-    const int wcl = min(w, W - 1);
-    const float* xbase[kColCH];
-    const float* ybase[kColCH];
-#pragma unroll
-    for (int c = 0; c < kColCH; ++c) {
-        const long long plane = ((long long)b * p.D + min(d0 + c, p.D - 1)) * H * (long long)W + wcl;
-        xbase[c] = p.x + plane;
-        ybase[c] = p.y + plane;
-    }
-    // records: LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write; the destination is wave-uniform
-    // base + lane * 16, i.e. the batch image is filled in 1-KiB runs).  A batch is kColT * CH4 runs, run r = row
-    // r / CH4, pieces [64 (r % CH4), +64) of that row's 64 * CH4; the wave takes runs wv, wv + kColWaves, ...
-    // Piece e of a row is bytes [16 (e % CH4), +16) of the record of column e / CH4 (clamped into the map).
-    constexpr int NRUN = kColT * CH4;
-    constexpr int RPW = (NRUN + kColWaves - 1) / kColWaves;          // runs per wave
-    unsigned pofs[RPW];                                              // the lane's source offset inside a record row (floats)
-#pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-        const int r = min(wv + kColWaves * j, NRUN - 1);
-        const int e = (r % CH4) * 64 + lane;
-        pofs[j] = (unsigned)(min(e / CH4, W - 1 - w0) * kRS + (e % CH4) * 4);
-    }
-    auto fetch = [&](int tau0, int buf) {
-#pragma unroll
-        for (int j = 0; j < RPW; ++j) {
-            const int r = wv + kColWaves * j;                        // wave-uniform
-            if (NRUN % kColWaves == 0 || r < NRUN) {
-                const int row = row_of(min(tau0 + r / CH4, tau_end - 1));
-                const float* g = recb + ((long long)row * W + w0) * kRS + pofs[j];
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                                 (__attribute__((address_space(3))) void*)(s_col + buf * BUF + r * 256),
-                                                 16, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < kColT; ++i) {
-            const long long roff = (long long)row_of(min(tau0 + i, tau_end - 1)) * W;      // wave-uniform
-#pragma unroll
-            for (int c = 0; c < kColCH; ++c) {
-                ur[c][i] = xbase[c][roff];
-                yr[c][i] = (PHASE == 3 && p.accumulate) ? ybase[c][roff] : 0.0f;
-            }
-        }
-    };
-
-    fetch(tau_begin, 0);
-    int buf = 0;
-    for (int tau0 = tau_begin; tau0 < tau_end; tau0 += kColT, buf ^= 1) {
-        float uc[kColCH][kColT], yc[kColCH][kColT];
-#pragma unroll
-        for (int c = 0; c < kColCH; ++c)
-#pragma unroll
-            for (int i = 0; i < kColT; ++i) { uc[c][i] = ur[c][i]; yc[c][i] = yr[c][i]; }
-        // one barrier per batch: it publishes this batch's image (every wave waited for its own DMA runs) and
-        // retires the other buffer (all waves finished the previous batch), which the next fetch overwrites
-        __syncthreads();
-        if (tau0 + kColT < tau_end) fetch(tau0 + kColT, buf ^ 1);
-        const float* s_rec = s_col + buf * BUF;
-
-#pragma unroll
-        for (int i = 0; i < kColT; ++i) {
-            if (tau0 + i < tau_end) {                                  // uniform
-                const float* rc = &s_rec[(i * 64 + lane) * RSL];
-                const float4 dr = *reinterpret_cast<const float4*>(rc);
-                float4 bq[NP / 4], cq[NP / 4];
-#pragma unroll
-                for (int r = 0; r < NP / 4; ++r) {
-                    bq[r] = *reinterpret_cast<const float4*>(rc + kRecPad + 4 * r);
-                    if (PHASE == 3) cq[r] = *reinterpret_cast<const float4*>(rc + kRecPad + NP + 4 * r);
-                }
-                float dtv[kColCH];
-#pragma unroll
-                for (int c = 0; c < kColCH; ++c)
-                    dtv[c] = fmaf(wdt[c][3], dr.w, fmaf(wdt[c][2], dr.z, fmaf(wdt[c][1], dr.y, fmaf(wdt[c][0], dr.x, bias[c]))));
-                static_assert(kColCH == 2, "softplus pairing assumes two channels per wave");
-                const v2f sp = softplus2((v2f){dtv[0], dtv[1]});
-                dtv[0] = sp.x; dtv[1] = sp.y;
-                const int hrow = row_of(tau0 + i);
-#pragma unroll
-                for (int c = 0; c < kColCH; ++c) {
-                    const float dt = dtv[c], ut = uc[c][i];
-                    const v2f dt2 = splat(dt), du2 = splat(dt * ut);
-                    if (PHASE == 1) sum_dt[c] += dt;
-                    v2f y2 = splat(0.0f);
-#pragma unroll
-                    for (int r = 0; r < NP / 4; ++r) {
-                        const v2f a0 = exp2_2(dt2 * A2[c][2 * r]);
-                        const v2f a1 = exp2_2(dt2 * A2[c][2 * r + 1]);
-                        h[c][2 * r] = a0 * h[c][2 * r] + du2 * (v2f){bq[r].x, bq[r].y};
-                        h[c][2 * r + 1] = a1 * h[c][2 * r + 1] + du2 * (v2f){bq[r].z, bq[r].w};
-                        if (PHASE == 3) {
-                            y2 = (v2f){cq[r].x, cq[r].y} * h[c][2 * r] + y2;
-                            y2 = (v2f){cq[r].z, cq[r].w} * h[c][2 * r + 1] + y2;
-                        }
-                    }
-                    if (PHASE == 3 && colok && chok[c]) {
-                        float* o = p.y + (((long long)b * p.D + d0 + c) * H + hrow) * W + w;
-                        *o = fmaf(Dd[c], ut, y2.x + y2.y) + yc[c][i];
-                    }
-                }
-            }
-        }
-    }
-
-    if (PHASE == 1 && colok) {
-#pragma unroll
-        for (int c = 0; c < kColCH; ++c) {
-            if (!chok[c]) continue;
-            const long long wsrow = (chunk * p.B * p.D + (long long)b * p.D + d0 + c) * NP;
-#pragma unroll
-            for (int q = 0; q < NP / 4; ++q) {
-                *reinterpret_cast<float4*>(p.wsH + wsrow + 4 * q) =
-                    make_float4(h[c][2 * q].x, h[c][2 * q].y, h[c][2 * q + 1].x, h[c][2 * q + 1].y);
-                const v2f p0 = exp2_2(splat(sum_dt[c]) * A2[c][2 * q]);
-                const v2f p1 = exp2_2(splat(sum_dt[c]) * A2[c][2 * q + 1]);
-                *reinterpret_cast<float4*>(p.wsP + wsrow + 4 * q) = make_float4(p0.x, p0.y, p1.x, p1.y);
             }
         }
     }

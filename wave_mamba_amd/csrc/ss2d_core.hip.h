@@ -208,7 +208,9 @@ __device__ __forceinline__ void core_lds_fence() {       // LDS hand-off between
 
 // PHASE 1: chunk summaries.  PHASE 3: scan from the carried-in state, emits y.
 // RHI: dt_rank > 2 (the dt projection reads four record slots instead of two).
-template <int NP, int NW, int PHASE, bool RHI, typename TP, bool COL, bool REV>
+// VEC: 16-byte tile accesses (W % 4 == 0, 16-byte aligned planes) or element-wise ones with per-element masks (any W, fp32
+// planes: odd map widths are rare - the network pads its input to multiples of 8 - and take the same kernel, slower).
+template <int NP, int NW, int PHASE, bool RHI, typename TP, bool COL, bool REV, bool VEC>
 __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const int b, const int wg, float* smem) {
     using Cfg = CoreCfg<NP>;
     constexpr int NTB = Cfg::NTB, NQ = Cfg::NQ, RS = Cfg::RS, ROW = Cfg::ROW, XT = Cfg::XT;
@@ -332,10 +334,15 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
     // the tile is staged, one tile later.  Per thread and float4 i: element offset = tbase[i] + ti * tdelta (D * L < 2^31,
     // host check), valid iff the static mask bit i is set and the thread's tile column (row mode) / tile row (column
     // mode) `vc` lies in the tile's valid range - only a chunk's last tile is ever partial.
+    // Element-wise form (VEC == false): the four elements of a quad are checked one by one (tile column in row mode,
+    // image column in column mode) and nothing is prefetched - the tile is loaded when it is staged, which exposes one
+    // load latency per tile (16 more offsets in flight on top of the scan's registers would spill at N <= 16, where a
+    // 16-wave workgroup has 128 registers per lane).
     unsigned tbase[4];
     int smask = 0, vc, tdelta;
+    int wq0[4] = {0, 0, 0, 0};                           // column mode: image column of the quad's first element
     if (!COL) {
-        vc = 4 * tq;                                     // L % 4 == 0, chunk % 16 == 0: quads are all-in or all-out
+        vc = 4 * tq;                                     // VEC: L % 4 == 0, chunk % 16 == 0: quads are all-in or all-out
         tdelta = REV ? -16 : 16;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -350,28 +357,46 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
         for (int i = 0; i < 4; ++i) {
             const int e = i * 64 * NW + tid;
             const int q = e % QPR, ch = e / (QPR * 16);
-            const int wq = wlo + 4 * q;                                              // W % 4 == 0
+            const int wq = wlo + 4 * q;                                              // VEC: W % 4 == 0
+            wq0[i] = wq;
             tbase[i] = ((unsigned)ch * (unsigned)H + (unsigned)((REV ? H - 16 - t_begin : t_begin) + vc)) * (unsigned)W + (unsigned)wq;
-            smask |= (ch < D && wq >= 0 && wq < W) << i;
+            smask |= (ch < D && (VEC ? (wq >= 0 && wq < W) : true)) << i;
         }
     }
     auto tile_ok = [&](int ti, int i) -> bool {
         const int tl = min(16, t_end - (t_begin + 16 * ti));
         const int v_lo = REV ? 16 - tl : 0, v_hi = REV ? 16 : tl;
-        return ((smask >> i) & 1) && vc >= v_lo && vc < v_hi;
+        return ((smask >> i) & 1) && (COL || VEC ? (vc >= v_lo && vc < v_hi) : true);
+    };
+    auto elem_ok = [&](int ti, int i, int j) -> bool {    // element-wise form only
+        if (!tile_ok(ti, i)) return false;
+        if (COL) return wq0[i] + j >= 0 && wq0[i] + j < W;
+        const int tl = min(16, t_end - (t_begin + 16 * ti));
+        const int v_lo = REV ? 16 - tl : 0, v_hi = REV ? 16 : tl;
+        return vc + j >= v_lo && vc + j < v_hi;
     };
     auto tile_off = [&](int ti, int i) -> unsigned { return tbase[i] + (unsigned)(ti * tdelta); };
     auto fetch = [&](int ti) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const unsigned off = tile_ok(ti, i) ? tile_off(ti, i) : 0u;
-            xp[i] = IO::load(xb + off);
+            if constexpr (VEC) {
+                const unsigned off = tile_ok(ti, i) ? tile_off(ti, i) : 0u;
+                xp[i] = IO::load(xb + off);
+            }
         }
     };
     auto stage = [&](int ti) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float4 v4 = tile_ok(ti, i) ? IO::cvt(xp[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v4;
+            if constexpr (VEC) v4 = tile_ok(ti, i) ? IO::cvt(xp[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            else {
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = ld1(xb + (elem_ok(ti, i, j) ? tile_off(ti, i) + (unsigned)j : 0u));
+                v4 = make_float4(elem_ok(ti, i, 0) ? e[0] : 0.f, elem_ok(ti, i, 1) ? e[1] : 0.f,
+                                 elem_ok(ti, i, 2) ? e[2] : 0.f, elem_ok(ti, i, 3) ? e[3] : 0.f);
+            }
             if (!COL) {
                 *reinterpret_cast<float4*>(&sx[(16 * i + trow) * ROW + 4 * tq]) = v4;
             } else {
@@ -385,6 +410,17 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
                     s_x[owner * XT + ch * ROW + r] = v[j];
                 }
             }
+        }
+    };
+    // a quad of the y tile back to memory
+    auto put = [&](int ti, int i, float4 v4) {
+        if constexpr (VEC) {
+            if (tile_ok(ti, i)) IO::store(yb + tile_off(ti, i), v4);
+        } else {
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (elem_ok(ti, i, j)) st1(yb + (tile_off(ti, i) + (unsigned)j), v[j]);
         }
     };
 
@@ -557,9 +593,7 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
             if (!COL) {
                 core_lds_fence();
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (tile_ok(ti, i))
-                        IO::store(yb + tile_off(ti, i), *reinterpret_cast<const float4*>(&sx[(16 * i + trow) * ROW + 4 * tq]));
+                for (int i = 0; i < 4; ++i) put(ti, i, *reinterpret_cast<const float4*>(&sx[(16 * i + trow) * ROW + 4 * tq]));
                 core_lds_fence();                        // the y tile is read before the next stage() overwrites it
             } else {
                 core_barrier();
@@ -577,16 +611,14 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
                 }
                 // a fully valid tile (the usual case) stores without per-element branches: the 16 LDS reads above are
                 // in flight together instead of four read-wait-store rounds
-                const bool full = tl == 16 && D == 64 && wlo >= 0 && wlo + NW <= W;     // uniform
+                const bool full = VEC && tl == 16 && D == 64 && wlo >= 0 && wlo + NW <= W;     // uniform
                 if (full) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         IO::store(yb + tile_off(ti, i), make_float4(v[i][0], v[i][1], v[i][2], v[i][3]));
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (tile_ok(ti, i))
-                            IO::store(yb + tile_off(ti, i), make_float4(v[i][0], v[i][1], v[i][2], v[i][3]));
+                    for (int i = 0; i < 4; ++i) put(ti, i, make_float4(v[i][0], v[i][1], v[i][2], v[i][3]));
                 }
                 core_barrier();
             }
@@ -645,7 +677,7 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
 // same XCD (workgroup id -> XCD id % 8), whose L2 then holds the line.
 // second launch-bound: minimum waves per SIMD (N <= 16: four, i.e. <= 128 registers - one 16-wave or two 8-wave
 // workgroups per compute unit; N = 32: two)
-template <int NP, int NW, int PHASE, bool RHI, typename TP = float>
+template <int NP, int NW, int PHASE, bool RHI, typename TP = float, bool VEC = true>
 __global__ __launch_bounds__(64 * NW, NP == 16 ? 4 : 2) void ss2d_core_kernel(CoreArgs p) {
     extern __shared__ __attribute__((aligned(16))) float core_smem[];
     const int per_b = 2 * p.row_wgs + 2 * p.col_wgs;
@@ -671,32 +703,36 @@ __global__ __launch_bounds__(64 * NW, NP == 16 ? 4 : 2) void ss2d_core_kernel(Co
         const int idx = r >> 1;
         const int wg = (((idx >> 3) << 2) + (idx & 3)) * 2 + ((idx >> 2) & 1);
         if (wg >= p.col_tiles * p.col_nseg || !((p.dirmask >> ((r & 1) * 2 + 1)) & 1)) return;
-        if (r & 1) core_body<NP, NW, PHASE, RHI, TP, true, true>(p, 3, b, wg, core_smem);
-        else core_body<NP, NW, PHASE, RHI, TP, true, false>(p, 1, b, wg, core_smem);
+        if (r & 1) core_body<NP, NW, PHASE, RHI, TP, true, true, VEC>(p, 3, b, wg, core_smem);
+        else core_body<NP, NW, PHASE, RHI, TP, true, false, VEC>(p, 1, b, wg, core_smem);
     } else {
         const int wg = r >> 1;
         if (!((p.dirmask >> ((r & 1) * 2)) & 1)) return;
-        if (r & 1) core_body<NP, NW, PHASE, RHI, TP, false, true>(p, 2, b, wg, core_smem);
-        else core_body<NP, NW, PHASE, RHI, TP, false, false>(p, 0, b, wg, core_smem);
+        if (r & 1) core_body<NP, NW, PHASE, RHI, TP, false, true, VEC>(p, 2, b, wg, core_smem);
+        else core_body<NP, NW, PHASE, RHI, TP, false, false, VEC>(p, 0, b, wg, core_smem);
     }
 }
 
 // merged output for callers of the plain operator (training): y0 <- ((y0 + y2) + y1) + y3, the reference's order of
 // y1 + y2 + y3 + y4 (:490: out_y[:, 0], inv_y[:, 0], wh_y, invwh_y)
-template <typename TP>
+template <typename TP, bool VEC>
 __global__ __launch_bounds__(256) void ss2d_sum4_kernel(TP* __restrict__ y0, const TP* __restrict__ y2,
                                                         const TP* __restrict__ y1, const TP* __restrict__ y3,
-                                                        long long n4) {
+                                                        long long n) {          // n: quads (VEC) or elements
     using IO = CoreIO<TP>;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    float4 a = IO::cvt(IO::load(y0 + 4 * i));
-    const float4 c = IO::cvt(IO::load(y2 + 4 * i));
-    const float4 bq = IO::cvt(IO::load(y1 + 4 * i));
-    const float4 e = IO::cvt(IO::load(y3 + 4 * i));
-    a.x = ((a.x + c.x) + bq.x) + e.x; a.y = ((a.y + c.y) + bq.y) + e.y;
-    a.z = ((a.z + c.z) + bq.z) + e.z; a.w = ((a.w + c.w) + bq.w) + e.w;
-    IO::store(y0 + 4 * i, a);
+    if (i >= n) return;
+    if constexpr (VEC) {
+        float4 a = IO::cvt(IO::load(y0 + 4 * i));
+        const float4 c = IO::cvt(IO::load(y2 + 4 * i));
+        const float4 bq = IO::cvt(IO::load(y1 + 4 * i));
+        const float4 e = IO::cvt(IO::load(y3 + 4 * i));
+        a.x = ((a.x + c.x) + bq.x) + e.x; a.y = ((a.y + c.y) + bq.y) + e.y;
+        a.z = ((a.z + c.z) + bq.z) + e.z; a.w = ((a.w + c.w) + bq.w) + e.w;
+        IO::store(y0 + 4 * i, a);
+    } else {
+        st1(y0 + i, ((ld1(y0 + i) + ld1(y2 + i)) + ld1(y1 + i)) + ld1(y3 + i));
+    }
 }
 
 }  // namespace wm

@@ -195,69 +195,6 @@ static int scan_launch(const ScanArgs& a, const ScanPlan& pl, hipStream_t st) {
     return launch_status();
 }
 
-// ------------------------------------------------------------------------------------------------
-// fused SS2D core host side
-// ------------------------------------------------------------------------------------------------
-struct Ss2dPlan {
-    int row_chunk, row_nchunks;            // k = 0, 2
-    int col_seg, col_nseg; long long col_nchunks;   // k = 1, 3
-    size_t rec_bytes, ws_half_bytes, seg_bytes, total_bytes;
-};
-
-static int ss2d_plan(Ss2dPlan& pl, int B, int D, int H, int W, int N, int R) {
-    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || N <= 0 || R <= 0) return WM_EINVAL;
-    if (N > 16 || R > kRecPad || D > 64) return WM_EUNSUPPORTED;
-    const long long L = (long long)H * W;
-    if (L > 0x7fffffffLL) return WM_EUNSUPPORTED;
-    // row directions: one wave per (batch, chunk)
-    long long want = (256LL * 12 * 4 + B - 1) / B;
-    long long cl = (L + want - 1) / want;
-    cl = ((cl + 15) / 16) * 16;
-    if (cl < 64) cl = 64;
-    pl.row_chunk = (int)cl;
-    pl.row_nchunks = (int)((L + cl - 1) / cl);
-    // column directions: one 16-wave workgroup per (64-column tile, segment, batch, 32-channel group)
-    const int coltiles = (W + 63) / 64, cgroups = (D + kColCH * kColWaves - 1) / (kColCH * kColWaves);
-    // segments per column: all workgroups do the same work and WM_COL_SLOTS of them are resident at once (two per
-    // compute unit: 240 registers, 36 KB of LDS), so the launch takes ceil(workgroups / slots) rounds of one
-    // segment each - pick the count that minimises rounds x (segment rows + a per-workgroup prologue / epilogue
-    // worth ~24 rows).  A fixed target count left the last round of the UHD level-1 / level-2 launches 34 % / 17 % full.
-    long long sl = H;
-    {
-        double best = 1e30;
-        for (int n = 1; n <= 64; ++n) {
-            long long s_rows = (H + n - 1) / n;
-            s_rows = ((s_rows + kColT - 1) / kColT) * kColT;
-            if (s_rows < 16) s_rows = 16;
-            const long long nn = (H + s_rows - 1) / s_rows;
-            const long long wgs = (((long long)coltiles * nn * B + 7) / 8) * 8 * cgroups;
-            const long long rounds = (wgs + WM_COL_SLOTS - 1) / WM_COL_SLOTS;
-            const double cost = (double)rounds * (double)(s_rows + 24);
-            if (cost < best * 0.999) { best = cost; sl = s_rows; }
-        }
-    }
-    pl.col_seg = (int)sl;
-    pl.col_nseg = (int)((H + sl - 1) / sl);
-    pl.col_nchunks = (long long)W * pl.col_nseg;
-    if (pl.col_nchunks > 0x7fffffffLL) return WM_EUNSUPPORTED;
-    pl.rec_bytes = (size_t)B * 4 * L * kRS * sizeof(float);
-    const long long maxchunks = pl.col_nchunks > pl.row_nchunks ? pl.col_nchunks : pl.row_nchunks;
-    pl.ws_half_bytes = (size_t)maxchunks * B * D * 16 * sizeof(float);
-    pl.seg_bytes = (size_t)2 * carry_nsegs(maxchunks) * B * D * 16 * sizeof(float);
-    pl.total_bytes = pl.rec_bytes + 4 * (2 * pl.ws_half_bytes + pl.seg_bytes);      // one summary set per direction
-    return WM_OK;
-}
-
-// PHASE 1 = chunk summaries (skipped by the caller when the direction is a single chunk), PHASE 3 = scan with carry-in
-template <int PHASE, bool REV>
-static void ss2d_launch_row(Ss2dArgs a, const Ss2dPlan& pl, bool vec, hipStream_t st) {
-    a.chunk_len = pl.row_chunk; a.nchunks = pl.row_nchunks; a.nseg = 0;
-    const dim3 grid((unsigned)pl.row_nchunks, (unsigned)a.B), block(64);
-    ProfScope ps(PHASE == 1 ? 11 : 9, st);
-    if (vec) hipLaunchKernelGGL((ss2d_row_kernel<PHASE, REV, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((ss2d_row_kernel<PHASE, REV, false>), grid, block, 0, st, a);
-}
-
 // > 64 KB of dynamic LDS is an opt-in per kernel function AND per device: one flag per (instantiation, device).
 // `flags` is the caller's function-local static array; returns WM_OK or WM_EHIP.
 static int lds_optin(const void* fn, int bytes, bool (&flags)[64]) {
@@ -272,18 +209,6 @@ static int lds_optin(const void* fn, int bytes, bool (&flags)[64]) {
     return WM_OK;
 }
 
-template <int PHASE, bool REV>
-static void ss2d_launch_col(Ss2dArgs a, const Ss2dPlan& pl, hipStream_t st) {
-    a.chunk_len = pl.col_seg; a.nseg = pl.col_nseg; a.nchunks = (int)pl.col_nchunks;
-    const int cgroups = (a.D + kColCH * kColWaves - 1) / (kColCH * kColWaves);
-    const long long ntiles = (long long)((a.W + 63) / 64) * pl.col_nseg * a.B;
-    const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8 * cgroups)), block(64 * kColWaves);    // XCD-aware order, see kernel
-    static bool configured[64] = {};                     // the chunk-scan image is 72 KB of dynamic LDS
-    if (PHASE == 3) (void)lds_optin((const void*)ss2d_col_kernel<3, REV>, col_lds_bytes<3>(), configured);   // a failure shows at the launch
-    ProfScope ps(PHASE == 1 ? 11 : 9, st);
-    hipLaunchKernelGGL((ss2d_col_kernel<PHASE, REV>), grid, block, col_lds_bytes<PHASE>(), st, a);
-}
-
 }  // namespace wm
 
 using namespace wm;
@@ -293,7 +218,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 16; }
+int wm_abi_version(void) { return 17; }
 
 #ifndef WM_BUILD_ID
 #define WM_BUILD_ID "unknown"
@@ -543,84 +468,6 @@ int wm_dwconv3x3_fwd(const void* x, const float* weight, const float* bias, void
 }
 
 }  // extern "C"
-// The first-generation core (projection records in HBM, separate row / column kernels): kept for maps whose width is
-// not a multiple of 4 (the tile loaders of ss2d_core.hip.h are 16-byte accesses); N <= 16 only.
-static int core_fwd_legacy(const float* x, const float* x_proj_weight, const float* dt_projs_weight,
-                     const float* dt_projs_bias, const float* A_logs, const float* Ds, float* y_row_fwd,
-                     float* y_row_rev, float* y_col_fwd, float* y_col_rev, int merged, void* workspace,
-                     size_t workspace_bytes, int B, int D, int H, int W, int N, int R, void* stream) {
-    Ss2dPlan pl;
-    int rc = ss2d_plan(pl, B, D, H, W, N, R);
-    if (rc) return rc;
-    if (!x || !x_proj_weight || !dt_projs_weight || !dt_projs_bias || !A_logs || !Ds || !y_row_fwd) return WM_ENULL;
-    if (!merged && (!y_row_rev || !y_col_fwd || !y_col_rev)) return WM_ENULL;
-    if (!workspace) return WM_ENULL;
-    if (workspace_bytes < pl.total_bytes) return WM_EWORKSPACE;
-    if (!aligned16(workspace)) return WM_EALIGN;
-    hipStream_t st = (hipStream_t)stream;
-    Ss2dArgs a;
-    a.x = x; a.rec = (float*)workspace; a.Wx = x_proj_weight; a.Wdt = dt_projs_weight; a.dtb = dt_projs_bias;
-    a.A_logs = A_logs; a.Ds = Ds;
-    a.wsP = (float*)((char*)workspace + pl.rec_bytes);
-    a.wsH = (float*)((char*)workspace + pl.rec_bytes + pl.ws_half_bytes);
-    a.B = B; a.D = D; a.H = H; a.W = W; a.L = H * W; a.N = N; a.R = R;
-    a.k = 0; a.y = y_row_fwd; a.accumulate = 0; a.chunk_len = 0; a.nchunks = 0; a.nseg = 0;
-    {
-        ProfScope ps(6, st);
-        const int groups = (a.L + 31) / 32;
-        long long waves = (long long)B * groups;
-        int blocks = (int)((waves + kProjWaves - 1) / kProjWaves);
-        if (blocks > 256 * 2) blocks = 256 * 2;                     // persistent: two workgroups per compute unit
-        hipLaunchKernelGGL(ss2d_proj_kernel, dim3((unsigned)blocks), dim3(64 * kProjWaves), 0, st, a, groups);
-    }
-    const bool vec = (a.L % 4 == 0) && aligned16(x) && aligned16(y_row_fwd) && (merged || aligned16(y_row_rev));
-    // Per direction k its own summary set, so that the four reduce launches, ONE set of carry launches for all four
-    // directions, and the four scan launches follow each other (the carries are a few microseconds each: 12 launches
-    // per call before).  Order of the scans = order of the accumulation into y: 0, 2, 1, 3 as before.
-    char* wsbase = (char*)workspace + pl.rec_bytes;
-    const size_t per_dir = 2 * pl.ws_half_bytes + pl.seg_bytes;
-    const long long nchains = (long long)B * D * 16;
-    float* yk[4] = {y_row_fwd, merged ? y_row_fwd : y_col_fwd, merged ? y_row_fwd : y_row_rev, merged ? y_row_fwd : y_col_rev};
-    Ss2dArgs ak[4];
-    for (int k = 0; k < 4; ++k) {
-        ak[k] = a;
-        ak[k].k = k; ak[k].y = yk[k]; ak[k].accumulate = (merged && k != 0) ? 1 : 0;
-        ak[k].wsP = (float*)(wsbase + k * per_dir);
-        ak[k].wsH = (float*)(wsbase + k * per_dir + pl.ws_half_bytes);
-    }
-    auto carry_dir = [&](int k, int nchunks) {
-        float* seg = (float*)(wsbase + k * per_dir + 2 * pl.ws_half_bytes);
-        const int nsegs = (int)carry_nsegs(nchunks);
-        return CarryDir{ak[k].wsP, ak[k].wsH, seg, seg + (size_t)nsegs * nchains, nchunks, nsegs};
-    };
-    const bool row_split = pl.row_nchunks > 1, col_split = pl.col_nchunks > 1;
-    if (row_split) { ss2d_launch_row<1, false>(ak[0], pl, vec, st); ss2d_launch_row<1, true>(ak[2], pl, vec, st); }
-    if (col_split) { ss2d_launch_col<1, false>(ak[1], pl, st); ss2d_launch_col<1, true>(ak[3], pl, st); }
-    const bool row_deep = pl.row_nchunks > 1024, col_deep = pl.col_nchunks > 1024;
-    if (row_split && col_split && row_deep == col_deep) {
-        CarryBatch cb{};
-        cb.d[0] = carry_dir(0, pl.row_nchunks); cb.d[1] = carry_dir(2, pl.row_nchunks);
-        cb.d[2] = carry_dir(1, (int)pl.col_nchunks); cb.d[3] = carry_dir(3, (int)pl.col_nchunks);
-        launch_carry_batch(cb, 4, nchains, st);
-    } else {
-        if (row_split) {
-            CarryBatch cb{};
-            cb.d[0] = carry_dir(0, pl.row_nchunks); cb.d[1] = carry_dir(2, pl.row_nchunks);
-            launch_carry_batch(cb, 2, nchains, st);
-        }
-        if (col_split) {
-            CarryBatch cb{};
-            cb.d[0] = carry_dir(1, (int)pl.col_nchunks); cb.d[1] = carry_dir(3, (int)pl.col_nchunks);
-            launch_carry_batch(cb, 2, nchains, st);
-        }
-    }
-    ss2d_launch_row<3, false>(ak[0], pl, vec, st);
-    ss2d_launch_row<3, true>(ak[2], pl, vec, st);
-    ss2d_launch_col<3, false>(ak[1], pl, st);
-    ss2d_launch_col<3, true>(ak[3], pl, st);
-    return launch_status();
-}
-
 namespace wm {
 // ------------------------------------------------------------------------------------------------
 // SS2D core, second generation (ss2d_core.hip.h): reduce (4 directions) -> carry -> scan (4 directions)
@@ -633,8 +480,6 @@ struct CorePlan {
     size_t half_bytes, ytmp_bytes, prep_bytes, total;   // one P (or H) array of one direction; merged-mode y buffers;
                                                         // the prep kernel's output; everything
 };
-
-static bool core_v2_shape(int W) { return W % 4 == 0; }
 
 // Length of one core launch (in row-tile times) under the dispatch model of core_plan's comment, replaying
 // ss2d_core_kernel's blockIdx -> (direction, slot) mapping.  Costs measured on MI355X (tools/bench_core.py with
@@ -717,7 +562,7 @@ static int core_plan(CorePlan& pl, int B, int D, int H, int W, int N, int R, int
     // (segments per column, tiles per row chunk) pair is replayed through that dispatch model with measured per-tile
     // costs (core_makespan) and the shortest launch wins, e.g. level 1: 240 column workgroups of 68 tiles + 272 row
     // workgroups of 60.  Plans are cached per shape (the search replays ~10^5 workgroups).
-    const long long RT = (L / 16 + NW - 1) / NW;                    // row workgroup-tiles per direction (L % 16 == 0: W % 4, H ...)
+    const long long RT = ((L + 15) / 16 + NW - 1) / NW;             // row workgroup-tiles per direction
     // Row workgroups hand their chunks to their waves on demand (ss2d_core.hip.h), kRowSplit chunks per wave.  Measured
     // (gpurun_out r3h, UHD levels 1 / 2 / 3, ms per call): 1 chunk per wave 3.564 / 1.034 / 0.323, 2: 3.541 / 1.046 /
     // 0.339, 3: 3.498 / 1.081 / 0.344, 4: 3.584 / 1.062 / 0.366 - shorter chunks do even out the waves' lifetimes (566-918 us
@@ -783,7 +628,7 @@ static int core_plan(CorePlan& pl, int B, int D, int H, int W, int N, int R, int
     return WM_OK;
 }
 
-template <int NP, int NW, bool RHI, typename TP>
+template <int NP, int NW, bool RHI, typename TP, bool VEC>
 static int core_launch(const CoreArgs& a, const CorePlan& pl, bool do_prep, hipStream_t st) {
     constexpr int lds = core_lds_bytes<NP, NW>();
     // > 64 KB of dynamic LDS is an opt-in per function AND per device
@@ -794,10 +639,10 @@ static int core_launch(const CoreArgs& a, const CorePlan& pl, bool do_prep, hipS
     {
         std::lock_guard<std::mutex> lk(mu);
         if (dev < 0 || dev >= 64 || !configured[dev]) {
-            hipError_t e = hipFuncSetAttribute((const void*)ss2d_core_kernel<NP, NW, 1, RHI, TP>,
+            hipError_t e = hipFuncSetAttribute((const void*)ss2d_core_kernel<NP, NW, 1, RHI, TP, VEC>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e == hipSuccess)
-                e = hipFuncSetAttribute((const void*)ss2d_core_kernel<NP, NW, 3, RHI, TP>,
+                e = hipFuncSetAttribute((const void*)ss2d_core_kernel<NP, NW, 3, RHI, TP, VEC>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) return WM_EHIP;
             if (dev >= 0 && dev < 64) configured[dev] = true;
@@ -813,7 +658,7 @@ static int core_launch(const CoreArgs& a, const CorePlan& pl, bool do_prep, hipS
     if (split) {
         {
             ProfScope ps(10, st);
-            hipLaunchKernelGGL((ss2d_core_kernel<NP, NW, 1, RHI, TP>), grid, block, lds, st, a);
+            hipLaunchKernelGGL((ss2d_core_kernel<NP, NW, 1, RHI, TP, VEC>), grid, block, lds, st, a);
         }
         ProfScope ps(3, st);
         CarryBatch cb{};
@@ -828,7 +673,7 @@ static int core_launch(const CoreArgs& a, const CorePlan& pl, bool do_prep, hipS
     }
     {
         ProfScope ps(8, st);
-        hipLaunchKernelGGL((ss2d_core_kernel<NP, NW, 3, RHI, TP>), grid, block, lds, st, a);
+        hipLaunchKernelGGL((ss2d_core_kernel<NP, NW, 3, RHI, TP, VEC>), grid, block, lds, st, a);
     }
     return launch_status();
 }
@@ -837,11 +682,6 @@ static int core_launch(const CoreArgs& a, const CorePlan& pl, bool do_prep, hipS
 extern "C" {
 size_t wm_ss2d_core_fwd_workspace_bytes(int B, int D, int H, int W, int N, int R, int merged) {
     // (sized for fp32 planes; bf16 planes need less for the merged mode's temporaries)
-    if (!core_v2_shape(W)) {
-        Ss2dPlan pl;
-        if (ss2d_plan(pl, B, D, H, W, N, R) != WM_OK) return 0;
-        return pl.total_bytes;
-    }
     CorePlan pl;
     if (core_plan(pl, B, D, H, W, N, R, merged) != WM_OK) return 0;
     return pl.total;
@@ -870,7 +710,6 @@ int wm_ss2d_core_prep(const float* x_proj_weight, const float* dt_projs_weight, 
 
 int wm_ss2d_core_plan(int B, int D, int H, int W, int N, int R, int* out10) {
     if (!out10) return WM_ENULL;
-    if (!core_v2_shape(W)) return WM_EUNSUPPORTED;
     CorePlan pl;
     const int rc = core_plan(pl, B, D, H, W, N, R, 0);
     if (rc) return rc;
@@ -888,12 +727,6 @@ int wm_ss2d_core_fwd(const void* x, const float* x_proj_weight, const float* dt_
                      void* stream) {
     if (B == 0 || D == 0 || H == 0 || W == 0) return (B < 0 || D < 0 || H < 0 || W < 0) ? WM_EINVAL : WM_OK;
     if (plane_dtype != WM_F32 && plane_dtype != WM_BF16) return WM_EUNSUPPORTED;
-    if (!core_v2_shape(W)) {
-        if (plane_dtype != WM_F32) return WM_EUNSUPPORTED;
-        return core_fwd_legacy((const float*)x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, (float*)y_row_fwd,
-                               (float*)y_row_rev, (float*)y_col_fwd, (float*)y_col_rev, merged, workspace, workspace_bytes, B, D,
-                               H, W, N, R, stream);
-    }
     CorePlan pl;
     int rc = core_plan(pl, B, D, H, W, N, R, merged);
     if (rc) return rc;
@@ -901,8 +734,17 @@ int wm_ss2d_core_fwd(const void* x, const float* x_proj_weight, const float* dt_
     if (!merged && (!y_row_rev || !y_col_fwd || !y_col_rev)) return WM_ENULL;
     if (!workspace) return WM_ENULL;
     if (workspace_bytes < pl.total) return WM_EWORKSPACE;
-    if (!aligned16(workspace) || !aligned16(x) || !aligned16(y_row_fwd) ||
-        (!merged && (!aligned16(y_row_rev) || !aligned16(y_col_fwd) || !aligned16(y_col_rev)))) return WM_EALIGN;
+    if (!aligned16(workspace)) return WM_EALIGN;
+    // 16-byte tile accesses when the map width allows them (every size the network itself produces: it pads its input
+    // to multiples of 8); otherwise the same kernels with element-wise tile accesses (fp32 planes only).
+    const bool planes16 = aligned16(x) && aligned16(y_row_fwd) &&
+                          (merged || (aligned16(y_row_rev) && aligned16(y_col_fwd) && aligned16(y_col_rev)));
+    const bool vec = (W % 4 == 0) && planes16;
+    if (!vec && plane_dtype != WM_F32) return (W % 4 == 0) ? WM_EALIGN : WM_EUNSUPPORTED;
+    {
+        auto mis4 = [](const void* q) { return q && ((uintptr_t)q & 3) != 0; };
+        if (mis4(x) || mis4(y_row_fwd) || (!merged && (mis4(y_row_rev) || mis4(y_col_fwd) || mis4(y_col_rev)))) return WM_EALIGN;
+    }
     hipStream_t st = (hipStream_t)stream;
     CoreArgs a;
     a.x = x; a.Wx = x_proj_weight; a.Wdt = dt_projs_weight; a.dtb = dt_projs_bias; a.A_logs = A_logs; a.Ds = Ds;
@@ -936,23 +778,28 @@ int wm_ss2d_core_fwd(const void* x, const float* x_proj_weight, const float* dt_
 #ifndef WM_CORE_NW
 #define WM_CORE_NW 16
 #endif
-#define WM_CORE_GO(TP)                                                                                                        \
+#define WM_CORE_GO(TP, VEC)                                                                                                   \
     do {                                                                                                                      \
         const bool dp = prepared == nullptr;                                                                                  \
-        if (pl.NP == 16) rc = R > 2 ? core_launch<16, WM_CORE_NW, true, TP>(a, pl, dp, st) : core_launch<16, WM_CORE_NW, false, TP>(a, pl, dp, st); \
-        else rc = R > 2 ? core_launch<32, 8, true, TP>(a, pl, dp, st) : core_launch<32, 8, false, TP>(a, pl, dp, st);          \
+        if (pl.NP == 16) rc = R > 2 ? core_launch<16, WM_CORE_NW, true, TP, VEC>(a, pl, dp, st) : core_launch<16, WM_CORE_NW, false, TP, VEC>(a, pl, dp, st); \
+        else rc = R > 2 ? core_launch<32, 8, true, TP, VEC>(a, pl, dp, st) : core_launch<32, 8, false, TP, VEC>(a, pl, dp, st); \
     } while (0)
-    if (plane_dtype == WM_F32) WM_CORE_GO(float); else WM_CORE_GO(bf16_t);
+    if (!vec) WM_CORE_GO(float, false);
+    else if (plane_dtype == WM_F32) WM_CORE_GO(float, true);
+    else WM_CORE_GO(bf16_t, true);
 #undef WM_CORE_GO
     if (rc) return rc;
     if (merged) {
-        const long long n4 = (long long)B * D * a.L / 4;
+        const long long n = (long long)B * D * a.L, n4 = n / 4;
         ProfScope ps(8, st);
-        if (plane_dtype == WM_F32)
-            hipLaunchKernelGGL(ss2d_sum4_kernel<float>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (float*)a.y[0],
+        if (!vec || (n & 3))
+            hipLaunchKernelGGL((ss2d_sum4_kernel<float, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (float*)a.y[0],
+                               (const float*)a.y[2], (const float*)a.y[1], (const float*)a.y[3], n);
+        else if (plane_dtype == WM_F32)
+            hipLaunchKernelGGL((ss2d_sum4_kernel<float, true>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (float*)a.y[0],
                                (const float*)a.y[2], (const float*)a.y[1], (const float*)a.y[3], n4);
         else
-            hipLaunchKernelGGL(ss2d_sum4_kernel<bf16_t>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (bf16_t*)a.y[0],
+            hipLaunchKernelGGL((ss2d_sum4_kernel<bf16_t, true>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (bf16_t*)a.y[0],
                                (const bf16_t*)a.y[2], (const bf16_t*)a.y[1], (const bf16_t*)a.y[3], n4);
     }
     return launch_status();

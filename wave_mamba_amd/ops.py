@@ -300,14 +300,15 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
 # fused SS2D four-direction core (forward / inference)
 # ------------------------------------------------------------------------------------------------
 def ss2d_core_supported(d_inner, d_state, dt_rank, width=None, height=None):
-    """Shapes the fused HIP core covers (else: direction glue + selective_scan_fn).  d_state in (16, 32] needs a map
-    width that is a multiple of 4 (pass `width` to check it); with `height` too, maps beyond the kernels' 32-bit
-    element offsets (d_inner * H * W >= 2^31, wavemamba_hip.hip: core_plan) are refused here instead of at the call."""
+    """Shapes the fused HIP core covers (else: direction glue + selective_scan_fn).  Any map size (widths that are not
+    a multiple of 4 take the kernels' element-wise tile accesses); with `width` and `height`, maps beyond the kernels'
+    32-bit element offsets (d_inner * H * W >= 2^31, wavemamba_hip.hip: core_plan) are refused here instead of at the
+    call."""
     if d_inner > 64 or dt_rank > 4 or d_state > 32:
         return False
-    if width is not None and height is not None and width % 4 == 0 and d_inner * width * height > 2 ** 31 - 1:
+    if width is not None and height is not None and d_inner * width * height > 2 ** 31 - 1:
         return False
-    return d_state <= 16 or width is None or width % 4 == 0
+    return True
 
 
 def ss2d_core_bwd_supported(d_inner, d_state, dt_rank):
@@ -467,7 +468,7 @@ def lfss_block_forward(tok, x_size, blk, tok_nchw=False, out_nchw=False):
     tok = tok.contiguous().float()
     dev = tok.device
     st = _stream()
-    # bf16 planes: the C = 32 kernels on maps the second-generation core serves (W % 4 == 0); else fp32 planes
+    # bf16 planes: the C = 32 kernels on maps with 16-byte tile accesses (W % 4 == 0); else fp32 planes
     pd = _PLANE_DTYPE if (C == 32 and W % 4 == 0) else torch.float32
     code = WM_F32 if pd == torch.float32 else WM_BF16
     x = torch.empty((B, D, H, W), dtype=pd, device=dev)
@@ -1145,7 +1146,7 @@ def conv2d_supported(x, weight, x2=None):
 # ------------------------------------------------------------------------------------------------
 PROF_KERNELS = ("haar_analysis", "haar_synthesis", "selscan_chunk_reduce", "selscan_carry",
                 "selscan_chunk_scan", "lfss_glue", "ss2d_proj", "dwconv3x3",
-                "ss2d_core_scan", "ss2d_legacy_scan", "ss2d_core_reduce", "ss2d_legacy_reduce", "selscan_bwd",
+                "ss2d_core_scan", "unused_9", "ss2d_core_reduce", "unused_11", "selscan_bwd",
                 "conv3x3", "conv1x1", "skff")
 
 
