@@ -6,7 +6,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import wave_mamba_amd as wm
 import bench
-ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=3); args = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=3); ap.add_argument("--wall-only", action="store_true"); args = ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 net = wm.WaveMamba(**bench.SHIPPED).train().to(dev)
@@ -16,6 +16,14 @@ lq, gt = torch.rand(8, 3, 512, 512, generator=g).to(dev), torch.rand(8, 3, 512, 
 for _ in range(3):
     wm.trainer.train_step(net, opt, lq, gt)
 torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+for _ in range(5):
+    wm.trainer.train_step(net, opt, lq, gt)
+torch.cuda.synchronize()
+print(f"wall clock, un-profiled: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms per step")
+if "--wall-only" in sys.argv:
+    sys.exit(0)
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     for _ in range(args.steps):

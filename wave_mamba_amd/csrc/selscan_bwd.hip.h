@@ -11,12 +11,16 @@
 //   ddelta_t = ddt_t * sigmoid(delta_t + bias)  (softplus; 1 above the threshold)    dbias = sum_t ddelta_t
 //
 // Same mapping as the forward (lane = channel, states in registers, B/C wave-uniform from LDS) and the
-// same L-split: chunks of 16 steps, each an independent single-wave workgroup:
-//   bwd-reduce : one forward pass per chunk -> P = prod a, H = local end state (forward carry) AND
-//                G = sum_s (prod_{r<=s} a_r) C_s dy_s, the chunk's contribution to the adjoint carry
-//                (forward-computable, so forward and adjoint summaries cost ONE pass of exponentials)
-//   carry      : the forward carry scan on H, and the same scan on the chunk-mirrored (P, G) arrays
-//   bwd-chunk  : forward sweep from H_in storing the state at every 4th step in LDS; then the four
+// same L-split, on two levels: a single-wave workgroup owns a BLOCK of `cpb` consecutive 16-step chunks.
+//   bwd-reduce : one forward pass over the block -> per block P = prod a, H = local end state (forward carry) AND
+//                G = sum_s (prod_{r<=s} a_r) C_s dy_s, the block's contribution to the adjoint carry
+//                (forward-computable, so forward and adjoint summaries cost ONE pass of exponentials); per chunk
+//                the state at the chunk's start RELATIVE to the block's start (h from zero) and S = sum of dt so far
+//   carry      : the forward carry scan on the block H, and the same scan on the block-mirrored (P, G) arrays - over
+//                L / (16 cpb) entries (round 3; one entry per 16-step chunk before: 4.6 ms of a 102-ms training step)
+//   bwd-chunk  : the block's chunks in REVERSE order, the adjoint state carried in registers from chunk to chunk; per
+//                chunk h_start = h_local + exp2(A S) H_in(block), then a
+//                forward sweep from h_start storing the state at every 4th step in LDS; then the four
 //                sub-tiles in reverse: recompute h_t and a_t for 4 steps into registers, walk them
 //                backwards.  dB/dC need a sum over the 64 lanes for 2N values per step: butterfly
 //                v_permlane32_swap -> v_permlane16_swap -> 4 DPP row-rotate adds (no LDS, no
@@ -36,11 +40,13 @@ constexpr int kPartPad = 4;        // per-(chunk, channel) partial record: NP (d
 struct ScanBwdArgs {
     const float *u, *delta, *A, *Bm, *Cm, *D, *bias, *dy;
     float *du, *ddelta, *dB, *dC;
-    float *wsP, *wsH;              // forward summaries   [chunk][chain]
-    float *wsPr, *wsG;             // adjoint summaries   [nchunks-1-chunk][chain]
-    float *part;                   // [chunk][batch*dim][NP + kPartPad]
+    float *wsP, *wsH;              // forward summaries   [block][chain]
+    float *wsPr, *wsG;             // adjoint summaries   [nblocks-1-block][chain]
+    float *wsHl, *wsS;             // per chunk: state at the chunk's start relative to its block's start [chunk][chain];
+                                   // sum of dt from the block's start [chunk][batch*dim]
+    float *part;                   // [batch*dim][block][NP + kPartPad]
     int batch, dim, L, N, G, dpg, wpg, nchunks, softplus, atomic_bc;
-    int cpb;                       // chunks per block: a block walks cpb consecutive 16-step chunks (one prologue, fewer launches of tiny workgroups)
+    int cpb, nblocks;              // chunks per block: a block walks cpb consecutive 16-step chunks; blocks per sequence
     // fused SS2D-core backward (MODE 1 forward time, MODE 2 reversed time; ss2d_bwd.hip.h): u = x and dy are
     // (batch, dim, L) planes of the scan layout, `A` holds A_logs, delta / B / C come from the record tile
     const float* rec;              // records of this direction, batch stride rec_bstride floats
@@ -234,6 +240,12 @@ __global__ __launch_bounds__(64) void selscan_bwd_reduce_kernel(ScanBwdArgs p) {
     bwd_load_A<NP, MODE>(p, ix.d, A2);
     const float bias = p.bias ? p.bias[ix.d] : 0.0f;
     const int c_first = blockIdx.x * p.cpb, c_end = min(p.nchunks, c_first + p.cpb);
+    const long long chains = (long long)p.batch * p.dim * NP;
+    const long long row = ((long long)ix.b * p.dim + ix.d) * NP;
+    v2f h[NP / 2], pf[NP / 2], gl[NP / 2];               // running over the whole block
+#pragma unroll
+    for (int n = 0; n < NP / 2; ++n) { h[n] = splat(0.f); pf[n] = splat(1.f); gl[n] = splat(0.f); }
+    float S = 0.0f;
     for (int chunk = c_first; chunk < c_end; ++chunk) {
     if (chunk != c_first) __syncthreads();               // the previous chunk's tiles are consumed
     const int t0 = chunk * kBT, t_end = min(p.L, t0 + kBT), tl = t_end - t0;
@@ -249,10 +261,14 @@ __global__ __launch_bounds__(64) void selscan_bwd_reduce_kernel(ScanBwdArgs p) {
         fused_load_all<NP, VEC, MODE == 2>(p, ix, t0, tl, lane, s_u, s_d, s_dy, s_B, s_C, s_dtr);
     }
     __syncthreads();
-
-    v2f h[NP / 2], pf[NP / 2], gl[NP / 2];
+    if (ix.live) {                                       // the chunk's start, relative to the block's start
+        float* o = p.wsHl + (long long)chunk * chains + row;
 #pragma unroll
-    for (int n = 0; n < NP / 2; ++n) { h[n] = splat(0.f); pf[n] = splat(1.f); gl[n] = splat(0.f); }
+        for (int q = 0; q < NP / 4; ++q)
+            *reinterpret_cast<float4*>(o + 4 * q) = make_float4(h[2 * q].x, h[2 * q].y, h[2 * q + 1].x, h[2 * q + 1].y);
+        p.wsS[(long long)chunk * p.batch * p.dim + (long long)ix.b * p.dim + ix.d] = S;
+    }
+
 #pragma unroll
     for (int q = 0; q < kBT / 4; ++q) {
         if (4 * q < tl) {
@@ -268,6 +284,7 @@ __global__ __launch_bounds__(64) void selscan_bwd_reduce_kernel(ScanBwdArgs p) {
                 const int tt = 4 * q + j;
                 if (tt < tl) {
                     const v2f dt2 = splat(dts[j]), du2 = splat(dts[j] * uu[j]), dy2 = splat(yy[j]);
+                    S += dts[j];
 #pragma unroll
                     for (int r = 0; r < NP / 4; ++r) {
                         const float4 bv = *reinterpret_cast<const float4*>(&s_B[tt * NP + 4 * r]);
@@ -283,10 +300,9 @@ __global__ __launch_bounds__(64) void selscan_bwd_reduce_kernel(ScanBwdArgs p) {
             }
         }
     }
+    }                                                    // next chunk of the block
     if (ix.live) {
-        const long long chains = (long long)p.batch * p.dim * NP;
-        const long long row = ((long long)ix.b * p.dim + ix.d) * NP;
-        const long long f = (long long)chunk * chains + row, m = (long long)(p.nchunks - 1 - chunk) * chains + row;
+        const long long f = (long long)blockIdx.x * chains + row, m = (long long)(p.nblocks - 1 - (int)blockIdx.x) * chains + row;
 #pragma unroll
         for (int q = 0; q < NP / 4; ++q) {
             const float4 P4 = make_float4(pf[2 * q].x, pf[2 * q].y, pf[2 * q + 1].x, pf[2 * q + 1].y);
@@ -296,7 +312,6 @@ __global__ __launch_bounds__(64) void selscan_bwd_reduce_kernel(ScanBwdArgs p) {
             *reinterpret_cast<float4*>(p.wsG + m + 4 * q) = make_float4(gl[2 * q].x, gl[2 * q].y, gl[2 * q + 1].x, gl[2 * q + 1].y);
         }
     }
-    }                                                    // next chunk of the block
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -320,8 +335,28 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
     const long long rowbase = ((long long)ix.b * p.dim + ix.ch0) * L;
     const long long bcbase = ((long long)ix.b * p.G + ix.g) * p.N * L;
     const int c_first = blockIdx.x * p.cpb, c_end = min(p.nchunks, c_first + p.cpb);
-    for (int chunk = c_first; chunk < c_end; ++chunk) {
-    if (chunk != c_first) __syncthreads();               // the previous chunk's tiles are consumed
+    const long long chains = (long long)p.batch * p.dim * NP;
+    const long long row = ((long long)ix.b * p.dim + ix.d) * NP;
+    // the block's carried-in forward state and adjoint state (the adjoint one then runs through the block's chunks in
+    // registers, last chunk first)
+    v2f Hin[NP / 2], gacc[NP / 2];
+#pragma unroll
+    for (int q = 0; q < NP / 4; ++q) {
+        float4 hv = make_float4(0.f, 0.f, 0.f, 0.f), gv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ix.live && p.nblocks > 1) {
+            hv = *reinterpret_cast<const float4*>(p.wsH + (long long)blockIdx.x * chains + row + 4 * q);
+            gv = *reinterpret_cast<const float4*>(p.wsG + (long long)(p.nblocks - 1 - (int)blockIdx.x) * chains + row + 4 * q);
+        }
+        Hin[2 * q] = (v2f){hv.x, hv.y}; Hin[2 * q + 1] = (v2f){hv.z, hv.w};
+        gacc[2 * q] = (v2f){gv.x, gv.y}; gacc[2 * q + 1] = (v2f){gv.z, gv.w};
+    }
+    v2f dA[NP / 2];                                      // parameter-gradient partials of the whole block
+#pragma unroll
+    for (int n = 0; n < NP / 2; ++n) dA[n] = splat(0.f);
+    float dDp = 0.0f, dbp = 0.0f;
+    float dwp[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int chunk = c_end - 1; chunk >= c_first; --chunk) {
+    if (chunk != c_end - 1) __syncthreads();             // the previous chunk's tiles are consumed
     const int t0 = chunk * kBT, t_end = min(p.L, t0 + kBT), tl = t_end - t0;
     if constexpr (MODE == 0) {
         bwd_load_rows<VEC>(p.u + rowbase, L, t0, t_end, ix.nch, lane, s_u);
@@ -333,18 +368,19 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
         fused_load_all<NP, VEC, MODE == 2>(p, ix, t0, tl, lane, s_u, s_d, s_dy, s_B, s_C, s_dtr);
     }
 
-    const long long chains = (long long)p.batch * p.dim * NP;
-    const long long row = ((long long)ix.b * p.dim + ix.d) * NP;
-    v2f h[NP / 2], gacc[NP / 2];
+    // state at the chunk's start = (state from zero at the block's start) + (decay since the block's start) x H_in
+    v2f h[NP / 2];
+    {
+        float Sc = 0.0f;
+        if (ix.live && p.nchunks > 1) Sc = p.wsS[(long long)chunk * p.batch * p.dim + (long long)ix.b * p.dim + ix.d];
+        const v2f S2 = splat(Sc);
 #pragma unroll
-    for (int q = 0; q < NP / 4; ++q) {
-        float4 hv = make_float4(0.f, 0.f, 0.f, 0.f), gv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ix.live && p.nchunks > 1) {
-            hv = *reinterpret_cast<const float4*>(p.wsH + (long long)chunk * chains + row + 4 * q);
-            gv = *reinterpret_cast<const float4*>(p.wsG + (long long)(p.nchunks - 1 - chunk) * chains + row + 4 * q);
+        for (int q = 0; q < NP / 4; ++q) {
+            float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ix.live && p.nchunks > 1) hv = *reinterpret_cast<const float4*>(p.wsHl + (long long)chunk * chains + row + 4 * q);
+            h[2 * q] = exp2_2(S2 * A2[2 * q]) * Hin[2 * q] + (v2f){hv.x, hv.y};
+            h[2 * q + 1] = exp2_2(S2 * A2[2 * q + 1]) * Hin[2 * q + 1] + (v2f){hv.z, hv.w};
         }
-        h[2 * q] = (v2f){hv.x, hv.y}; h[2 * q + 1] = (v2f){hv.z, hv.w};
-        gacc[2 * q] = (v2f){gv.x, gv.y}; gacc[2 * q + 1] = (v2f){gv.z, gv.w};
     }
     __syncthreads();
 
@@ -380,11 +416,6 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
             }
         }
     }
-
-    v2f dA[NP / 2];
-#pragma unroll
-    for (int n = 0; n < NP / 2; ++n) dA[n] = splat(0.f);
-    float dDp = 0.0f, dbp = 0.0f;
 
 #pragma unroll
     for (int st = NSUB - 1; st >= 0; --st) {
@@ -511,14 +542,6 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
             }
         }
     }
-    if (ix.live) {
-        // layout [b*dim + d][chunk][NP + pad]: the finish kernel streams one channel's partials contiguously
-        float* pr = p.part + (((long long)ix.b * p.dim + ix.d) * p.nchunks + chunk) * (NP + kPartPad);
-#pragma unroll
-        for (int q = 0; q < NP / 4; ++q)
-            *reinterpret_cast<float4*>(pr + 4 * q) = make_float4(dA[2 * q].x, dA[2 * q].y, dA[2 * q + 1].x, dA[2 * q + 1].y);
-        *reinterpret_cast<float4*>(pr + NP) = make_float4(dDp, dbp, 0.f, 0.f);
-    }
     } else {
     // ---- fused core: dx += du; d dt_r = Wdt^T ddelta (channel sum), dWdt partial; gradient planes ------------
     constexpr bool REV = MODE == 2;
@@ -526,7 +549,6 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
     float wdt[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) wdt[r] = (r < p.R && ix.live) ? p.Wdt[(long long)ix.d * p.R + r] : 0.0f;
-    float dwp[4] = {0.f, 0.f, 0.f, 0.f};
     float ddl[kBT];
 #pragma unroll
     for (int tt = 0; tt < kBT; ++tt) {
@@ -599,16 +621,19 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
             }
         }
     }
+    }
+    }                                                    // next chunk of the block (in reverse)
     if (ix.live) {
-        float* pr = p.part + (((long long)ix.b * p.dim + ix.d) * p.nchunks + chunk) * (NP + kPartPadFused);
+        // one partial record per block, layout [b*dim + d][block][NP + pad]: the finish kernel streams one channel's
+        // partials contiguously
+        constexpr int PAD = MODE == 0 ? kPartPad : kPartPadFused;
+        float* pr = p.part + (((long long)ix.b * p.dim + ix.d) * p.nblocks + blockIdx.x) * (NP + PAD);
 #pragma unroll
         for (int q = 0; q < NP / 4; ++q)
             *reinterpret_cast<float4*>(pr + 4 * q) = make_float4(dA[2 * q].x, dA[2 * q].y, dA[2 * q + 1].x, dA[2 * q + 1].y);
         *reinterpret_cast<float4*>(pr + NP) = make_float4(dDp, dbp, dwp[0], dwp[1]);
-        *reinterpret_cast<float4*>(pr + NP + 4) = make_float4(dwp[2], dwp[3], 0.f, 0.f);
+        if (MODE != 0) *reinterpret_cast<float4*>(pr + NP + 4) = make_float4(dwp[2], dwp[3], 0.f, 0.f);
     }
-    }
-    }                                                    // next chunk of the block
 }
 
 // dA (dim, N), dD (dim), dbias (dim) = sums of the per-chunk partials over chunks and batch.

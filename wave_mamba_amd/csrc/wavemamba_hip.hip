@@ -344,8 +344,34 @@ int wm_selscan_fwd(const float* u, const float* delta, const float* A, const flo
 
 }  // extern "C" (templates below need C++ linkage)
 namespace wm {
-struct BwdPlan { int NP, wpg, rows, nchunks; long long chains; size_t arr_bytes, seg_bytes, part_bytes, total; };
-static int bwd_plan(BwdPlan& pl, int batch, int dim, int L, int N, int G) {
+struct BwdPlan {
+    int NP, wpg, rows, nchunks, cpb, nblocks; long long chains;
+    size_t blk_bytes, arr_bytes, s_bytes, seg_bytes, part_bytes, total;
+    // workspace: [P | H | Pr | G] block summaries (blk_bytes each), per-chunk local states (arr_bytes), per-chunk dt sums
+    // (s_bytes), carry scratch for two scans (seg_bytes), per-block parameter-gradient partials (part_bytes)
+    size_t off_hl() const { return 4 * blk_bytes; }
+    size_t off_s() const { return off_hl() + arr_bytes; }
+    size_t off_seg() const { return off_s() + s_bytes; }
+    size_t off_part() const { return off_seg() + seg_bytes; }
+};
+// chunks per block of the two backward kernels: enough single-wave blocks to fill the chip (the reduce kernel holds 9
+// per compute unit = 2,304 at once).  The summaries the carry kernels walk are per BLOCK, so longer blocks also mean a
+// shorter carry and fewer partial records.  BASELINE config 3 training step on one MI355X (tools/train_breakdown.py,
+// gpurun_out r3z): at least 8192 blocks / at most 8 chunks each 101.2 ms, 4096 / 8 99.7, 2048 / 16 95.9, 1024 / 32 97.5.
+#ifndef WM_BWD_CPB_MAX
+#define WM_BWD_CPB_MAX 16
+#endif
+#ifndef WM_BWD_MIN_BLOCKS
+#define WM_BWD_MIN_BLOCKS 2048
+#endif
+// blocks of the finish kernel per channel: a thread adds up at most ~4 records per batch item
+static int bwd_finish_split(int nblocks, int npp) {
+    const int stride = (256 / npp) * npp;
+    const long long per = (long long)nblocks * npp;
+    long long y = (per + 4LL * stride - 1) / (4LL * stride);
+    return (int)(y < 1 ? 1 : (y > 64 ? 64 : y));
+}
+static int bwd_plan(BwdPlan& pl, int batch, int dim, int L, int N, int G, int part_pad = kPartPad) {
     if (batch <= 0 || dim <= 0 || L <= 0 || N <= 0 || G <= 0) return WM_EINVAL;
     if (N > 32) return WM_EUNSUPPORTED;
     if (dim % G != 0) return WM_EINVAL;
@@ -355,40 +381,58 @@ static int bwd_plan(BwdPlan& pl, int batch, int dim, int L, int N, int G) {
     if (rows > 65535) return WM_EUNSUPPORTED;
     pl.rows = (int)rows;
     pl.nchunks = (L + kBT - 1) / kBT;
+    {
+        const long long blocks1 = (long long)pl.nchunks * pl.rows;
+        const int cpb = (int)(blocks1 / (long long)WM_BWD_MIN_BLOCKS);
+        pl.cpb = cpb < 1 ? 1 : (cpb > WM_BWD_CPB_MAX ? WM_BWD_CPB_MAX : cpb);
+    }
+    pl.nblocks = (pl.nchunks + pl.cpb - 1) / pl.cpb;
     pl.chains = (long long)batch * dim * pl.NP;
-    pl.arr_bytes = (size_t)pl.nchunks * pl.chains * sizeof(float);
-    pl.seg_bytes = (size_t)2 * carry_nsegs(pl.nchunks) * pl.chains * sizeof(float);
-    pl.part_bytes = (size_t)pl.nchunks * batch * dim * (pl.NP + kPartPad) * sizeof(float);
-    pl.total = 4 * pl.arr_bytes + pl.seg_bytes + pl.part_bytes;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    pl.blk_bytes = up((size_t)pl.nblocks * pl.chains * sizeof(float));
+    pl.arr_bytes = up((size_t)pl.nchunks * pl.chains * sizeof(float));
+    pl.s_bytes = up((size_t)pl.nchunks * batch * dim * sizeof(float));
+    pl.seg_bytes = up((size_t)4 * carry_nsegs(pl.nblocks) * pl.chains * sizeof(float));
+    pl.part_bytes = up((size_t)pl.nblocks * batch * dim * (pl.NP + part_pad) * sizeof(float));
+    pl.total = pl.off_part() + pl.part_bytes;
     return WM_OK;
 }
 
-// chunks per block of the two backward kernels: enough blocks to fill the chip several times over, at most 8 chunks each
-static int bwd_chunks_per_block(const BwdPlan& pl) {
-    const long long blocks1 = (long long)pl.nchunks * pl.rows;
-    int cpb = (int)(blocks1 / (256LL * 32));
-    return cpb < 1 ? 1 : (cpb > 8 ? 8 : cpb);
+// forward and adjoint carry of one direction in ONE batch launch (same length, same depth)
+static void bwd_launch_carry(const ScanBwdArgs& a, const BwdPlan& pl, float* seg, hipStream_t st) {
+    CarryBatch cb{};
+    const int nsegs = (int)carry_nsegs(pl.nblocks);
+    const size_t one = (size_t)nsegs * pl.chains;
+    cb.d[0] = CarryDir{a.wsP, a.wsH, seg, seg + one, pl.nblocks, nsegs};
+    cb.d[1] = CarryDir{a.wsPr, a.wsG, seg + 2 * one, seg + 3 * one, pl.nblocks, nsegs};
+    launch_carry_batch(cb, 2, pl.chains, st);
+}
+static void bwd_bind_workspace(ScanBwdArgs& a, const BwdPlan& pl, char* w, float*& seg) {
+    a.wsP = (float*)w; a.wsH = (float*)(w + pl.blk_bytes); a.wsPr = (float*)(w + 2 * pl.blk_bytes);
+    a.wsG = (float*)(w + 3 * pl.blk_bytes);
+    a.wsHl = (float*)(w + pl.off_hl()); a.wsS = (float*)(w + pl.off_s());
+    seg = (float*)(w + pl.off_seg());
+    a.part = (float*)(w + pl.off_part());
+    a.nchunks = pl.nchunks; a.cpb = pl.cpb; a.nblocks = pl.nblocks;
 }
 
 template <int NP, bool VEC>
 static int bwd_launch(const ScanBwdArgs& a0, const BwdPlan& pl, float* seg, float* dA, float* dD, float* dbias,
                       hipStream_t st) {
     ScanBwdArgs a = a0;
-    a.cpb = bwd_chunks_per_block(pl);
-    const dim3 grid((unsigned)((pl.nchunks + a.cpb - 1) / a.cpb), (unsigned)pl.rows), block(64);
+    const dim3 grid((unsigned)pl.nblocks, (unsigned)pl.rows), block(64);
     ProfScope ps(12, st);
     if (pl.nchunks > 1) {
         hipLaunchKernelGGL((selscan_bwd_reduce_kernel<NP, VEC, 0>), grid, block, 0, st, a);
-        launch_carry(a.wsP, a.wsH, seg, pl.chains, pl.nchunks, st);
-        launch_carry(a.wsPr, a.wsG, seg, pl.chains, pl.nchunks, st);
+        if (pl.nblocks > 1) bwd_launch_carry(a, pl, seg, st);
     }
     hipLaunchKernelGGL((selscan_bwd_chunk_kernel<NP, VEC, 0>), grid, block, 0, st, a);
     hipMemsetAsync(dA, 0, (size_t)a.dim * a.N * sizeof(float), st);
     if (dD) hipMemsetAsync(dD, 0, (size_t)a.dim * sizeof(float), st);
     if (dbias) hipMemsetAsync(dbias, 0, (size_t)a.dim * sizeof(float), st);
-    const int ysplit = pl.nchunks >= 2048 ? 16 : (pl.nchunks >= 256 ? 4 : 1);
+    const int ysplit = bwd_finish_split(pl.nblocks, NP + kPartPad);
     hipLaunchKernelGGL(selscan_bwd_finish_kernel, dim3((unsigned)a.dim, (unsigned)ysplit), dim3(256), 0, st,
-                       (const float*)a.part, dA, dD, dbias, a.batch, a.dim, a.N, NP + kPartPad, pl.nchunks,
+                       (const float*)a.part, dA, dD, dbias, a.batch, a.dim, a.N, NP + kPartPad, pl.nblocks,
                        (const float*)nullptr, (float*)nullptr, 0, NP);
     return launch_status();
 }
@@ -418,13 +462,10 @@ int wm_selscan_bwd(const float* u, const float* delta, const float* A, const flo
     ScanBwdArgs a;
     a.u = u; a.delta = delta; a.A = A; a.Bm = Bm; a.Cm = Cm; a.D = D; a.bias = delta_bias; a.dy = dy;
     a.du = du; a.ddelta = ddelta; a.dB = dB; a.dC = dC;
-    char* w = (char*)workspace;
-    a.wsP = (float*)w; a.wsH = (float*)(w + pl.arr_bytes); a.wsPr = (float*)(w + 2 * pl.arr_bytes);
-    a.wsG = (float*)(w + 3 * pl.arr_bytes);
-    float* seg = (float*)(w + 4 * pl.arr_bytes);
-    a.part = (float*)(w + 4 * pl.arr_bytes + pl.seg_bytes);
+    float* seg = nullptr;
+    bwd_bind_workspace(a, pl, (char*)workspace, seg);
     a.batch = batch; a.dim = dim; a.L = L; a.N = N; a.G = G; a.dpg = dim / G; a.wpg = pl.wpg;
-    a.nchunks = pl.nchunks; a.softplus = delta_softplus ? 1 : 0; a.atomic_bc = pl.wpg > 1 ? 1 : 0;
+    a.softplus = delta_softplus ? 1 : 0; a.atomic_bc = pl.wpg > 1 ? 1 : 0;
     if (a.atomic_bc) {
         const size_t nb = (size_t)batch * G * N * L * sizeof(float);
         hipError_t e = hipMemsetAsync(dB, 0, nb, st);
@@ -816,7 +857,7 @@ static int core_bwd_plan(CoreBwdPlan& pl, int B, int D, int H, int W, int N, int
     if (N > 32 || R > kRecPad || D > 64) return WM_EUNSUPPORTED;
     pl.L = (long long)H * W;
     if (pl.L > 0x7fffffffLL) return WM_EUNSUPPORTED;
-    int rc = bwd_plan(pl.scan, B, D, (int)pl.L, N, 1);
+    int rc = bwd_plan(pl.scan, B, D, (int)pl.L, N, 1, kPartPadFused);
     if (rc) return rc;
     pl.CP = R + 2 * N;
     pl.NP = N <= 16 ? 16 : 32;
@@ -826,9 +867,9 @@ static int core_bwd_plan(CoreBwdPlan& pl, int B, int D, int H, int W, int N, int
     pl.rec_bytes = up((size_t)B * pl.ndir * pl.L * pl.RS * sizeof(float));
     pl.gpl_bytes = up((size_t)B * 2 * pl.CP * pl.L * sizeof(float));
     pl.map_bytes = up((size_t)B * D * pl.L * sizeof(float));
-    pl.part_bytes = up((size_t)pl.scan.nchunks * B * D * (pl.NP + kPartPadFused) * sizeof(float));
-    pl.scan_bytes = up(4 * pl.scan.arr_bytes + pl.scan.seg_bytes);
-    pl.total = pl.rec_bytes + pl.gpl_bytes + 4 * pl.map_bytes + pl.scan_bytes + pl.part_bytes;
+    pl.part_bytes = 0;                                            // (inside scan_bytes)
+    pl.scan_bytes = up(pl.scan.total);
+    pl.total = pl.rec_bytes + pl.gpl_bytes + 4 * pl.map_bytes + pl.scan_bytes;
     return WM_OK;
 }
 
@@ -836,18 +877,16 @@ static int core_bwd_plan(CoreBwdPlan& pl, int B, int D, int H, int W, int N, int
 template <int NP, bool VEC, int MODE>
 static void core_bwd_dir(ScanBwdArgs a, const CoreBwdPlan& pl, float* seg, const float* A_logs_k, float* dA_logs_k,
                          float* dD_k, float* dbias_k, float* dWdt_k, hipStream_t st) {
-    a.cpb = bwd_chunks_per_block(pl.scan);
-    const dim3 grid((unsigned)((pl.scan.nchunks + a.cpb - 1) / a.cpb), (unsigned)pl.scan.rows), block(64);
+    const dim3 grid((unsigned)pl.scan.nblocks, (unsigned)pl.scan.rows), block(64);
     if (pl.scan.nchunks > 1) {
         hipLaunchKernelGGL((selscan_bwd_reduce_kernel<NP, VEC, MODE>), grid, block, 0, st, a);
-        launch_carry(a.wsP, a.wsH, seg, pl.scan.chains, pl.scan.nchunks, st);
-        launch_carry(a.wsPr, a.wsG, seg, pl.scan.chains, pl.scan.nchunks, st);
+        if (pl.scan.nblocks > 1) bwd_launch_carry(a, pl.scan, seg, st);
     }
     hipLaunchKernelGGL((selscan_bwd_chunk_kernel<NP, VEC, MODE>), grid, block, 0, st, a);
-    const int ysplit = pl.scan.nchunks >= 2048 ? 16 : (pl.scan.nchunks >= 256 ? 4 : 1);
+    const int ysplit = bwd_finish_split(pl.scan.nblocks, NP + kPartPadFused);
     hipLaunchKernelGGL(selscan_bwd_finish_kernel, dim3((unsigned)a.dim, (unsigned)ysplit), dim3(256), 0, st,
                        (const float*)a.part, dA_logs_k, dD_k, dbias_k, a.batch, a.dim, a.N, NP + kPartPadFused,
-                       pl.scan.nchunks, A_logs_k, dWdt_k, a.R, NP);
+                       pl.scan.nblocks, A_logs_k, dWdt_k, a.R, NP);
 }
 }  // namespace wm
 extern "C" {
@@ -882,10 +921,7 @@ int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt
     float* dyTa = (float*)w; w += pl.map_bytes;
     float* dyTb = (float*)w; w += pl.map_bytes;
     float* dxT = (float*)w; w += pl.map_bytes;
-    float* wsP = (float*)w; float* wsH = (float*)(w + pl.scan.arr_bytes); float* wsPr = (float*)(w + 2 * pl.scan.arr_bytes);
-    float* wsG = (float*)(w + 3 * pl.scan.arr_bytes); float* seg = (float*)(w + 4 * pl.scan.arr_bytes);
-    w += pl.scan_bytes;
-    float* part = (float*)w;
+    char* scan_ws = w;
 
     hipError_t e = hipMemsetAsync(dx, 0, (size_t)B * D * L * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(dx_proj_weight, 0, (size_t)4 * CP * D * sizeof(float), st);
@@ -931,8 +967,9 @@ int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt
             a.u = xl; a.delta = nullptr; a.A = A_logs + (size_t)k * D * N; a.Bm = nullptr; a.Cm = nullptr;
             a.D = Ds + (size_t)k * D; a.bias = dt_projs_bias + (size_t)k * D; a.dy = dyl[kk];
             a.du = dxl; a.ddelta = nullptr; a.dB = nullptr; a.dC = nullptr;
-            a.wsP = wsP; a.wsH = wsH; a.wsPr = wsPr; a.wsG = wsG; a.part = part;
-            a.batch = B; a.dim = D; a.L = (int)L; a.N = N; a.G = 1; a.dpg = D; a.wpg = 1; a.nchunks = pl.scan.nchunks;
+            float* seg = nullptr;
+            bwd_bind_workspace(a, pl.scan, scan_ws, seg);
+            a.batch = B; a.dim = D; a.L = (int)L; a.N = N; a.G = 1; a.dpg = D; a.wpg = 1;
             a.softplus = 1; a.atomic_bc = 0;
             // records: (B, 4, L, 36) indexed by direction k, or (B, 2, L, 68) indexed by the layout's pair index kk
             a.rec = rec + (size_t)(pl.NP == 16 ? k : kk) * L * pl.RS; a.rec_bstride = (long long)pl.ndir * L * pl.RS;
