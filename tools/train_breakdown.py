@@ -6,17 +6,23 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import wave_mamba_amd as wm
 import bench
-ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=3); ap.add_argument("--wall-only", action="store_true"); args = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=3); ap.add_argument("--wall-only", action="store_true")
+args = ap.parse_args()
+# (torch.backends.cudnn.benchmark = True, which the reference's train.py:129 sets, is NOT an option here: without a
+# find-db MIOpen's exhaustive search compiles and times every solver per shape - the three warm-up steps did not finish in
+# 25 minutes on the GPU box, gpurun_out r3z.)
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 net = wm.WaveMamba(**bench.SHIPPED).train().to(dev)
 opt = wm.trainer.make_optimizer(net)
 g = torch.Generator().manual_seed(1234)
 lq, gt = torch.rand(8, 3, 512, 512, generator=g).to(dev), torch.rand(8, 3, 512, 512, generator=g).to(dev)
+import time
+t0 = time.perf_counter()
 for _ in range(3):
     wm.trainer.train_step(net, opt, lq, gt)
 torch.cuda.synchronize()
-import time
+print(f"three warm-up steps: {time.perf_counter() - t0:.1f} s")
 t0 = time.perf_counter()
 for _ in range(5):
     wm.trainer.train_step(net, opt, lq, gt)

@@ -1105,6 +1105,31 @@ class _Conv2dTrain(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _Conv2dAten(torch.autograd.Function):
+    """ATen's fp32 convolution (stride 1, 'same' padding) with the BIAS gradient on the HIP plane-sum kernel: autograd's
+    own `grad_output.sum((0, 2, 3))` is ATen's generic strided reduction - 141 launches, 5.4 ms of a 95-ms BASELINE
+    config-3 training step (tools/train_breakdown.py); input and weight gradients stay ATen's (MIOpen)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return F.conv2d(x, weight, bias, stride=1, padding=weight.shape[2] // 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        ks = weight.shape[2]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gx, gw, _ = torch.ops.aten.convolution_backward(
+                gy, x, weight, None, [1, 1], [ks // 2, ks // 2], [1, 1], False, [0, 0], 1,
+                [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False])
+        if ctx.needs_input_grad[2]:
+            gb = plane_sums(gy)
+        return gx, gw, gb
+
+
 # Training convolutions.  The split-bf16 matrix-core kernel carries 16 significant bits per operand (3-4e-6 relative on an
 # output): right for inference (the contract's bar is 1e-4 on outputs), but in the training step those 3e-6 on the
 # activations become ~1e-4 on the parameter gradients of the deepest block, whose 8 x 8 maps make every gradient a short
@@ -1131,7 +1156,9 @@ def conv2d_train(x, weight, bias=None):
     set_train_conv_bf16x3(True) - the split-bf16 matrix-core kernel for forward and input gradient (_Conv2dTrain)."""
     _require_cuda("conv2d_train", x, weight, bias)
     if not _TRAIN_CONV_BF16X3:
-        return F.conv2d(x.float(), weight, bias, stride=1, padding=weight.shape[2] // 2)
+        if bias is None or not bias.requires_grad:
+            return F.conv2d(x.float(), weight, bias, stride=1, padding=weight.shape[2] // 2)
+        return _Conv2dAten.apply(x.float(), weight, bias)
     return _Conv2dTrain.apply(x.contiguous().float(), weight, bias)
 
 
