@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import wave_mamba_amd as wm
 import bench
 ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=3); ap.add_argument("--wall-only", action="store_true")
+ap.add_argument("--detail", default="", help="comma-separated kernel-name substrings: print every launch's duration (us) of the last profiled step")
 args = ap.parse_args()
 # (torch.backends.cudnn.benchmark = True, which the reference's train.py:129 sets, is NOT an option here: without a
 # find-db MIOpen's exhaustive search compiles and times every solver per shape - the three warm-up steps did not finish in
@@ -40,6 +41,12 @@ for e in prof.events():
     if e.device_type == torch.autograd.DeviceType.CUDA:
         k = e.name.split("(")[0][:110]
         agg[k][0] += 1; agg[k][1] += e.device_time
+if args.detail:
+    evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    for sub in args.detail.split(","):
+        d = [e.device_time for e in evs if sub in e.name]
+        d = d[len(d) * (args.steps - 1) // args.steps:]
+        print(f"# {sub}: {len(d)} launches in the last step, us: " + " ".join(f"{x:.0f}" for x in d))
 tot = sum(v[1] for v in agg.values())
 print(f"GPU kernel time per step: {tot / args.steps / 1e3:.2f} ms in {sum(v[0] for v in agg.values()) / args.steps:.0f} kernels")
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:

@@ -307,34 +307,42 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int chb = (a.mbase + m) * 32 + 4 * khalf;
+        // Epilogue loads are UNCONDITIONAL, from channel indices clamped to Cout - 1 (the stores are guarded): a
+        // `ch < Cout ? load : 0` per element is a branch and a full wait per load - 16 bias loads, then 16 gate / residual
+        // loads per row, one after the other (tools/isa_load_waits.py: 119 full waits in the 1x1 kernel).
         float bv[16], b1v[G1X1 ? 16 : 1];
+        if (a.bias) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ch = chb + (i & 3) + 8 * (i >> 2);
-            bv[i] = (a.bias && ch < a.Cout) ? a.bias[ch] : 0.0f;
-            if (G1X1) b1v[i] = (a.bias1 && ch < a.Cout) ? a.bias1[ch] : 0.0f;
+            for (int i = 0; i < 16; ++i) bv[i] = a.bias[min(chb + (i & 3) + 8 * (i >> 2), a.Cout - 1)];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bv[i] = 0.0f;
+        }
+        if constexpr (G1X1) {
+            if (a.bias1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) b1v[i] = a.bias1[min(chb + (i & 3) + 8 * (i >> 2), a.Cout - 1)];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) b1v[i] = 0.0f;
+            }
         }
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             const int h = h0 + wave * RW + r;
             if (h >= H || w >= W) continue;
             const long long o = (((long long)b * a.Cout + chb) * H + h) * W + w;
+            const long long oplane = ((long long)b * a.Cout * H + h) * W + w;        // channel 0 of this pixel
             // all gate / residual loads of the 16 channels first, then the stores: y may alias neither, but the
             // compiler cannot know and would wait for every load before the store that follows it
             float gv[16], rv[16];
             if (a.gate) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int dc = (i & 3) + 8 * (i >> 2);
-                    gv[i] = (full || chb + dc < a.Cout) ? a.gate[o + dc * HW] : 0.0f;
-                }
+                for (int i = 0; i < 16; ++i) gv[i] = a.gate[oplane + (long long)min(chb + (i & 3) + 8 * (i >> 2), a.Cout - 1) * HW];
             }
             if (a.res) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int dc = (i & 3) + 8 * (i >> 2);
-                    rv[i] = (full || chb + dc < a.Cout) ? a.res[o + dc * HW] : 0.0f;
-                }
+                for (int i = 0; i < 16; ++i) rv[i] = a.res[oplane + (long long)min(chb + (i & 3) + 8 * (i >> 2), a.Cout - 1) * HW];
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {

@@ -66,13 +66,31 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const TP* __restrict__ x
             v[0] = left; v[1] = q.x; v[2] = q.y; v[3] = q.z; v[4] = q.w; v[5] = right;
         };
 
+        // 16-byte form: a row's loads are issued UNCONDITIONALLY from clamped addresses (the quad, and the one halo element
+        // the wave's first / last lane needs from memory), two rows ahead of their use, and masked when consumed.  Written
+        // as `ok ? load : 0` the loads sat behind branches with a full wait each, and the halo load was issued only after
+        // the quad had arrived and been shuffled: two exposed memory latencies per output row (tools/isa_load_waits.py).
+        auto fetch = [&](int r, float (&q)[4], float& e) {
+            const int rc = min(max(r, 0), H - 1);
+            const TP* rowp = xp + (long long)rc * W;
+            load4(rowp + (colok ? w0 : 0), q);
+            int we = lane == 0 ? w0 - 1 : w0 + 4;
+            we = min(max(we, 0), W - 1);
+            e = ld1(rowp + we);
+        };
+        auto finish = [&](int r, const float (&q)[4], float e, float (&v)[6]) {
+            const bool rowok = r >= 0 && r < H, ok = rowok && colok;
+            const float q0 = ok ? q[0] : 0.f, q1 = ok ? q[1] : 0.f, q2 = ok ? q[2] : 0.f, q3 = ok ? q[3] : 0.f;
+            float left = __shfl_up(q3, 1), right = __shfl_down(q0, 1);
+            if (lane == 0) left = (rowok && w0 - 1 >= 0 && w0 - 1 < W) ? e : 0.0f;
+            if (lane == 63) right = (rowok && w0 + 4 < W) ? e : 0.0f;
+            v[0] = left; v[1] = q0; v[2] = q1; v[3] = q2; v[4] = q3; v[5] = right;
+        };
+
         if (h0 < H) {                                     // uniform per wave (threadIdx.y, blockIdx.y)
             float r0[6], r1[6], r2[6];
-            load_row(h0 - 1, r0);
-            load_row(h0, r1);
             const int hend = min(H, h0 + kDwRows);
-            for (int h = h0; h < hend; ++h) {
-                load_row(h + 1, r2);
+            auto body = [&](int h) {
                 float o[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -95,6 +113,27 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const TP* __restrict__ x
                 }
 #pragma unroll
                 for (int j = 0; j < 6; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; }
+            };
+            if constexpr (VEC) {
+                float qa[4], qb[4], qc[4], qn[4], ea, eb, ec, en;
+                fetch(h0 - 1, qa, ea); fetch(h0, qb, eb); fetch(h0 + 1, qc, ec);
+                finish(h0 - 1, qa, ea, r0);
+                finish(h0, qb, eb, r1);
+                for (int h = h0; h < hend; ++h) {
+                    fetch(h + 2, qn, en);                  // (past the strip's / the image's end: a clamped row, unused or masked)
+                    finish(h + 1, qc, ec, r2);
+                    body(h);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) qc[j] = qn[j];
+                    ec = en;
+                }
+            } else {
+                load_row(h0 - 1, r0);
+                load_row(h0, r1);
+                for (int h = h0; h < hend; ++h) {
+                    load_row(h + 1, r2);
+                    body(h);
+                }
             }
         }
     }

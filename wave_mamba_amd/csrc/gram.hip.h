@@ -20,6 +20,7 @@ typedef float gram_f4 __attribute__((ext_vector_type(4)));
 constexpr int kGramWaves = 8;          // waves per block: their 32x32 partials meet in LDS
 constexpr int kGramPart = 32 * 32 + 64; // floats per block partial: G (32 x 32), nx (32), ny (32)
 // part: [B][gridDim.x][kGramPart]
+template <bool VEC /* L % 4 == 0 and 16-byte aligned operands */>
 __global__ __launch_bounds__(64 * kGramWaves) void gram32_kernel(const float* __restrict__ X, const float* __restrict__ Y,
                                                      float* __restrict__ part, int C, long long L, long long slice) {
     const int lane = threadIdx.x & 63;
@@ -31,7 +32,6 @@ __global__ __launch_bounds__(64 * kGramWaves) void gram32_kernel(const float* __
     const long long l_begin = wave * slice, l_end = min(L, l_begin + slice);
     const float* xb = X + (long long)b * C * L;
     const float* yb = Y + (long long)b * C * L;
-    const bool vec = (L & 3) == 0;
 
     gram_f4 acc[2][2];
 #pragma unroll
@@ -40,17 +40,21 @@ __global__ __launch_bounds__(64 * kGramWaves) void gram32_kernel(const float* __
         for (int c = 0; c < 2; ++c) acc[a][c] = (gram_f4){0.f, 0.f, 0.f, 0.f};
     float sx[2] = {0.f, 0.f}, sy[2] = {0.f, 0.f};
 
+    // 16-byte form: UNCONDITIONAL loads from clamped addresses, zeroed afterwards (an `ok ? load : 0` is a branch around
+    // the load with a full wait behind it: the eight loads of an iteration went out one at a time, tools/isa_load_waits.py)
     auto load4 = [&](const float* base, int row, long long l) -> float4 {
+        if constexpr (VEC) {
+            const bool ok = row < C && l < l_end;
+            const float4 v = *reinterpret_cast<const float4*>(base + (ok ? (long long)row * L + l : 0LL));
+            return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < C) {
             const float* q = base + (long long)row * L + l;
-            if (vec) { if (l < l_end) v = *reinterpret_cast<const float4*>(q); }
-            else {
-                if (l + 0 < l_end) v.x = q[0];
-                if (l + 1 < l_end) v.y = q[1];
-                if (l + 2 < l_end) v.z = q[2];
-                if (l + 3 < l_end) v.w = q[3];
-            }
+            if (l + 0 < l_end) v.x = q[0];
+            if (l + 1 < l_end) v.y = q[1];
+            if (l + 2 < l_end) v.z = q[2];
+            if (l + 3 < l_end) v.w = q[3];
         }
         return v;
     };

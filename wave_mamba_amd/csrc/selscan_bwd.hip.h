@@ -94,6 +94,15 @@ __device__ __forceinline__ BwdTileIdx bwd_decode(const ScanBwdArgs& p, int wr, i
     return r;
 }
 
+// 16-byte load that is UNCONDITIONAL (clamped to the array's first element when `ok` is false) and zeroed afterwards: an
+// `ok ? load : 0` compiles to a branch around the load with an s_waitcnt vmcnt(0) right behind it, so a tile's loads went
+// out one at a time, each waiting out its own latency (tools/train_breakdown.py --detail: the kernels of this file had a
+// floor of 30 / 63 us per launch however small the map).
+__device__ __forceinline__ float4 bwd_ld4(const float* __restrict__ base, long long off, bool ok) {
+    const float4 v = *reinterpret_cast<const float4*>(base + (ok ? off : 0LL));
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
 // cooperative load of one [64 rows][16 steps] tile (rows = this wave's channels) into LDS
 template <bool VEC>
 __device__ __forceinline__ void bwd_load_rows(const float* __restrict__ base, long long L, int t0, int t_end,
@@ -103,15 +112,14 @@ __device__ __forceinline__ void bwd_load_rows(const float* __restrict__ base, lo
     for (int i = 0; i < 4; ++i) {
         const int r = 16 * i + trow;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < nch) {
+        if constexpr (VEC) {     // unconditional load from a clamped address, zeroed afterwards (see bwd_ld4)
+            v = bwd_ld4(base, (long long)r * L + t, r < nch && t < t_end);
+        } else if (r < nch) {
             const float* q = base + (long long)r * L + t;
-            if constexpr (VEC) { if (t < t_end) v = *reinterpret_cast<const float4*>(q); }
-            else {
-                if (t + 0 < t_end) v.x = q[0];
-                if (t + 1 < t_end) v.y = q[1];
-                if (t + 2 < t_end) v.z = q[2];
-                if (t + 3 < t_end) v.w = q[3];
-            }
+            if (t + 0 < t_end) v.x = q[0];
+            if (t + 1 < t_end) v.y = q[1];
+            if (t + 2 < t_end) v.z = q[2];
+            if (t + 3 < t_end) v.w = q[3];
         }
         *reinterpret_cast<float4*>(&s[r * kBRow + 4 * tq]) = v;
     }
@@ -125,15 +133,14 @@ __device__ __forceinline__ void bwd_load_bc(const float* __restrict__ base, long
     for (int i = 0; i < NP / 16; ++i) {
         const int n = 16 * i + trow;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < N) {
+        if constexpr (VEC) {
+            v = bwd_ld4(base, (long long)n * L + t, n < N && t < t_end);
+        } else if (n < N) {
             const float* q = base + (long long)n * L + t;
-            if constexpr (VEC) { if (t < t_end) v = *reinterpret_cast<const float4*>(q); }
-            else {
-                if (t + 0 < t_end) v.x = q[0];
-                if (t + 1 < t_end) v.y = q[1];
-                if (t + 2 < t_end) v.z = q[2];
-                if (t + 3 < t_end) v.w = q[3];
-            }
+            if (t + 0 < t_end) v.x = q[0];
+            if (t + 1 < t_end) v.y = q[1];
+            if (t + 2 < t_end) v.z = q[2];
+            if (t + 3 < t_end) v.w = q[3];
         }
         s[(4 * tq + 0) * NP + n] = v.x; s[(4 * tq + 1) * NP + n] = v.y;
         s[(4 * tq + 2) * NP + n] = v.z; s[(4 * tq + 3) * NP + n] = v.w;
@@ -158,15 +165,14 @@ __device__ __forceinline__ void fused_load_rows(const float* __restrict__ base, 
     for (int i = 0; i < 4; ++i) {
         const int r = 16 * i + trow;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < nch) {
+        if constexpr (VEC) {
+            v = bwd_ld4(base, (long long)r * L + ft.plo + c, r < nch && c >= ft.c_lo && c < ft.c_hi);
+        } else if (r < nch) {
             const float* q = base + (long long)r * L + ft.plo + c;
-            if constexpr (VEC) { if (c >= ft.c_lo && c < ft.c_hi) v = *reinterpret_cast<const float4*>(q); }
-            else {
-                if (c + 0 >= ft.c_lo && c + 0 < ft.c_hi) v.x = q[0];
-                if (c + 1 >= ft.c_lo && c + 1 < ft.c_hi) v.y = q[1];
-                if (c + 2 >= ft.c_lo && c + 2 < ft.c_hi) v.z = q[2];
-                if (c + 3 >= ft.c_lo && c + 3 < ft.c_hi) v.w = q[3];
-            }
+            if (c + 0 >= ft.c_lo && c + 0 < ft.c_hi) v.x = q[0];
+            if (c + 1 >= ft.c_lo && c + 1 < ft.c_hi) v.y = q[1];
+            if (c + 2 >= ft.c_lo && c + 2 < ft.c_hi) v.z = q[2];
+            if (c + 3 >= ft.c_lo && c + 3 < ft.c_hi) v.w = q[3];
         }
         if (REV) *reinterpret_cast<float4*>(&s[r * kBRow + 4 * (3 - tq)]) = make_float4(v.w, v.z, v.y, v.x);
         else *reinterpret_cast<float4*>(&s[r * kBRow + 4 * tq]) = v;
@@ -182,8 +188,7 @@ __device__ __forceinline__ void fused_load_rec(const float* __restrict__ rec, co
         const int f = lane + 64 * j;                              // float4 index inside the 16 x RS tile
         if (f < kBT * RS / 4) {
             const int col = (4 * f) / RS, within = 4 * f - col * RS;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (col >= ft.c_lo && col < ft.c_hi) v = *reinterpret_cast<const float4*>(rec + ft.plo * RS + 4 * f);
+            const float4 v = bwd_ld4(rec, ft.plo * RS + 4 * f, col >= ft.c_lo && col < ft.c_hi);
             const int tt = REV ? kBT - 1 - col : col;
             float* dst = within == 0 ? s_dtr + tt * 4
                                      : (within < 4 + NP ? s_B + tt * NP + (within - 4) : s_C + tt * NP + (within - 4 - NP));
@@ -196,21 +201,30 @@ __device__ __forceinline__ void fused_load_rec(const float* __restrict__ rec, co
 // bwd-reduce: forward (P, H) and adjoint (G) chunk summaries in one pass
 // ------------------------------------------------------------------------------------------------
 // the per-channel decay rates: A (op boundary) or -exp(A_logs) (fused core), pre-multiplied by log2(e)
+// (All loads first, from clamped indices, then the selects: `n < N ? load : 0` per element is a branch and a full wait per
+// load - 16 of them, one after the other, were most of the 30 / 63 us these kernels took on the smallest maps.)
 template <int NP, int MODE>
 __device__ __forceinline__ void bwd_load_A(const ScanBwdArgs& p, int d, v2f (&A2)[NP / 2]) {
+    float raw[NP];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) raw[n] = p.A[(long long)d * p.N + min(n, p.N - 1)];
 #pragma unroll
     for (int n = 0; n < NP; ++n) {
-        float a = 0.0f;
-        if (n < p.N) {
-            const float raw = p.A[(long long)d * p.N + n];
-            a = (MODE == 0 ? raw : -expf(raw)) * 1.4426950408889634f;
-        }
+        const float a = n < p.N ? (MODE == 0 ? raw[n] : -expf(raw[n])) * 1.4426950408889634f : 0.0f;
         if (n & 1) A2[n / 2].y = a; else A2[n / 2].x = a;
     }
 }
+// the dt projection row of this lane's channel (fused core), zero beyond R / for dead lanes
+__device__ __forceinline__ void bwd_load_wdt(const ScanBwdArgs& p, const BwdTileIdx& ix, float (&wdt)[4]) {
+    float raw[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) raw[r] = p.Wdt[(long long)ix.d * p.R + min(r, p.R - 1)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wdt[r] = (r < p.R && ix.live) ? raw[r] : 0.0f;
+}
 // fused core: every operand tile of one chunk into LDS (s_d = raw delta = Wdt . dt_r, bias added by the caller)
 template <int NP, bool VEC, bool REV>
-__device__ __forceinline__ void fused_load_all(const ScanBwdArgs& p, const BwdTileIdx& ix, int t0, int tl, int lane,
+__device__ __forceinline__ void fused_load_all(const ScanBwdArgs& p, const BwdTileIdx& ix, int t0, int tl, int lane, const float (&wdt)[4],
                                                float* s_u, float* s_d, float* s_dy, float* s_B, float* s_C, float* s_dtr) {
     const FusedTile<REV> ft(p.L, t0, tl);
     const long long rowbase = ((long long)ix.b * p.dim + ix.ch0) * p.L;
@@ -218,9 +232,6 @@ __device__ __forceinline__ void fused_load_all(const ScanBwdArgs& p, const BwdTi
     fused_load_rows<REV, VEC>(p.dy + rowbase, p.L, ft, ix.nch, lane, s_dy);
     fused_load_rec<REV, NP>(p.rec + ix.b * p.rec_bstride, ft, lane, s_dtr, s_B, s_C);
     __syncthreads();
-    float wdt[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) wdt[r] = (r < p.R && ix.live) ? p.Wdt[(long long)ix.d * p.R + r] : 0.0f;
 #pragma unroll
     for (int tt = 0; tt < kBT; ++tt) {
         const float4 dr = *reinterpret_cast<const float4*>(&s_dtr[tt * 4]);
@@ -239,6 +250,8 @@ __global__ __launch_bounds__(64) void selscan_bwd_reduce_kernel(ScanBwdArgs p) {
     v2f A2[NP / 2];
     bwd_load_A<NP, MODE>(p, ix.d, A2);
     const float bias = p.bias ? p.bias[ix.d] : 0.0f;
+    float wdt[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (MODE != 0) bwd_load_wdt(p, ix, wdt);
     const int c_first = blockIdx.x * p.cpb, c_end = min(p.nchunks, c_first + p.cpb);
     const long long chains = (long long)p.batch * p.dim * NP;
     const long long row = ((long long)ix.b * p.dim + ix.d) * NP;
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(64) void selscan_bwd_reduce_kernel(ScanBwdArgs p) {
         bwd_load_bc<NP, VEC>(p.Bm + bcbase, L, t0, t_end, p.N, lane, s_B);
         bwd_load_bc<NP, VEC>(p.Cm + bcbase, L, t0, t_end, p.N, lane, s_C);
     } else {
-        fused_load_all<NP, VEC, MODE == 2>(p, ix, t0, tl, lane, s_u, s_d, s_dy, s_B, s_C, s_dtr);
+        fused_load_all<NP, VEC, MODE == 2>(p, ix, t0, tl, lane, wdt, s_u, s_d, s_dy, s_B, s_C, s_dtr);
     }
     __syncthreads();
     if (ix.live) {                                       // the chunk's start, relative to the block's start
@@ -332,6 +345,8 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
     bwd_load_A<NP, MODE>(p, ix.d, A2);
     const float bias = p.bias ? p.bias[ix.d] : 0.0f;
     const float Dd = p.D ? p.D[ix.d] : 0.0f;
+    float wdt[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (MODE != 0) bwd_load_wdt(p, ix, wdt);
     const long long rowbase = ((long long)ix.b * p.dim + ix.ch0) * L;
     const long long bcbase = ((long long)ix.b * p.G + ix.g) * p.N * L;
     const int c_first = blockIdx.x * p.cpb, c_end = min(p.nchunks, c_first + p.cpb);
@@ -340,15 +355,24 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
     // the block's carried-in forward state and adjoint state (the adjoint one then runs through the block's chunks in
     // registers, last chunk first)
     v2f Hin[NP / 2], gacc[NP / 2];
+    {
+        float4 hv[NP / 4], gv[NP / 4];
+        if (p.nblocks > 1) {                             // uniform: ONE branch around all the loads (dead lanes read channel ch0's row)
 #pragma unroll
-    for (int q = 0; q < NP / 4; ++q) {
-        float4 hv = make_float4(0.f, 0.f, 0.f, 0.f), gv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ix.live && p.nblocks > 1) {
-            hv = *reinterpret_cast<const float4*>(p.wsH + (long long)blockIdx.x * chains + row + 4 * q);
-            gv = *reinterpret_cast<const float4*>(p.wsG + (long long)(p.nblocks - 1 - (int)blockIdx.x) * chains + row + 4 * q);
+            for (int q = 0; q < NP / 4; ++q) {
+                hv[q] = *reinterpret_cast<const float4*>(p.wsH + (long long)blockIdx.x * chains + row + 4 * q);
+                gv[q] = *reinterpret_cast<const float4*>(p.wsG + (long long)(p.nblocks - 1 - (int)blockIdx.x) * chains + row + 4 * q);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NP / 4; ++q) hv[q] = gv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        Hin[2 * q] = (v2f){hv.x, hv.y}; Hin[2 * q + 1] = (v2f){hv.z, hv.w};
-        gacc[2 * q] = (v2f){gv.x, gv.y}; gacc[2 * q + 1] = (v2f){gv.z, gv.w};
+        const float lv = ix.live ? 1.0f : 0.0f;
+#pragma unroll
+        for (int q = 0; q < NP / 4; ++q) {
+            Hin[2 * q] = (v2f){hv[q].x, hv[q].y} * lv; Hin[2 * q + 1] = (v2f){hv[q].z, hv[q].w} * lv;
+            gacc[2 * q] = (v2f){gv[q].x, gv[q].y} * lv; gacc[2 * q + 1] = (v2f){gv[q].z, gv[q].w} * lv;
+        }
     }
     v2f dA[NP / 2];                                      // parameter-gradient partials of the whole block
 #pragma unroll
@@ -365,21 +389,28 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
         bwd_load_bc<NP, VEC>(p.Bm + bcbase, L, t0, t_end, p.N, lane, s_B);
         bwd_load_bc<NP, VEC>(p.Cm + bcbase, L, t0, t_end, p.N, lane, s_C);
     } else {
-        fused_load_all<NP, VEC, MODE == 2>(p, ix, t0, tl, lane, s_u, s_d, s_dy, s_B, s_C, s_dtr);
+        fused_load_all<NP, VEC, MODE == 2>(p, ix, t0, tl, lane, wdt, s_u, s_d, s_dy, s_B, s_C, s_dtr);
     }
 
     // state at the chunk's start = (state from zero at the block's start) + (decay since the block's start) x H_in
     v2f h[NP / 2];
     {
         float Sc = 0.0f;
-        if (ix.live && p.nchunks > 1) Sc = p.wsS[(long long)chunk * p.batch * p.dim + (long long)ix.b * p.dim + ix.d];
+        float4 hv[NP / 4];
+        if (p.nchunks > 1) {                             // uniform
+            Sc = p.wsS[(long long)chunk * p.batch * p.dim + (long long)ix.b * p.dim + ix.d];
+#pragma unroll
+            for (int q = 0; q < NP / 4; ++q) hv[q] = *reinterpret_cast<const float4*>(p.wsHl + (long long)chunk * chains + row + 4 * q);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NP / 4; ++q) hv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float lv = ix.live ? 1.0f : 0.0f;
         const v2f S2 = splat(Sc);
 #pragma unroll
         for (int q = 0; q < NP / 4; ++q) {
-            float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ix.live && p.nchunks > 1) hv = *reinterpret_cast<const float4*>(p.wsHl + (long long)chunk * chains + row + 4 * q);
-            h[2 * q] = exp2_2(S2 * A2[2 * q]) * Hin[2 * q] + (v2f){hv.x, hv.y};
-            h[2 * q + 1] = exp2_2(S2 * A2[2 * q + 1]) * Hin[2 * q + 1] + (v2f){hv.z, hv.w};
+            h[2 * q] = exp2_2(S2 * A2[2 * q]) * Hin[2 * q] + (v2f){hv[q].x, hv[q].y} * lv;
+            h[2 * q + 1] = exp2_2(S2 * A2[2 * q + 1]) * Hin[2 * q + 1] + (v2f){hv[q].z, hv[q].w} * lv;
         }
     }
     __syncthreads();
@@ -546,9 +577,6 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
     // ---- fused core: dx += du; d dt_r = Wdt^T ddelta (channel sum), dWdt partial; gradient planes ------------
     constexpr bool REV = MODE == 2;
     const FusedTile<REV> ft(L, t0, tl);
-    float wdt[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) wdt[r] = (r < p.R && ix.live) ? p.Wdt[(long long)ix.d * p.R + r] : 0.0f;
     float ddl[kBT];
 #pragma unroll
     for (int tt = 0; tt < kBT; ++tt) {

@@ -49,8 +49,9 @@ struct ProjBwdArgs {
     const float* Wx0;          // x_proj_weight of direction kk = 0: (CP, D)
     const float* Wx1;          // ... kk = 1
     float* dx;                 // (B, D, L), accumulated into
-    float* dWx0;               // (CP, D), accumulated into by atomics (zeroed by the caller)
+    float* dWx0;               // (CP, D), written by projgrad_finish_kernel
     float* dWx1;
+    float* part;               // projgrad block partials [kk][block (x, b)][16 RT x 64]
     int B, D, CP;
     long long L;
 };
@@ -92,13 +93,21 @@ __global__ __launch_bounds__(256) void projbwd_dx_kernel(const ProjBwdArgs a) {
 }
 
 typedef float pg_f4 __attribute__((ext_vector_type(4)));
-constexpr int kPgWaves = 16;
+constexpr int kPgWaves = 8;      // (512 threads: up to 256 registers per lane - the 16 RT x 64 accumulator plus 14 loads in flight)
 
-// dWx_kk[c][d] += sum_p g[b][kk][c][p] x[b][d][p] for a slice of p per wave: fp32 MFMA 16x16x4 with both operands read
-// as 16-byte runs of 4 consecutive positions (rows = planes), 3 x 4 output tiles (48 x 64), block-level sum by LDS
-// atomics (16 waves per block: 4 resident waves per SIMD hide the load latency), then one global atomic per element
-// per block.  grid (blocks, B, 2), block (64 * kPgWaves).
-template <int RT /* 16-row tiles of gradient planes: 3 (CP <= 48) or 5 (CP <= 80) */>
+// dWx_kk[c][d] += sum_p g[b][kk][c][p] x[b][d][p] for a slice of p per wave, on the bf16 matrix cores with both operands
+// split into two bf16 terms (hi + lo; the product accumulated in fp32 as hi.hi + hi.lo + lo.hi, ~4e-6 relative per product,
+// the same three-product form as the forward's x_proj): K = 32 positions per v_mfma_f32_16x16x32_bf16, lane (row i16, kq)
+// feeds positions 8 kq .. 8 kq + 7 of its plane row - two 16-byte loads per operand tile.  Round 2 used the fp32-input
+// v_mfma_f32_16x16x4_f32, which runs at the fp32 VECTOR rate: 48 of them per 16 positions made the kernel matrix-bound
+// (3.9 ms of a 92-ms BASELINE config-3 training step).  RT x 4 output tiles (16 RT x 64), block-level sum by LDS atomics
+// (16 waves per block), then the block's 16 RT x 64 partial goes to the workspace and projgrad_finish_kernel adds the
+// blocks up (global atomics from 256 blocks onto the same 2,304 addresses serialise in the memory-side cache - the 8 XCDs'
+// L2s do not share lines).  grid (blocks, B, 2), block (64 * kPgWaves).
+#ifndef WM_PROJGRAD_F32
+#define WM_PROJGRAD_F32 0
+#endif
+template <int RT /* 16-row tiles of gradient planes: 3 (CP <= 48) or 5 (CP <= 80) */, bool VEC /* L % 4 == 0, 16-byte aligned planes */>
 __global__ __launch_bounds__(64 * kPgWaves) void projgrad_kernel(const ProjBwdArgs a, long long slice) {
     __shared__ float s_part[16 * RT * 64];                          // the block's waves meet here by LDS atomics
     for (int e = threadIdx.x; e < 16 * RT * 64; e += 64 * kPgWaves) s_part[e] = 0.0f;
@@ -110,26 +119,31 @@ __global__ __launch_bounds__(64 * kPgWaves) void projgrad_kernel(const ProjBwdAr
     const long long l_begin = wave * slice, l_end = min(a.L, l_begin + slice);
     const float* gb = a.g + (((long long)b * 2 + kk) * a.CP) * a.L;
     const float* xb = a.x + (long long)b * a.D * a.L;
-    const bool vec = (a.L & 3) == 0;
     pg_f4 acc[RT][4];
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (pg_f4){0.f, 0.f, 0.f, 0.f};
+    // The 16-byte form loads UNCONDITIONALLY from a clamped address and zeroes afterwards: an `ok ? load : 0` is a branch
+    // around the load with an s_waitcnt vmcnt(0) behind it, i.e. the 14 loads of an iteration one after the other, each
+    // waiting out its own latency - the kernel took 122 us at EVERY map size (8 iterations per wave at 64 x 64).
     auto load4 = [&](const float* base, int row, int nrows, long long l) -> float4 {
+        if constexpr (VEC) {     // (a compile-time switch: a run-time one is a branch per load again)
+            const bool ok = row < nrows && l < l_end;
+            const float4 v = *reinterpret_cast<const float4*>(base + (ok ? (long long)row * a.L + l : 0LL));
+            return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < nrows) {
             const float* q = base + (long long)row * a.L + l;
-            if (vec) { if (l < l_end) v = *reinterpret_cast<const float4*>(q); }
-            else {
-                if (l + 0 < l_end) v.x = q[0];
-                if (l + 1 < l_end) v.y = q[1];
-                if (l + 2 < l_end) v.z = q[2];
-                if (l + 3 < l_end) v.w = q[3];
-            }
+            if (l + 0 < l_end) v.x = q[0];
+            if (l + 1 < l_end) v.y = q[1];
+            if (l + 2 < l_end) v.z = q[2];
+            if (l + 3 < l_end) v.w = q[3];
         }
         return v;
     };
+#if WM_PROJGRAD_F32
     for (long long l0 = l_begin; l0 < l_end; l0 += 16) {
         const long long l = l0 + 4 * kq;
         float4 ga[RT], xa[4];
@@ -148,6 +162,42 @@ __global__ __launch_bounds__(64 * kPgWaves) void projgrad_kernel(const ProjBwdAr
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv, xv, acc[i][j], 0, 0, 0);
                 }
     }
+#else
+    auto split8 = [&](const float4 lo4, const float4 hi4, core_bf8& h, core_bf8& l) {
+        const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            core_bf2 h2, l2;
+            core_split2(v[j], v[j + 1], h2, l2);
+            h[j] = h2[0]; h[j + 1] = h2[1]; l[j] = l2[0]; l[j + 1] = l2[1];
+        }
+    };
+    for (long long l0 = l_begin; l0 < l_end; l0 += 32) {
+        const long long l = l0 + 8 * kq;
+        // all 2 (RT + 4) loads of the iteration first, then the splits: written as load-split-load-split the compiler
+        // kept that order, with a full wait after every load
+        float4 xr[4][2], gr[RT][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xr[j][0] = load4(xb, i16 + 16 * j, a.D, l); xr[j][1] = load4(xb, i16 + 16 * j, a.D, l + 4); }
+#pragma unroll
+        for (int i = 0; i < RT; ++i) { gr[i][0] = load4(gb, i16 + 16 * i, a.CP, l); gr[i][1] = load4(gb, i16 + 16 * i, a.CP, l + 4); }
+        __builtin_amdgcn_sched_barrier(0);
+        core_bf8 xh[4], xl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split8(xr[j][0], xr[j][1], xh[j], xl[j]);
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            core_bf8 gh, gl;
+            split8(gr[i][0], gr[i][1], gh, gl);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl, xh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, xl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, xh[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+#endif
     // D layout: lane holds rows 4 kq .. 4 kq + 3 of column i16
 #pragma unroll
     for (int i = 0; i < RT; ++i)
@@ -156,12 +206,24 @@ __global__ __launch_bounds__(64 * kPgWaves) void projgrad_kernel(const ProjBwdAr
 #pragma unroll
             for (int r = 0; r < 4; ++r) atomicAdd(&s_part[(16 * i + 4 * kq + r) * 64 + 16 * j + i16], acc[i][j][r]);
     __syncthreads();
-    float* dW = kk ? a.dWx1 : a.dWx0;
-    for (int e = threadIdx.x; e < 16 * RT * 64; e += 64 * kPgWaves) {
-        const float t = s_part[e];
-        const int c = e >> 6, d = e & 63;
-        if (c < a.CP && d < a.D) atomicAdd(dW + (long long)c * a.D + d, t);
+    float* o = a.part + (((long long)kk * gridDim.y + b) * gridDim.x + blockIdx.x) * (16 * RT * 64);
+    for (int e = threadIdx.x; e < 16 * RT * 64; e += 64 * kPgWaves) o[e] = s_part[e];
+}
+// dWx_kk[c][d] = sum over the nb block partials.  grid (RT * 4, 2), block (256): thread = one element, reading its column
+// of the [block][16 RT x 64] array (consecutive threads, consecutive words).
+template <int RT>
+__global__ __launch_bounds__(256) void projgrad_finish_kernel(const ProjBwdArgs a, int nb) {
+    const int e = blockIdx.x * 256 + threadIdx.x, kk = blockIdx.y;
+    const float* p = a.part + (long long)kk * nb * (16 * RT * 64) + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = 0;
+    for (; i + 3 < nb; i += 4) {
+        s0 += p[(long long)i * (16 * RT * 64)]; s1 += p[(long long)(i + 1) * (16 * RT * 64)];
+        s2 += p[(long long)(i + 2) * (16 * RT * 64)]; s3 += p[(long long)(i + 3) * (16 * RT * 64)];
     }
+    for (; i < nb; ++i) s0 += p[(long long)i * (16 * RT * 64)];
+    const int c = e >> 6, d = e & 63;
+    if (c < a.CP && d < a.D) (kk ? a.dWx1 : a.dWx0)[(long long)c * a.D + d] = (s0 + s1) + (s2 + s3);
 }
 
 // dW[o][i] += sum_t gy[t][o] x[t][i] for token-major operands gy (T, O), x (T, I): the weight gradient of nn.Linear

@@ -852,6 +852,12 @@ struct CoreBwdPlan {
     BwdPlan scan; long long L; int CP, NP, RS, ndir;      // RS: record stride, ndir: directions per record set (4 / 2)
     size_t rec_bytes, gpl_bytes, map_bytes, part_bytes, scan_bytes, total;
 };
+// waves of the x_proj weight-gradient kernel per (batch item, direction): >= 256 positions each, whole blocks
+static long long core_bwd_pg_waves(long long L) {
+    long long waves = (L + 255) / 256;
+    if (waves > 4096) waves = 4096;
+    return ((waves + kPgWaves - 1) / kPgWaves) * kPgWaves;
+}
 static int core_bwd_plan(CoreBwdPlan& pl, int B, int D, int H, int W, int N, int R) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || N <= 0 || R <= 0) return WM_EINVAL;
     if (N > 32 || R > kRecPad || D > 64) return WM_EUNSUPPORTED;
@@ -867,9 +873,10 @@ static int core_bwd_plan(CoreBwdPlan& pl, int B, int D, int H, int W, int N, int
     pl.rec_bytes = up((size_t)B * pl.ndir * pl.L * pl.RS * sizeof(float));
     pl.gpl_bytes = up((size_t)B * 2 * pl.CP * pl.L * sizeof(float));
     pl.map_bytes = up((size_t)B * D * pl.L * sizeof(float));
-    pl.part_bytes = 0;                                            // (inside scan_bytes)
+    // block partials of the x_proj weight gradient: [2 directions][B x blocks][16 RT x 64]
+    pl.part_bytes = up((size_t)2 * B * (core_bwd_pg_waves(pl.L) / kPgWaves) * 16 * (pl.NP == 16 ? 3 : 5) * 64 * sizeof(float));
     pl.scan_bytes = up(pl.scan.total);
-    pl.total = pl.rec_bytes + pl.gpl_bytes + 4 * pl.map_bytes + pl.scan_bytes;
+    pl.total = pl.rec_bytes + pl.gpl_bytes + 4 * pl.map_bytes + pl.scan_bytes + pl.part_bytes;
     return WM_OK;
 }
 
@@ -921,10 +928,11 @@ int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt
     float* dyTa = (float*)w; w += pl.map_bytes;
     float* dyTb = (float*)w; w += pl.map_bytes;
     float* dxT = (float*)w; w += pl.map_bytes;
-    char* scan_ws = w;
+    char* scan_ws = w; w += pl.scan_bytes;
+    float* pgpart = (float*)w;
 
+    // (dx_proj_weight: every element is written by projgrad_finish_kernel)
     hipError_t e = hipMemsetAsync(dx, 0, (size_t)B * D * L * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(dx_proj_weight, 0, (size_t)4 * CP * D * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(ddt_projs_weight, 0, (size_t)4 * D * R * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(ddt_projs_bias, 0, (size_t)4 * D * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(dA_logs, 0, (size_t)4 * D * N * sizeof(float), st);
@@ -997,17 +1005,20 @@ int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt
             hipLaunchKernelGGL(projbwd_dx_kernel<36>, dim3((unsigned)((L + 255) / 256), (unsigned)B), dim3(256), 0, st, g);
         else
             hipLaunchKernelGGL(projbwd_dx_kernel<68>, dim3((unsigned)((L + 255) / 256), (unsigned)B), dim3(256), 0, st, g);
-        long long waves = (L + 255) / 256;                                  // >= 256 positions per wave
-        if (waves > 4096) waves = 4096;
-        waves = ((waves + kPgWaves - 1) / kPgWaves) * kPgWaves;
-        long long slice = (L + waves - 1) / waves;
-        slice = ((slice + 15) / 16) * 16;
-        if (pl.NP == 16)
-            hipLaunchKernelGGL(projgrad_kernel<3>, dim3((unsigned)(waves / kPgWaves), (unsigned)B, 2), dim3(64 * kPgWaves), 0,
-                               st, g, slice);
-        else
-            hipLaunchKernelGGL(projgrad_kernel<5>, dim3((unsigned)(waves / kPgWaves), (unsigned)B, 2), dim3(64 * kPgWaves), 0,
-                               st, g, slice);
+        g.part = pgpart;
+        const long long pgwaves = core_bwd_pg_waves(L);
+        long long slice = (L + pgwaves - 1) / pgwaves;
+        slice = ((slice + 31) / 32) * 32;                                   // whole K-steps of 32 positions
+        const unsigned pgb = (unsigned)(pgwaves / kPgWaves);
+        const bool pgvec = (L % 4 == 0) && aligned16(gpl) && aligned16(xl);
+#define WM_PG(RT)                                                                                                            \
+        do {                                                                                                                 \
+            if (pgvec) hipLaunchKernelGGL((projgrad_kernel<RT, true>), dim3(pgb, (unsigned)B, 2), dim3(64 * kPgWaves), 0, st, g, slice); \
+            else hipLaunchKernelGGL((projgrad_kernel<RT, false>), dim3(pgb, (unsigned)B, 2), dim3(64 * kPgWaves), 0, st, g, slice);      \
+            hipLaunchKernelGGL(projgrad_finish_kernel<RT>, dim3(RT * 4, 2), dim3(256), 0, st, g, (int)(pgb * B));            \
+        } while (0)
+        if (pl.NP == 16) WM_PG(3); else WM_PG(5);
+#undef WM_PG
         if (layout) {
             const dim3 tg((unsigned)((H + 31) / 32), (unsigned)((W + 31) / 32), (unsigned)(B * D)), tb(32, 8);
             hipLaunchKernelGGL(transpose_planes_kernel, tg, tb, 0, st, (const float*)dxT, dx, W, H, 1);   // dx += (dx^T)^T
@@ -1194,8 +1205,12 @@ int wm_gram_fwd(const float* X, const float* Y, float* G, float* nx, float* ny, 
     if (workspace_bytes < (size_t)B * nblk * kGramPart * sizeof(float)) return WM_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)workspace;
-    hipLaunchKernelGGL(gram32_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(64 * kGramWaves), 0, st, X, Y, part, C,
-                       (long long)L, slice);
+    if (L % 4 == 0)
+        hipLaunchKernelGGL(gram32_kernel<true>, dim3((unsigned)nblk, (unsigned)B), dim3(64 * kGramWaves), 0, st, X, Y, part, C,
+                           (long long)L, slice);
+    else
+        hipLaunchKernelGGL(gram32_kernel<false>, dim3((unsigned)nblk, (unsigned)B), dim3(64 * kGramWaves), 0, st, X, Y, part, C,
+                           (long long)L, slice);
     hipLaunchKernelGGL(gram_reduce_kernel, dim3(kGramPart / 64, (unsigned)B), dim3(256), 0, st, (const float*)part, G, nx, ny,
                        C, (int)nblk);
     return launch_status();
