@@ -116,10 +116,15 @@ __global__ __launch_bounds__(64, WM_LB_WAVES) void selscan_chunk_kernel(ScanArgs
 
     // per-lane constants
     v2f A2[NP / 2];                                   // A * log2(e), as (n, n+1) pairs
+    {
+        float raw[NP];                                // (all loads first, from clamped indices: see fetch below)
 #pragma unroll
-    for (int n = 0; n < NP; ++n) {
-        const float a = (n < p.N) ? p.A[(long long)d * p.N + n] * 1.4426950408889634f : 0.0f;
-        if (n & 1) A2[n / 2].y = a; else A2[n / 2].x = a;
+        for (int n = 0; n < NP; ++n) raw[n] = p.A[(long long)d * p.N + min(n, p.N - 1)];
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+            const float a = (n < p.N) ? raw[n] * 1.4426950408889634f : 0.0f;
+            if (n & 1) A2[n / 2].y = a; else A2[n / 2].x = a;
+        }
     }
     const float bias = p.bias ? p.bias[d] : 0.0f;
     const float Dd = (PHASE == 3 && p.D) ? p.D[d] : 0.0f;
@@ -152,26 +157,24 @@ __global__ __launch_bounds__(64, WM_LB_WAVES) void selscan_chunk_kernel(ScanArgs
 
     auto fetch = [&](int t0) {
         if constexpr (VEC) {
+            // UNCONDITIONAL loads from clamped offsets, masked when the tile is staged: an `ok ? load : 0` is a branch
+            // around the load with a full wait behind it - the ten loads of a tile went out one at a time, each waiting
+            // out its own latency (tools/isa_load_waits.py)
             const int t = t0 + 4 * tq;
             const bool tin = t < t_end;                  // L % 4 == 0: a quad is all-in or all-out
 #pragma unroll
             for (int i = 0; i < kNld; ++i) {
                 const int r = kRpi * i + trow;
-                const bool ok = tin && r < nch;
-                ru[i] = ok ? *reinterpret_cast<const float4*>(ub + (long long)r * L + t)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-                rd[i] = ok ? *reinterpret_cast<const float4*>(db + (long long)r * L + t)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                const long long off = (tin && r < nch) ? (long long)r * L + t : 0LL;
+                ru[i] = *reinterpret_cast<const float4*>(ub + off);
+                rd[i] = *reinterpret_cast<const float4*>(db + off);
             }
 #pragma unroll
             for (int i = 0; i < NBQ; ++i) {
                 const int n = kRpi * i + trow;
-                const bool ok = tin && n < p.N;
-                rB[i] = ok ? *reinterpret_cast<const float4*>(Bb + (long long)n * L + t)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (PHASE == 3)
-                    rC[i] = ok ? *reinterpret_cast<const float4*>(Cb + (long long)n * L + t)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
+                const long long off = (tin && n < p.N) ? (long long)n * L + t : 0LL;
+                rB[i] = *reinterpret_cast<const float4*>(Bb + off);
+                if (PHASE == 3) rC[i] = *reinterpret_cast<const float4*>(Cb + off);
             }
         } else {
             // scalar path: same element->register mapping, element-wise guards
@@ -200,22 +203,30 @@ __global__ __launch_bounds__(64, WM_LB_WAVES) void selscan_chunk_kernel(ScanArgs
         }
     };
 
-    auto stage = [&]() {          // registers -> LDS (u/delta row-major padded, B/C transposed)
+    auto stage = [&](int t0) {    // registers -> LDS (u/delta row-major padded, B/C transposed); t0: the staged tile's first step
+        const bool tin = !VEC || t0 + 4 * tq < t_end;
+        // (component-wise selects: a ternary on the float4 STRUCT goes through memory and drags the staging registers
+        // into scratch)
+        auto sel4 = [](bool ok, const float4& v) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); };
 #pragma unroll
         for (int i = 0; i < kNld; ++i) {
             const int r = kRpi * i + trow;
-            *reinterpret_cast<float4*>(&s_u[r * kRow + 4 * tq]) = ru[i];
-            *reinterpret_cast<float4*>(&s_d[r * kRow + 4 * tq]) = rd[i];
+            const bool ok = !VEC || (tin && r < nch);
+            *reinterpret_cast<float4*>(&s_u[r * kRow + 4 * tq]) = sel4(ok, ru[i]);
+            *reinterpret_cast<float4*>(&s_d[r * kRow + 4 * tq]) = sel4(ok, rd[i]);
         }
 #pragma unroll
         for (int i = 0; i < NBQ; ++i) {
             const int n = kRpi * i + trow;
             if (n < NP) {
-                s_B[(4 * tq + 0) * NP + n] = rB[i].x; s_B[(4 * tq + 1) * NP + n] = rB[i].y;
-                s_B[(4 * tq + 2) * NP + n] = rB[i].z; s_B[(4 * tq + 3) * NP + n] = rB[i].w;
+                const bool ok = !VEC || (tin && n < p.N);
+                const float4 bq = sel4(ok, rB[i]);
+                s_B[(4 * tq + 0) * NP + n] = bq.x; s_B[(4 * tq + 1) * NP + n] = bq.y;
+                s_B[(4 * tq + 2) * NP + n] = bq.z; s_B[(4 * tq + 3) * NP + n] = bq.w;
                 if (PHASE == 3) {
-                    s_C[(4 * tq + 0) * NP + n] = rC[i].x; s_C[(4 * tq + 1) * NP + n] = rC[i].y;
-                    s_C[(4 * tq + 2) * NP + n] = rC[i].z; s_C[(4 * tq + 3) * NP + n] = rC[i].w;
+                    const float4 cq = sel4(ok, rC[i]);
+                    s_C[(4 * tq + 0) * NP + n] = cq.x; s_C[(4 * tq + 1) * NP + n] = cq.y;
+                    s_C[(4 * tq + 2) * NP + n] = cq.z; s_C[(4 * tq + 3) * NP + n] = cq.w;
                 }
             }
         }
@@ -223,7 +234,7 @@ __global__ __launch_bounds__(64, WM_LB_WAVES) void selscan_chunk_kernel(ScanArgs
 
     fetch(t_begin);
     for (int t0 = t_begin; t0 < t_end; t0 += kTile) {
-        stage();
+        stage(t0);
         __syncthreads();
         if (t0 + kTile < t_end) fetch(t0 + kTile);      // in flight during the scan below
         const int tl = min(kTile, t_end - t0);           // wave-uniform
