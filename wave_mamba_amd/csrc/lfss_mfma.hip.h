@@ -88,8 +88,11 @@ __device__ __forceinline__ int aop_slot(int j, int l) { return ((j >> 2) * 64 + 
 // channel held by accumulator register j in lanes of half h
 __device__ __forceinline__ int acc_chan(int j, int h) { return (j & 3) + 8 * (j >> 2) + 4 * h; }
 
+// waves per SIMD the middle kernel is compiled for.  Four (128 registers) spilled 46 vector registers of the ny = 4 fp32
+// form to scratch; three (163 registers, no spills) is 5 % faster on the kernel (6.92 -> 6.60 ms per UHD step for the
+// block glue, tools: build_variant.sh mid3, bench.py twice each, gpurun_out r3z).
 #ifndef WM_LFSS_MID_WAVES
-#define WM_LFSS_MID_WAVES 4
+#define WM_LFSS_MID_WAVES 3
 #endif
 #ifndef WM_LFSS_IN_WAVES
 #define WM_LFSS_IN_WAVES 4
