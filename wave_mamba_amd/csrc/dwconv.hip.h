@@ -178,22 +178,32 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
             if (lane == 63) right = (rowok && w0 + 4 < W) ? xp[(long long)r * W + w0 + 4] : 0.0f;
             v[0] = left; v[1] = q.x; v[2] = q.y; v[3] = q.z; v[4] = q.w; v[5] = right;
         };
+        // 16-byte form: as in the forward kernel - unconditional loads from clamped addresses (x quad, its halo element,
+        // the gy quad), one row ahead of their use, masked when consumed
+        auto fetch = [&](int r, float4& q, float& e, float4& gq) {     // x row r (+ halo), gy row r - 1
+            const int rc = min(max(r, 0), H - 1), gc = min(max(r - 1, 0), H - 1);
+            const float* rowp = xp + (long long)rc * W;
+            q = *reinterpret_cast<const float4*>(rowp + (colok ? w0 : 0));
+            int we = lane == 0 ? w0 - 1 : w0 + 4;
+            we = min(max(we, 0), W - 1);
+            e = rowp[we];
+            gq = *reinterpret_cast<const float4*>(gp + (long long)gc * W + (colok ? w0 : 0));
+        };
+        auto finish = [&](int r, const float4& q, float e, float (&v)[6]) {
+            const bool rowok = r >= 0 && r < H, ok = rowok && colok;
+            const float q0 = ok ? q.x : 0.f, q1 = ok ? q.y : 0.f, q2 = ok ? q.z : 0.f, q3 = ok ? q.w : 0.f;
+            float left = __shfl_up(q3, 1), right = __shfl_down(q0, 1);
+            if (lane == 0) left = (rowok && w0 - 1 >= 0 && w0 - 1 < W) ? e : 0.0f;
+            if (lane == 63) right = (rowok && w0 + 4 < W) ? e : 0.0f;
+            v[0] = left; v[1] = q0; v[2] = q1; v[3] = q2; v[4] = q3; v[5] = right;
+        };
         float acc[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) acc[i] = 0.0f;
         if (h0 < H) {
             float r0[6], r1[6], r2[6];
-            load_row(h0 - 1, r0);
-            load_row(h0, r1);
             const int hend = min(H, h0 + kDwRows);
-            for (int h = h0; h < hend; ++h) {
-                load_row(h + 1, r2);
-                float g[4] = {0.f, 0.f, 0.f, 0.f};
-                if (colok) {
-                    const float* p = gp + (long long)h * W + w0;
-                    if constexpr (VEC) { const float4 q = *reinterpret_cast<const float4*>(p); g[0] = q.x; g[1] = q.y; g[2] = q.z; g[3] = q.w; }
-                    else { g[0] = p[0]; if (w0 + 1 < W) g[1] = p[1]; if (w0 + 2 < W) g[2] = p[2]; if (w0 + 3 < W) g[3] = p[3]; }
-                }
+            auto body = [&](const float (&g)[4]) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -206,6 +216,32 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
                 }
 #pragma unroll
                 for (int j = 0; j < 6; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; }
+            };
+            if constexpr (VEC) {
+                float4 qa, qb, qc, qn, ga, gb, gc4, gn;
+                float ea, eb, ec, en;
+                fetch(h0 - 1, qa, ea, ga); fetch(h0, qb, eb, gb); fetch(h0 + 1, qc, ec, gc4);   // gc4 = gy row h0
+                finish(h0 - 1, qa, ea, r0);
+                finish(h0, qb, eb, r1);
+                for (int h = h0; h < hend; ++h) {
+                    fetch(h + 2, qn, en, gn);              // x row h + 2, gy row h + 1
+                    finish(h + 1, qc, ec, r2);
+                    const float g[4] = {colok ? gc4.x : 0.f, colok ? gc4.y : 0.f, colok ? gc4.z : 0.f, colok ? gc4.w : 0.f};
+                    body(g);
+                    qc = qn; ec = en; gc4 = gn;
+                }
+            } else {
+            load_row(h0 - 1, r0);
+            load_row(h0, r1);
+            for (int h = h0; h < hend; ++h) {
+                load_row(h + 1, r2);
+                float g[4] = {0.f, 0.f, 0.f, 0.f};
+                if (colok) {
+                    const float* p = gp + (long long)h * W + w0;
+                    g[0] = p[0]; if (w0 + 1 < W) g[1] = p[1]; if (w0 + 2 < W) g[2] = p[2]; if (w0 + 3 < W) g[3] = p[3];
+                }
+                body(g);
+            }
             }
         }
 #pragma unroll

@@ -54,6 +54,7 @@ struct ScanBwdArgs {
     float* dplanes;                // (R + 2N, L) gradient planes [d dt_r | dB | dC] of this direction, batch stride dpl_bstride
     long long rec_bstride, dpl_bstride;
     int R;
+    int accumulate;                // fused core: dx += du (the layout's second direction) instead of dx = du (its first: no memset, no read)
 };
 constexpr int kPartPadFused = 8;   // fused partial record: NP (dA) + [dD, dbias, dWdt[0..3], 0, 0]
 
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
     {
         const int trow = lane >> 2, tq = lane & 3, c = 4 * tq;
         const bool cok = c >= ft.c_lo && c < ft.c_hi;                   // VEC: the whole quad is valid or not
-        // dx += du (du sits in s_dy, LDS column = scan time)
+        // dx (+)= du (du sits in s_dy, LDS column = scan time)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 16 * i + trow;
@@ -617,13 +618,17 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
                 float* o = p.du + rowbase + (long long)r * L + ft.plo + c;
                 if constexpr (VEC) {
                     if (cok) {
-                        const float4 e = *reinterpret_cast<const float4*>(o);
-                        *reinterpret_cast<float4*>(o) = make_float4(e.x + a.x, e.y + a.y, e.z + a.z, e.w + a.w);
+                        if (p.accumulate) {                            // uniform
+                            const float4 e = *reinterpret_cast<const float4*>(o);
+                            a = make_float4(e.x + a.x, e.y + a.y, e.z + a.z, e.w + a.w);
+                        }
+                        *reinterpret_cast<float4*>(o) = a;
                     }
                 } else {
                     const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (c + j >= ft.c_lo && c + j < ft.c_hi) o[j] += av[j];
+                    for (int j = 0; j < 4; ++j)
+                        if (c + j >= ft.c_lo && c + j < ft.c_hi) o[j] = p.accumulate ? o[j] + av[j] : av[j];
                 }
             }
         }

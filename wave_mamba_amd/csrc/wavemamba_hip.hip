@@ -465,7 +465,7 @@ int wm_selscan_bwd(const float* u, const float* delta, const float* A, const flo
     float* seg = nullptr;
     bwd_bind_workspace(a, pl, (char*)workspace, seg);
     a.batch = batch; a.dim = dim; a.L = L; a.N = N; a.G = G; a.dpg = dim / G; a.wpg = pl.wpg;
-    a.softplus = delta_softplus ? 1 : 0; a.atomic_bc = pl.wpg > 1 ? 1 : 0;
+    a.softplus = delta_softplus ? 1 : 0; a.atomic_bc = pl.wpg > 1 ? 1 : 0; a.accumulate = 0;
     if (a.atomic_bc) {
         const size_t nb = (size_t)batch * G * N * L * sizeof(float);
         hipError_t e = hipMemsetAsync(dB, 0, nb, st);
@@ -931,9 +931,9 @@ int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt
     char* scan_ws = w; w += pl.scan_bytes;
     float* pgpart = (float*)w;
 
-    // (dx_proj_weight: every element is written by projgrad_finish_kernel)
-    hipError_t e = hipMemsetAsync(dx, 0, (size_t)B * D * L * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(ddt_projs_weight, 0, (size_t)4 * D * R * sizeof(float), st);
+    // (dx_proj_weight: every element is written by projgrad_finish_kernel; dx and its transposed twin: the first direction
+    // of each layout writes every element, the second and the projection backward accumulate)
+    hipError_t e = hipMemsetAsync(ddt_projs_weight, 0, (size_t)4 * D * R * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(ddt_projs_bias, 0, (size_t)4 * D * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(dA_logs, 0, (size_t)4 * D * N * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(dDs, 0, (size_t)4 * D * sizeof(float), st);
@@ -949,8 +949,6 @@ int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt
             hipLaunchKernelGGL(transpose_planes_kernel, tg, tb, 0, st, x, xT, H, W, 0);
             hipLaunchKernelGGL(transpose_planes_kernel, tg, tb, 0, st, dy_col_fwd, dyTa, H, W, 0);
             if (dy_col_rev != dy_col_fwd) hipLaunchKernelGGL(transpose_planes_kernel, tg, tb, 0, st, dy_col_rev, dyTb, H, W, 0);
-            e = hipMemsetAsync(dxT, 0, (size_t)B * D * L * sizeof(float), st);
-            if (e != hipSuccess) return (int)e;
             xl = xT; dxl = dxT; dyl[0] = dyTa; dyl[1] = dy_col_rev != dy_col_fwd ? dyTb : dyTa;
         }
         {   // records of this layout (all four directions' projections; the two of this layout are used)
@@ -983,6 +981,7 @@ int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt
             a.rec = rec + (size_t)(pl.NP == 16 ? k : kk) * L * pl.RS; a.rec_bstride = (long long)pl.ndir * L * pl.RS;
             a.Wdt = dt_projs_weight + (size_t)k * D * R; a.R = R;
             a.dplanes = gpl + (size_t)kk * CP * L; a.dpl_bstride = 2LL * CP * L;
+            a.accumulate = kk;
             const bool vec = (L % 4 == 0) && aligned16(xl) && aligned16(dyl[kk]) && aligned16(dxl) && aligned16(gpl);
             float* dA_k = dA_logs + (size_t)k * D * N; float* dD_k = dDs + (size_t)k * D;
             float* db_k = ddt_projs_bias + (size_t)k * D; float* dW_k = ddt_projs_weight + (size_t)k * D * R;
