@@ -298,6 +298,18 @@ int wm_image_post_u8(const float* in, uint8_t* image, int h, int w, int Hp, int 
  * wavemamba_arch.py:345 / :386) in training.  (O, I) in {(128,32), (32,64), (64,16), (16,32), (32,16), (16,16), (64,32),
  * (32,32), (16,64)}: the in_proj / out_proj shapes of hidden_dim 32, 16, 8. */
 int wm_linear_wgrad(const float* gy, const float* x, float* dW, int64_t T, int O, int I, void* stream);
+/* Weight gradient of a dense convolution (stride 1, 'same' zero padding, ks = 1 or 3):
+ *   dW[co][ci][ky][kx] = sum_{b,h,w} gy[b][co][h][w] * x[b][ci][h + ky - ks/2][w + kx - ks/2]
+ * - what autograd evaluates for the weight of every nn.Conv2d reached from WaveMamba.forward in training (ATen:
+ * convolution_backward, output_mask[1]; on ROCm MIOpen's NHWC implicit-GEMM kernels between layout transposes).
+ * gy (B, Cout, H, W), x (B, Cin, H, W) fp32 NCHW, 16-byte aligned; dW (Cout, Cin, ks, ks) is overwritten.
+ * bf16 matrix cores with split operands (three products, ~4e-6 per product, fp32 accumulation).
+ * Supported: W % 32 == 0, Cout <= 16, 32, 64 or 96 (tiles of 16: 1, 2, 4, 6); else WM_EUNSUPPORTED (workspace_bytes 0) and
+ * the caller keeps ATen's gradient.
+ */
+size_t wm_conv2d_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int ks);
+int wm_conv2d_wgrad(const float* gy, const float* x, float* dW, void* workspace, size_t workspace_bytes, int B, int Cin, int Cout,
+                    int H, int W, int ks, void* stream);
 
 /* sums (C) = sum over batch and plane of x (B, C, H, W): the bias gradient of a convolution (training). */
 int wm_plane_sums(const float* x, float* sums, int B, int C, int H, int W, void* stream);

@@ -1487,8 +1487,48 @@ def test_conv2d_train_gradients_vs_torch_autograd(ks, B, Cin, Cout, H, W, bias, 
     finally:
         wm.ops.set_train_conv_bf16x3(prev)
     assert_close(got.detach(), ref.detach().float(), 2e-5 if fast else 2e-6, "conv2d_train forward")
+    hip_gw = wm.ops.conv2d_wgrad_supported(qs[0], qs[1])     # W % 32 == 0: the weight gradient is the split-bf16 HIP kernel's
     for a, r, nm in zip(ggot, gref, ("gx", "gw", "gb")):
-        assert_close(a, r.float(), 5e-5 if fast else 2e-6, f"conv2d_train {nm} ks={ks}")
+        bar = 5e-5 if fast else (2e-5 if (nm == "gw" and hip_gw) else 2e-6)
+        assert_close(a, r.float(), bar, f"conv2d_train {nm} ks={ks}")
+
+
+@pytest.mark.parametrize("ks,B,Cin,Cout,H,W", [
+    (3, 2, 64, 64, 8, 32),       # the HFE / plumbing 3x3: four output tiles x nine taps
+    (3, 1, 32, 96, 5, 64),       # h_out_conv: 96 output channels = two passes (64 + 32)
+    (3, 2, 3, 32, 6, 32),        # conv_01: a 3-channel input (one ragged input tile)
+    (3, 2, 64, 32, 4, 32),
+    (3, 1, 32, 3, 4, 32),        # last: 3 output channels (one ragged output tile)
+    (3, 1, 16, 16, 1, 32),       # a single row: both vertical taps fall outside everywhere
+    (1, 2, 32, 64, 4, 64),       # in_proj
+    (1, 1, 192, 32, 3, 32),      # twelve input tiles
+    (1, 1, 4, 32, 2, 32),
+    (1, 3, 12, 32, 5, 96),
+    (1, 2, 32, 96, 3, 32),       # ffn-like 1x1: six output tiles
+    (3, 8, 64, 64, 64, 64),      # BASELINE config 3, level 3: many units per wave, several blocks
+])
+def test_conv2d_wgrad_vs_float64(ks, B, Cin, Cout, H, W):
+    """wm_conv2d_wgrad (bf16 matrix cores, split operands) against the float64 weight gradient of F.conv2d: every tap,
+    ragged channel tiles, image borders in both directions; written (not accumulated) output."""
+    gg = gen(ks * 1000 + Cin * 7 + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=gg)
+    gy = torch.randn(B, Cout, H, W, generator=gg)
+    w = torch.zeros(Cout, Cin, ks, ks, dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(F.conv2d(x.double(), w, None, padding=ks // 2), w, gy.double())
+    prev_any, wm.ops._CONV_WGRAD_ANY_SIZE = wm.ops._CONV_WGRAD_ANY_SIZE, True      # (small 3x3 maps default to ATen: speed only)
+    try:
+        assert wm.ops.conv2d_wgrad_supported(x.to(DEV), w)
+        got = wm.ops.conv2d_wgrad(gy.to(DEV), x.to(DEV), ks)
+        assert_close(got, ref.float(), 1e-5, f"conv2d_wgrad ks={ks} {Cin}->{Cout} {H}x{W}")
+        again = wm.ops.conv2d_wgrad(gy.to(DEV), x.to(DEV), ks)
+        assert_close(again, got, 1e-6, "conv2d_wgrad run-to-run")        # (LDS atomics order the four waves' sums)
+        # the same through autograd (conv2d_train's default mode), input and bias gradients from ATen / the plane-sum kernel
+        xs = x.to(DEV).requires_grad_(True); ws = (torch.randn(Cout, Cin, ks, ks, generator=gg) * 0.1).to(DEV).requires_grad_(True)
+        y = wm.ops.conv2d_train(xs, ws, None)
+        gx, gw = torch.autograd.grad(y, (xs, ws), gy.to(DEV))
+        assert_close(gw, ref.float(), 1e-5, "conv2d_train gw")
+    finally:
+        wm.ops._CONV_WGRAD_ANY_SIZE = prev_any
 
 
 @pytest.mark.parametrize("T,O,I", [(5000, 128, 32), (777, 32, 64), (64, 16, 16), (3, 64, 16), (100003, 32, 32)])

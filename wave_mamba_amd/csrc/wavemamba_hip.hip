@@ -25,6 +25,7 @@
 #include "ss2d_bwd.hip.h"
 #include "imageio.hip.h"
 #include "gates.hip.h"
+#include "conv_wgrad.hip.h"
 
 namespace wm {
 
@@ -218,7 +219,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 17; }
+int wm_abi_version(void) { return 18; }
 
 #ifndef WM_BUILD_ID
 #define WM_BUILD_ID "unknown"
@@ -1349,6 +1350,74 @@ int wm_linear_wgrad(const float* gy, const float* x, float* dW, int64_t T, int O
     WM_LW(8, 2) WM_LW(2, 4) WM_LW(4, 1) WM_LW(1, 2) WM_LW(2, 1) WM_LW(1, 1) WM_LW(4, 2) WM_LW(2, 2) WM_LW(1, 4)
 #undef WM_LW
     return WM_EUNSUPPORTED;
+}
+
+// ---- dense convolution weight gradient (conv_wgrad.hip.h) -----------------------------------------------------------
+static int conv_wgrad_blocks(long long nunits, int ntiles_in, int* upw) {
+    // 4 waves per block on one input tile; about one block per compute unit in all (256 / input tiles position blocks): a
+    // block's fixed cost - zeroing and adding up OT x TAPS KB of LDS, its partial, the finish kernel's pass over it - is
+    // what more blocks buy (8 x 64 -> 64 x 256 x 256, 3x3: 512 position blocks 0.60 ms, 128: 0.28, 64: 0.28; 128 x 128 maps:
+    // 128 blocks 0.152, 64: 0.115; tools/bench_conv_wgrad.py)
+#ifndef WM_CW_TARGET
+#define WM_CW_TARGET 256
+#endif
+#ifndef WM_CW_MINUNITS
+#define WM_CW_MINUNITS 4
+#endif
+    long long blocks = WM_CW_TARGET / ntiles_in;
+    const long long most = nunits / (kCwWaves * WM_CW_MINUNITS);
+    if (blocks > most) blocks = most;
+    if (blocks < 1) blocks = 1;
+    const long long per = (nunits + blocks * kCwWaves - 1) / (blocks * kCwWaves);
+    *upw = (int)per;
+    return (int)((nunits + per * kCwWaves - 1) / (per * kCwWaves));
+}
+size_t wm_conv2d_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int ks) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (ks != 1 && ks != 3) || W % 32 != 0) return 0;
+    const int OT = (Cout + 15) / 16;
+    if (OT > 6 || (OT != 1 && OT != 2 && OT != 4 && OT != 6)) return 0;
+    int upw;
+    const int nb = conv_wgrad_blocks((long long)B * H * (W / 32), (Cin + 15) / 16, &upw);
+    return (size_t)((Cin + 15) / 16) * nb * OT * ks * ks * 256 * sizeof(float);
+}
+int wm_conv2d_wgrad(const float* gy, const float* x, float* dW, void* workspace, size_t workspace_bytes, int B, int Cin, int Cout,
+                    int H, int W, int ks, void* stream) {
+    if (B < 0 || Cin <= 0 || Cout <= 0 || H < 0 || W < 0) return WM_EINVAL;
+    if (ks != 1 && ks != 3) return WM_EUNSUPPORTED;
+    if (!dW) return WM_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0 || H == 0 || W == 0) {
+        hipError_t e = hipMemsetAsync(dW, 0, (size_t)Cout * Cin * ks * ks * sizeof(float), st);
+        return e == hipSuccess ? WM_OK : (int)e;
+    }
+    const size_t need = wm_conv2d_wgrad_workspace_bytes(B, Cin, Cout, H, W, ks);
+    if (need == 0) return WM_EUNSUPPORTED;                        // W % 32 != 0, more than 96 output channels, ...
+    if ((long long)B * (Cin > Cout ? Cin : Cout) * H * W > 0x7fffffffffLL || (long long)B * H * (W / 32) > 0x7fffff00LL) return WM_EUNSUPPORTED;
+    if (!gy || !x || !workspace) return WM_ENULL;
+    if (workspace_bytes < need) return WM_EWORKSPACE;
+    if (!aligned16(gy) || !aligned16(x) || !aligned16(workspace)) return WM_EALIGN;
+    ConvWgradArgs a;
+    a.gy = gy; a.x = x; a.part = (float*)workspace; a.dW = dW; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+    a.nunits = (long long)B * H * (W / 32);
+    a.nblocks = conv_wgrad_blocks(a.nunits, (Cin + 15) / 16, &a.upw);
+    const int OT = (Cout + 15) / 16, ITN = (Cin + 15) / 16;
+#define WM_CW(KS, OTV, CO0, NCO)                                                                                         \
+    do {                                                                                                                 \
+        constexpr int lds = OTV * KS * KS * 256 * 4;                                                                     \
+        static bool configured[64] = {};                                                                                 \
+        if (lds > 65536) { const int rc = wm::lds_optin((const void*)conv_wgrad_kernel<KS, OTV>, lds, configured); if (rc) return rc; } \
+        a.co0 = (CO0); a.nco = (NCO);                                                                                    \
+        hipLaunchKernelGGL((conv_wgrad_kernel<KS, OTV>), WM_CW_ITFAST ? dim3((unsigned)(a.nblocks * ITN)) : dim3((unsigned)a.nblocks, (unsigned)ITN), dim3(64 * kCwWaves), lds, st, a); \
+        hipLaunchKernelGGL((conv_wgrad_finish_kernel<KS, OTV>), dim3((unsigned)(OTV * KS * KS), (unsigned)ITN), dim3(256), 0, st, a); \
+    } while (0)
+    if (ks == 3) {
+        if (OT == 1) WM_CW(3, 1, 0, Cout); else if (OT == 2) WM_CW(3, 2, 0, Cout); else if (OT == 4) WM_CW(3, 4, 0, Cout);
+        else { WM_CW(3, 4, 0, 64); WM_CW(3, 2, 64, Cout - 64); }     // 65 .. 96 output channels: two passes (same workspace, stream order)
+    } else {
+        if (OT == 1) WM_CW(1, 1, 0, Cout); else if (OT == 2) WM_CW(1, 2, 0, Cout); else if (OT == 4) WM_CW(1, 4, 0, Cout); else WM_CW(1, 6, 0, Cout);
+    }
+#undef WM_CW
+    return launch_status();
 }
 
 int wm_plane_sums(const float* x, float* sums, int B, int C, int H, int W, void* stream) {

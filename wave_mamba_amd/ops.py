@@ -1097,18 +1097,66 @@ class _Conv2dTrain(torch.autograd.Function):
             wt = weight.detach().transpose(0, 1).flip(2, 3).contiguous()          # (Cin, Cout, ks, ks)
             gx = conv2d(gy, wt, None, dynamic_weight=True)
         if ctx.needs_input_grad[1]:
-            ks = weight.shape[2]
-            _, gw, _ = torch.ops.aten.convolution_backward(
-                gy, x, weight, None, [1, 1], [ks // 2, ks // 2], [1, 1], False, [0, 0], 1, [False, True, False])
+            gw = _conv_weight_grad(gy, x, weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = plane_sums(gy)
         return gx, gw, gb
 
 
+# Weight gradients of the dense convolutions in training: the HIP kernel (conv_wgrad.hip.h: K = positions on the bf16 matrix
+# cores, split operands) instead of MIOpen's NHWC implicit-GEMM kernels and their layout transposes / hipBLASLt for 1x1.
+# A leaf gradient - its ~4e-6 per product propagates nowhere.  WM_TRAIN_CONV_WGRAD=0 keeps ATen's.
+_TRAIN_CONV_WGRAD_HIP = os.environ.get("WM_TRAIN_CONV_WGRAD", "1") == "1"
+
+
+_CONV_WGRAD_ANY_SIZE = False      # tests: True sends the small 3x3 maps to the HIP kernel too
+
+
+def set_train_conv_wgrad_hip(on):
+    global _TRAIN_CONV_WGRAD_HIP
+    prev, _TRAIN_CONV_WGRAD_HIP = _TRAIN_CONV_WGRAD_HIP, bool(on)
+    return prev
+
+
+def conv2d_wgrad_supported(x, weight):
+    Cout, Cin, ks, ks2 = weight.shape
+    # (3x3 on maps below 2048 row segments - 8 x 64 x 64 - stays with MIOpen: 0.05 against 0.08 ms, tools/bench_conv_wgrad.py)
+    return (x.is_cuda and x.dtype == torch.float32 and ks == ks2 and ks in (1, 3) and x.shape[3] % 32 == 0
+            and (Cout + 15) // 16 in (1, 2, 4, 6) and not (ks == 3 and 64 < Cout <= 80)
+            and (ks == 1 or _CONV_WGRAD_ANY_SIZE or x.shape[0] * x.shape[2] * (x.shape[3] // 32) >= 2048))
+
+
+def conv2d_wgrad(gy, x, ks):
+    """dW (Cout, Cin, ks, ks) of a stride-1 'same' convolution from gy (B, Cout, H, W) and x (B, Cin, H, W)."""
+    lib = _lib.load()
+    _require_cuda("conv2d_wgrad", gy, x)
+    B, Cout, H, W = gy.shape
+    Cin = x.shape[1]
+    gy = gy.contiguous().float(); x = x.contiguous().float()
+    need = lib.wm_conv2d_wgrad_workspace_bytes(B, Cin, Cout, H, W, ks)
+    if need == 0:
+        raise RuntimeError("wm_conv2d_wgrad: unsupported shape (see conv2d_wgrad_supported)")
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    dW = torch.empty(Cout, Cin, ks, ks, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.wm_conv2d_wgrad(_ptr(gy), _ptr(x), _ptr(dW), _ptr(ws), need, B, Cin, Cout, H, W, ks, _stream()), "wm_conv2d_wgrad")
+    return dW
+
+
+def _conv_weight_grad(gy, x, weight):
+    ks = weight.shape[2]
+    if _TRAIN_CONV_WGRAD_HIP and conv2d_wgrad_supported(x, weight):
+        return conv2d_wgrad(gy, x, ks)
+    _, gw, _ = torch.ops.aten.convolution_backward(
+        gy, x, weight, None, [1, 1], [ks // 2, ks // 2], [1, 1], False, [0, 0], 1, [False, True, False])
+    return gw
+
+
 class _Conv2dAten(torch.autograd.Function):
-    """ATen's fp32 convolution (stride 1, 'same' padding) with the BIAS gradient on the HIP plane-sum kernel: autograd's
-    own `grad_output.sum((0, 2, 3))` is ATen's generic strided reduction - 141 launches, 5.4 ms of a 95-ms BASELINE
-    config-3 training step (tools/train_breakdown.py); input and weight gradients stay ATen's (MIOpen)."""
+    """ATen's fp32 convolution (stride 1, 'same' padding) and input gradient, with the BIAS gradient on the HIP plane-sum
+    kernel (autograd's own `grad_output.sum((0, 2, 3))` is ATen's generic strided reduction - 141 launches, 5.4 ms of a
+    95-ms BASELINE config-3 training step, tools/train_breakdown.py) and the WEIGHT gradient on the HIP matrix-core
+    kernel (`_conv_weight_grad`)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -1121,10 +1169,11 @@ class _Conv2dAten(torch.autograd.Function):
         gy = gy.contiguous()
         ks = weight.shape[2]
         gx = gw = gb = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            gx, gw, _ = torch.ops.aten.convolution_backward(
-                gy, x, weight, None, [1, 1], [ks // 2, ks // 2], [1, 1], False, [0, 0], 1,
-                [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False])
+        if ctx.needs_input_grad[0]:
+            gx, _, _ = torch.ops.aten.convolution_backward(
+                gy, x, weight, None, [1, 1], [ks // 2, ks // 2], [1, 1], False, [0, 0], 1, [True, False, False])
+        if ctx.needs_input_grad[1]:
+            gw = _conv_weight_grad(gy, x, weight)
         if ctx.needs_input_grad[2]:
             gb = plane_sums(gy)
         return gx, gw, gb
@@ -1156,7 +1205,7 @@ def conv2d_train(x, weight, bias=None):
     set_train_conv_bf16x3(True) - the split-bf16 matrix-core kernel for forward and input gradient (_Conv2dTrain)."""
     _require_cuda("conv2d_train", x, weight, bias)
     if not _TRAIN_CONV_BF16X3:
-        if bias is None or not bias.requires_grad:
+        if not ((bias is not None and bias.requires_grad) or weight.requires_grad):
             return F.conv2d(x.float(), weight, bias, stride=1, padding=weight.shape[2] // 2)
         return _Conv2dAten.apply(x.float(), weight, bias)
     return _Conv2dTrain.apply(x.contiguous().float(), weight, bias)
