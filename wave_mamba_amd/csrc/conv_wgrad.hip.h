@@ -13,14 +13,15 @@
 // accumulated in fp32 as hi.hi + hi.lo + lo.hi (~4e-6 relative per product; a leaf gradient: nothing propagates the error);
 // K = 32 consecutive positions of one image row per v_mfma_f32_16x16x32_bf16: lane (row i16, kq) feeds positions
 // 8 kq .. 8 kq + 7 of its channel plane - two 16-byte loads per operand tile, straight from NCHW.
-//   * A workgroup = 4 waves on ONE 16-channel tile of the input (blockIdx.y), every output tile and every tap: a wave
-//     walks its own run of (image, row, 32-column segment) units with OT x TAPS accumulator tiles in registers
-//     (144 registers at 64 output channels x 9 taps); the operand split work is then unique per wave for x (the 3 x 3
-//     shifted windows come from ONE 10-element load per row: columns -1 .. 8 of the lane's eight) and small for gy.
+//   * A wave owns ONE 16-channel tile of the input, every output tile and every tap: OT x TAPS accumulator tiles in
+//     registers (144 at 64 output channels x 9 taps); the operand split work is then unique per wave for x (the 3 x 3
+//     shifted windows come from ONE 10-element load per row: columns -1 .. 8 of the lane's eight) and small for gy.  The
+//     4 waves of a workgroup are the (up to 4) input tiles over the SAME run of units - they read the same gy - and a
+//     wave walks its units down a 32-column segment, keeping two of the three input rows from the unit before.
 //   * Zero padding: a tap row outside the image is skipped (uniform); the two columns outside it are the first element of
 //     the window in the row's first segment / the last in its last segment - masked per lane.
-//   * The waves of a block add their tiles in LDS, the block writes ONE partial, a second small kernel adds the blocks'
-//     partials into dW (no global atomics).
+//   * Every wave writes its accumulators as one partial; a second small kernel adds the partials of an input tile into
+//     dW (no atomics anywhere: bit-reproducible).
 // Needs W % 32 == 0 (every map of the network: 512 / 256 / 128 / 64 wide at the training size) - else WM_EUNSUPPORTED and
 // the caller stays on ATen.
 #pragma once
@@ -32,12 +33,12 @@ namespace wm {
 struct ConvWgradArgs {
     const float* gy;           // (B, Cout, H, W)
     const float* x;            // (B, Cin, H, W)
-    float* part;               // [ci tile][block][OT * TAPS][16 (co)][16 (ci)]
+    float* part;               // [ci tile][position sub-range][OT * TAPS][16 (co)][16 (ci)]
     float* dW;                 // (Cout, Cin, KS, KS)
     int B, Cin, Cout, H, W;
-    int upw;                   // units (32-column row segments) per wave
+    int upw;                   // units (32-column row segments) per position sub-range
     long long nunits;          // B * H * (W / 32)
-    int nblocks;               // position blocks (gridDim.x)
+    int nparts;                // position sub-ranges = partials per input tile
     int co0, nco;              // output channels co0 .. co0 + nco - 1 in this launch (96 = 64 + 32: the accumulators of six
                                // tiles x nine taps do not fit the registers)
 };
@@ -45,20 +46,24 @@ struct ConvWgradArgs {
 typedef float cw_f4 __attribute__((ext_vector_type(4)));
 constexpr int kCwWaves = 4;
 
+// tiles of the input a workgroup's waves share (wave -> tile wv % tpw of tile group blockIdx.y, position sub-range wv / tpw)
+__host__ __device__ inline int cw_tiles_per_wg(int nit) { return nit >= 4 ? 4 : (nit == 3 ? 3 : nit); }
+
+#ifndef WM_CW_WAVES_PER_SIMD
+#define WM_CW_WAVES_PER_SIMD 2
+#endif
 template <int KS, int OT>
-__global__ __launch_bounds__(64 * kCwWaves, 2) void conv_wgrad_kernel(const ConvWgradArgs a) {
+__global__ __launch_bounds__(64 * kCwWaves, WM_CW_WAVES_PER_SIMD) void conv_wgrad_kernel(const ConvWgradArgs a) {
     constexpr int TAPS = KS * KS, PAD = KS / 2;
-    extern __shared__ __attribute__((aligned(16))) float cw_smem[];          // [OT * TAPS][256]
-    for (int e = threadIdx.x; e < OT * TAPS * 256; e += 64 * kCwWaves) cw_smem[e] = 0.0f;
-    __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
-#ifndef WM_CW_ITFAST
-#define WM_CW_ITFAST 1
-#endif
     const int nit = (a.Cin + 15) >> 4;
-    const int it = WM_CW_ITFAST ? (int)(blockIdx.x % nit) : (int)blockIdx.y;        // input-channel tile
-    const int pblk = WM_CW_ITFAST ? (int)(blockIdx.x / nit) : (int)blockIdx.x;      // position block
+    const int tpw = cw_tiles_per_wg(nit), gpw = kCwWaves / tpw;   // input tiles / position sub-ranges per workgroup
+    const int it = (int)blockIdx.y * tpw + wv % tpw;              // input-channel tile of this wave
+    const int g = wv / tpw;
+    if (it >= nit || g >= gpw) return;                            // (3 tiles: the fourth wave idles; ragged last tile group)
+    const int prange = (int)blockIdx.x * gpw + g;                 // position sub-range = the partial this wave writes
+    if (prange >= a.nparts) return;                               // (ragged last workgroup)
     const int ci = 16 * it + i16;
     const bool ci_ok = ci < a.Cin;
     const int segs = a.W >> 5;
@@ -69,40 +74,58 @@ __global__ __launch_bounds__(64 * kCwWaves, 2) void conv_wgrad_kernel(const Conv
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) acc[o][t] = (cw_f4){0.f, 0.f, 0.f, 0.f};
 
-    const int u_begin = (pblk * kCwWaves + wv) * a.upw;         // (nunits < 2^31: host check)
+    // Units in COLUMN order: u -> (image b, 32-column segment seg, row h), h fastest.  The waves of a workgroup that share a
+    // position sub-range read the same gy (one first-level cache serves them), and walking DOWN a segment a wave keeps two
+    // of a unit's three input rows in registers from the unit before: first the kernel ran row-major units with one input
+    // tile per WORKGROUP - every gy line crossed the L2 once per input tile, every x row three times - and sat at the L2's
+    // bandwidth (0.27 ms for 8 x 64 -> 64 x 256 x 256 whatever was done about latency or MFMA order).
+    const int u_begin = prange * a.upw;                           // (nunits < 2^31: host check)
     const int u_end = (int)min(a.nunits, (long long)u_begin + a.upw);
-    for (int u = u_begin; u < u_end; ++u) {
-        const int seg = u % segs;
-        const int bh = u / segs;
-        const int h = bh % a.H, b = bh / a.H;
+    struct Row { float4 q[2]; float e[2]; };                      // columns w .. w + 7, and w - 1 / w + 8
+    struct Raw { float4 g[OT][2]; Row x[KS]; };
+    auto load_row = [&](const float* xp, int r, int w, Row& row) {
+        const float* rp = xp + (long long)min(max(r, 0), a.H - 1) * a.W;
+        row.q[0] = *reinterpret_cast<const float4*>(rp + w);
+        row.q[1] = *reinterpret_cast<const float4*>(rp + w + 4);
+        if (KS == 3) { row.e[0] = rp[max(w - 1, 0)]; row.e[1] = rp[min(w + 8, a.W - 1)]; }
+    };
+    // operands of unit u; `below`: u is the unit right under the one `prev` holds -> two of its rows are prev's
+    auto fetch = [&](int u, Raw& r, const Raw& prev, bool below) {
+        const int h = u % a.H;
+        const int bs = u / a.H;
+        const int seg = bs % segs, b = bs / segs;
         const int w = 32 * seg + 8 * kq;                          // the lane's first column
-        // ---- every load of the unit first (unconditional, clamped), then the splits and the products
         const float* gp = a.gy + ((long long)b * a.Cout) * HW + (long long)h * a.W + w;
-        float4 gr[OT][2];
 #pragma unroll
         for (int o = 0; o < OT; ++o) {
             const int co = min(a.co0 + 16 * o + i16, a.Cout - 1);
-            gr[o][0] = *reinterpret_cast<const float4*>(gp + (long long)co * HW);
-            gr[o][1] = *reinterpret_cast<const float4*>(gp + (long long)co * HW + 4);
+            r.g[o][0] = *reinterpret_cast<const float4*>(gp + (long long)co * HW);
+            r.g[o][1] = *reinterpret_cast<const float4*>(gp + (long long)co * HW + 4);
         }
         const float* xp = a.x + ((long long)b * a.Cin + min(ci, a.Cin - 1)) * HW;
-        float4 xr[KS][2];
-        float xe[KS][2];                                          // columns w - 1 and w + 8 (3x3 only)
+        if (KS == 3 && below) {                                   // uniform
+            r.x[0] = prev.x[1]; r.x[1] = prev.x[KS - 1];
+            load_row(xp, h + 1, w, r.x[KS - 1]);
+        } else {
 #pragma unroll
-        for (int ky = 0; ky < KS; ++ky) {
-            const int r = min(max(h + ky - PAD, 0), a.H - 1);
-            const float* rp = xp + (long long)r * a.W;
-            xr[ky][0] = *reinterpret_cast<const float4*>(rp + w);
-            xr[ky][1] = *reinterpret_cast<const float4*>(rp + w + 4);
-            if (KS == 3) { xe[ky][0] = rp[max(w - 1, 0)]; xe[ky][1] = rp[min(w + 8, a.W - 1)]; }
+            for (int ky = 0; ky < KS; ++ky) load_row(xp, h + ky - PAD, w, r.x[ky]);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // gy tiles -> bf16 hi / lo (rows beyond Cout: zero)
+    };
+#ifndef WM_CW_PREFETCH
+#define WM_CW_PREFETCH 0
+#endif
+    Raw cur, nxt;
+    if (u_begin < u_end) fetch(u_begin, cur, cur, false);
+    for (int u = u_begin; u < u_end; ++u) {
+        if (WM_CW_PREFETCH && u + 1 < u_end) fetch(u + 1, nxt, cur, (u + 1) % a.H != 0);   // uniform
+        const int h = u % a.H;
+        const int w = 32 * ((u / a.H) % segs) + 8 * kq;
+        // gy tiles -> bf16 hi / lo (rows beyond the launch's output channels: zero)
         core_bf8 gh[OT], gl[OT];
 #pragma unroll
         for (int o = 0; o < OT; ++o) {
             const bool ok = 16 * o + i16 < a.nco;
-            const float v[8] = {gr[o][0].x, gr[o][0].y, gr[o][0].z, gr[o][0].w, gr[o][1].x, gr[o][1].y, gr[o][1].z, gr[o][1].w};
+            const float v[8] = {cur.g[o][0].x, cur.g[o][0].y, cur.g[o][0].z, cur.g[o][0].w, cur.g[o][1].x, cur.g[o][1].y, cur.g[o][1].z, cur.g[o][1].w};
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
                 core_bf2 h2, l2;
@@ -115,11 +138,12 @@ __global__ __launch_bounds__(64 * kCwWaves, 2) void conv_wgrad_kernel(const Conv
             const int r = h + ky - PAD;
             if (r < 0 || r >= a.H) continue;                      // uniform: a tap row outside the image contributes nothing
             // the ten columns w - 1 .. w + 8 of this row as bf16 hi / lo; e[j] = column w - 1 + j
+            const Row& row = cur.x[ky];
             float e[10];
-            e[0] = (KS == 3 && w > 0) ? xe[ky][0] : 0.0f;
-            e[1] = xr[ky][0].x; e[2] = xr[ky][0].y; e[3] = xr[ky][0].z; e[4] = xr[ky][0].w;
-            e[5] = xr[ky][1].x; e[6] = xr[ky][1].y; e[7] = xr[ky][1].z; e[8] = xr[ky][1].w;
-            e[9] = (KS == 3 && w + 8 < a.W) ? xe[ky][1] : 0.0f;
+            e[0] = (KS == 3 && w > 0) ? row.e[0] : 0.0f;
+            e[1] = row.q[0].x; e[2] = row.q[0].y; e[3] = row.q[0].z; e[4] = row.q[0].w;
+            e[5] = row.q[1].x; e[6] = row.q[1].y; e[7] = row.q[1].z; e[8] = row.q[1].w;
+            e[9] = (KS == 3 && w + 8 < a.W) ? row.e[1] : 0.0f;
             __bf16 eh[10], el[10];
 #pragma unroll
             for (int j = 0; j < 10; j += 2) {
@@ -127,33 +151,36 @@ __global__ __launch_bounds__(64 * kCwWaves, 2) void conv_wgrad_kernel(const Conv
                 core_split2(ci_ok ? e[j] : 0.f, ci_ok ? e[j + 1] : 0.f, h2, l2);
                 eh[j] = h2[0]; eh[j + 1] = h2[1]; el[j] = l2[0]; el[j + 1] = l2[1];
             }
+            // the KS windows first, then the products TERM by term over every (tap, output tile): consecutive MFMAs land
+            // on different accumulators
+            core_bf8 xh[KS], xl[KS];
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx) {
                 const int s0 = KS == 3 ? kx : 1;                  // window = columns w + kx - PAD .. + 7 = e[s0 .. s0 + 7]
-                core_bf8 xh, xl;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { xh[j] = eh[s0 + j]; xl[j] = el[s0 + j]; }
-#pragma unroll
-                for (int o = 0; o < OT; ++o) {
-                    cw_f4 c = acc[o][ky * KS + kx];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl[o], xh, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[o], xl, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[o], xh, c, 0, 0, 0);
-                    acc[o][ky * KS + kx] = c;
-                }
+                for (int j = 0; j < 8; ++j) { xh[kx][j] = eh[s0 + j]; xl[kx][j] = el[s0 + j]; }
             }
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+                    for (int o = 0; o < OT; ++o)
+                        acc[o][ky * KS + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            term == 0 ? gl[o] : gh[o], term == 1 ? xl[kx] : xh[kx], acc[o][ky * KS + kx], 0, 0, 0);
         }
+        if (WM_CW_PREFETCH) cur = nxt;
+        else if (u + 1 < u_end) { nxt = cur; fetch(u + 1, cur, nxt, (u + 1) % a.H != 0); }
     }
-    // D layout: lane holds rows 4 kq .. 4 kq + 3 (co within the tile) of column i16 (ci within the tile)
+    // D layout: lane holds rows 4 kq .. 4 kq + 3 (co within the tile) of column i16 (ci within the tile).  Every wave
+    // writes its own partial (no sums across waves: bit-reproducible).
+    float* out = a.part + ((long long)it * a.nparts + prange) * (OT * TAPS * 256);
 #pragma unroll
     for (int o = 0; o < OT; ++o)
 #pragma unroll
         for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(&cw_smem[(o * TAPS + t) * 256 + (4 * kq + r) * 16 + i16], acc[o][t][r]);
-    __syncthreads();
-    float* out = a.part + ((long long)it * a.nblocks + pblk) * (OT * TAPS * 256);
-    for (int e = threadIdx.x; e < OT * TAPS * 256; e += 64 * kCwWaves) out[e] = cw_smem[e];
+            for (int r = 0; r < 4; ++r) out[(o * TAPS + t) * 256 + (4 * kq + r) * 16 + i16] = acc[o][t][r];
 }
 
 // dW[co][ci][tap] = sum over the position blocks' partials.  One thread per element of a partial, in the PARTIAL's order
@@ -168,14 +195,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_finish_kernel(const ConvWgradA
     const int c16 = f & 15, r16 = (f >> 4) & 15, tile = f >> 8, tap = tile % TAPS, o = tile / TAPS;
     const int co = 16 * o + r16, ci = 16 * it + c16;              // co: within this launch
     if (co >= a.nco || ci >= a.Cin) return;
-    const float* p = a.part + ((long long)it * a.nblocks) * PER + f;
+    const float* p = a.part + ((long long)it * a.nparts) * PER + f;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int i = 0;
-    for (; i + 3 < a.nblocks; i += 4) {
+    for (; i + 3 < a.nparts; i += 4) {
         s0 += p[(long long)i * PER]; s1 += p[(long long)(i + 1) * PER];
         s2 += p[(long long)(i + 2) * PER]; s3 += p[(long long)(i + 3) * PER];
     }
-    for (; i < a.nblocks; ++i) s0 += p[(long long)i * PER];
+    for (; i < a.nparts; ++i) s0 += p[(long long)i * PER];
     a.dW[((long long)(a.co0 + co) * a.Cin + ci) * TAPS + tap] = (s0 + s1) + (s2 + s3);
 }
 

@@ -1353,32 +1353,38 @@ int wm_linear_wgrad(const float* gy, const float* x, float* dW, int64_t T, int O
 }
 
 // ---- dense convolution weight gradient (conv_wgrad.hip.h) -----------------------------------------------------------
-static int conv_wgrad_blocks(long long nunits, int ntiles_in, int* upw) {
-    // 4 waves per block on one input tile; about one block per compute unit in all (256 / input tiles position blocks): a
-    // block's fixed cost - zeroing and adding up OT x TAPS KB of LDS, its partial, the finish kernel's pass over it - is
-    // what more blocks buy (8 x 64 -> 64 x 256 x 256, 3x3: 512 position blocks 0.60 ms, 128: 0.28, 64: 0.28; 128 x 128 maps:
-    // 128 blocks 0.152, 64: 0.115; tools/bench_conv_wgrad.py)
+// position sub-ranges (= partials per input tile) of the weight-gradient launch; *blocks = workgroups along x
+static int conv_wgrad_parts(long long nunits, int ntiles_in, int* upw, int* blocks) {
+    // About one 4-wave workgroup per compute unit: a wave's fixed cost - its OT x TAPS KB partial and the finish kernel's
+    // pass over it - is what more of them buy (tools/bench_conv_wgrad.py).  A workgroup holds tpw input tiles x gpw
+    // position sub-ranges.
 #ifndef WM_CW_TARGET
 #define WM_CW_TARGET 256
 #endif
 #ifndef WM_CW_MINUNITS
 #define WM_CW_MINUNITS 4
 #endif
-    long long blocks = WM_CW_TARGET / ntiles_in;
-    const long long most = nunits / (kCwWaves * WM_CW_MINUNITS);
-    if (blocks > most) blocks = most;
-    if (blocks < 1) blocks = 1;
-    const long long per = (nunits + blocks * kCwWaves - 1) / (blocks * kCwWaves);
+    const int tpw = cw_tiles_per_wg(ntiles_in), gpw = kCwWaves / tpw;
+    const int ygroups = (ntiles_in + tpw - 1) / tpw;
+    long long wgs = WM_CW_TARGET / ygroups;
+    if (wgs < 1) wgs = 1;
+    long long parts = wgs * gpw;
+    const long long most = nunits / WM_CW_MINUNITS;
+    if (parts > most) parts = most;
+    if (parts < 1) parts = 1;
+    const long long per = (nunits + parts - 1) / parts;
     *upw = (int)per;
-    return (int)((nunits + per * kCwWaves - 1) / (per * kCwWaves));
+    parts = (nunits + per - 1) / per;
+    *blocks = (int)((parts + gpw - 1) / gpw);
+    return (int)parts;
 }
 size_t wm_conv2d_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int ks) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (ks != 1 && ks != 3) || W % 32 != 0) return 0;
     const int OT = (Cout + 15) / 16;
     if (OT > 6 || (OT != 1 && OT != 2 && OT != 4 && OT != 6)) return 0;
-    int upw;
-    const int nb = conv_wgrad_blocks((long long)B * H * (W / 32), (Cin + 15) / 16, &upw);
-    return (size_t)((Cin + 15) / 16) * nb * OT * ks * ks * 256 * sizeof(float);
+    int upw, blocks;
+    const int np = conv_wgrad_parts((long long)B * H * (W / 32), (Cin + 15) / 16, &upw, &blocks);
+    return (size_t)((Cin + 15) / 16) * np * OT * ks * ks * 256 * sizeof(float);
 }
 int wm_conv2d_wgrad(const float* gy, const float* x, float* dW, void* workspace, size_t workspace_bytes, int B, int Cin, int Cout,
                     int H, int W, int ks, void* stream) {
@@ -1399,15 +1405,14 @@ int wm_conv2d_wgrad(const float* gy, const float* x, float* dW, void* workspace,
     ConvWgradArgs a;
     a.gy = gy; a.x = x; a.part = (float*)workspace; a.dW = dW; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     a.nunits = (long long)B * H * (W / 32);
-    a.nblocks = conv_wgrad_blocks(a.nunits, (Cin + 15) / 16, &a.upw);
+    int blocks = 1;
+    a.nparts = conv_wgrad_parts(a.nunits, (Cin + 15) / 16, &a.upw, &blocks);
     const int OT = (Cout + 15) / 16, ITN = (Cin + 15) / 16;
+    const int ygroups = (ITN + cw_tiles_per_wg(ITN) - 1) / cw_tiles_per_wg(ITN);
 #define WM_CW(KS, OTV, CO0, NCO)                                                                                         \
     do {                                                                                                                 \
-        constexpr int lds = OTV * KS * KS * 256 * 4;                                                                     \
-        static bool configured[64] = {};                                                                                 \
-        if (lds > 65536) { const int rc = wm::lds_optin((const void*)conv_wgrad_kernel<KS, OTV>, lds, configured); if (rc) return rc; } \
         a.co0 = (CO0); a.nco = (NCO);                                                                                    \
-        hipLaunchKernelGGL((conv_wgrad_kernel<KS, OTV>), WM_CW_ITFAST ? dim3((unsigned)(a.nblocks * ITN)) : dim3((unsigned)a.nblocks, (unsigned)ITN), dim3(64 * kCwWaves), lds, st, a); \
+        hipLaunchKernelGGL((conv_wgrad_kernel<KS, OTV>), dim3((unsigned)blocks, (unsigned)ygroups), dim3(64 * kCwWaves), 0, st, a); \
         hipLaunchKernelGGL((conv_wgrad_finish_kernel<KS, OTV>), dim3((unsigned)(OTV * KS * KS), (unsigned)ITN), dim3(256), 0, st, a); \
     } while (0)
     if (ks == 3) {

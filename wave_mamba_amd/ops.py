@@ -1109,9 +1109,6 @@ class _Conv2dTrain(torch.autograd.Function):
 _TRAIN_CONV_WGRAD_HIP = os.environ.get("WM_TRAIN_CONV_WGRAD", "1") == "1"
 
 
-_CONV_WGRAD_ANY_SIZE = False      # tests: True sends the small 3x3 maps to the HIP kernel too
-
-
 def set_train_conv_wgrad_hip(on):
     global _TRAIN_CONV_WGRAD_HIP
     prev, _TRAIN_CONV_WGRAD_HIP = _TRAIN_CONV_WGRAD_HIP, bool(on)
@@ -1120,10 +1117,8 @@ def set_train_conv_wgrad_hip(on):
 
 def conv2d_wgrad_supported(x, weight):
     Cout, Cin, ks, ks2 = weight.shape
-    # (3x3 on maps below 2048 row segments - 8 x 64 x 64 - stays with MIOpen: 0.05 against 0.08 ms, tools/bench_conv_wgrad.py)
     return (x.is_cuda and x.dtype == torch.float32 and ks == ks2 and ks in (1, 3) and x.shape[3] % 32 == 0
-            and (Cout + 15) // 16 in (1, 2, 4, 6) and not (ks == 3 and 64 < Cout <= 80)
-            and (ks == 1 or _CONV_WGRAD_ANY_SIZE or x.shape[0] * x.shape[2] * (x.shape[3] // 32) >= 2048))
+            and (Cout + 15) // 16 in (1, 2, 4, 6) and not (ks == 3 and 64 < Cout <= 80))
 
 
 def conv2d_wgrad(gy, x, ks):
