@@ -183,27 +183,33 @@ __global__ __launch_bounds__(64 * kCwWaves, WM_CW_WAVES_PER_SIMD) void conv_wgra
             for (int r = 0; r < 4; ++r) out[(o * TAPS + t) * 256 + (4 * kq + r) * 16 + i16] = acc[o][t][r];
 }
 
-// dW[co][ci][tap] = sum over the position blocks' partials.  One thread per element of a partial, in the PARTIAL's order
-// (input tile, output tile x tap, co row, ci column: consecutive threads read consecutive words of every block's partial;
-// the scattered side is the 4-byte store into dW).  grid (ceil(OT * TAPS * 256 / 256), input tiles), block (256).
+// dW[co][ci][tap] = sum over the partials of an input tile.  A block = 16 consecutive elements of a partial (one co row
+// of one tile: a 64-byte run) x 16 groups of partials: thread (e16, pg) adds every 16th partial, the 16 group sums meet in
+// LDS in a fixed order (bit-reproducible).  One thread per element looping over ALL partials was a chain of ~100 dependent
+// loads on a grid of 8-16 blocks: 29 us per 1x1 convolution, more than its main kernel.
+// grid (OT * TAPS * 16, input tiles), block (256).
 template <int KS, int OT>
 __global__ __launch_bounds__(256) void conv_wgrad_finish_kernel(const ConvWgradArgs a) {
     constexpr int TAPS = KS * KS, PER = OT * TAPS * 256;
-    const int f = blockIdx.x * 256 + threadIdx.x;                 // element of one partial
-    if (f >= PER) return;
+    __shared__ float s_sum[16][17];
+    const int e16 = threadIdx.x & 15, pg = threadIdx.x >> 4;
+    const int f = blockIdx.x * 16 + e16;                          // element of one partial
     const int it = blockIdx.y;
-    const int c16 = f & 15, r16 = (f >> 4) & 15, tile = f >> 8, tap = tile % TAPS, o = tile / TAPS;
-    const int co = 16 * o + r16, ci = 16 * it + c16;              // co: within this launch
-    if (co >= a.nco || ci >= a.Cin) return;
     const float* p = a.part + ((long long)it * a.nparts) * PER + f;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int i = 0;
-    for (; i + 3 < a.nparts; i += 4) {
-        s0 += p[(long long)i * PER]; s1 += p[(long long)(i + 1) * PER];
-        s2 += p[(long long)(i + 2) * PER]; s3 += p[(long long)(i + 3) * PER];
+    float s0 = 0.f, s1 = 0.f;
+    int i = pg;
+    for (; i + 16 < a.nparts; i += 32) { s0 += p[(long long)i * PER]; s1 += p[(long long)(i + 16) * PER]; }
+    if (i < a.nparts) s0 += p[(long long)i * PER];
+    s_sum[pg][e16] = s0 + s1;
+    __syncthreads();
+    if (pg == 0) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += s_sum[q][e16];
+        const int c16 = f & 15, r16 = (f >> 4) & 15, tile = f >> 8, tap = tile % TAPS, o = tile / TAPS;
+        const int co = 16 * o + r16, ci = 16 * it + c16;          // co: within this launch
+        if (co < a.nco && ci < a.Cin) a.dW[((long long)(a.co0 + co) * a.Cin + ci) * TAPS + tap] = t;
     }
-    for (; i < a.nparts; ++i) s0 += p[(long long)i * PER];
-    a.dW[((long long)(a.co0 + co) * a.Cin + ci) * TAPS + tap] = (s0 + s1) + (s2 + s3);
 }
 
 }  // namespace wm

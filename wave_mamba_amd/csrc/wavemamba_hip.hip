@@ -1413,7 +1413,7 @@ int wm_conv2d_wgrad(const float* gy, const float* x, float* dW, void* workspace,
     do {                                                                                                                 \
         a.co0 = (CO0); a.nco = (NCO);                                                                                    \
         hipLaunchKernelGGL((conv_wgrad_kernel<KS, OTV>), dim3((unsigned)blocks, (unsigned)ygroups), dim3(64 * kCwWaves), 0, st, a); \
-        hipLaunchKernelGGL((conv_wgrad_finish_kernel<KS, OTV>), dim3((unsigned)(OTV * KS * KS), (unsigned)ITN), dim3(256), 0, st, a); \
+        hipLaunchKernelGGL((conv_wgrad_finish_kernel<KS, OTV>), dim3((unsigned)(OTV * KS * KS * 16), (unsigned)ITN), dim3(256), 0, st, a); \
     } while (0)
     if (ks == 3) {
         if (OT == 1) WM_CW(3, 1, 0, Cout); else if (OT == 2) WM_CW(3, 2, 0, Cout); else if (OT == 4) WM_CW(3, 4, 0, Cout);
