@@ -42,6 +42,14 @@ FUSED_BYTES_PER_POS = 512        # SURVEY.md 8d "fused SS2D-core (stretch, repor
 # kernel classes of the selective-scan op whose HIP events are recorded in the instrumented pass
 CORE_CLASSES = ("ss2d_core_reduce", "selscan_carry", "ss2d_core_scan")
 EXP_PEAK = 18.5e12               # v_exp_f32 lane-ops/s chip-wide, tools/microbench.hip on MI355X
+# The LFSSBlock kernels around the scan.  SURVEY 8d gives bytes for the wavelets and the scan
+# only; for these the algorithmic bytes are what each kernel must move at the shipped width (C = 32, D = 64, fp32 planes):
+#   lfss_in   reads tokens (4C) and writes x, z (2 x 4D)                                   = 640 B / position
+#   dwconv3x3 reads x and writes conv(x) (2 x 4D)                                          = 512
+#   lfss_mid  reads the scan's `LFSS_MID_NY` y buffers, z and the tokens, writes tok1 and f (4 D NY + 4D + 4C + 4C + 4D)
+#   lfss_out  reads f (4D) and tok1 (4C), writes the block's output (4C)                   = 512
+LFSS_MID_NY = 4
+LFSS_BYTES_PER_POS = {"lfss_in": 640, "dwconv3x3": 512, "lfss_mid": 256 * LFSS_MID_NY + 256 + 128 + 128 + 256, "lfss_out": 512}
 
 
 def pad_to(x, mult=128):
@@ -101,6 +109,27 @@ def max_over_ranks(seconds, world, device):
 def whole_job_value(world, steps, units_per_step, seconds):
     """units all ranks processed / max-over-ranks time (weak scaling: every rank does `steps` steps)."""
     return world * steps * units_per_step / seconds
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_command(nproc, argv, port=None, script=None):
+    """The command line `python bench.py --gpus N` turns into when no launcher set WORLD_SIZE."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()),
+            script or os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(nproc, argv):
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL needs it)
+    return subprocess.call(launch_command(nproc, argv), env=env)
 
 
 def image_seed(rank):
@@ -254,9 +283,48 @@ def train_leg(device, steps, with_cpu_loss, batch=8, size=512):
                "frac": SCAN_BWD_BYTES_PER_POS * pos / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if bwd_ms else None},
            "selective_scan_forward": {"ms_per_step": fwd_ms,
                                       "frac": SCAN_BYTES_PER_POS[16] * pos / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fwd_ms else None},
-           "losses_after_steps": state["losses"], "first_step_loss_parity": loss_parity,
+           "losses_after_steps": wm.trainer.loss_values(state["losses"]), "first_step_loss_parity": loss_parity,
            "peak_mem_GB": torch.cuda.max_memory_allocated(device) / 2 ** 30}
     del net, opt
+    torch.cuda.empty_cache()
+    return res
+
+
+def ddp_train_leg(device, rank, world, steps, reduce_device, batch=8, size=512):
+    """BASELINE config 3 as worded (N > 1, every rank): DistributedDataParallel over the ranks (base_model.py:111-114), batch 8
+    synthetic 512 x 512 pairs per GPU, `steps` optimize_parameters() between barriers, max over ranks -> whole-job training
+    images/s (weak scaling).  The same steps under `no_sync()` (no gradient all-reduce) give the exposed cost of the one
+    exchange step this path has: the 6.05 MB gradient all-reduce over RCCL / xGMI."""
+    torch.manual_seed(0)
+    net = wm.WaveMamba(**SHIPPED).train().to(device)
+    model = wm.trainer.wrap_ddp(net, device)
+    opt = wm.trainer.make_optimizer(model)
+    g = torch.Generator().manual_seed(image_seed(rank))
+    lq, gt = torch.rand(batch, 3, size, size, generator=g).to(device), torch.rand(batch, 3, size, size, generator=g).to(device)
+    state = {}
+
+    def step():
+        state["losses"] = wm.trainer.train_step(model, opt, lq, gt)
+
+    def step_nosync():
+        with model.no_sync():
+            wm.trainer.train_step(model, opt, lq, gt)
+    sync, barrier = torch.cuda.synchronize, dist.barrier
+    t_ddp = max_over_ranks(timed_steps(step, steps, 2, sync, barrier), world, reduce_device)
+    losses = wm.trainer.loss_values(state["losses"])
+    t_local = None
+    if hasattr(model, "no_sync"):
+        t_local = max_over_ranks(timed_steps(step_nosync, steps, 1, sync, barrier), world, reduce_device)
+    nparam = sum(p.numel() for p in net.parameters())
+    res = {"workload": f"BASELINE config 3: DDP over {world} ranks, batch {batch} x 3x{size}x{size} synthetic pairs per GPU, "
+                       f"shipped config, L1 + 0.1 FFT-L1, AdamW; one gradient all-reduce of {4 * nparam / 1e6:.2f} MB per step "
+                       f"+ the 2-scalar loss reduce (base_model.py:392)",
+           "images_per_s": whole_job_value(world, steps, batch, t_ddp), "ms_per_step": 1e3 * t_ddp / steps, "steps": steps,
+           "ms_per_step_without_allreduce": None if t_local is None else 1e3 * t_local / steps,
+           "exposed_allreduce_ms_per_step": None if t_local is None else 1e3 * (t_ddp - t_local) / steps,
+           "scaling": "weak", "losses_rank0_mean": losses,
+           "peak_mem_GB": torch.cuda.max_memory_allocated(device) / 2 ** 30}
+    del model, net, opt
     torch.cuda.empty_cache()
     return res
 
@@ -304,12 +372,17 @@ def main():
                     help="seconds the CPU leg may take; if (1 + cpu-forwards) x warm-up time exceeds it, one timed forward")
     ap.add_argument("--graph", action="store_true", help="also time the step replayed from a HIP graph")
     ap.add_argument("--no-train", action="store_true",
-                    help="skip the training leg (BASELINE config 3 on one GPU: batch 8 x 512 x 512, rank 0, N = 1)")
+                    help="skip the training leg (BASELINE config 3: batch 8 x 512 x 512 per GPU; N = 1: rank 0 alone, "
+                         "N > 1: DistributedDataParallel over all ranks)")
     ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--no-bf16", action="store_true",
                     help="skip the bf16-storage leg (BASELINE config 2 as worded: bf16 planes between the kernels; rank 0, N = 1)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without an outer launcher: start the N ranks ourselves, exactly as the driver would
+        # (one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1), and hand its exit code back.
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     rank, world, local_rank = rank_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path is HIP-only (no CPU fallback)")
@@ -422,6 +495,12 @@ def main():
             train = train_leg(device, args.train_steps, with_cpu_loss=not args.no_cpu_baseline)
         except Exception as e:
             train = {"error": f"{type(e).__name__}: {e}"[:300]}
+    ddp = None
+    if world > 1 and not args.no_train and not args.timed_only:
+        try:
+            ddp = ddp_train_leg(device, rank, world, args.train_steps, "cpu" if share else device)
+        except Exception as e:
+            ddp = {"error": f"{type(e).__name__}: {e}"[:300]}
     elapsed = max_over_ranks(elapsed, world, "cpu" if share else device)
 
     if rank == 0:
@@ -438,6 +517,12 @@ def main():
             if name in table:
                 gbs = haar_b / (table[name]["ms_per_step"] * 1e-3) / 1e9
                 table[name].update({"algorithmic_GB_per_step": haar_b / 1e9, "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS})
+        for name, bpp in LFSS_BYTES_PER_POS.items():
+            if name in table:
+                gb = bpp * pos / 1e9                          # one launch per LFSSBlock over its L positions: `pos` in total
+                gbs = gb / (table[name]["ms_per_step"] * 1e-3)
+                table[name].update({"algorithmic_bytes_per_position": bpp, "algorithmic_GB_per_step": gb,
+                                    "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS})
         core_ms = sum(table[k]["ms_per_step"] for k in CORE_CLASSES if k in table)
         calls = table.get("ss2d_core_scan", {}).get("launches_per_step", 0)
         scan_bytes = SCAN_BYTES_PER_POS[16] * pos
@@ -479,7 +564,18 @@ def main():
                         "passes (chunk-reduce, chunk-scan) plus four packed fp32 operations per state-step",
                 "exp_frac": (2 * 4096 * pos / (core_ms * 1e-3) / EXP_PEAK) if core_ms else None},
         }
-        hot_names = ("haar_analysis", "haar_synthesis", "lfss_glue", "dwconv3x3") + CORE_CLASSES
+        hot_names = ("haar_analysis", "haar_synthesis", "lfss_in", "lfss_mid", "lfss_out", "dwconv3x3") + CORE_CLASSES
+        # SURVEY.md 8d "for the sum": DWT + IWT + scans = 2.81 + 2.81 + 26.20 GB per UHD image over the time of EVERY
+        # hot-path kernel (wavelets, LFSSBlock glue, depth-wise conv, the scan op), each alone on the GPU
+        hot_iso_ms = sum((iso[k] if k in iso else table[k]["ms_per_step"]) for k in table if k in hot_names)
+        hot_bytes = 2 * haar_b + scan_bytes
+        hot_sum = {"definition": "SURVEY.md 8d hot-path sum: DWT + IWT (2*e*B*C*H*W per level each) + scans (3584 B / position), "
+                                 "over the summed duration of every hot-path kernel class (haar, lfss_in / mid / out, depth-wise "
+                                 "conv + SiLU, scan reduce / carry / scan), single-stream pass",
+                   "algorithmic_GB_per_step": hot_bytes / 1e9, "ms_per_step": hot_iso_ms,
+                   "achieved_GBps": hot_bytes / (hot_iso_ms * 1e-3) / 1e9 if hot_iso_ms else None,
+                   "frac": hot_bytes / (hot_iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if hot_iso_ms else None,
+                   "ceiling_images_per_s": HBM_PEAK_GBS * 1e9 / hot_bytes}
         line = {
             "metric": "UHD (3840x2160) images/sec fwd", "value": whole_job_value(world, args.steps, 1, elapsed),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -493,8 +589,9 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
             "roofline_table": table,
             "hot_path_ms_per_step": sum(table[k]["ms_per_step"] for k in table if k in hot_names),
+            "hot_path_sum": hot_sum,
             "selscan_op_boundary": op_boundary, "hip_graph_replay": hip_graph, "bf16_storage": bf16,
-            "concurrent_forwards": concurrent, "training_config3_one_gpu": train,
+            "concurrent_forwards": concurrent, "training_config3_one_gpu": train, "training_config3_ddp": ddp,
         }
         print(json.dumps(line))
     if world > 1:

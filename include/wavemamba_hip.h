@@ -354,18 +354,19 @@ int wm_skff_fwd(const float* x0, const float* x1, const float* x2, const float* 
  * Profiling hooks used by bench.py (HIP events recorded on the launch stream around each kernel
  * class).  Disabled by default; when disabled the library records nothing.
  *   kernel ids: 0 haar analysis (dwt fwd / iwt bwd), 1 haar synthesis (iwt fwd / dwt bwd),
- *               2 scan chunk-reduce, 3 scan carry, 4 scan chunk-scan (drop-in op), 5 lfss glue (in/mid/out),
- *               6 ss2d projection records (core backward), 7 depth-wise conv, 8 ss2d core chunk-scan
- *               (+ the merged-output sum), 9 unused (the first-generation core's chunk-scan until round 3), 10 ss2d core
- *               chunk-reduce (+ the parameter prep), 11 unused, 12 selective-scan backward (all phases),
- *               13 dense 3x3 convolution, 14 1x1 convolution, 15 SKFF (all three kernels)
+ *               2 scan chunk-reduce, 3 scan carry, 4 scan chunk-scan (drop-in op), 5 wm_lfss_in_fwd,
+ *               6 ss2d projection records (core backward), 7 depth-wise conv + SiLU (SS2D.conv2d), 8 ss2d core chunk-scan
+ *               (+ the merged-output sum), 9 wm_lfss_mid_fwd, 10 ss2d core chunk-reduce (+ the parameter prep),
+ *               11 wm_lfss_out_fwd / wm_lfss_out_conv_fwd, 12 selective-scan backward (all phases),
+ *               13 dense 3x3 convolution, 14 1x1 convolution, 15 SKFF (all three kernels), 16 LayerNorm2d,
+ *               17 depth-wise conv without SiLU (HFE branch, ffn), 18-19 unused
  * wm_prof_enable(mask): bit k of `mask` switches recording for kernel id k (0 = off, ~0u = every class);
  * a non-zero mask also clears what was recorded before.  Two hipEventRecord calls cost ~10 us of stream
  * time per launch, so a caller timing a whole step enables only the classes it needs.
  * wm_prof_collect synchronises the recorded events (host-blocking) and returns, per kernel id,
  * the number of launches and their summed duration in milliseconds since the last wm_prof_enable(mask != 0).
  * -------------------------------------------------------------------------------------------- */
-#define WM_PROF_NKERNELS 16
+#define WM_PROF_NKERNELS 20
 void wm_prof_enable(unsigned mask);
 int wm_prof_collect(int* launches /*[WM_PROF_NKERNELS]*/, double* total_ms /*[WM_PROF_NKERNELS]*/);
 

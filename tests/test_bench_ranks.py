@@ -79,3 +79,37 @@ def test_train_bench_shares_the_rank_helpers():
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "train_bench.py")).read()
     for name in ("bench.rank_env", "bench.timed_steps", "bench.max_over_ranks", "bench.whole_job_value"):
         assert name in src, name
+
+
+def test_bench_self_launch_starts_one_rank_per_gpu(tmp_path):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset) re-executes itself under
+    torch.distributed.run with N ranks on 127.0.0.1 (round 3's bench died on `assert world == args.gpus` there).  The
+    launcher is exercised for real on CPU with a stand-in script that does what bench.main does first: read the rank
+    environment, join the process group, reduce a per-rank value."""
+    import subprocess
+    import sys
+    import bench
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "3"], port=1234)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "1234"
+    assert cmd[-5] == os.path.abspath(bench.__file__) and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rank_probe.py"
+    script.write_text(
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import bench\n"
+        "rank, world, local = bench.rank_env()\n"
+        "assert world == int(sys.argv[sys.argv.index('--gpus') + 1])\n"
+        "dist.init_process_group('gloo')\n"
+        "t = bench.max_over_ranks(1.0 + rank, world, 'cpu')\n"
+        f"open(os.path.join({str(tmp_path)!r}, f'rank{{rank}}.txt'), 'w').write(f'{{world}} {{local}} {{t}}')\n"
+        "dist.destroy_process_group()\n")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    rc = subprocess.call(bench.launch_command(2, ["--gpus", "2"], script=str(script)), env=env, timeout=300)
+    assert rc == 0
+    assert [open(tmp_path / f"rank{r}.txt").read() for r in range(2)] == ["2 0 2.0", "2 1 2.0"]
+    # main() takes that branch before it touches the GPU
+    src = open(os.path.join(root, "bench.py")).read()
+    assert src.index('"WORLD_SIZE" not in os.environ') < src.index("torch.cuda.is_available()")

@@ -92,3 +92,27 @@ def test_core_work_split_is_consistent():
     assert out[2] == 1 and out[5] // 16 < 1088 // 16            # one segment per column; row chunks shorter than a column
     assert lib.wm_ss2d_core_plan(1, 64, 8, 8, 64, 2, out) == -5        # N > 32
     assert lib.wm_ss2d_core_prep_bytes(16) > 0 and lib.wm_ss2d_core_prep_bytes(33) == 0
+
+
+def test_core_plan_cache_keeps_serving_new_shapes():
+    """the plan cache stopped inserting at 256 shapes, so every later shape re-ran the list-scheduling search on
+    every call (5-18 ms under a global mutex, 14 core calls per image).  It is an LRU now: after far more distinct shapes
+    than it holds, a NEW shape is searched once and then served from the cache, and plans are unchanged by eviction."""
+    import ctypes
+    import time
+    from wave_mamba_amd import _lib
+    lib = _lib.load()
+    out, again = (ctypes.c_int * 10)(), (ctypes.c_int * 10)()
+    assert lib.wm_ss2d_core_plan(1, 64, 272, 480, 16, 2, out) == 0
+    first = list(out)
+    for i in range(1300):                                        # > the cache's 1024 entries, all distinct (small maps: fast searches)
+        assert lib.wm_ss2d_core_plan(1, 64, 16 + 8 * (i % 50), 16 + 4 * (i // 50), 16, 2, again) == 0
+    t0 = time.perf_counter()
+    assert lib.wm_ss2d_core_plan(1, 64, 1096, 1928, 16, 2, again) == 0          # a new, UHD-sized shape: searched now
+    cold = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(20):
+        assert lib.wm_ss2d_core_plan(1, 64, 1096, 1928, 16, 2, out) == 0 and list(out) == list(again)
+    warm = (time.perf_counter() - t0) / 20
+    assert warm < 2e-3 and warm < 0.5 * max(cold, 4e-3), (cold, warm)           # cached: no search per call
+    assert lib.wm_ss2d_core_plan(1, 64, 272, 480, 16, 2, out) == 0 and list(out) == first   # evicted and re-planned: same plan

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the N > 1 paths.
+"""CPU, world sizes 2 and 4 over gloo: the N > 1 paths.
 
   * training: DistributedDataParallel over image batches, one gradient all-reduce per step; the
     averaged gradients must equal the single-process gradients on the concatenated batch
@@ -43,7 +43,8 @@ def _worker(rank, world, port, out_dir):
         opt = wm.trainer.make_optimizer(ddp)
         g = torch.Generator().manual_seed(1234)
         lq, gt = torch.rand(4, 3, 32, 32, generator=g), torch.rand(4, 3, 32, 32, generator=g)
-        shard = slice(rank * 2, rank * 2 + 2)                     # EnlargedSampler-style rank shard
+        per = 4 // world
+        shard = slice(rank * per, rank * per + per)               # EnlargedSampler-style rank shard
         opt.zero_grad()
         out = ddp(lq[shard])
         l_pix, l_freq = wm.trainer.losses(out, gt[shard])
@@ -63,18 +64,19 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-def test_ddp_two_ranks_match_single_process(tmp_path):
-    world = 2
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 4])
+def test_ddp_ranks_match_single_process(world, tmp_path):
     mp.spawn(_worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
-    r0 = torch.load(tmp_path / "rank0.pt")
-    r1 = torch.load(tmp_path / "rank1.pt")
-    # gradients are identical on both ranks after the all-reduce, and so are the updated weights
-    for k in r0["grads"]:
-        assert torch.equal(r0["grads"][k], r1["grads"][k]), k
-    assert torch.equal(r0["w0"], r1["w0"])
-    assert r0["tmax"] == r1["tmax"] == 2.0
-    assert r0["ysum"] != r1["ysum"]                              # replicas saw different images
+    res = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+    r0 = res[0]
+    # gradients are identical on every rank after the all-reduce, and so are the updated weights
+    for r in res[1:]:
+        for k in r0["grads"]:
+            assert torch.equal(r0["grads"][k], r["grads"][k]), k
+        assert torch.equal(r0["w0"], r["w0"])
+        assert r["tmax"] == r0["tmax"] == float(world)
+    assert len({r["ysum"] for r in res}) == world                # replicas saw different images
 
     # single process on the concatenated batch: mean-reduced losses => same gradients
     import wave_mamba_amd as wm

@@ -19,9 +19,10 @@ DEV = "cuda:0"
 # of the deepest block: |g| 1e-7 .. 1e-3 against 1e-1 elsewhere) is only defined to a few 1e-5 in fp32 by ANY
 # implementation, the reference's included.  The yardstick is therefore the FLOAT64 evaluation of the reference's own
 # code (tests/golden/train_grads_wf8_f64.npz, model_shipped_meta.json: grad_fingerprint_f64; make_golden*.py):
-#     err(build, truth) <= max(1e-4, 2 err(reference fp32, truth))   per tensor - no other allowance.
+#     err(build, truth) <= max(1e-4, 2 err(reference fp32, truth))   per tensor - no other allowance, and never more than
+# 5e-4 in absolute terms (a tensor the reference itself gets wrong by more than 2.5e-4 would otherwise pass anything).
 def truth_bar(err_ref):
-    return max(1e-4, 2.0 * err_ref)
+    return min(max(1e-4, 2.0 * err_ref), 5e-4)
 
 
 TOL = 1e-4
@@ -1251,6 +1252,117 @@ def test_ss2d_core_backward_vs_unfused_autograd(B, D, H, W, N, R, merged):
         assert_vs_truth(a, b, tr, f"fused core bwd {nm} {(B, D, H, W, N, R)} merged={merged}")
 
 
+def core_truth_subset_f64(x, Wx, Wdt, bias, A_logs, Ds, dy, chans):
+    """SS2D.forward_core's backward (:446-478 under autograd) in FLOAT64 ON THE GPU with the
+    SEQUENTIAL recurrence, for the channels `chans` of every direction and a merged output gradient dy (B, D, L): the truth
+    at map sizes where autograd through a float64 Python loop cannot run (L = 65,536 at BASELINE config 3's level 1).
+    Operands are formed the way the reference forms them (all 64 channels enter x_dbl), the recurrence runs one step per
+    launch (h_t = a_t h_{t-1} + b_t forward, g_t = C_t dy_t + a_{t+1} g_{t+1} backward), everything else is vectorised.
+    Returns per-channel gradients (4, S, ...): dA_logs, dDs, d dt_projs_bias, d dt_projs_weight."""
+    x, Wx, Wdt, bias, A_logs, Ds, dy = [t.detach().double() for t in (x, Wx, Wdt, bias, A_logs, Ds, dy)]
+    B, D, H, W = x.shape
+    L, N, R, S = H * W, A_logs.shape[1], Wdt.shape[2], len(chans)
+    ci = torch.tensor(chans, device=x.device)
+
+    def seq(t, k):          # (B, C, H, W) map -> (B, C, L) in direction k's scan order (:451-452)
+        v = t.reshape(B, -1, L) if k % 2 == 0 else t.transpose(2, 3).reshape(B, -1, L)
+        return torch.flip(v, dims=[-1]) if k >= 2 else v
+
+    dyk_map = dy.view(B, D, H, W)
+    a_l, b_l, c_l, pack = [], [], [], []
+    for k in range(4):
+        xs = seq(x, k)
+        x_dbl = torch.einsum("bdl,cd->bcl", xs, Wx[k])
+        dt_r, Bk, Ck = x_dbl[:, :R], x_dbl[:, R:R + N], x_dbl[:, R + N:]
+        delta = torch.einsum("brl,dr->bdl", dt_r, Wdt[k, ci]) + bias[k, ci].view(1, S, 1)
+        dt = F.softplus(delta)
+        u = xs[:, ci]
+        dyk = seq(dyk_map, k)[:, ci]
+        A = -torch.exp(A_logs[k * D + ci])                                            # (S, N)
+        tm = lambda t: t.permute(2, 0, 1).contiguous()                               # (B, S, L) -> (L, B, S)
+        a_l.append(torch.exp(tm(dt)[..., None] * A))                                  # (L, B, S, N)
+        b_l.append(tm(dt * u)[..., None] * Bk.permute(2, 0, 1)[:, :, None, :])
+        c_l.append(tm(dyk)[..., None] * Ck.permute(2, 0, 1)[:, :, None, :])
+        pack.append((dt, u, dyk, delta, A, Bk, dt_r))
+    a_all, b_all, c_all = (torch.cat(v, dim=2) for v in (a_l, b_l, c_l))              # (L, B, 4 S, N)
+    del a_l, b_l, c_l
+    h_all = torch.empty_like(b_all)
+    h_all[0] = b_all[0]
+    for t in range(1, L):
+        torch.addcmul(b_all[t], a_all[t], h_all[t - 1], out=h_all[t])
+    g_all = b_all                                                                     # (b is consumed: reuse its storage)
+    g_all[L - 1] = c_all[L - 1]
+    for t in range(L - 2, -1, -1):
+        torch.addcmul(c_all[t], a_all[t + 1], g_all[t + 1], out=g_all[t])
+    hprev = torch.cat([torch.zeros_like(h_all[:1]), h_all[:-1]], dim=0)
+    gah = g_all * a_all * hprev                                                       # g_t a_t h_{t-1}
+    del hprev, h_all, a_all, c_all
+    out = {"dA_logs": [], "dDs": [], "dbias": [], "dWdt": []}
+    for k, (dt, u, dyk, delta, A, Bk, dt_r) in enumerate(pack):
+        gk, gahk = g_all[:, :, k * S:(k + 1) * S], gah[:, :, k * S:(k + 1) * S]       # (L, B, S, N)
+        dtm = dt.permute(2, 0, 1)
+        dA = (gahk * dtm[..., None]).sum(dim=(0, 1))
+        gB = (gk * Bk.permute(2, 0, 1)[:, :, None, :]).sum(-1)                        # <g_t, B_t>   (L, B, S)
+        ddt = (gahk * A).sum(-1) + u.permute(2, 0, 1) * gB
+        ddelta = ddt * torch.sigmoid(delta.permute(2, 0, 1))
+        out["dA_logs"].append(dA * A)
+        out["dDs"].append((dyk * u).sum(dim=(0, 2)))
+        out["dbias"].append(ddelta.sum(dim=(0, 1)))
+        out["dWdt"].append(torch.einsum("lbs,brl->sr", ddelta, dt_r))
+    return {n: torch.stack(v) for n, v in out.items()}
+
+
+@pytest.mark.parametrize("B,D,H,W", [(8, 64, 256, 256), (8, 64, 128, 128), (8, 64, 64, 64), (1, 64, 544, 960)])
+def test_ss2d_core_backward_at_training_sizes(B, D, H, W):
+    """wm_ss2d_core_bwd at the map sizes BASELINE config 3 times it at (batch 8, levels 1-3 of 512 x 512 crops: L = 65,536
+    = 256 blocks of 256 steps per direction, two-level carries, batch strides, many projgrad partials, real transposes) and at
+    one UHD level-2 map.  (1) Every gradient against autograd through the UNFUSED path (torch direction glue + einsums + the
+    op-boundary HIP scan with its own backward): dx / dWx <= 1e-4.  (2) The per-channel parameter gradients (dA_logs, dDs,
+    d dt_projs_bias, d dt_projs_weight) of four channels of EVERY direction against the float64 sequential recurrence on
+    the same operands (core_truth_subset_f64), judged like every gradient test: err <= max(1e-4, 2 err(unfused fp32))."""
+    N, R = 16, 2
+    x, Wx, Wdt, bias, A_logs, Ds = [t.to(DEV).requires_grad_(True) for t in random_core_case(B, D, H, W, N, R, seed=H + W + B)]
+    L = H * W
+    params = [x, Wx, Wdt, bias, A_logs, Ds]
+    dy = torch.randn(B, D, L, device=DEV, generator=torch.Generator(device=DEV).manual_seed(7))
+
+    def unfused():
+        xs = torch.stack([x.view(B, -1, L), x.transpose(2, 3).contiguous().view(B, -1, L)], dim=1).view(B, 2, -1, L)
+        xs = torch.cat([xs, torch.flip(xs, dims=[-1])], dim=1)
+        x_dbl = torch.einsum("b k d l, k c d -> b k c l", xs, Wx)
+        dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
+        dts = torch.einsum("b k r l, k d r -> b k d l", dts, Wdt)
+        out = wm.ops.selective_scan_fn(xs.reshape(B, -1, L), dts.reshape(B, -1, L), -torch.exp(A_logs), Bs.contiguous(),
+                                       Cs.contiguous(), Ds, None, bias.reshape(-1), True).view(B, 4, -1, L)
+        inv = torch.flip(out[:, 2:4], dims=[-1]).view(B, 2, -1, L)
+        wh = out[:, 1].view(B, -1, W, H).transpose(2, 3).contiguous().view(B, -1, L)
+        invwh = inv[:, 1].view(B, -1, W, H).transpose(2, 3).contiguous().view(B, -1, L)
+        return out[:, 0] + inv[:, 0] + wh + invwh
+
+    y_ref = unfused()
+    ref = torch.autograd.grad(y_ref, params, dy)
+    y_got = wm.ops.ss2d_core(*params, merged=True)
+    assert_close(y_got, y_ref, TOL, f"fused core forward {(B, D, H, W)}")
+    del y_ref
+    got = torch.autograd.grad(y_got, params, dy)
+    names = ("dx", "dWx", "dWdt", "dbias", "dA_logs", "dDs")
+    for a, b, nm in zip(got, ref, names):
+        assert torch.isfinite(a).all(), nm
+        assert_close(a, b, TOL, f"fused core bwd {nm} {(B, D, H, W)} vs unfused autograd")
+    chans = [0, 21, 42, 63]
+    truth = core_truth_subset_f64(x, Wx, Wdt, bias, A_logs, Ds, dy, chans)
+    ci = torch.tensor(chans, device=DEV)
+    sel = {"dA_logs": lambda g: g.view(4, D, N)[:, ci], "dDs": lambda g: g.view(4, D)[:, ci],
+           "dbias": lambda g: g.view(4, D)[:, ci], "dWdt": lambda g: g.view(4, D, R)[:, ci]}
+    worst = {}
+    for nm, pick in sel.items():
+        i = names.index(nm)
+        worst[nm] = (max(rel_err(pick(got[i]), truth[nm])), max(rel_err(pick(ref[i]), truth[nm])))
+        assert_vs_truth(pick(got[i]), pick(ref[i]), truth[nm], f"fused core bwd {nm} {(B, D, H, W)} channels {chans}")
+    print(f"core bwd {(B, D, H, W)} vs float64 recurrence (fused, unfused): " +
+          ", ".join(f"{k} {v[0]:.1e}/{v[1]:.1e}" for k, v in worst.items()))
+
+
 def test_trainable_lfss_block_d_state_32(golden):
     """BASELINE config 5's block in training: LFSSBlock(32, d_state=32) forward + backward on the HIP training path
     (fused core forward wm_ss2d_core_fwd, backward wm_ss2d_core_bwd at N = 32) against the REFERENCE's autograd
@@ -1657,6 +1769,111 @@ def test_checkpoint_round_trip_on_gpu(tmp_path):
     assert wm.trainer.resume_training(sp, [ob]) == (0, 1)
     for (ka, va), (kb, vb) in zip(oa.state_dict()["state"].items(), ob.state_dict()["state"].items()):
         assert all(torch.equal(va[n].cpu(), vb[n].cpu()) for n in ("exp_avg", "exp_avg_sq")), ka
+
+
+def test_training_step_shipped_config_256_vs_reference(golden):
+    """One reference training step (femasr_model.py:157-185) of the SHIPPED config on 2 x 3 x 256 x 256 - level-1 maps of
+    128 x 128, L = 16,384: 64 backward blocks per direction, two-level carries, several weight-gradient partials per
+    convolution - against the REFERENCE's own autograd (tests/golden/train_grads_shipped256.npz, make_golden_grads_256.py):
+    losses, prediction, and EVERY parameter gradient (whole tensor up to 1,024 elements, else 1,024 strided elements + whole-
+    tensor sums) judged against the float64 evaluation of the reference's code like every gradient test of this file."""
+    import bench
+    g = golden("train_grads_shipped256")
+    torch.manual_seed(0)
+    net = wm.WaveMamba(**bench.SHIPPED).train().to(DEV)
+    lq = torch.rand(2, 3, 256, 256, generator=gen(1234)).to(DEV)
+    gt = torch.rand(2, 3, 256, 256, generator=gen(4321)).to(DEV)
+    pred = net(lq)
+    l_pix, l_fft = wm.trainer.losses(pred, gt)
+    (l_pix + l_fft).backward()
+    assert abs(float(l_pix.detach()) - float(g["losses"][0])) < 1e-5 and abs(float(l_fft.detach()) - float(g["losses"][1])) < 1e-5
+    assert_vs_truth(pred.detach().flatten()[::97], g["pred_sample"], g["pred_sample_f64"], "prediction")
+
+    def sample_index(numel, sample=1024):          # make_golden_grads_256.sample_index
+        if numel <= sample:
+            return torch.arange(numel)
+        return (torch.arange(sample, dtype=torch.int64) * numel) // sample
+
+    bad, worst, n = [], (0.0, 0.0, None), 0
+    for k, p in net.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        flat = p.grad.detach().flatten().double().cpu()
+        idx = sample_index(flat.numel())
+        truth, ref = g["t." + k].double(), g["g." + k].double()
+        e_got = max(rel_err(flat[idx], truth))
+        e_ref = max(max(rel_err(ref, truth)), float(g["e." + k][0]), float(g["e." + k][1]))
+        # whole-tensor sums against the float64 ones (catches an error outside the sampled elements)
+        f = g["f." + k]
+        e_sum = abs(float(flat.sum()) - float(f[3])) / max(float(f[4]), 1e-300)
+        e_l2 = abs(float(flat.norm()) - float(f[5])) / max(float(f[5]), 1e-300)
+        r_sum = abs(float(f[0]) - float(f[3])) / max(float(f[4]), 1e-300)
+        e_got, e_ref = max(e_got, e_sum, e_l2), max(e_ref, r_sum)
+        worst = max(worst, (e_got, e_ref, k))
+        n += 1
+        if e_got > truth_bar(e_ref):
+            bad.append((e_got, e_ref, k))
+    print("shipped config 256 x 256, %d tensors: worst gradient error vs float64 truth %.3e (reference fp32 %.3e) %s" % ((n,) + worst))
+    assert not bad, "gradients off the float64 truth (build, reference fp32, name): " + \
+        "; ".join("%.3e %.3e %s" % b for b in sorted(bad, reverse=True)[:8])
+
+
+@pytest.mark.parametrize("ks,B,Cin,Cout,H,W", [
+    (3, 8, 64, 64, 256, 256),    # BASELINE config 3, level 1: the HFE / plumbing 3x3 at the size the bench times it at
+    (3, 8, 64, 32, 256, 256),
+    (3, 8, 32, 96, 256, 256),    # h_out_conv
+    (3, 8, 3, 32, 512, 512),     # conv_01 at full resolution
+    (3, 8, 32, 3, 512, 512),     # last
+    (3, 8, 64, 64, 128, 128),    # level 2
+    (1, 8, 64, 64, 256, 256),
+    (1, 8, 32, 64, 128, 128),
+])
+def test_conv2d_wgrad_at_training_sizes_vs_float64(ks, B, Cin, Cout, H, W):
+    """wm_conv2d_wgrad at BASELINE config 3's sizes (batch 8, 512 x 512 crops: many units per wave, every block of the
+    grid, the finish kernel over hundreds of partials) against the FLOAT64 weight gradient, formed on the GPU tap by tap
+    as dW[o, i, ky, kx] = sum_{b, y, x} gy[b, o, y, x] x[b, i, y + ky - p, x + kx - p] with a float64 matrix product;
+    ATen's fp32 weight gradient (what the kernel replaced) is the fp32 reference of the criterion."""
+    gg = torch.Generator(device=DEV).manual_seed(ks * 1000 + Cin * 7 + Cout + H)
+    x = torch.randn(B, Cin, H, W, device=DEV, generator=gg)
+    gy = torch.randn(B, Cout, H, W, device=DEV, generator=gg)
+    pad = ks // 2
+    xp = F.pad(x.double(), (pad, pad, pad, pad))
+    gy2 = gy.double().permute(1, 0, 2, 3).reshape(Cout, -1)
+    truth = torch.empty(Cout, Cin, ks, ks, dtype=torch.float64, device=DEV)
+    for ky in range(ks):
+        for kx in range(ks):
+            xs = xp[:, :, ky:ky + H, kx:kx + W].permute(1, 0, 2, 3).reshape(Cin, -1)
+            truth[:, :, ky, kx] = gy2 @ xs.t()
+    w = torch.zeros(Cout, Cin, ks, ks, device=DEV)
+    assert wm.ops.conv2d_wgrad_supported(x, w)
+    got = wm.ops.conv2d_wgrad(gy, x, ks)
+    aten = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    e_got, e_ref = max(rel_err(got, truth)), max(rel_err(aten, truth))
+    print(f"conv2d_wgrad ks={ks} {B}x{Cin}->{Cout} {H}x{W}: {e_got:.2e} of the float64 gradient (ATen fp32: {e_ref:.2e})")
+    assert e_got <= 2e-5, f"conv2d_wgrad ks={ks} {Cin}->{Cout} {H}x{W}: {e_got:.3e} vs float64"
+    assert torch.equal(wm.ops.conv2d_wgrad(gy, x, ks), got), "conv2d_wgrad: not bit-reproducible run to run"
+
+
+def test_whole_model_gradients_hip_wgrad_vs_aten_wgrad():
+    """(was tools/wgrad_vs_aten.py) One training step of the shipped config on 4 x 3 x 256 x 256 with the HIP convolution
+    weight gradient against the same step with ATen's: every parameter gradient within 2e-5 (they differ only in the
+    weight-gradient kernels: ~4e-6 per product from the split-bf16 operands)."""
+    import bench
+    lq = torch.rand(4, 3, 256, 256, generator=gen(11)).to(DEV)
+    gt = torch.rand(4, 3, 256, 256, generator=gen(12)).to(DEV)
+    grads = []
+    try:
+        for hip in (True, False):
+            wm.ops.set_train_conv_wgrad_hip(hip)
+            torch.manual_seed(0)
+            net = wm.WaveMamba(**bench.SHIPPED).train().to(DEV)
+            l_pix, l_fft = wm.trainer.losses(net(lq), gt)
+            (l_pix + l_fft).backward()
+            grads.append({k: p.grad.detach().clone() for k, p in net.named_parameters()})
+    finally:
+        wm.ops.set_train_conv_wgrad_hip(True)
+    worst = max((max(rel_err(grads[0][k], grads[1][k])), k) for k in grads[0])
+    print("HIP vs ATen convolution weight gradient, whole model: worst tensor %.3e (%s)" % worst)
+    assert worst[0] <= 2e-5, worst
 
 
 def test_training_step_at_config3_size():

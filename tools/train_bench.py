@@ -48,7 +48,7 @@ wm.ops.prof_enable(True)
 el = bench.timed_steps(step, args.steps, 0, torch.cuda.synchronize, dist.barrier if world > 1 else (lambda: None))
 prof = wm.ops.prof_collect(); wm.ops.prof_enable(False)
 el = bench.max_over_ranks(el, world, dev)
-losses = state["losses"]
+losses = wm.trainer.loss_values(state["losses"])
 if rank == 0:
     print(json.dumps({"metric": "training images/sec (UHD-LL config, 512x512 crops)", "value": bench.whole_job_value(world, args.steps, args.batch, el),
                       "unit": "images/s", "n_gpus": world, "steps": args.steps, "ms_per_step": 1e3 * el / args.steps,

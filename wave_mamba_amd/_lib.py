@@ -9,8 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WAVEMAMBA_HIP_LIB") or os.path.join(HERE, "libwavemamba_hip.so")  # env: A/B builds
 
 WM_F32, WM_BF16 = 0, 1
-WM_PROF_NKERNELS = 16
-ABI_VERSION = 18
+WM_OK, WM_EINVAL, WM_ENULL, WM_EALIGN, WM_EWORKSPACE, WM_EUNSUPPORTED, WM_EHIP = 0, -1, -2, -3, -4, -5, -6
+WM_PROF_NKERNELS = 20
+ABI_VERSION = 19
 
 _c = ctypes
 _p, _i, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
@@ -91,18 +92,21 @@ def load():
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:
         raise WaveMambaHipError(f"cannot load {LIB_PATH}: {e}") from e
-    ab = bool(os.environ.get("WAVEMAMBA_HIP_LIB")) and os.environ.get("WAVEMAMBA_HIP_AB") == "1"   # tools: older A/B builds
     for name, (res, args) in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
-            if ab:
-                continue
             raise WaveMambaHipError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.wm_abi_version() != ABI_VERSION and not ab:
+    # WAVEMAMBA_HIP_LIB may point at another BUILD of these sources (A/B timing of compile-time variants, tools/), never at
+    # another ABI: a library with a different argument list would be called with shifted arguments (round 3 tolerated that
+    # under WAVEMAMBA_HIP_AB=1; the mode is gone - ADVICE r3).
+    if lib.wm_abi_version() != ABI_VERSION:
         raise WaveMambaHipError(f"ABI mismatch: library {lib.wm_abi_version()} != binding {ABI_VERSION}")
+    if os.environ.get("WAVEMAMBA_HIP_LIB"):
+        import sys
+        print(f"[wave_mamba_amd] WAVEMAMBA_HIP_LIB: using {LIB_PATH} (build {lib.wm_build_id().decode()})", file=sys.stderr)
     _lib = lib
     return lib
 

@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <array>
 #include <atomic>
+#include <list>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -219,7 +221,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 18; }
+int wm_abi_version(void) { return 19; }
 
 #ifndef WM_BUILD_ID
 #define WM_BUILD_ID "unknown"
@@ -492,7 +494,7 @@ int wm_dwconv3x3_fwd(const void* x, const float* weight, const float* bias, void
     const dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 4 * kDwRows - 1) / (4 * kDwRows)),
                     (unsigned)(planes < 65535 ? planes : 65535));
     hipStream_t st = (hipStream_t)stream;
-    ProfScope ps(7, st);
+    ProfScope ps(act == 1 ? 7 : 17, st);       // + SiLU: SS2D's conv2d (:486-487, hot path); the others belong to the HFE branch / the ffn
 #define WM_DW(ACT, VEC)                                                                                                  \
     do {                                                                                                                 \
         if (plane_dtype == WM_F32)                                                                                       \
@@ -625,12 +627,20 @@ static int core_plan(CorePlan& pl, int B, int D, int H, int W, int N, int R, int
         pl.row_wgs = (pl.row_nchunks + pl.row_cpw - 1) / pl.row_cpw;
     };
     {
+        // shape -> plan, most recently used first; the least recently used entry is evicted at kPlanCache entries (a
+        // serving process meets an open-ended set of image sizes - three pyramid levels each; a cache that stopped
+        // inserting when full re-ran the 5-18 ms search on every call for every later shape)
+        constexpr size_t kPlanCache = 1024;
         static std::mutex mu;
-        static std::vector<std::pair<std::array<int, 6>, Cand>> cache;
+        static std::list<std::pair<std::array<int, 6>, Cand>> lru;
+        static std::map<std::array<int, 6>, std::list<std::pair<std::array<int, 6>, Cand>>::iterator> index;
         const std::array<int, 6> key = {B, D, H, W, pl.NP, NW};
         std::lock_guard<std::mutex> lk(mu);
         const Cand* hit = nullptr;
-        for (const auto& e : cache) if (e.first == key) { hit = &e.second; break; }
+        {
+            const auto it = index.find(key);
+            if (it != index.end()) { lru.splice(lru.begin(), lru, it->second); hit = &lru.front().second; }
+        }
         if (hit) fill(*hit);
         else {
             double best = 1e300; Cand bc{((H + 15) / 16) * 16, 1, 32};
@@ -657,7 +667,9 @@ static int core_plan(CorePlan& pl, int B, int D, int H, int W, int N, int R, int
                 }
             }
             fill(bc);
-            if (cache.size() < 256) cache.emplace_back(key, bc);
+            lru.emplace_front(key, bc);
+            index[key] = lru.begin();
+            if (lru.size() > kPlanCache) { index.erase(lru.back().first); lru.pop_back(); }
         }
     }
     pl.max_chunks = pl.col_nchunks > pl.row_nchunks ? pl.col_nchunks : pl.row_nchunks;
@@ -1027,13 +1039,13 @@ int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt
     return launch_status();
 }
 
-#define WM_LFSS_DISPATCH(KERNEL, ...)                                                              \
+#define WM_LFSS_DISPATCH(PROFCLASS, KERNEL, ...)                                                   \
     do {                                                                                           \
         const long long total = (long long)B * L;                                                  \
         if (total == 0) return WM_OK;                                                              \
         const dim3 grid((unsigned)((total + 255) / 256)), block(256);                              \
         hipStream_t st = (hipStream_t)stream;                                                      \
-        ProfScope ps(5, st);                                                                       \
+        ProfScope ps(PROFCLASS, st);                                                               \
         if (C == 32) hipLaunchKernelGGL((KERNEL<32>), grid, block, 0, st, __VA_ARGS__);            \
         else if (C == 16) hipLaunchKernelGGL((KERNEL<16>), grid, block, 0, st, __VA_ARGS__);       \
         else if (C == 8) hipLaunchKernelGGL((KERNEL<8>), grid, block, 0, st, __VA_ARGS__);         \
@@ -1063,7 +1075,7 @@ int wm_lfss_in_fwd(const float* tok, int tok_nchw, const float* ln_w, const floa
                                ln_b, ln_eps, in_proj_weight, (bf16_t*)x_, (bf16_t*)z_, B, (long long)L, ngl, ngroups, gpw);
         return launch_status();
     }
-    WM_LFSS_DISPATCH(lfss_in_kernel, tok, tok_nchw, ln_w, ln_b, ln_eps, in_proj_weight, x, z, B, (long long)L);
+    WM_LFSS_DISPATCH(5, lfss_in_kernel, tok, tok_nchw, ln_w, ln_b, ln_eps, in_proj_weight, x, z, B, (long long)L);
 }
 
 int wm_lfss_mid_fwd(const void* ysum_, int ny, int64_t ystride, const void* z_, const float* tok, int tok_nchw, const float* out_norm_w,
@@ -1083,7 +1095,7 @@ int wm_lfss_mid_fwd(const void* ysum_, int ny, int64_t ystride, const void* z_, 
         const int gpw = lfss_groups_per_wave(ngroups, 1024 * WM_LFSS_MID_WAVES);
         const long long waves = (ngroups + gpw - 1) / gpw;
         hipStream_t st = (hipStream_t)stream;
-        ProfScope ps(5, st);
+        ProfScope ps(9, st);
 #define WM_MID(NY, TP) hipLaunchKernelGGL((lfss_mid_mfma_kernel<NY, TP>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, \
                            (const TP*)ysum_, (long long)ystride, (const TP*)z_, tok, tok_nchw,                                     \
                            out_norm_w, out_norm_b, out_norm_eps, out_proj_weight, skip_scale, ln2_w, ln2_b, ln2_eps,               \
@@ -1093,7 +1105,7 @@ int wm_lfss_mid_fwd(const void* ysum_, int ny, int64_t ystride, const void* z_, 
 #undef WM_MID
         return launch_status();
     }
-    WM_LFSS_DISPATCH(lfss_mid_kernel, ysum, ny, (long long)ystride, z, tok, tok_nchw, out_norm_w, out_norm_b, out_norm_eps, out_proj_weight,
+    WM_LFSS_DISPATCH(9, lfss_mid_kernel, ysum, ny, (long long)ystride, z, tok, tok_nchw, out_norm_w, out_norm_b, out_norm_eps, out_proj_weight,
                      skip_scale, ln2_w, ln2_b, ln2_eps, conv1_weight, conv1_bias, tok1, f, B, (long long)L);
 }
 
@@ -1110,7 +1122,7 @@ int wm_lfss_out_fwd(const void* fc_, const float* tok1, const float* conv3_weigh
         const int gpw = lfss_groups_per_wave(ngroups, 2048);
         const long long waves = (ngroups + gpw - 1) / gpw;
         hipStream_t st = (hipStream_t)stream;
-        ProfScope ps(5, st);
+        ProfScope ps(11, st);
         if (plane_dtype == WM_F32)
             hipLaunchKernelGGL(lfss_out_mfma_kernel<float>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, fc, tok1,
                                conv3_weight, conv3_bias, skip_scale2, out, out_nchw, B, (long long)L, ngl, ngroups, gpw);
@@ -1119,7 +1131,7 @@ int wm_lfss_out_fwd(const void* fc_, const float* tok1, const float* conv3_weigh
                                tok1, conv3_weight, conv3_bias, skip_scale2, out, out_nchw, B, (long long)L, ngl, ngroups, gpw);
         return launch_status();
     }
-    WM_LFSS_DISPATCH(lfss_out_kernel, fc, tok1, conv3_weight, conv3_bias, skip_scale2, out, out_nchw, B, (long long)L);
+    WM_LFSS_DISPATCH(11, lfss_out_kernel, fc, tok1, conv3_weight, conv3_bias, skip_scale2, out, out_nchw, B, (long long)L);
 }
 
 int wm_lfss_out_conv_fwd(const void* f_, const float* conv2_weight, const float* conv2_bias, const float* tok1,
@@ -1138,7 +1150,7 @@ int wm_lfss_out_conv_fwd(const void* f_, const float* conv2_weight, const float*
     const int gpw = lfss_groups_per_wave(ngroups, 2048);
     const long long waves = (ngroups + gpw - 1) / gpw;
     hipStream_t st = (hipStream_t)stream;
-    ProfScope ps(5, st);
+    ProfScope ps(11, st);
     if (plane_dtype == WM_F32)
         hipLaunchKernelGGL(lfss_out_conv_mfma_kernel<float>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, (const float*)f_,
                            conv2_weight, conv2_bias, tok1, conv3_weight, conv3_bias, skip_scale2, out, out_nchw, B, H, W, ngl,
@@ -1158,12 +1170,12 @@ int wm_layernorm2d_fwd(const float* x, const float* weight, const float* bias, f
         const long long total = (long long)B * L;
         if (total == 0) return WM_OK;
         hipStream_t st = (hipStream_t)stream;
-        ProfScope ps(5, st);
+        ProfScope ps(16, st);
         hipLaunchKernelGGL((layernorm2d_kernel<64>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, weight, bias,
                            eps, y, B, (long long)L);
         return launch_status();
     }
-    WM_LFSS_DISPATCH(layernorm2d_kernel, x, weight, bias, eps, y, B, (long long)L);
+    WM_LFSS_DISPATCH(16, layernorm2d_kernel, x, weight, bias, eps, y, B, (long long)L);
 }
 
 }  // extern "C"

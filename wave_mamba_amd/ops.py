@@ -344,9 +344,14 @@ def _ss2d_core_prepared(params):
     sig = tuple((p.data_ptr(), p._version, p.dtype) for p in params)
     ent = _CORE_PREP_CACHE.get(key)
     if ent is not None and all(r() is p for r, p in zip(ent[0], params)) and ent[1] == sig:
-        if ent[4] != cur.cuda_stream and not torch.cuda.is_current_stream_capturing():
-            cur.wait_event(ent[3])
-            ent[2].record_stream(cur)
+        if ent[4] != cur.cuda_stream:
+            if torch.cuda.is_current_stream_capturing():
+                # an event recorded outside the capture cannot be waited for inside it: block the HOST until the producer
+                # (a warm-up forward on another stream that was never joined) is done, then the buffer is simply there
+                ent[3].synchronize()
+            else:
+                cur.wait_event(ent[3])
+                ent[2].record_stream(cur)
         return ent[2]
     if torch.cuda.is_current_stream_capturing():
         return None                                  # cold cache under capture: the call prepares for itself, inside the graph
@@ -927,9 +932,9 @@ def _conv2d_wfrag(weight, cache=True):
     if ent is not None and ent[0]() is weight and ent[1] == weight.data_ptr() and ent[2] == weight._version:
         if ent[5] != cur.cuda_stream:
             if torch.cuda.is_current_stream_capturing():
-                # an event recorded outside the capture can be neither waited for nor queried inside it: the cache must
-                # be warm (one eager forward, synchronised) before a graph is captured - then the fragments are simply there
-                pass
+                # an event recorded outside the capture cannot be waited for inside it: block the HOST until the producer
+                # (a warm-up forward on another stream that was never joined) is done - then the fragments are simply there
+                ent[4].synchronize()
             else:
                 cur.wait_event(ent[4])
                 ent[3].record_stream(cur)
@@ -1121,27 +1126,42 @@ def conv2d_wgrad_supported(x, weight):
             and (Cout + 15) // 16 in (1, 2, 4, 6) and not (ks == 3 and 64 < Cout <= 80))
 
 
-def conv2d_wgrad(gy, x, ks):
+def conv2d_wgrad(gy, x, ks, _refusal=RuntimeError):
     """dW (Cout, Cin, ks, ks) of a stride-1 'same' convolution from gy (B, Cout, H, W) and x (B, Cin, H, W)."""
     lib = _lib.load()
     _require_cuda("conv2d_wgrad", gy, x)
     B, Cout, H, W = gy.shape
     Cin = x.shape[1]
     gy = gy.contiguous().float(); x = x.contiguous().float()
+    if x.dim() != 4 or gy.dim() != 4 or gy.shape[0] != x.shape[0] or gy.shape[2:] != x.shape[2:]:
+        raise _refusal(f"wm_conv2d_wgrad: gy {tuple(gy.shape)} does not match x {tuple(x.shape)}")
     need = lib.wm_conv2d_wgrad_workspace_bytes(B, Cin, Cout, H, W, ks)
     if need == 0:
-        raise RuntimeError("wm_conv2d_wgrad: unsupported shape (see conv2d_wgrad_supported)")
+        raise _refusal("wm_conv2d_wgrad: unsupported shape (see conv2d_wgrad_supported)")
     ws = torch.empty(need, dtype=torch.uint8, device=x.device)
     dW = torch.empty(Cout, Cin, ks, ks, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        check(lib.wm_conv2d_wgrad(_ptr(gy), _ptr(x), _ptr(dW), _ptr(ws), need, B, Cin, Cout, H, W, ks, _stream()), "wm_conv2d_wgrad")
+        rc = lib.wm_conv2d_wgrad(_ptr(gy), _ptr(x), _ptr(dW), _ptr(ws), need, B, Cin, Cout, H, W, ks, _stream())
+    if rc in (_lib.WM_EUNSUPPORTED, _lib.WM_EALIGN) and _refusal is not RuntimeError:
+        raise _refusal(f"wm_conv2d_wgrad refused the call (code {rc})")
+    check(rc, "wm_conv2d_wgrad")
     return dW
 
 
+class _WgradRefused(RuntimeError):
+    pass
+
+
 def _conv_weight_grad(gy, x, weight):
+    """HIP matrix-core weight gradient, or ATen's for anything the kernel refuses - by the Python predicate, by
+    wm_conv2d_wgrad_workspace_bytes (its shape limits) or by the call itself (WM_EUNSUPPORTED / WM_EALIGN): a training step
+    never dies on a shape, as conv_wgrad.hip.h promises."""
     ks = weight.shape[2]
     if _TRAIN_CONV_WGRAD_HIP and conv2d_wgrad_supported(x, weight):
-        return conv2d_wgrad(gy, x, ks)
+        try:
+            return conv2d_wgrad(gy, x, ks, _refusal=_WgradRefused)
+        except _WgradRefused:
+            pass
     _, gw, _ = torch.ops.aten.convolution_backward(
         gy, x, weight, None, [1, 1], [ks // 2, ks // 2], [1, 1], False, [0, 0], 1, [False, True, False])
     return gw
@@ -1216,9 +1236,9 @@ def conv2d_supported(x, weight, x2=None):
 # profiling hooks (bench.py)
 # ------------------------------------------------------------------------------------------------
 PROF_KERNELS = ("haar_analysis", "haar_synthesis", "selscan_chunk_reduce", "selscan_carry",
-                "selscan_chunk_scan", "lfss_glue", "ss2d_proj", "dwconv3x3",
-                "ss2d_core_scan", "unused_9", "ss2d_core_reduce", "unused_11", "selscan_bwd",
-                "conv3x3", "conv1x1", "skff")
+                "selscan_chunk_scan", "lfss_in", "ss2d_proj", "dwconv3x3",
+                "ss2d_core_scan", "lfss_mid", "ss2d_core_reduce", "lfss_out", "selscan_bwd",
+                "conv3x3", "conv1x1", "skff", "layernorm2d", "dwconv3x3_other", "unused_18", "unused_19")
 
 
 def prof_enable(on=True):

@@ -42,25 +42,35 @@ def wrap_ddp(net, device=None, find_unused_parameters=False):
 
 
 def train_step(net, optimizer, lq, gt):
-    """One optimize_parameters(): zero_grad, forward, L1 + 0.1*FFT, backward (DDP all-reduce), step."""
+    """One optimize_parameters(): zero_grad, forward, L1 + 0.1*FFT, backward (DDP all-reduce), step.
+    Returns the reduced losses as 0-dim DEVICE tensors: nothing in a step waits for the GPU (the reference converts them
+    when it logs, every `print_freq` iterations - `loss_values()` is that conversion; a `float()` here was a host sync
+    per iteration, under DDP on every rank)."""
     optimizer.zero_grad(set_to_none=True)
     out = net(lq)
     l_pix, l_freq = losses(out, gt)
     (l_pix + l_freq).mean().backward()
     optimizer.step()
-    return reduce_loss_dict({"l_pix": l_pix.detach(), "l_freq": l_freq.detach()})
+    return reduce_loss_dict({"l_pix": l_pix.detach(), "l_freq": l_freq.detach()}, as_float=False)
 
 
-def reduce_loss_dict(loss_dict):
-    """base_model.py:376-401: sum-reduce to rank 0 then divide by world size."""
+def loss_values(loss_dict):
+    """{name: python float} of a train_step() result (synchronises: call it when logging, not every step)."""
+    return {k: float(v) for k, v in loss_dict.items()}
+
+
+def reduce_loss_dict(loss_dict, as_float=True):
+    """base_model.py:376-401: sum-reduce to rank 0 then divide by world size (the values mean something on rank 0 only,
+    as in the reference).  as_float=False keeps 0-dim tensors on their device (no host synchronisation)."""
+    conv = (lambda v: float(v)) if as_float else (lambda v: v)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return {k: float(v) for k, v in loss_dict.items()}
+        return {k: conv(v) for k, v in loss_dict.items()}
     keys = sorted(loss_dict)
     vec = torch.stack([loss_dict[k].float() for k in keys])
     dist.reduce(vec, dst=0)
     if dist.get_rank() == 0:
         vec /= dist.get_world_size()
-    return {k: float(v) for k, v in zip(keys, vec)}
+    return {k: conv(v) for k, v in zip(keys, vec.unbind(0))}
 
 
 # ---- reference-format checkpoints (basicsr/models/base_model.py:214-261, :299-326, :328-373) -----------------------
