@@ -333,10 +333,11 @@ __global__ __launch_bounds__(64, WM_LB_WAVES) void selscan_chunk_kernel(ScanArgs
 // dependent FMA chain never waits on memory), the 64 segment aggregates of a chain are combined
 // through LDS, then each thread re-walks its segment replacing the end state H[c] by the carry-in.
 constexpr int kCarrySeg = 64;
-// Up to four independent carry problems over the same chains in one launch (blockIdx.z): the fused SS2D core runs
-// its four directions' carries together - they are latency-bound launches of a few microseconds each.
+// Up to eight independent carry problems over the same chains in one launch (blockIdx.z): the fused SS2D core runs
+// its four directions' carries together (forward: four; backward: four forward + four adjoint ones) - they are
+// latency-bound launches of a few microseconds each.
 struct CarryDir { float* wsP; float* wsH; float* segP; float* segH; int nchunks; int nsegs; };
-struct CarryBatch { CarryDir d[4]; };
+struct CarryBatch { CarryDir d[8]; };
 
 template <bool SEGS>      // SEGS: scan the per-segment aggregates (segP, segH) instead of the chunk summaries
 __global__ __launch_bounds__(1024) void selscan_carry_kernel(CarryBatch cb, long long nchains) {

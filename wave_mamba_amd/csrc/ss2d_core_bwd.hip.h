@@ -1,0 +1,795 @@
+// ss2d_core_bwd.hip.h - backward of the fused SS2D core, second generation (round 4), for gfx950.
+//
+// Reference: autograd of SS2D.forward_core (/root/reference/basicsr/archs/wavemamba_arch.py:446-478; reached from
+// basicsr/models/femasr_model.py:181): the x_proj / dt_proj einsums (:453-455) and the selective scan (:465-471) of one
+// direction over one layout (row-major map, or its transposed copy for the column directions).  Math: selscan_bwd.hip.h.
+//
+// What changed against the first generation (selscan_bwd_{reduce,chunk}_kernel<., ., MODE 1 / 2> + ss2d_proj_kernel +
+// projbwd_dx_kernel + projgrad_kernel, 21.7 ms of a 78.7-ms BASELINE config-3 training step):
+//   * the projection records (dt_r | B | C) are RECOMPUTED from the staged x tile on the bf16 matrix cores (the forward's
+//     three-product split and weight fragments, ss2d_core.hip.h) in both passes - the record kernel and its 144 B per
+//     position and direction of HBM traffic (written once, read twice) are gone;
+//   * the gradient kernel is a workgroup of NP / 8 waves that SPLIT THE STATES: every wave owns 8 of a channel's states
+//     (four packed pairs) of the same 64 channels and 16-step chunk.  The single-wave kernel held all 16 states of a
+//     channel, the four-step window (h, a) and the 32 dB / dC products in 256 VGPRs + 236 AGPRs used as spill space
+//     (724 v_accvgpr_read + 240 v_accvgpr_write per 16 steps) at ONE wave per SIMD: every LDS / transcendental latency
+//     and every second issue cycle of a plain fp32 operation was exposed (3,300 cycles per wave-step against ~1,200 of
+//     arithmetic).  A half-state wave needs ~190 registers and shares the operand tiles, so two to four waves fit a SIMD;
+//     the partial sums over the states (du, d dt) are linear and are combined once per chunk through LDS;
+//   * the projection backward runs inside the same kernel while the gradient tile [dB | dC | d dt_r] x 16 steps is in LDS:
+//     dx += Wx^T g and dWx += g x^T on the bf16 matrix cores (split operands, three products), dWx accumulated in registers
+//     over the block's chunks - the gradient planes (144 B per position and direction), projbwd_dx_kernel and
+//     projgrad_kernel are gone; per-block partials of every parameter gradient are added by ONE finish launch per call.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "selscan_bwd.hip.h"
+#include "ss2d_core.hip.h"
+
+namespace wm {
+
+struct CoreBwdArgs {
+    const float* x;          // (B, D, L) planes of this layout (the map, or its transposed copy)
+    const float* dy;         // (B, D, L) gradient of this direction's output, same layout
+    float* dx;               // (B, D, L): written (accumulate == 0) or accumulated into
+    const float* prep;       // ss2d_core_prep_kernel's output for this direction: fragments | A log2(e) | per-channel constants
+    const uint4* wT;         // core_bwd_prep_kernel's output for this direction: Wx^T fragments [4 tiles][K-step][hi | lo][lane]
+    const float* WxR;        // x_proj_weight[k] rows [0, R): (R, D) - the dt_r part of dx
+    float *wsP, *wsH;        // forward block summaries [block][chain]
+    float *wsPr, *wsG;       // adjoint block summaries [nblocks - 1 - block][chain]
+    float *wsHl, *wsS;       // per chunk: state at the chunk's start relative to its block's start; dt sum from the block's start
+    float* part;             // [b * D + d][block][NP + 8]: dA | dD, dbias, dWdt[0..3], 0, 0
+    float* wpart;            // [b][block][tile = row tile * 4 + channel tile][64 lanes][4]: dWx block partials (MFMA D layout)
+    int batch, dim, L, N, R, nchunks, cpb, nblocks, accumulate;
+};
+
+template <int NP> struct BwdCfg {
+    static constexpr int NW = NP / 8;                    // waves per gradient workgroup: 8 states (4 packed pairs) each
+    static constexpr int NTB = NP / 16, NT3 = 2 * NTB + 1;
+    static constexpr int KS = NP / 16;                   // K-steps of 32 of the dx product (K = 2 NP: dB | dC)
+    static constexpr int NRED = 2 * NP + 4;              // gradient tile rows: dB (NP) | dC (NP) | d dt_r (4)
+    static constexpr int NWT = NT3 * 4;                  // dWx tiles: x_proj row tiles (dt_r | B.. | C..) x 4 channel tiles
+    static constexpr int TPW = (NWT + NW - 1) / NW;      // ... per wave
+    static constexpr int O_U = 0, O_DY = 64 * kBRow, O_D = 2 * 64 * kBRow, O_DTR = 3 * 64 * kBRow, O_B = O_DTR + kBT * 4,
+                         O_C = O_B + kBT * NP, O_HS = O_C + kBT * NP, O_RED = O_HS + NW * 4 * 8 * 64,
+                         TOTAL = O_RED + NRED * kBRow;  // floats: 36,928 B (N <= 16), 57,920 B (N <= 32)
+    static constexpr int WT_U4 = 4 * KS * 2 * 64;        // uint4 per direction of the Wx^T fragments
+};
+
+// Wx^T fragments for dx += Wx^T g.  Block k = direction k.  A operand of v_mfma_f32_16x16x32_bf16, tile t (channels
+// 16 t .. 16 t + 15), K-step s (gradient rows 32 s .. 32 s + 31 of [dB | dC]): lane (i16 = l & 15, kq = l >> 4) holds
+// Wx[k][R + c][16 t + i16] for c = 32 s + 4 j + kq, j = 0..7 (the K order the kernel reads the gradient tile in), split into
+// bf16 hi / lo.  c runs over [dB rows | dC rows] = x_proj rows R .. R + 2 N (padded rows: zero).
+template <int NP>
+__global__ __launch_bounds__(256) void core_bwd_prep_kernel(const float* __restrict__ Wx, uint4* __restrict__ wT, int D, int N, int R) {
+    using Cfg = BwdCfg<NP>;
+    const int k = blockIdx.x;
+    const int Cx = R + 2 * N;
+    uint32_t* out = reinterpret_cast<uint32_t*>(wT + (size_t)k * Cfg::WT_U4);
+    for (int e = threadIdx.x; e < 4 * Cfg::KS * 64 * 4; e += 256) {          // one (hi, lo) pair of pairs per item
+        const int jp = e & 3, l = (e >> 2) & 63, s = (e >> 8) % Cfg::KS, t = (e >> 8) / Cfg::KS;
+        const int i16 = l & 15, kq = l >> 4, d = 16 * t + i16;
+        float v[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = 32 * s + 4 * (2 * jp + i) + kq;                    // row of [dB (NP) | dC (NP)]
+            const int n = c < NP ? c : c - NP;
+            const int row = c < NP ? R + n : R + N + n;
+            v[i] = (n < N && d < D) ? Wx[((long long)k * Cx + row) * D + d] : 0.0f;
+        }
+        core_bf2 hi, lo;
+        core_split2(v[0], v[1], hi, lo);
+        const int base = ((t * Cfg::KS + s) * 2) * 256 + l * 4 + jp;         // [tile][K-step][split][lane][4 dwords]
+        out[base] = *reinterpret_cast<uint32_t*>(&hi);
+        out[base + 256] = *reinterpret_cast<uint32_t*>(&lo);
+    }
+}
+
+// 16 per-lane values -> their sums over the 64 lanes; afterwards every lane of 16-lane row r holds the totals of values
+// 4 r .. 4 r + 3 in out[0..3].
+__device__ __forceinline__ void wave_reduce16(const float (&v)[16], float (&out)[4]) {
+    float r1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const u32x2 s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j]), __float_as_uint(v[j + 8]), false, false);
+        r1[j] = __uint_as_float(s.x) + __uint_as_float(s.y);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32x2 s = __builtin_amdgcn_permlane16_swap(__float_as_uint(r1[j]), __float_as_uint(r1[j + 4]), false, false);
+        out[j] = row_sum16(__uint_as_float(s.x) + __uint_as_float(s.y));
+    }
+}
+
+// The B operands of the x_proj product from the staged x tile [64 channels][kBRow]: lane (c16 = step, g4) of K-step s2 holds
+// channels 32 s2 + 4 j + g4, j = 0..7 (the prep kernel's K order), split into bf16 hi / lo.
+__device__ __forceinline__ void bwd_x_operands(const float* __restrict__ s_u, int lane, core_bf8 (&xh)[2], core_bf8 (&xl)[2]) {
+    const int g4 = lane >> 4, c16 = lane & 15;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        float xf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xf[j] = s_u[(32 * s2 + 4 * j + g4) * kBRow + c16];
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            core_bf2 h2, l2;
+            core_split2(xf[j], xf[j + 1], h2, l2);
+            xh[s2][j] = h2[0]; xh[s2][j + 1] = h2[1]; xl[s2][j] = l2[0]; xl[s2][j + 1] = l2[1];
+        }
+    }
+}
+// Row tile t of (dt_r | B.. | C..)[16 steps] = Wx[k] x tile (forward: ss2d_core.hip.h), written to the record arrays
+// s_dtr [tt][4], s_B [tt][NP], s_C [tt][NP].  `frag`: the direction's prepared fragments (global memory, first-level-cache
+// resident: 1 KB per (tile, K-step, split), read by every workgroup of the launch).
+template <int NP>
+__device__ __forceinline__ void bwd_project_tile(int t, const uint4* __restrict__ frag, int lane, const core_bf8 (&xh)[2],
+                                                 const core_bf8 (&xl)[2], float* __restrict__ s_dtr, float* __restrict__ s_B,
+                                                 float* __restrict__ s_C) {
+    constexpr int NTB = NP / 16;
+    const int g4 = lane >> 4, c16 = lane & 15;
+    uint4 wq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wq[i] = frag[(t * 4 + i) * 64 + lane];       // [K-step 0: hi, lo | K-step 1: hi, lo]
+    core_f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const core_bf8 wh = *reinterpret_cast<const core_bf8*>(&wq[2 * s2]);
+        const core_bf8 wl = *reinterpret_cast<const core_bf8*>(&wq[2 * s2 + 1]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[s2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[s2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[s2], acc, 0, 0, 0);
+    }
+    // D layout: lane holds rows 4 g4 .. 4 g4 + 3 of tile column c16 (= step)
+    if (t == 0) { if (g4 == 0) *reinterpret_cast<core_f4*>(s_dtr + c16 * 4) = acc; }
+    else if (t <= NTB) *reinterpret_cast<core_f4*>(s_B + c16 * NP + 16 * (t - 1) + 4 * g4) = acc;
+    else *reinterpret_cast<core_f4*>(s_C + c16 * NP + 16 * (t - 1 - NTB) + 4 * g4) = acc;
+}
+
+// one float4 of a [64 rows][16 steps] operand tile: rows 16 i + (lane >> 2), columns 4 (lane & 3) .. + 3 (mirrored when REV)
+template <bool REV, bool VEC>
+__device__ __forceinline__ void bwd_tile_quad(const float* __restrict__ base, long long L, const FusedTile<REV>& ft, int nch,
+                                              int lane, int i, float* __restrict__ s) {
+    const int trow = lane >> 2, tq = lane & 3, c = 4 * tq;
+    const int r = 16 * i + trow;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (VEC) {
+        v = bwd_ld4(base, (long long)r * L + ft.plo + c, r < nch && c >= ft.c_lo && c < ft.c_hi);
+    } else {
+        // element-wise: every access guarded (odd map sizes are not the training path)
+        const bool rok = r < nch;
+        const float* q = base + (rok ? (long long)r * L + ft.plo + c : 0LL);
+        if (rok && c + 0 >= ft.c_lo && c + 0 < ft.c_hi) v.x = q[0];
+        if (rok && c + 1 >= ft.c_lo && c + 1 < ft.c_hi) v.y = q[1];
+        if (rok && c + 2 >= ft.c_lo && c + 2 < ft.c_hi) v.z = q[2];
+        if (rok && c + 3 >= ft.c_lo && c + 3 < ft.c_hi) v.w = q[3];
+    }
+    if (REV) *reinterpret_cast<float4*>(&s[r * kBRow + 4 * (3 - tq)]) = make_float4(v.w, v.z, v.y, v.x);
+    else *reinterpret_cast<float4*>(&s[r * kBRow + 4 * tq]) = v;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// pass 1: block summaries (single wave per block; selscan_bwd_reduce_kernel with the projection inside)
+// ------------------------------------------------------------------------------------------------------------------
+template <int NP, bool VEC, bool REV>
+__device__ __forceinline__ void core_bwd_reduce_body(const CoreBwdArgs& p, float* smem) {
+    using PC = CoreCfg<NP>;
+    constexpr int NT3 = 2 * (NP / 16) + 1;
+    float* s_u = smem; float* s_dy = smem + 64 * kBRow;
+    float* s_dtr = smem + 2 * 64 * kBRow; float* s_B = s_dtr + kBT * 4; float* s_C = s_B + kBT * NP;
+    const int lane = threadIdx.x;
+    const int b = blockIdx.y;
+    const int nch = min(64, p.dim);
+    const bool live = lane < nch;
+    const int d = live ? lane : 0;
+    const long long L = p.L;
+    const uint4* frag = reinterpret_cast<const uint4*>(p.prep);
+    v2f A2[NP / 2];
+#pragma unroll
+    for (int i = 0; i < NP / 2; ++i) A2[i] = *reinterpret_cast<const v2f*>(p.prep + PC::P_A2 + (i * 64 + lane) * 2);
+    float wdt[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wdt[r] = p.prep[PC::P_LC + r * 64 + lane];
+    const float bias = p.prep[PC::P_LC + 4 * 64 + lane];
+    const int c_first = blockIdx.x * p.cpb, c_end = min(p.nchunks, c_first + p.cpb);
+    const long long chains = (long long)p.batch * p.dim * NP;
+    const long long row = ((long long)b * p.dim + d) * NP;
+    const long long rowbase = (long long)b * p.dim * L;
+    v2f h[NP / 2], pf[NP / 2], gl[NP / 2];
+#pragma unroll
+    for (int n = 0; n < NP / 2; ++n) { h[n] = splat(0.f); pf[n] = splat(1.f); gl[n] = splat(0.f); }
+    float S = 0.0f;
+    for (int chunk = c_first; chunk < c_end; ++chunk) {
+        if (chunk != c_first) __syncthreads();
+        const int t0 = chunk * kBT, tl = min((int)p.L, t0 + kBT) - t0;
+        const FusedTile<REV> ft(L, t0, tl);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bwd_tile_quad<REV, VEC>(p.x + rowbase, L, ft, nch, lane, i, s_u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bwd_tile_quad<REV, VEC>(p.dy + rowbase, L, ft, nch, lane, i, s_dy);
+        __syncthreads();
+        {
+            core_bf8 xh[2], xl[2];
+            bwd_x_operands(s_u, lane, xh, xl);
+#pragma unroll
+            for (int t = 0; t < NT3; ++t) bwd_project_tile<NP>(t, frag, lane, xh, xl, s_dtr, s_B, s_C);
+        }
+        __syncthreads();
+        if (live) {                                      // the chunk's start, relative to the block's start
+            float* o = p.wsHl + (long long)chunk * chains + row;
+#pragma unroll
+            for (int q = 0; q < NP / 4; ++q)
+                *reinterpret_cast<float4*>(o + 4 * q) = make_float4(h[2 * q].x, h[2 * q].y, h[2 * q + 1].x, h[2 * q + 1].y);
+            p.wsS[(long long)chunk * p.batch * p.dim + (long long)b * p.dim + d] = S;
+        }
+#pragma unroll
+        for (int q = 0; q < kBT / 4; ++q) {
+            if (4 * q < tl) {
+                const float4 u4 = *reinterpret_cast<const float4*>(&s_u[lane * kBRow + 4 * q]);
+                const float4 y4 = *reinterpret_cast<const float4*>(&s_dy[lane * kBRow + 4 * q]);
+                const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, yy[4] = {y4.x, y4.y, y4.z, y4.w};
+                float xr[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 dr = *reinterpret_cast<const float4*>(&s_dtr[(4 * q + j) * 4]);
+                    xr[j] = fmaf(wdt[3], dr.w, fmaf(wdt[2], dr.z, fmaf(wdt[1], dr.y, fmaf(wdt[0], dr.x, bias))));
+                }
+                const v2f da = softplus2((v2f){xr[0], xr[1]}), db = softplus2((v2f){xr[2], xr[3]});
+                const float dts[4] = {da.x, da.y, db.x, db.y};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int tt = 4 * q + j;
+                    if (tt < tl) {
+                        const v2f dt2 = splat(dts[j]), du2 = splat(dts[j] * uu[j]), dy2 = splat(yy[j]);
+                        S += dts[j];
+#pragma unroll
+                        for (int r = 0; r < NP / 4; ++r) {
+                            const float4 bv = *reinterpret_cast<const float4*>(&s_B[tt * NP + 4 * r]);
+                            const float4 cv = *reinterpret_cast<const float4*>(&s_C[tt * NP + 4 * r]);
+                            const v2f a0 = exp2_2(dt2 * A2[2 * r]), a1 = exp2_2(dt2 * A2[2 * r + 1]);
+                            h[2 * r] = a0 * h[2 * r] + du2 * (v2f){bv.x, bv.y};
+                            h[2 * r + 1] = a1 * h[2 * r + 1] + du2 * (v2f){bv.z, bv.w};
+                            pf[2 * r] *= a0; pf[2 * r + 1] *= a1;
+                            gl[2 * r] = pf[2 * r] * (dy2 * (v2f){cv.x, cv.y}) + gl[2 * r];
+                            gl[2 * r + 1] = pf[2 * r + 1] * (dy2 * (v2f){cv.z, cv.w}) + gl[2 * r + 1];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (live) {
+        const long long f = (long long)blockIdx.x * chains + row, m = (long long)(p.nblocks - 1 - (int)blockIdx.x) * chains + row;
+#pragma unroll
+        for (int q = 0; q < NP / 4; ++q) {
+            const float4 P4 = make_float4(pf[2 * q].x, pf[2 * q].y, pf[2 * q + 1].x, pf[2 * q + 1].y);
+            *reinterpret_cast<float4*>(p.wsP + f + 4 * q) = P4;
+            *reinterpret_cast<float4*>(p.wsPr + m + 4 * q) = P4;
+            *reinterpret_cast<float4*>(p.wsH + f + 4 * q) = make_float4(h[2 * q].x, h[2 * q].y, h[2 * q + 1].x, h[2 * q + 1].y);
+            *reinterpret_cast<float4*>(p.wsG + m + 4 * q) = make_float4(gl[2 * q].x, gl[2 * q].y, gl[2 * q + 1].x, gl[2 * q + 1].y);
+        }
+    }
+}
+
+// grid (nblocks, B, 2): blockIdx.z = the layout's forward (a0) / reversed (a1) direction
+template <int NP, bool VEC>
+__global__ __launch_bounds__(64, NP == 16 ? 3 : 2) void core_bwd_reduce_kernel(CoreBwdArgs a0, CoreBwdArgs a1) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 64 * kBRow + kBT * 4 + 2 * kBT * NP];
+    if (blockIdx.z == 0) core_bwd_reduce_body<NP, VEC, false>(a0, smem);
+    else core_bwd_reduce_body<NP, VEC, true>(a1, smem);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// pass 2: the gradients.  Workgroup = NW waves, wave w owns states 8 w .. 8 w + 7 of the 64 channels.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NP, bool VEC, bool REV>
+__global__ __launch_bounds__(64 * BwdCfg<NP>::NW, 2) void core_bwd_chunk_kernel(CoreBwdArgs p) {
+    using Cfg = BwdCfg<NP>;
+    using PC = CoreCfg<NP>;
+    constexpr int NW = Cfg::NW, NSUB = kBT / kBS, NTB = Cfg::NTB, NT3 = Cfg::NT3, KS = Cfg::KS, TPW = Cfg::TPW;
+    constexpr int SPW = kBT / NW;                        // steps a wave finalises per chunk
+    __shared__ __attribute__((aligned(16))) float smem[Cfg::TOTAL];
+    float* s_u = smem + Cfg::O_U; float* s_dy = smem + Cfg::O_DY; float* s_d = smem + Cfg::O_D;
+    float* s_dtr = smem + Cfg::O_DTR; float* s_B = smem + Cfg::O_B; float* s_C = smem + Cfg::O_C;
+    float* s_hs = smem + Cfg::O_HS; float* s_red = smem + Cfg::O_RED;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const int nch = min(64, p.dim);
+    const bool live = lane < nch;
+    const float lv = live ? 1.0f : 0.0f;
+    const int d = live ? lane : 0;
+    const long long L = p.L;
+    const uint4* frag = reinterpret_cast<const uint4*>(p.prep);
+
+    // ---- per-lane constants of this wave's four state pairs
+    v2f A2[4], Aln[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        A2[i] = *reinterpret_cast<const v2f*>(p.prep + PC::P_A2 + ((4 * w + i) * 64 + lane) * 2);
+        Aln[i] = A2[i] * 0.6931471805599453f;            // A = A2 ln 2
+    }
+    float wdt[4], wxr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        wdt[r] = p.prep[PC::P_LC + r * 64 + lane];
+        wxr[r] = (r < p.R && live) ? p.WxR[(long long)min(r, p.R - 1) * p.dim + d] : 0.0f;
+    }
+    const float bias = p.prep[PC::P_LC + 4 * 64 + lane];
+    const float Dd = p.prep[PC::P_LC + 5 * 64 + lane];
+    const int c_first = blockIdx.x * p.cpb, c_end = min(p.nchunks, c_first + p.cpb);
+    const long long chains = (long long)p.batch * p.dim * NP;
+    const long long row = ((long long)b * p.dim + d) * NP + 8 * w;
+    const long long rowbase = (long long)b * p.dim * L;
+
+    // rows of the gradient tile nobody writes (d dt_r ranks >= R): zero once
+    for (int e = tid; e < 4 * kBRow; e += 64 * NW) s_red[2 * NP * kBRow + e] = 0.0f;
+
+    v2f Hin[4], gacc[4];
+    {
+        float4 hv[2], gv[2];
+        if (p.nblocks > 1) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                hv[q] = *reinterpret_cast<const float4*>(p.wsH + (long long)blockIdx.x * chains + row + 4 * q);
+                gv[q] = *reinterpret_cast<const float4*>(p.wsG + (long long)(p.nblocks - 1 - (int)blockIdx.x) * chains + row + 4 * q);
+            }
+        } else {
+            hv[0] = hv[1] = gv[0] = gv[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            Hin[2 * q] = (v2f){hv[q].x, hv[q].y} * lv; Hin[2 * q + 1] = (v2f){hv[q].z, hv[q].w} * lv;
+            gacc[2 * q] = (v2f){gv[q].x, gv[q].y} * lv; gacc[2 * q + 1] = (v2f){gv[q].z, gv[q].w} * lv;
+        }
+    }
+    v2f dA[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dA[i] = splat(0.f);
+    float dDp = 0.0f, dbp = 0.0f, dwp[2] = {0.f, 0.f};   // dwp: ranks 2 w, 2 w + 1 (waves 0 and 1)
+    core_f4 wacc[TPW];                                   // dWx tiles id = w + NW i
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) wacc[i] = (core_f4){0.f, 0.f, 0.f, 0.f};
+
+    for (int chunk = c_end - 1; chunk >= c_first; --chunk) {
+        if (chunk != c_end - 1) __syncthreads();         // the previous chunk's tiles are consumed
+        const int t0 = chunk * kBT, tl = min((int)p.L, t0 + kBT) - t0;
+        const FusedTile<REV> ft(L, t0, tl);
+        // ---- operand tiles: x and dy, eight quads of 16 rows shared out among the waves
+#pragma unroll
+        for (int it = 0; it < 8 / NW; ++it) {
+            const int q = w + NW * it;
+            if (q < 4) bwd_tile_quad<REV, VEC>(p.x + rowbase, L, ft, nch, lane, q, s_u);
+            else bwd_tile_quad<REV, VEC>(p.dy + rowbase, L, ft, nch, lane, q - 4, s_dy);
+        }
+        if (tl < kBT)                                     // a ragged last chunk: no stale gradient columns
+            for (int e = tid; e < Cfg::NRED * kBRow; e += 64 * NW) s_red[e] = 0.0f;
+        __syncthreads();
+        // ---- records: row tiles shared out among the waves
+        {
+            core_bf8 xh[2], xl[2];
+            bwd_x_operands(s_u, lane, xh, xl);
+#pragma unroll
+            for (int i = 0; i < (NT3 + NW - 1) / NW; ++i) {
+                const int t = w + NW * i;
+                if (t < NT3) bwd_project_tile<NP>(t, frag, lane, xh, xl, s_dtr, s_B, s_C);
+            }
+        }
+        __syncthreads();
+        // ---- dt of the 16 steps -> s_d (lane-private rows): steps 4 q with q = w, w + NW, .. per wave
+#pragma unroll
+        for (int i = 0; i < (kBT / 4 + NW - 1) / NW; ++i) {
+            const int q = w + NW * i;
+            if (q < kBT / 4) {
+                float xr[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 dr = *reinterpret_cast<const float4*>(&s_dtr[(4 * q + j) * 4]);
+                    xr[j] = fmaf(wdt[3], dr.w, fmaf(wdt[2], dr.z, fmaf(wdt[1], dr.y, fmaf(wdt[0], dr.x, bias))));
+                }
+                const v2f da = softplus2((v2f){xr[0], xr[1]}), db = softplus2((v2f){xr[2], xr[3]});
+                *reinterpret_cast<float4*>(&s_d[lane * kBRow + 4 * q]) = make_float4(da.x, da.y, db.x, db.y);
+            }
+        }
+        __syncthreads();
+        // ---- state at the chunk's start = (state from zero at the block's start) + (decay since the block's start) x H_in
+        v2f h[4];
+        {
+            float Sc = 0.0f;
+            float4 hv[2];
+            if (p.nchunks > 1) {
+                Sc = p.wsS[(long long)chunk * p.batch * p.dim + (long long)b * p.dim + d];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) hv[q] = *reinterpret_cast<const float4*>(p.wsHl + (long long)chunk * chains + row + 4 * q);
+            } else {
+                hv[0] = hv[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            const v2f S2 = splat(Sc);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                h[2 * q] = exp2_2(S2 * A2[2 * q]) * Hin[2 * q] + (v2f){hv[q].x, hv[q].y} * lv;
+                h[2 * q + 1] = exp2_2(S2 * A2[2 * q + 1]) * Hin[2 * q + 1] + (v2f){hv[q].z, hv[q].w} * lv;
+            }
+        }
+        // ---- forward sweep storing the sub-tile start states (this wave's slots: [w][sub-tile][8 states][lane])
+        float* hs = s_hs + (w * NSUB * 8) * 64 + lane;
+#pragma unroll 1
+        for (int st = 0; st < NSUB; ++st) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { hs[(st * 8 + 2 * i) * 64] = h[i].x; hs[(st * 8 + 2 * i + 1) * 64] = h[i].y; }
+            if (st < NSUB - 1) {
+                const float4 dt4 = *reinterpret_cast<const float4*>(&s_d[lane * kBRow + 4 * st]);
+                const float4 u4 = *reinterpret_cast<const float4*>(&s_u[lane * kBRow + 4 * st]);
+                const float dtv[4] = {dt4.x, dt4.y, dt4.z, dt4.w}, uv[4] = {u4.x, u4.y, u4.z, u4.w};
+#pragma unroll
+                for (int j = 0; j < kBS; ++j) {
+                    const int tt = st * kBS + j;
+                    if (tt < tl) {
+                        const v2f dt2 = splat(dtv[j]), du2 = splat(dtv[j] * uv[j]);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const float4 bv = *reinterpret_cast<const float4*>(&s_B[tt * NP + 8 * w + 4 * q]);
+                            h[2 * q] = exp2_2(dt2 * A2[2 * q]) * h[2 * q] + du2 * (v2f){bv.x, bv.y};
+                            h[2 * q + 1] = exp2_2(dt2 * A2[2 * q + 1]) * h[2 * q + 1] + du2 * (v2f){bv.z, bv.w};
+                        }
+                    }
+                }
+            }
+        }
+        // ---- the four sub-tiles, last first
+#pragma unroll 1
+        for (int st = NSUB - 1; st >= 0; --st) {
+            float psb[kBS], psd[kBS];
+#pragma unroll
+            for (int j = 0; j < kBS; ++j) psb[j] = psd[j] = 0.0f;
+            if (st * kBS < tl) {
+                const float4 dt4 = *reinterpret_cast<const float4*>(&s_d[lane * kBRow + 4 * st]);
+                const float4 u4 = *reinterpret_cast<const float4*>(&s_u[lane * kBRow + 4 * st]);
+                const float4 y4 = *reinterpret_cast<const float4*>(&s_dy[lane * kBRow + 4 * st]);
+                const float dtv[4] = {dt4.x, dt4.y, dt4.z, dt4.w}, uv[4] = {u4.x, u4.y, u4.z, u4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w};
+                v2f hh[kBS][4], aa[kBS][4], hc[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hc[i] = (v2f){hs[(st * 8 + 2 * i) * 64], hs[(st * 8 + 2 * i + 1) * 64]};
+#pragma unroll
+                for (int j = 0; j < kBS; ++j) {
+                    const int tt = st * kBS + j;
+                    const v2f dt2 = splat(dtv[j]), du2 = splat(dtv[j] * uv[j]);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const float4 bv = *reinterpret_cast<const float4*>(&s_B[tt * NP + 8 * w + 4 * q]);
+                        aa[j][2 * q] = exp2_2(dt2 * A2[2 * q]);
+                        aa[j][2 * q + 1] = exp2_2(dt2 * A2[2 * q + 1]);
+                        hc[2 * q] = aa[j][2 * q] * hc[2 * q] + du2 * (v2f){bv.x, bv.y};
+                        hc[2 * q + 1] = aa[j][2 * q + 1] * hc[2 * q + 1] + du2 * (v2f){bv.z, bv.w};
+                        hh[j][2 * q] = hc[2 * q]; hh[j][2 * q + 1] = hc[2 * q + 1];
+                    }
+                }
+#pragma unroll
+                for (int j = kBS - 1; j >= 0; --j) {
+                    const int tt = st * kBS + j;
+                    if (tt < tl) {
+                        const float dt = dtv[j], ut = uv[j], dyt = yv[j];
+                        const v2f dt2 = splat(dt), du2 = splat(dt * ut), dy2 = splat(dyt);
+                        v2f sdu = splat(0.f), sdt = splat(0.f);
+                        float prod[16];                               // [0, 8): dB products, [8, 16): dC products
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const float4 bv = *reinterpret_cast<const float4*>(&s_B[tt * NP + 8 * w + 4 * q]);
+                            const float4 cv = *reinterpret_cast<const float4*>(&s_C[tt * NP + 8 * w + 4 * q]);
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const int i = 2 * q + e;
+                                const v2f B2 = e ? (v2f){bv.z, bv.w} : (v2f){bv.x, bv.y};
+                                const v2f C2 = e ? (v2f){cv.z, cv.w} : (v2f){cv.x, cv.y};
+                                const v2f g = C2 * dy2 + gacc[i];          // g_t
+                                const v2f ahp = hh[j][i] - du2 * B2;       // a_t h_{t-1}
+                                const v2f gah = g * ahp;
+                                dA[i] = gah * dt2 + dA[i];
+                                sdt = gah * Aln[i] + sdt;
+                                sdu = g * B2 + sdu;
+                                const v2f pb = g * du2, pc = hh[j][i] * dy2;
+                                prod[2 * i] = pb.x; prod[2 * i + 1] = pb.y;
+                                prod[8 + 2 * i] = pc.x; prod[8 + 2 * i + 1] = pc.y;
+                                gacc[i] = aa[j][i] * g;                    // a_t g_t, carried to step t-1
+                            }
+                        }
+                        psb[j] = sdu.x + sdu.y;
+                        psd[j] = sdt.x + sdt.y;
+                        float o[4];
+                        wave_reduce16(prod, o);           // (dead lanes hold zeros: their u, dy rows are zero-filled)
+                        if ((lane & 15) == 0) {
+                            const int rg = lane >> 4;     // row rg holds values 4 rg .. 4 rg + 3: 0..7 dB n, 8..15 dC n (n local)
+                            float* dst = s_red + ((rg >> 1) * NP + 8 * w + 4 * (rg & 1)) * kBRow + tt;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) dst[i * kBRow] = o[i];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // keep the next step's operand reads out of this step's registers
+                }
+            }
+            // this wave's shares of <g, B> and <g, A a h> of the sub-tile's four steps take the consumed slot
+#pragma unroll
+            for (int j = 0; j < kBS; ++j) { hs[(st * 8 + 2 * j) * 64] = psb[j]; hs[(st * 8 + 2 * j + 1) * 64] = psd[j]; }
+        }
+        __syncthreads();
+        // ---- closing the steps: du_t, ddelta_t from the waves' shares; wave w closes steps SPW w .. SPW w + SPW - 1
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) {
+            const int tt = SPW * w + s, st = tt >> 2, j = tt & 3;
+            float dd = 0.0f;
+            if (tt < tl) {
+                float sb = 0.0f, sd = 0.0f;
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) {
+                    sb += s_hs[((ww * NSUB + st) * 8 + 2 * j) * 64 + lane];
+                    sd += s_hs[((ww * NSUB + st) * 8 + 2 * j + 1) * 64 + lane];
+                }
+                const float ut = s_u[lane * kBRow + tt], dyt = s_dy[lane * kBRow + tt], dt = s_d[lane * kBRow + tt];
+                const float4 dr = *reinterpret_cast<const float4*>(&s_dtr[tt * 4]);
+                const float xraw = fmaf(wdt[3], dr.w, fmaf(wdt[2], dr.z, fmaf(wdt[1], dr.y, fmaf(wdt[0], dr.x, bias))));
+                const float ddt = sd + ut * sb;
+                dd = xraw > 20.0f ? ddt : ddt / (1.0f + __expf(-xraw));
+                dDp = fmaf(dyt, ut, dDp);
+                dbp += dd;
+                s_dy[lane * kBRow + tt] = fmaf(dt, sb, Dd * dyt);        // du_t takes dy_t's slot
+            }
+            s_d[lane * kBRow + tt] = dd;                                  // ddelta_t takes dt_t's slot (0 beyond the tail)
+        }
+        __syncthreads();
+        // ---- d dt_r[r][tt] = sum over channels of ddelta[d][tt] Wdt[d][r] (ranks 2 w, 2 w + 1: waves 0 and 1) + dWdt partial
+        if (w < 2 && 2 * w < p.R) {
+            float ddl[kBT];
+#pragma unroll
+            for (int q = 0; q < kBT / 4; ++q) {
+                const float4 v4 = *reinterpret_cast<const float4*>(&s_d[lane * kBRow + 4 * q]);
+                ddl[4 * q] = v4.x; ddl[4 * q + 1] = v4.y; ddl[4 * q + 2] = v4.z; ddl[4 * q + 3] = v4.w;
+            }
+            float v[32], o[8];
+#pragma unroll
+            for (int tt = 0; tt < kBT; ++tt) {
+                const float4 dr = *reinterpret_cast<const float4*>(&s_dtr[tt * 4]);
+                const float r0 = w ? dr.z : dr.x, r1 = w ? dr.w : dr.y;
+                dwp[0] = fmaf(ddl[tt], r0, dwp[0]); dwp[1] = fmaf(ddl[tt], r1, dwp[1]);
+                v[2 * tt] = ddl[tt] * (w ? wdt[2] : wdt[0]); v[2 * tt + 1] = ddl[tt] * (w ? wdt[3] : wdt[1]);
+            }
+            wave_reduce32(v, o);
+            if ((lane & 15) == 0) {
+                const int rg = lane >> 4;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int val = 8 * rg + i;                           // = 2 tt + e
+                    s_red[(2 * NP + 2 * w + (val & 1)) * kBRow + (val >> 1)] = o[i];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- dx tile (in s_dy) += Wx^T [dB | dC] on the matrix cores (kept in registers until the dt_r part is in) ...
+        core_f4 dacc[(4 + NW - 1) / NW];
+        {
+            const int g4 = lane >> 4, c16 = lane & 15;
+            core_bf8 gh[KS], gl[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                float gf[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gf[j] = s_red[(32 * s + 4 * j + g4) * kBRow + c16];
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    core_bf2 h2, l2;
+                    core_split2(gf[j], gf[j + 1], h2, l2);
+                    gh[s][j] = h2[0]; gh[s][j + 1] = h2[1]; gl[s][j] = l2[0]; gl[s][j + 1] = l2[1];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < (4 + NW - 1) / NW; ++i) {
+                const int t = w + NW * i;
+                core_f4 acc = {0.f, 0.f, 0.f, 0.f};
+                if (t < 4) {
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        const uint4 wh4 = p.wT[((t * KS + s) * 2 + 0) * 64 + lane], wl4 = p.wT[((t * KS + s) * 2 + 1) * 64 + lane];
+                        const core_bf8 wh = *reinterpret_cast<const core_bf8*>(&wh4);
+                        const core_bf8 wl = *reinterpret_cast<const core_bf8*>(&wl4);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, gh[s], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gl[s], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh[s], acc, 0, 0, 0);
+                    }
+                }
+                dacc[i] = acc;
+            }
+        }
+        // ... the dt_r part per lane (= channel), for the steps this wave closed
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) {
+            const int tt = SPW * w + s;
+            float a = s_dy[lane * kBRow + tt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a = fmaf(wxr[r], s_red[(2 * NP + r) * kBRow + tt], a);
+            s_dy[lane * kBRow + tt] = a;
+        }
+        __syncthreads();
+        {   // D layout: lane (c16 = step, g4) holds channels 16 t + 4 g4 .. + 3: every element has one owner
+            const int g4 = lane >> 4, c16 = lane & 15;
+#pragma unroll
+            for (int i = 0; i < (4 + NW - 1) / NW; ++i) {
+                const int t = w + NW * i;
+                if (t < 4) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s_dy[(16 * t + 4 * g4 + r) * kBRow + c16] += dacc[i][r];
+                }
+            }
+        }
+        // ---- dWx += g x^T: row tile rt of [d dt_r | dB.. | dC..] x channel tile ct, K = the 16 steps (lanes kq >= 2: zeros)
+        {
+            const int i16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int id = w + NW * i;
+                if (id < Cfg::NWT) {
+                    const int rt = id >> 2, ct = id & 3;
+                    const int grow = rt == 0 ? 2 * NP + (i16 & 3) : 16 * (rt - 1) + i16;
+                    const bool gok = kq < 2 && (rt > 0 || i16 < 4);
+                    const float4 g0 = *reinterpret_cast<const float4*>(&s_red[grow * kBRow + 8 * (kq & 1)]);
+                    const float4 g1 = *reinterpret_cast<const float4*>(&s_red[grow * kBRow + 8 * (kq & 1) + 4]);
+                    const float4 x0 = *reinterpret_cast<const float4*>(&s_u[(16 * ct + i16) * kBRow + 8 * (kq & 1)]);
+                    const float4 x1 = *reinterpret_cast<const float4*>(&s_u[(16 * ct + i16) * kBRow + 8 * (kq & 1) + 4]);
+                    const float gm = gok ? 1.0f : 0.0f, xm = kq < 2 ? 1.0f : 0.0f;
+                    const float gv[8] = {g0.x * gm, g0.y * gm, g0.z * gm, g0.w * gm, g1.x * gm, g1.y * gm, g1.z * gm, g1.w * gm};
+                    const float xv[8] = {x0.x * xm, x0.y * xm, x0.z * xm, x0.w * xm, x1.x * xm, x1.y * xm, x1.z * xm, x1.w * xm};
+                    core_bf8 ah, al, bh, bl;
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        core_bf2 h2, l2;
+                        core_split2(gv[j], gv[j + 1], h2, l2);
+                        ah[j] = h2[0]; ah[j + 1] = h2[1]; al[j] = l2[0]; al[j + 1] = l2[1];
+                        core_split2(xv[j], xv[j + 1], h2, l2);
+                        bh[j] = h2[0]; bh[j + 1] = h2[1]; bl[j] = l2[0]; bl[j + 1] = l2[1];
+                    }
+                    wacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, wacc[i], 0, 0, 0);
+                    wacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, wacc[i], 0, 0, 0);
+                    wacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, wacc[i], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- dx (+)= du: four quads of 16 rows shared out among the waves (LDS column = scan time)
+        {
+            const int trow = lane >> 2, tq = lane & 3, c = 4 * tq;
+            const bool cok = c >= ft.c_lo && c < ft.c_hi;                  // VEC: the whole quad is valid or not
+#pragma unroll
+            for (int it = 0; it < (4 + NW - 1) / NW; ++it) {
+                const int q = w + NW * it;
+                const int r = 16 * q + trow;
+                if (q < 4 && r < nch) {
+                    float4 a = *reinterpret_cast<const float4*>(&s_dy[r * kBRow + (REV ? 4 * (3 - tq) : 4 * tq)]);
+                    if (REV) a = make_float4(a.w, a.z, a.y, a.x);
+                    float* o = p.dx + rowbase + (long long)r * L + ft.plo + c;
+                    if constexpr (VEC) {
+                        if (cok) {
+                            if (p.accumulate) {                            // uniform
+                                const float4 e = *reinterpret_cast<const float4*>(o);
+                                a = make_float4(e.x + a.x, e.y + a.y, e.z + a.z, e.w + a.w);
+                            }
+                            *reinterpret_cast<float4*>(o) = a;
+                        }
+                    } else {
+                        const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (c + j >= ft.c_lo && c + j < ft.c_hi) o[j] = p.accumulate ? o[j] + av[j] : av[j];
+                    }
+                }
+            }
+        }
+    }                                                    // next chunk of the block (in reverse)
+
+    // ---- one partial record per block: [b * dim + d][block][NP + 8] = dA | dD, dbias, dWdt[0..3], 0, 0
+    __syncthreads();
+    float* sx = s_hs;                                    // [wave][4 values][lane]: dD, dbias shares; dWdt ranks of waves 0 / 1
+    sx[(w * 4 + 0) * 64 + lane] = dDp; sx[(w * 4 + 1) * 64 + lane] = dbp;
+    sx[(w * 4 + 2) * 64 + lane] = dwp[0]; sx[(w * 4 + 3) * 64 + lane] = dwp[1];
+    __syncthreads();
+    if (live) {
+        float* pr = p.part + (((long long)b * p.dim + d) * p.nblocks + blockIdx.x) * (NP + kPartPadFused);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            *reinterpret_cast<float4*>(pr + 8 * w + 4 * q) = make_float4(dA[2 * q].x, dA[2 * q].y, dA[2 * q + 1].x, dA[2 * q + 1].y);
+        if (w == 0) {
+            float tD = 0.0f, tb = 0.0f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) { tD += sx[(ww * 4 + 0) * 64 + lane]; tb += sx[(ww * 4 + 1) * 64 + lane]; }
+            *reinterpret_cast<float4*>(pr + NP) = make_float4(tD, tb, sx[(0 * 4 + 2) * 64 + lane], sx[(0 * 4 + 3) * 64 + lane]);
+            *reinterpret_cast<float4*>(pr + NP + 4) = make_float4(sx[(1 * 4 + 2) * 64 + lane], sx[(1 * 4 + 3) * 64 + lane], 0.f, 0.f);
+        }
+    }
+    {
+        float* wp = p.wpart + (((long long)b * p.nblocks + blockIdx.x) * Cfg::NWT) * 256;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int id = w + NW * i;
+            if (id < Cfg::NWT) *reinterpret_cast<core_f4*>(wp + id * 256 + lane * 4) = wacc[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// finish: parameter gradients from the per-block partials, all four directions in one launch
+// ------------------------------------------------------------------------------------------------------------------
+struct CoreBwdFinishArgs {
+    const float* part[4];    // direction k: [b * D + d][block][NPP]
+    const float* wpart[4];   // direction k: [b][block][tile][256]
+    float* wsum;             // scratch [4][slices][NWT * 256]
+    const float* A_logs;     // (4 D, N)
+    float *dA_logs, *dDs, *dbias, *dWdt, *dWx;      // (4 D, N), (4 D), (4 D), (4, D, R), (4, R + 2 N, D)
+    int batch, dim, N, R, NP, nblocks, slices;
+};
+
+// dA_logs / dDs / d dt_projs_bias / d dt_projs_weight: grid (D, 1, 4), block 256.  One block per (channel, direction)
+// streams its [batch][block][NPP] partials; a thread keeps a fixed column j = f mod NPP by striding in multiples of NPP,
+// then a fixed-order sum over the threads of a column (no atomics: bit-reproducible).
+__global__ __launch_bounds__(256) void core_bwd_finish_kernel(const CoreBwdFinishArgs a) {
+    __shared__ float s[256];
+    const int d = blockIdx.x, k = blockIdx.z;
+    const int NPP = a.NP + kPartPadFused;
+    const int stride = (256 / NPP) * NPP;
+    const int t = threadIdx.x;
+    float acc = 0.0f;
+    if (t < stride) {
+        const long long per = (long long)a.nblocks * NPP;
+        for (int b = 0; b < a.batch; ++b) {
+            const float* base = a.part[k] + ((long long)b * a.dim + d) * per;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            long long f = t;
+            for (; f + 3LL * stride < per; f += 4LL * stride) {
+                s0 += base[f]; s1 += base[f + stride]; s2 += base[f + 2LL * stride]; s3 += base[f + 3LL * stride];
+            }
+            for (; f < per; f += stride) s0 += base[f];
+            acc += (s0 + s1) + (s2 + s3);
+        }
+    }
+    s[t] = acc;
+    __syncthreads();
+    if (t < NPP) {
+        float tot = 0.0f;
+        for (int q = t; q < stride; q += NPP) tot += s[q];
+        const long long kd = (long long)k * a.dim + d;
+        if (t < a.N) a.dA_logs[kd * a.N + t] = -expf(a.A_logs[kd * a.N + t]) * tot;          // dA_logs = dA * A
+        else if (t == a.NP) a.dDs[kd] = tot;
+        else if (t == a.NP + 1) a.dbias[kd] = tot;
+        else if (t >= a.NP + 2 && t < a.NP + 2 + a.R) a.dWdt[kd * a.R + (t - a.NP - 2)] = tot;
+    }
+}
+
+// dWx, stage 1: grid (NWT, slices, 4), block 256: thread = one element of a tile, sums its slice of the (batch x block)
+// partials -> wsum[k][slice][tile][256].
+__global__ __launch_bounds__(256) void core_bwd_wsum_kernel(const CoreBwdFinishArgs a, int NWT) {
+    const int tile = blockIdx.x, sl = blockIdx.y, k = blockIdx.z;
+    const long long nb = (long long)a.batch * a.nblocks;
+    const long long per = (nb + a.slices - 1) / a.slices;
+    const long long i0 = sl * per, i1 = min(nb, i0 + per);
+    const float* p = a.wpart[k] + (long long)tile * 256 + threadIdx.x;
+    const long long st = (long long)NWT * 256;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    long long i = i0;
+    for (; i + 3 < i1; i += 4) { s0 += p[i * st]; s1 += p[(i + 1) * st]; s2 += p[(i + 2) * st]; s3 += p[(i + 3) * st]; }
+    for (; i < i1; ++i) s0 += p[i * st];
+    a.wsum[(((long long)k * a.slices + sl) * NWT + tile) * 256 + threadIdx.x] = (s0 + s1) + (s2 + s3);
+}
+// stage 2: grid (NWT, 1, 4): adds the slices and scatters the tile (MFMA D layout: lane (col = l & 15, kq = l >> 4), register r
+// -> row 4 kq + r) to x_proj_weight's rows: tile row tiles are [d dt_r (rows 0 .. R) | B (R .. R + N) | C (R + N .. R + 2 N)].
+__global__ __launch_bounds__(256) void core_bwd_wfin_kernel(const CoreBwdFinishArgs a, int NWT) {
+    const int tile = blockIdx.x, k = blockIdx.z;
+    const int rt = tile >> 2, ct = tile & 3;
+    const int NTB = a.NP / 16;
+    const int e = threadIdx.x, lane = e >> 2, r = e & 3;
+    const float* p = a.wsum + ((long long)k * a.slices * NWT + tile) * 256 + e;
+    float tot = 0.0f;
+    for (int sl = 0; sl < a.slices; ++sl) tot += p[(long long)sl * NWT * 256];
+    const int i = 4 * (lane >> 4) + r, dch = 16 * ct + (lane & 15);
+    int row = -1;
+    if (rt == 0) { if (i < a.R) row = i; }
+    else if (rt <= NTB) { const int n = 16 * (rt - 1) + i; if (n < a.N) row = a.R + n; }
+    else { const int n = 16 * (rt - 1 - NTB) + i; if (n < a.N) row = a.R + a.N + n; }
+    if (row >= 0 && dch < a.dim) a.dWx[((long long)k * (a.R + 2 * a.N) + row) * a.dim + dch] = tot;
+}
+
+}  // namespace wm

@@ -25,6 +25,7 @@
 #include "conv2d_ws.hip.h"
 #include "hfe.hip.h"
 #include "ss2d_bwd.hip.h"
+#include "ss2d_core_bwd.hip.h"
 #include "imageio.hip.h"
 #include "gates.hip.h"
 #include "conv_wgrad.hip.h"
@@ -911,27 +912,11 @@ static void core_bwd_dir(ScanBwdArgs a, const CoreBwdPlan& pl, float* seg, const
 }  // namespace wm
 extern "C" {
 
-size_t wm_ss2d_core_bwd_workspace_bytes(int B, int D, int H, int W, int N, int R) {
-    CoreBwdPlan pl;
-    if (core_bwd_plan(pl, B, D, H, W, N, R) != WM_OK) return 0;
-    return pl.total;
-}
-
-int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt_projs_weight,
-                     const float* dt_projs_bias, const float* A_logs, const float* Ds, const float* dy_row_fwd,
-                     const float* dy_row_rev, const float* dy_col_fwd, const float* dy_col_rev, float* dx,
-                     float* dx_proj_weight, float* ddt_projs_weight, float* ddt_projs_bias, float* dA_logs, float* dDs,
-                     void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int N, int R, void* stream) {
-    if (B == 0 || D == 0 || H == 0 || W == 0) return (B < 0 || D < 0 || H < 0 || W < 0) ? WM_EINVAL : WM_OK;
-    CoreBwdPlan pl;
-    int rc = core_bwd_plan(pl, B, D, H, W, N, R);
-    if (rc) return rc;
-    if (!x || !x_proj_weight || !dt_projs_weight || !dt_projs_bias || !A_logs || !Ds || !dy_row_fwd || !dy_row_rev ||
-        !dy_col_fwd || !dy_col_rev || !dx || !dx_proj_weight || !ddt_projs_weight || !ddt_projs_bias || !dA_logs || !dDs ||
-        !workspace) return WM_ENULL;
-    if (workspace_bytes < pl.total) return WM_EWORKSPACE;
-    if (!aligned16(workspace)) return WM_EALIGN;
-    hipStream_t st = (hipStream_t)stream;
+static int core_bwd_v1(const CoreBwdPlan& pl, const float* x, const float* x_proj_weight, const float* dt_projs_weight,
+                       const float* dt_projs_bias, const float* A_logs, const float* Ds, const float* dy_row_fwd,
+                       const float* dy_row_rev, const float* dy_col_fwd, const float* dy_col_rev, float* dx,
+                       float* dx_proj_weight, float* ddt_projs_weight, float* ddt_projs_bias, float* dA_logs, float* dDs,
+                       void* workspace, int B, int D, int H, int W, int N, int R, hipStream_t st) {
     const long long L = pl.L;
     const int CP = pl.CP;
     char* w = (char*)workspace;
@@ -1037,6 +1022,184 @@ int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt
         }
     }
     return launch_status();
+}
+
+}  // extern "C"
+namespace wm {
+// ---- second generation (ss2d_core_bwd.hip.h) ---------------------------------------------------------------------------
+struct CoreBwdPlan2 {
+    BwdPlan scan; long long L; int NP, NWT, slices;
+    size_t prep_bytes, wt_bytes, map_bytes, scan_bytes, wpart_bytes, wsum_bytes, total;
+};
+static int core_bwd_plan2(CoreBwdPlan2& pl, int B, int D, int H, int W, int N, int R) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || N <= 0 || R <= 0) return WM_EINVAL;
+    if (N > 32 || R > kRecPad || D > 64) return WM_EUNSUPPORTED;
+    pl.L = (long long)H * W;
+    if (pl.L > 0x7fffffffLL) return WM_EUNSUPPORTED;
+    if (B > 65535) return WM_EUNSUPPORTED;
+    int rc = bwd_plan(pl.scan, B, D, (int)pl.L, N, 1, kPartPadFused);
+    if (rc) return rc;
+    pl.NP = N <= 16 ? 16 : 32;
+    pl.NWT = pl.NP == 16 ? BwdCfg<16>::NWT : BwdCfg<32>::NWT;
+    const long long nb = (long long)B * pl.scan.nblocks;
+    pl.slices = (int)(nb < 64 ? 1 : (nb / 32 > 64 ? 64 : nb / 32));           // >= 32 partials per slice, <= 64 slices
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    pl.prep_bytes = up((size_t)4 * (pl.NP == 16 ? CoreCfg<16>::PREP : CoreCfg<32>::PREP) * sizeof(float));
+    pl.wt_bytes = up((size_t)4 * (pl.NP == 16 ? BwdCfg<16>::WT_U4 : BwdCfg<32>::WT_U4) * sizeof(uint4));
+    pl.map_bytes = up((size_t)B * D * pl.L * sizeof(float));
+    pl.scan_bytes = up(pl.scan.total);
+    pl.wpart_bytes = up((size_t)nb * pl.NWT * 256 * sizeof(float));
+    pl.wsum_bytes = up((size_t)4 * pl.slices * pl.NWT * 256 * sizeof(float));
+    pl.total = pl.prep_bytes + pl.wt_bytes + 4 * pl.map_bytes + 4 * pl.scan_bytes + 4 * pl.wpart_bytes + pl.wsum_bytes;
+    return WM_OK;
+}
+
+template <int NP>
+static int core_bwd_v2(const CoreBwdPlan2& pl, const float* x, const float* x_proj_weight, const float* dt_projs_weight,
+                       const float* dt_projs_bias, const float* A_logs, const float* Ds, const float* dy_row_fwd,
+                       const float* dy_row_rev, const float* dy_col_fwd, const float* dy_col_rev, float* dx,
+                       float* dx_proj_weight, float* ddt_projs_weight, float* ddt_projs_bias, float* dA_logs, float* dDs,
+                       void* workspace, int B, int D, int H, int W, int N, int R, hipStream_t st) {
+    using Cfg = BwdCfg<NP>;
+    const long long L = pl.L;
+    char* w = (char*)workspace;
+    float* prep = (float*)w; w += pl.prep_bytes;
+    uint4* wT = (uint4*)w; w += pl.wt_bytes;
+    float* xT = (float*)w; w += pl.map_bytes;
+    float* dyTa = (float*)w; w += pl.map_bytes;
+    float* dyTb = (float*)w; w += pl.map_bytes;
+    float* dxT = (float*)w; w += pl.map_bytes;
+    char* scan_ws[4];
+    for (int k = 0; k < 4; ++k) { scan_ws[k] = w; w += pl.scan_bytes; }
+    float* wpart[4];
+    for (int k = 0; k < 4; ++k) { wpart[k] = (float*)w; w += pl.wpart_bytes; }
+    float* wsum = (float*)w;
+
+    ProfScope ps(12, st);
+    // parameters -> forward-style fragments / constants, and the transposed fragments of the dx product
+    hipLaunchKernelGGL((ss2d_core_prep_kernel<NP>), dim3(4), dim3(256), 0, st, x_proj_weight, dt_projs_weight, dt_projs_bias,
+                       A_logs, Ds, prep, D, N, R);
+    hipLaunchKernelGGL((core_bwd_prep_kernel<NP>), dim3(4), dim3(256), 0, st, x_proj_weight, wT, D, N, R);
+    {   // the column directions scan the transposed map
+        const dim3 tg((unsigned)((W + 31) / 32), (unsigned)((H + 31) / 32), (unsigned)(B * D)), tb(32, 8);
+        hipLaunchKernelGGL(transpose_planes_kernel, tg, tb, 0, st, x, xT, H, W, 0);
+        hipLaunchKernelGGL(transpose_planes_kernel, tg, tb, 0, st, dy_col_fwd, dyTa, H, W, 0);
+        if (dy_col_rev != dy_col_fwd) hipLaunchKernelGGL(transpose_planes_kernel, tg, tb, 0, st, dy_col_rev, dyTb, H, W, 0);
+    }
+    const float* dyT_rev = dy_col_rev != dy_col_fwd ? dyTb : dyTa;
+    CoreBwdArgs a[4];
+    float* seg[4];
+    const int CP = R + 2 * N;
+    for (int k = 0; k < 4; ++k) {
+        const bool col = k & 1;
+        CoreBwdArgs& q = a[k];
+        q.x = col ? xT : x;
+        q.dy = k == 0 ? dy_row_fwd : k == 2 ? dy_row_rev : k == 1 ? (const float*)dyTa : dyT_rev;
+        q.dx = col ? dxT : dx;
+        q.prep = prep + (size_t)k * CoreCfg<NP>::PREP;
+        q.wT = wT + (size_t)k * Cfg::WT_U4;
+        q.WxR = x_proj_weight + (size_t)k * CP * D;
+        ScanBwdArgs t{};
+        bwd_bind_workspace(t, pl.scan, scan_ws[k], seg[k]);
+        q.wsP = t.wsP; q.wsH = t.wsH; q.wsPr = t.wsPr; q.wsG = t.wsG; q.wsHl = t.wsHl; q.wsS = t.wsS; q.part = t.part;
+        q.wpart = wpart[k];
+        q.batch = B; q.dim = D; q.L = (int)L; q.N = N; q.R = R;
+        q.nchunks = pl.scan.nchunks; q.cpb = pl.scan.cpb; q.nblocks = pl.scan.nblocks;
+        q.accumulate = k >= 2;                           // a layout's first direction writes dx, its second adds
+    }
+    const bool vec = (L % 4 == 0) && aligned16(x) && aligned16(dx) && aligned16(dy_row_fwd) && aligned16(dy_row_rev) &&
+                     aligned16(xT) && aligned16(dyTa) && aligned16(dyTb) && aligned16(dxT);
+    const dim3 grid((unsigned)pl.scan.nblocks, (unsigned)B);
+    if (pl.scan.nchunks > 1) {
+        const dim3 g2(grid.x, grid.y, 2);
+        for (int layout = 0; layout < 2; ++layout) {
+            if (vec) hipLaunchKernelGGL((core_bwd_reduce_kernel<NP, true>), g2, dim3(64), 0, st, a[layout], a[layout + 2]);
+            else hipLaunchKernelGGL((core_bwd_reduce_kernel<NP, false>), g2, dim3(64), 0, st, a[layout], a[layout + 2]);
+        }
+        if (pl.scan.nblocks > 1) {                       // all eight carries (four forward, four adjoint) in one batch
+            CarryBatch cb{};
+            const int nsegs = (int)carry_nsegs(pl.scan.nblocks);
+            const size_t one = (size_t)nsegs * pl.scan.chains;
+            for (int k = 0; k < 4; ++k) {
+                cb.d[2 * k] = CarryDir{a[k].wsP, a[k].wsH, seg[k], seg[k] + one, pl.scan.nblocks, nsegs};
+                cb.d[2 * k + 1] = CarryDir{a[k].wsPr, a[k].wsG, seg[k] + 2 * one, seg[k] + 3 * one, pl.scan.nblocks, nsegs};
+            }
+            launch_carry_batch(cb, 8, pl.scan.chains, st);
+        }
+    }
+    const int order[4] = {0, 2, 1, 3};
+    for (int i = 0; i < 4; ++i) {
+        const int k = order[i];
+        const dim3 blk(64 * Cfg::NW);
+        if (k < 2) { if (vec) hipLaunchKernelGGL((core_bwd_chunk_kernel<NP, true, false>), grid, blk, 0, st, a[k]);
+                     else hipLaunchKernelGGL((core_bwd_chunk_kernel<NP, false, false>), grid, blk, 0, st, a[k]); }
+        else       { if (vec) hipLaunchKernelGGL((core_bwd_chunk_kernel<NP, true, true>), grid, blk, 0, st, a[k]);
+                     else hipLaunchKernelGGL((core_bwd_chunk_kernel<NP, false, true>), grid, blk, 0, st, a[k]); }
+    }
+    {
+        const dim3 tg((unsigned)((H + 31) / 32), (unsigned)((W + 31) / 32), (unsigned)(B * D)), tb(32, 8);
+        hipLaunchKernelGGL(transpose_planes_kernel, tg, tb, 0, st, (const float*)dxT, dx, W, H, 1);   // dx += (dx^T)^T
+    }
+    CoreBwdFinishArgs f;
+    for (int k = 0; k < 4; ++k) { f.part[k] = a[k].part; f.wpart[k] = wpart[k]; }
+    f.wsum = wsum; f.A_logs = A_logs; f.dA_logs = dA_logs; f.dDs = dDs; f.dbias = ddt_projs_bias; f.dWdt = ddt_projs_weight;
+    f.dWx = dx_proj_weight; f.batch = B; f.dim = D; f.N = N; f.R = R; f.NP = NP; f.nblocks = pl.scan.nblocks; f.slices = pl.slices;
+    hipLaunchKernelGGL(core_bwd_finish_kernel, dim3((unsigned)D, 1, 4), dim3(256), 0, st, f);
+    hipLaunchKernelGGL(core_bwd_wsum_kernel, dim3((unsigned)Cfg::NWT, (unsigned)pl.slices, 4), dim3(256), 0, st, f, (int)Cfg::NWT);
+    hipLaunchKernelGGL(core_bwd_wfin_kernel, dim3((unsigned)Cfg::NWT, 1, 4), dim3(256), 0, st, f, (int)Cfg::NWT);
+    return launch_status();
+}
+
+// WM_CORE_BWD_V1=1 in the environment keeps the first-generation backward (A/B timing, tools/)
+static bool core_bwd_use_v1() {
+    static const bool v1 = [] { const char* e = getenv("WM_CORE_BWD_V1"); return e && atoi(e) != 0; }();
+    return v1;
+}
+}  // namespace wm
+extern "C" {
+
+size_t wm_ss2d_core_bwd_workspace_bytes(int B, int D, int H, int W, int N, int R) {
+    if (core_bwd_use_v1()) {
+        CoreBwdPlan pl;
+        if (core_bwd_plan(pl, B, D, H, W, N, R) != WM_OK) return 0;
+        return pl.total;
+    }
+    CoreBwdPlan2 pl;
+    if (core_bwd_plan2(pl, B, D, H, W, N, R) != WM_OK) return 0;
+    return pl.total;
+}
+
+int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt_projs_weight,
+                     const float* dt_projs_bias, const float* A_logs, const float* Ds, const float* dy_row_fwd,
+                     const float* dy_row_rev, const float* dy_col_fwd, const float* dy_col_rev, float* dx,
+                     float* dx_proj_weight, float* ddt_projs_weight, float* ddt_projs_bias, float* dA_logs, float* dDs,
+                     void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int N, int R, void* stream) {
+    if (B == 0 || D == 0 || H == 0 || W == 0) return (B < 0 || D < 0 || H < 0 || W < 0) ? WM_EINVAL : WM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const bool nul = !x || !x_proj_weight || !dt_projs_weight || !dt_projs_bias || !A_logs || !Ds || !dy_row_fwd || !dy_row_rev ||
+                     !dy_col_fwd || !dy_col_rev || !dx || !dx_proj_weight || !ddt_projs_weight || !ddt_projs_bias || !dA_logs ||
+                     !dDs || !workspace;
+    if (core_bwd_use_v1()) {
+        CoreBwdPlan pl;
+        int rc = core_bwd_plan(pl, B, D, H, W, N, R);
+        if (rc) return rc;
+        if (nul) return WM_ENULL;
+        if (workspace_bytes < pl.total) return WM_EWORKSPACE;
+        if (!aligned16(workspace)) return WM_EALIGN;
+        return core_bwd_v1(pl, x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, dy_row_fwd, dy_row_rev, dy_col_fwd,
+                           dy_col_rev, dx, dx_proj_weight, ddt_projs_weight, ddt_projs_bias, dA_logs, dDs, workspace, B, D, H, W, N, R, st);
+    }
+    CoreBwdPlan2 pl;
+    int rc = core_bwd_plan2(pl, B, D, H, W, N, R);
+    if (rc) return rc;
+    if (nul) return WM_ENULL;
+    if (workspace_bytes < pl.total) return WM_EWORKSPACE;
+    if (!aligned16(workspace)) return WM_EALIGN;
+    if (pl.NP == 16)
+        return core_bwd_v2<16>(pl, x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, dy_row_fwd, dy_row_rev, dy_col_fwd,
+                               dy_col_rev, dx, dx_proj_weight, ddt_projs_weight, ddt_projs_bias, dA_logs, dDs, workspace, B, D, H, W, N, R, st);
+    return core_bwd_v2<32>(pl, x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, dy_row_fwd, dy_row_rev, dy_col_fwd,
+                           dy_col_rev, dx, dx_proj_weight, ddt_projs_weight, ddt_projs_bias, dA_logs, dDs, workspace, B, D, H, W, N, R, st);
 }
 
 #define WM_LFSS_DISPATCH(PROFCLASS, KERNEL, ...)                                                   \
