@@ -26,7 +26,30 @@
 #include "selscan_bwd.hip.h"
 #include "ss2d_core.hip.h"
 
+#ifndef WM_BWD_MFMA_NOP
+#define WM_BWD_MFMA_NOP 1        // wait states between a chain of matrix instructions and the first VALU / LDS use of its result
+#endif
+#ifndef WM_BWD_DX_LATE
+#define WM_BWD_DX_LATE 0         // experiment: keep the dx product in registers across one more workgroup barrier before adding it
+#endif
+
 namespace wm {
+
+// The accumulator of a v_mfma chain, about to be read by a VALU / LDS instruction.  The compiler's own wait (s_nop 6 behind
+// v_mfma_f32_16x16x32_bf16) left the lanes 48..63 of the dx product stale now and then on MI355X (tools/debug_core_bwd.py:
+// rows 12..15 of every 16-channel tile, run-to-run different, only in the kernel instantiation whose schedule puts the
+// adds right behind the chain); 16 more wait states tied to the register cost nothing measurable.
+__device__ __forceinline__ void mfma_settle(core_f4& acc) {
+#if WM_BWD_MFMA_NOP
+    asm volatile("s_nop 15\n\ts_nop 0" : "+v"(acc));
+#endif
+}
+
+__device__ __forceinline__ float add_f32_plain(float a, float b) {
+    float r;
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 struct CoreBwdArgs {
     const float* x;          // (B, D, L) planes of this layout (the map, or its transposed copy)
@@ -52,7 +75,7 @@ template <int NP> struct BwdCfg {
     static constexpr int TPW = (NWT + NW - 1) / NW;      // ... per wave
     static constexpr int O_U = 0, O_DY = 64 * kBRow, O_D = 2 * 64 * kBRow, O_DTR = 3 * 64 * kBRow, O_B = O_DTR + kBT * 4,
                          O_C = O_B + kBT * NP, O_HS = O_C + kBT * NP, O_RED = O_HS + NW * 4 * 8 * 64,
-                         TOTAL = O_RED + NRED * kBRow;  // floats: 36,928 B (N <= 16), 57,920 B (N <= 32)
+                         O_WXR = O_RED + NRED * kBRow, TOTAL = O_WXR + 4 * 64;  // floats: 37,952 B (N <= 16), 58,944 B (N <= 32)
     static constexpr int WT_U4 = 4 * KS * 2 * 64;        // uint4 per direction of the Wx^T fragments
 };
 
@@ -139,6 +162,7 @@ __device__ __forceinline__ void bwd_project_tile(int t, const uint4* __restrict_
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[s2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[s2], acc, 0, 0, 0);
     }
+    mfma_settle(acc);
     // D layout: lane holds rows 4 g4 .. 4 g4 + 3 of tile column c16 (= step)
     if (t == 0) { if (g4 == 0) *reinterpret_cast<core_f4*>(s_dtr + c16 * 4) = acc; }
     else if (t <= NTB) *reinterpret_cast<core_f4*>(s_B + c16 * NP + 16 * (t - 1) + 4 * g4) = acc;
@@ -290,7 +314,7 @@ __global__ __launch_bounds__(64 * BwdCfg<NP>::NW, 2) void core_bwd_chunk_kernel(
     __shared__ __attribute__((aligned(16))) float smem[Cfg::TOTAL];
     float* s_u = smem + Cfg::O_U; float* s_dy = smem + Cfg::O_DY; float* s_d = smem + Cfg::O_D;
     float* s_dtr = smem + Cfg::O_DTR; float* s_B = smem + Cfg::O_B; float* s_C = smem + Cfg::O_C;
-    float* s_hs = smem + Cfg::O_HS; float* s_red = smem + Cfg::O_RED;
+    float* s_hs = smem + Cfg::O_HS; float* s_red = smem + Cfg::O_RED; float* s_wxr = smem + Cfg::O_WXR;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
@@ -308,11 +332,13 @@ __global__ __launch_bounds__(64 * BwdCfg<NP>::NW, 2) void core_bwd_chunk_kernel(
         A2[i] = *reinterpret_cast<const v2f*>(p.prep + PC::P_A2 + ((4 * w + i) * 64 + lane) * 2);
         Aln[i] = A2[i] * 0.6931471805599453f;            // A = A2 ln 2
     }
-    float wdt[4], wxr[4];
+    float wdt[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        wdt[r] = p.prep[PC::P_LC + r * 64 + lane];
-        wxr[r] = (r < p.R && live) ? p.WxR[(long long)min(r, p.R - 1) * p.dim + d] : 0.0f;
+    for (int r = 0; r < 4; ++r) wdt[r] = p.prep[PC::P_LC + r * 64 + lane];
+    // x_proj_weight rows [0, R) by channel: the dt_r part of dx, applied when the du tile is stored
+    for (int e = tid; e < 4 * 64; e += 64 * NW) {
+        const int r = e >> 6, c = e & 63;
+        s_wxr[e] = (r < p.R && c < nch) ? p.WxR[(long long)r * p.dim + c] : 0.0f;
     }
     const float bias = p.prep[PC::P_LC + 4 * 64 + lane];
     const float Dd = p.prep[PC::P_LC + 5 * 64 + lane];
@@ -345,10 +371,10 @@ __global__ __launch_bounds__(64 * BwdCfg<NP>::NW, 2) void core_bwd_chunk_kernel(
     v2f dA[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) dA[i] = splat(0.f);
-    float dDp = 0.0f, dbp = 0.0f, dwp[2] = {0.f, 0.f};   // dwp: ranks 2 w, 2 w + 1 (waves 0 and 1)
-    core_f4 wacc[TPW];                                   // dWx tiles id = w + NW i
+    float dDp = 0.0f, dbp = 0.0f, dwp[4] = {0.f, 0.f, 0.f, 0.f};   // this wave's shares (the steps it closes)
+    core_f4 wacc[NT3 * (4 / NW)];                        // dWx tiles (row tile rt, channel tile w + NW c) at [rt * (4 / NW) + c]
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) wacc[i] = (core_f4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NT3 * (4 / NW); ++i) wacc[i] = (core_f4){0.f, 0.f, 0.f, 0.f};
 
     for (int chunk = c_end - 1; chunk >= c_first; --chunk) {
         if (chunk != c_end - 1) __syncthreads();         // the previous chunk's tiles are consumed
@@ -364,33 +390,27 @@ __global__ __launch_bounds__(64 * BwdCfg<NP>::NW, 2) void core_bwd_chunk_kernel(
         if (tl < kBT)                                     // a ragged last chunk: no stale gradient columns
             for (int e = tid; e < Cfg::NRED * kBRow; e += 64 * NW) s_red[e] = 0.0f;
         __syncthreads();
-        // ---- records: row tiles shared out among the waves
+        // ---- records: every wave computes the dt_r tile (and from it dt of the 16 steps) for itself - identical values, so
+        // the shared copies in s_dtr / s_d may be written by all of them - and ONE of the B / C tiles (NW = 2 NTB)
         {
             core_bf8 xh[2], xl[2];
             bwd_x_operands(s_u, lane, xh, xl);
-#pragma unroll
-            for (int i = 0; i < (NT3 + NW - 1) / NW; ++i) {
-                const int t = w + NW * i;
-                if (t < NT3) bwd_project_tile<NP>(t, frag, lane, xh, xl, s_dtr, s_B, s_C);
-            }
+            bwd_project_tile<NP>(0, frag, lane, xh, xl, s_dtr, s_B, s_C);
+            bwd_project_tile<NP>(1 + w, frag, lane, xh, xl, s_dtr, s_B, s_C);
         }
-        __syncthreads();
-        // ---- dt of the 16 steps -> s_d (lane-private rows): steps 4 q with q = w, w + NW, .. per wave
+        core_lds_fence();                                // s_dtr: written and read by this wave
 #pragma unroll
-        for (int i = 0; i < (kBT / 4 + NW - 1) / NW; ++i) {
-            const int q = w + NW * i;
-            if (q < kBT / 4) {
-                float xr[4];
+        for (int q = 0; q < kBT / 4; ++q) {
+            float xr[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 dr = *reinterpret_cast<const float4*>(&s_dtr[(4 * q + j) * 4]);
-                    xr[j] = fmaf(wdt[3], dr.w, fmaf(wdt[2], dr.z, fmaf(wdt[1], dr.y, fmaf(wdt[0], dr.x, bias))));
-                }
-                const v2f da = softplus2((v2f){xr[0], xr[1]}), db = softplus2((v2f){xr[2], xr[3]});
-                *reinterpret_cast<float4*>(&s_d[lane * kBRow + 4 * q]) = make_float4(da.x, da.y, db.x, db.y);
+            for (int j = 0; j < 4; ++j) {
+                const float4 dr = *reinterpret_cast<const float4*>(&s_dtr[(4 * q + j) * 4]);
+                xr[j] = fmaf(wdt[3], dr.w, fmaf(wdt[2], dr.z, fmaf(wdt[1], dr.y, fmaf(wdt[0], dr.x, bias))));
             }
+            const v2f da = softplus2((v2f){xr[0], xr[1]}), db = softplus2((v2f){xr[2], xr[3]});
+            *reinterpret_cast<float4*>(&s_d[lane * kBRow + 4 * q]) = make_float4(da.x, da.y, db.x, db.y);
         }
-        __syncthreads();
+        __syncthreads();                                 // B and C tiles of the other waves
         // ---- state at the chunk's start = (state from zero at the block's start) + (decay since the block's start) x H_in
         v2f h[4];
         {
@@ -511,59 +531,60 @@ __global__ __launch_bounds__(64 * BwdCfg<NP>::NW, 2) void core_bwd_chunk_kernel(
             for (int j = 0; j < kBS; ++j) { hs[(st * 8 + 2 * j) * 64] = psb[j]; hs[(st * 8 + 2 * j + 1) * 64] = psd[j]; }
         }
         __syncthreads();
-        // ---- closing the steps: du_t, ddelta_t from the waves' shares; wave w closes steps SPW w .. SPW w + SPW - 1
+        // ---- closing the steps: du_t, ddelta_t from the waves' shares; wave w closes steps SPW w .. SPW w + SPW - 1 and
+        // reduces their d dt_r[r][tt] = sum over channels of ddelta[d][tt] Wdt[d][r]
+        {
+            float ddv[SPW];
 #pragma unroll
-        for (int s = 0; s < SPW; ++s) {
-            const int tt = SPW * w + s, st = tt >> 2, j = tt & 3;
-            float dd = 0.0f;
-            if (tt < tl) {
-                float sb = 0.0f, sd = 0.0f;
+            for (int s = 0; s < SPW; ++s) {
+                const int tt = SPW * w + s, st = tt >> 2, j = tt & 3;
+                float dd = 0.0f;
+                if (tt < tl) {
+                    float sb = 0.0f, sd = 0.0f;
 #pragma unroll
-                for (int ww = 0; ww < NW; ++ww) {
-                    sb += s_hs[((ww * NSUB + st) * 8 + 2 * j) * 64 + lane];
-                    sd += s_hs[((ww * NSUB + st) * 8 + 2 * j + 1) * 64 + lane];
+                    for (int ww = 0; ww < NW; ++ww) {
+                        sb += s_hs[((ww * NSUB + st) * 8 + 2 * j) * 64 + lane];
+                        sd += s_hs[((ww * NSUB + st) * 8 + 2 * j + 1) * 64 + lane];
+                    }
+                    const float ut = s_u[lane * kBRow + tt], dyt = s_dy[lane * kBRow + tt], dt = s_d[lane * kBRow + tt];
+                    const float4 dr = *reinterpret_cast<const float4*>(&s_dtr[tt * 4]);
+                    const float xraw = fmaf(wdt[3], dr.w, fmaf(wdt[2], dr.z, fmaf(wdt[1], dr.y, fmaf(wdt[0], dr.x, bias))));
+                    const float ddt = sd + ut * sb;
+                    dd = xraw > 20.0f ? ddt : ddt / (1.0f + __expf(-xraw));
+                    dDp = fmaf(dyt, ut, dDp);
+                    dbp += dd;
+                    dwp[0] = fmaf(dd, dr.x, dwp[0]); dwp[1] = fmaf(dd, dr.y, dwp[1]);
+                    dwp[2] = fmaf(dd, dr.z, dwp[2]); dwp[3] = fmaf(dd, dr.w, dwp[3]);
+                    s_dy[lane * kBRow + tt] = fmaf(dt, sb, Dd * dyt);    // du_t takes dy_t's slot
                 }
-                const float ut = s_u[lane * kBRow + tt], dyt = s_dy[lane * kBRow + tt], dt = s_d[lane * kBRow + tt];
-                const float4 dr = *reinterpret_cast<const float4*>(&s_dtr[tt * 4]);
-                const float xraw = fmaf(wdt[3], dr.w, fmaf(wdt[2], dr.z, fmaf(wdt[1], dr.y, fmaf(wdt[0], dr.x, bias))));
-                const float ddt = sd + ut * sb;
-                dd = xraw > 20.0f ? ddt : ddt / (1.0f + __expf(-xraw));
-                dDp = fmaf(dyt, ut, dDp);
-                dbp += dd;
-                s_dy[lane * kBRow + tt] = fmaf(dt, sb, Dd * dyt);        // du_t takes dy_t's slot
+                ddv[s] = dd;
             }
-            s_d[lane * kBRow + tt] = dd;                                  // ddelta_t takes dt_t's slot (0 beyond the tail)
-        }
-        __syncthreads();
-        // ---- d dt_r[r][tt] = sum over channels of ddelta[d][tt] Wdt[d][r] (ranks 2 w, 2 w + 1: waves 0 and 1) + dWdt partial
-        if (w < 2 && 2 * w < p.R) {
-            float ddl[kBT];
 #pragma unroll
-            for (int q = 0; q < kBT / 4; ++q) {
-                const float4 v4 = *reinterpret_cast<const float4*>(&s_d[lane * kBRow + 4 * q]);
-                ddl[4 * q] = v4.x; ddl[4 * q + 1] = v4.y; ddl[4 * q + 2] = v4.z; ddl[4 * q + 3] = v4.w;
-            }
-            float v[32], o[8];
+            for (int pr = 0; pr < 2; ++pr) {
+                if (2 * pr < p.R) {                                       // uniform
+                    float v[16], o[4];
 #pragma unroll
-            for (int tt = 0; tt < kBT; ++tt) {
-                const float4 dr = *reinterpret_cast<const float4*>(&s_dtr[tt * 4]);
-                const float r0 = w ? dr.z : dr.x, r1 = w ? dr.w : dr.y;
-                dwp[0] = fmaf(ddl[tt], r0, dwp[0]); dwp[1] = fmaf(ddl[tt], r1, dwp[1]);
-                v[2 * tt] = ddl[tt] * (w ? wdt[2] : wdt[0]); v[2 * tt + 1] = ddl[tt] * (w ? wdt[3] : wdt[1]);
-            }
-            wave_reduce32(v, o);
-            if ((lane & 15) == 0) {
-                const int rg = lane >> 4;
+                    for (int i = 0; i < 16; ++i) v[i] = 0.0f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int val = 8 * rg + i;                           // = 2 tt + e
-                    s_red[(2 * NP + 2 * w + (val & 1)) * kBRow + (val >> 1)] = o[i];
+                    for (int s = 0; s < SPW; ++s) { v[2 * s] = ddv[s] * wdt[2 * pr]; v[2 * s + 1] = ddv[s] * wdt[2 * pr + 1]; }
+                    wave_reduce16(v, o);
+                    if ((lane & 15) == 0) {
+                        const int rg = lane >> 4;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int val = 4 * rg + i;                   // = 2 s + e
+                            if ((val >> 1) < SPW) s_red[(2 * NP + 2 * pr + (val & 1)) * kBRow + SPW * w + (val >> 1)] = o[i];
+                        }
+                    }
                 }
             }
         }
         __syncthreads();
-        // ---- dx tile (in s_dy) += Wx^T [dB | dC] on the matrix cores (kept in registers until the dt_r part is in) ...
-        core_f4 dacc[(4 + NW - 1) / NW];
+        // ---- dx tile (in s_dy) += Wx^T [dB | dC] on the matrix cores; D layout: lane (c16 = step, g4) holds channels
+        // 16 t + 4 g4 .. + 3 - every element of the tile has exactly one owner (the dt_r part of dx is added by the store)
+#if WM_BWD_DX_LATE
+        core_f4 dlate[(4 + NW - 1) / NW];
+#endif
         {
             const int g4 = lane >> 4, c16 = lane & 15;
             core_bf8 gh[KS], gl[KS];
@@ -582,8 +603,8 @@ __global__ __launch_bounds__(64 * BwdCfg<NP>::NW, 2) void core_bwd_chunk_kernel(
 #pragma unroll
             for (int i = 0; i < (4 + NW - 1) / NW; ++i) {
                 const int t = w + NW * i;
-                core_f4 acc = {0.f, 0.f, 0.f, 0.f};
                 if (t < 4) {
+                    core_f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int s = 0; s < KS; ++s) {
                         const uint4 wh4 = p.wT[((t * KS + s) * 2 + 0) * 64 + lane], wl4 = p.wT[((t * KS + s) * 2 + 1) * 64 + lane];
@@ -593,60 +614,59 @@ __global__ __launch_bounds__(64 * BwdCfg<NP>::NW, 2) void core_bwd_chunk_kernel(
                         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gl[s], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh[s], acc, 0, 0, 0);
                     }
+                    mfma_settle(acc);
+#if WM_BWD_DX_LATE
+                    dlate[i] = acc;
+#else
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s_dy[(16 * t + 4 * g4 + r) * kBRow + c16] += acc[r];
+#endif
                 }
-                dacc[i] = acc;
             }
         }
-        // ... the dt_r part per lane (= channel), for the steps this wave closed
-#pragma unroll
-        for (int s = 0; s < SPW; ++s) {
-            const int tt = SPW * w + s;
-            float a = s_dy[lane * kBRow + tt];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a = fmaf(wxr[r], s_red[(2 * NP + r) * kBRow + tt], a);
-            s_dy[lane * kBRow + tt] = a;
-        }
+#if WM_BWD_DX_LATE
         __syncthreads();
-        {   // D layout: lane (c16 = step, g4) holds channels 16 t + 4 g4 .. + 3: every element has one owner
+        {
             const int g4 = lane >> 4, c16 = lane & 15;
 #pragma unroll
             for (int i = 0; i < (4 + NW - 1) / NW; ++i) {
                 const int t = w + NW * i;
                 if (t < 4) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) s_dy[(16 * t + 4 * g4 + r) * kBRow + c16] += dacc[i][r];
+                    for (int r = 0; r < 4; ++r) s_dy[(16 * t + 4 * g4 + r) * kBRow + c16] += dlate[i][r];
                 }
             }
         }
-        // ---- dWx += g x^T: row tile rt of [d dt_r | dB.. | dC..] x channel tile ct, K = the 16 steps (lanes kq >= 2: zeros)
+#endif
+        // ---- dWx += g x^T: row tile rt of [d dt_r | dB.. | dC..] x channel tile ct, K = the 16 steps (lanes kq >= 2: zeros).
+        // Wave w owns the channel tiles ct = w, w + NW, .. and every row tile: each operand is split once.
         {
             const int i16 = lane & 15, kq = lane >> 4;
+            const float km = kq < 2 ? 1.0f : 0.0f;
+            auto split8 = [&](const float* src, float m, core_bf8& hi, core_bf8& lo) {
+                const float4 a0 = *reinterpret_cast<const float4*>(src), a1 = *reinterpret_cast<const float4*>(src + 4);
+                const float v[8] = {a0.x * m, a0.y * m, a0.z * m, a0.w * m, a1.x * m, a1.y * m, a1.z * m, a1.w * m};
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) {
-                const int id = w + NW * i;
-                if (id < Cfg::NWT) {
-                    const int rt = id >> 2, ct = id & 3;
-                    const int grow = rt == 0 ? 2 * NP + (i16 & 3) : 16 * (rt - 1) + i16;
-                    const bool gok = kq < 2 && (rt > 0 || i16 < 4);
-                    const float4 g0 = *reinterpret_cast<const float4*>(&s_red[grow * kBRow + 8 * (kq & 1)]);
-                    const float4 g1 = *reinterpret_cast<const float4*>(&s_red[grow * kBRow + 8 * (kq & 1) + 4]);
-                    const float4 x0 = *reinterpret_cast<const float4*>(&s_u[(16 * ct + i16) * kBRow + 8 * (kq & 1)]);
-                    const float4 x1 = *reinterpret_cast<const float4*>(&s_u[(16 * ct + i16) * kBRow + 8 * (kq & 1) + 4]);
-                    const float gm = gok ? 1.0f : 0.0f, xm = kq < 2 ? 1.0f : 0.0f;
-                    const float gv[8] = {g0.x * gm, g0.y * gm, g0.z * gm, g0.w * gm, g1.x * gm, g1.y * gm, g1.z * gm, g1.w * gm};
-                    const float xv[8] = {x0.x * xm, x0.y * xm, x0.z * xm, x0.w * xm, x1.x * xm, x1.y * xm, x1.z * xm, x1.w * xm};
-                    core_bf8 ah, al, bh, bl;
+                for (int j = 0; j < 8; j += 2) {
+                    core_bf2 h2, l2;
+                    core_split2(v[j], v[j + 1], h2, l2);
+                    hi[j] = h2[0]; hi[j + 1] = h2[1]; lo[j] = l2[0]; lo[j + 1] = l2[1];
+                }
+            };
+            core_bf8 bh[4 / NW], bl[4 / NW];
 #pragma unroll
-                    for (int j = 0; j < 8; j += 2) {
-                        core_bf2 h2, l2;
-                        core_split2(gv[j], gv[j + 1], h2, l2);
-                        ah[j] = h2[0]; ah[j + 1] = h2[1]; al[j] = l2[0]; al[j + 1] = l2[1];
-                        core_split2(xv[j], xv[j + 1], h2, l2);
-                        bh[j] = h2[0]; bh[j + 1] = h2[1]; bl[j] = l2[0]; bl[j + 1] = l2[1];
-                    }
-                    wacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, wacc[i], 0, 0, 0);
-                    wacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, wacc[i], 0, 0, 0);
-                    wacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, wacc[i], 0, 0, 0);
+            for (int c = 0; c < 4 / NW; ++c) split8(&s_u[(16 * (w + NW * c) + i16) * kBRow + 8 * (kq & 1)], km, bh[c], bl[c]);
+#pragma unroll
+            for (int rt = 0; rt < NT3; ++rt) {
+                const int grow = rt == 0 ? 2 * NP + (i16 & 3) : 16 * (rt - 1) + i16;
+                core_bf8 ah, al;
+                split8(&s_red[grow * kBRow + 8 * (kq & 1)], (rt > 0 || i16 < 4) ? km : 0.0f, ah, al);
+#pragma unroll
+                for (int c = 0; c < 4 / NW; ++c) {
+                    core_f4& acc = wacc[rt * (4 / NW) + c];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[c], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[c], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[c], acc, 0, 0, 0);
                 }
             }
         }
@@ -660,14 +680,27 @@ __global__ __launch_bounds__(64 * BwdCfg<NP>::NW, 2) void core_bwd_chunk_kernel(
                 const int q = w + NW * it;
                 const int r = 16 * q + trow;
                 if (q < 4 && r < nch) {
-                    float4 a = *reinterpret_cast<const float4*>(&s_dy[r * kBRow + (REV ? 4 * (3 - tq) : 4 * tq)]);
+                    const int col = REV ? 4 * (3 - tq) : 4 * tq;           // LDS column = scan time
+                    float4 a = *reinterpret_cast<const float4*>(&s_dy[r * kBRow + col]);
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {                       // + Wx[rows 0 .. R)^T d dt_r
+                        const float wv_ = s_wxr[rr * 64 + r];
+                        const float4 g4_ = *reinterpret_cast<const float4*>(&s_red[(2 * NP + rr) * kBRow + col]);
+                        a.x = fmaf(wv_, g4_.x, a.x); a.y = fmaf(wv_, g4_.y, a.y); a.z = fmaf(wv_, g4_.z, a.z); a.w = fmaf(wv_, g4_.w, a.w);
+                    }
                     if (REV) a = make_float4(a.w, a.z, a.y, a.x);
                     float* o = p.dx + rowbase + (long long)r * L + ft.plo + c;
                     if constexpr (VEC) {
                         if (cok) {
                             if (p.accumulate) {                            // uniform
                                 const float4 e = *reinterpret_cast<const float4*>(o);
-                                a = make_float4(e.x + a.x, e.y + a.y, e.z + a.z, e.w + a.w);
+                                // plain v_add_f32, spelled out: for the mirrored tile the compiler fused the reversal into
+                                // v_pk_add_f32 .. op_sel:[0,1] op_sel_hi:[1,0] on the freshly loaded registers, and on
+                                // MI355X the LOW result of that instruction came out as 0 in lanes 48..63 now and then
+                                // (tools/debug_core_bwd.py: the first direction's dx wiped in rows 12..15 of a tile, run-to-run
+                                // different; WM_CORE_BWD_DIRMASK=3, i.e. without the accumulating launches, is exact)
+                                a.x = add_f32_plain(e.x, a.x); a.y = add_f32_plain(e.y, a.y);
+                                a.z = add_f32_plain(e.z, a.z); a.w = add_f32_plain(e.w, a.w);
                             }
                             *reinterpret_cast<float4*>(o) = a;
                         }
@@ -684,9 +717,10 @@ __global__ __launch_bounds__(64 * BwdCfg<NP>::NW, 2) void core_bwd_chunk_kernel(
 
     // ---- one partial record per block: [b * dim + d][block][NP + 8] = dA | dD, dbias, dWdt[0..3], 0, 0
     __syncthreads();
-    float* sx = s_hs;                                    // [wave][4 values][lane]: dD, dbias shares; dWdt ranks of waves 0 / 1
-    sx[(w * 4 + 0) * 64 + lane] = dDp; sx[(w * 4 + 1) * 64 + lane] = dbp;
-    sx[(w * 4 + 2) * 64 + lane] = dwp[0]; sx[(w * 4 + 3) * 64 + lane] = dwp[1];
+    float* sx = s_hs;                                    // [wave][6 values][lane]: this wave's shares of dD, dbias, dWdt[0..3]
+    sx[(w * 6 + 0) * 64 + lane] = dDp; sx[(w * 6 + 1) * 64 + lane] = dbp;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sx[(w * 6 + 2 + r) * 64 + lane] = dwp[r];
     __syncthreads();
     if (live) {
         float* pr = p.part + (((long long)b * p.dim + d) * p.nblocks + blockIdx.x) * (NP + kPartPadFused);
@@ -694,20 +728,24 @@ __global__ __launch_bounds__(64 * BwdCfg<NP>::NW, 2) void core_bwd_chunk_kernel(
         for (int q = 0; q < 2; ++q)
             *reinterpret_cast<float4*>(pr + 8 * w + 4 * q) = make_float4(dA[2 * q].x, dA[2 * q].y, dA[2 * q + 1].x, dA[2 * q + 1].y);
         if (w == 0) {
-            float tD = 0.0f, tb = 0.0f;
+            float t6[6];
 #pragma unroll
-            for (int ww = 0; ww < NW; ++ww) { tD += sx[(ww * 4 + 0) * 64 + lane]; tb += sx[(ww * 4 + 1) * 64 + lane]; }
-            *reinterpret_cast<float4*>(pr + NP) = make_float4(tD, tb, sx[(0 * 4 + 2) * 64 + lane], sx[(0 * 4 + 3) * 64 + lane]);
-            *reinterpret_cast<float4*>(pr + NP + 4) = make_float4(sx[(1 * 4 + 2) * 64 + lane], sx[(1 * 4 + 3) * 64 + lane], 0.f, 0.f);
+            for (int i = 0; i < 6; ++i) {
+                t6[i] = 0.0f;
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) t6[i] += sx[(ww * 6 + i) * 64 + lane];
+            }
+            *reinterpret_cast<float4*>(pr + NP) = make_float4(t6[0], t6[1], t6[2], t6[3]);
+            *reinterpret_cast<float4*>(pr + NP + 4) = make_float4(t6[4], t6[5], 0.f, 0.f);
         }
     }
     {
         float* wp = p.wpart + (((long long)b * p.nblocks + blockIdx.x) * Cfg::NWT) * 256;
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int id = w + NW * i;
-            if (id < Cfg::NWT) *reinterpret_cast<core_f4*>(wp + id * 256 + lane * 4) = wacc[i];
-        }
+        for (int rt = 0; rt < NT3; ++rt)
+#pragma unroll
+            for (int c = 0; c < 4 / NW; ++c)
+                *reinterpret_cast<core_f4*>(wp + (rt * 4 + w + NW * c) * 256 + lane * 4) = wacc[rt * (4 / NW) + c];
     }
 }
 

@@ -1128,8 +1128,10 @@ static int core_bwd_v2(const CoreBwdPlan2& pl, const float* x, const float* x_pr
         }
     }
     const int order[4] = {0, 2, 1, 3};
+    static const int dirmask = [] { const char* e = getenv("WM_CORE_BWD_DIRMASK"); return e ? atoi(e) : 15; }();   // tools only
     for (int i = 0; i < 4; ++i) {
         const int k = order[i];
+        if (!((dirmask >> k) & 1)) continue;
         const dim3 blk(64 * Cfg::NW);
         if (k < 2) { if (vec) hipLaunchKernelGGL((core_bwd_chunk_kernel<NP, true, false>), grid, blk, 0, st, a[k]);
                      else hipLaunchKernelGGL((core_bwd_chunk_kernel<NP, false, false>), grid, blk, 0, st, a[k]); }
