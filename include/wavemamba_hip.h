@@ -318,6 +318,7 @@ int wm_plane_sums(const float* x, float* sums, int B, int C, int H, int W, void*
  * Element-wise gates and scaled skips of the LFSSBlock TRAINING path, forward and backward:
  *   wm_gate_fwd:      out = act(a) * b          act 1 = SiLU  (SS2D: y * F.silu(z),           wavemamba_arch.py:493)
  *                                               act 2 = GELU  (ffn:  F.gelu(x1) * x2, erf form, :228-229)
+ *                                               act 3 = sigmoid (PAConv: k3(x) * sigmoid(k2(x)), :697-699)
  *   wm_gate_bwd:      ga = g * b * act'(a),  gb = g * act(a)
  *   wm_scale_add_fwd: out = x * scale[c] + o    (LFSSBlock: input * skip_scale + ..., x * skip_scale2 + ..., :525-526)
  *   wm_scale_add_bwd: gx = g * scale[c],  gscale[c] = sum_{b, p} g * x   (zeroed here, accumulated with one atomic per block)

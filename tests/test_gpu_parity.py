@@ -1909,12 +1909,12 @@ def test_training_step_at_config3_size():
 # gates and scaled skips of the LFSSBlock training path (wm_gate_*, wm_scale_add_*): forward + backward vs fp64 autograd
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(2, 64, 16, 24), (1, 16, 5, 7), (3, 8, 9, 9)])
-@pytest.mark.parametrize("act", ["silu", "gelu"])
+@pytest.mark.parametrize("act", ["silu", "gelu", "sigmoid"])
 def test_gate_and_glu_gate_vs_fp64_autograd(shape, act):
     B, C, H, W = shape
     gg = gen(C * H + W)
     a, b, g = (torch.randn(B, C, H, W, generator=gg) * 2 for _ in range(3))
-    f = F.silu if act == "silu" else F.gelu
+    f = {"silu": F.silu, "gelu": F.gelu, "sigmoid": torch.sigmoid}[act]      # sigmoid: PAConv's k3(x) * sigmoid(k2(x)) (:697-699)
     a64, b64 = a.double().requires_grad_(True), b.double().requires_grad_(True)
     ref = f(a64) * b64
     ra, rb = torch.autograd.grad(ref, (a64, b64), g.double())

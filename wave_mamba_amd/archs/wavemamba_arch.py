@@ -98,19 +98,29 @@ def _conv(conv, x, x2=None, x2_index=None, gate=None, residual=None):
     if (hasattr(ops, "conv2d") and ops.conv2d_supported(x, conv.weight, x2)
             and not _needs_grad(conv, x, x2, gate, residual)):
         return ops.conv2d(x, conv.weight, conv.bias, x2, x2_index, gate, residual)
-    if x2 is not None:
-        if x2_index is not None:
-            x2 = torch.gather(x2, 1, x2_index.long()[:, :, None, None].expand(-1, -1, x2.shape[2], x2.shape[3]))
-        x = torch.cat([x, x2], dim=1)
+    x = _cat_gathered(x, x2, x2_index)
     if hasattr(ops, "conv2d_train") and ops.conv2d_supported(x, conv.weight) and torch.is_grad_enabled():
         y = ops.conv2d_train(x, conv.weight, conv.bias)             # fp32 (ATen) by default, split-bf16 HIP as a fast mode
     else:
         y = conv(x)
     if gate is not None:
-        y = y * torch.sigmoid(gate)
+        if (hasattr(ops, "gate_act") and torch.is_grad_enabled() and y.is_cuda and y.dtype == torch.float32
+                and ops.gate_supported(gate, y)):
+            y = ops.gate_act(gate, y, "sigmoid")                    # one launch forward, one backward (training)
+        else:
+            y = y * torch.sigmoid(gate)
     if residual is not None:
         y = y + residual
     return y
+
+
+def _cat_gathered(x, x2=None, x2_index=None):
+    """cat([x, gather(x2, 1, x2_index)], 1) (x2_index None: cat([x, x2], 1); x2 None: x)."""
+    if x2 is None:
+        return x
+    if x2_index is not None:
+        x2 = torch.gather(x2, 1, x2_index.long()[:, :, None, None].expand(-1, -1, x2.shape[2], x2.shape[3]))
+    return torch.cat([x, x2], dim=1)
 
 
 # ================================================================================================
@@ -460,8 +470,9 @@ class PAConv(nn.Module):
                                                          for t in (x, x2, self.k3.weight, self.k2.weight)))):
             # k3(x) * sigmoid(k2(x)): the 1x1 rides on the 3x3's centre tap, the gate never exists as a tensor
             return _conv(self.k4, ops.conv2d_gated(x, self.k3.weight, self.k2.weight, self.k2.bias, x2, x2_index))
-        gate = _conv(self.k2, x, x2, x2_index)
-        return _conv(self.k4, _conv(self.k3, x, x2, x2_index, gate=gate))
+        xin = _cat_gathered(x, x2, x2_index)            # once for both convolutions (and one scatter in the backward)
+        gate = _conv(self.k2, xin)
+        return _conv(self.k4, _conv(self.k3, xin, gate=gate))
 
 
 class Matching_transformation(nn.Module):

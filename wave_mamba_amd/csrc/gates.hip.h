@@ -4,7 +4,7 @@
 // `F.gelu(x1) * x2` (:228-229), LFSSBlock's two scaled skips `input * skip_scale + ...`, `x * skip_scale2 + ...`
 // (:525-526).  PyTorch spells each of them and its autograd as three to six bandwidth-bound launches over (B, 64, H, W)
 // planes (plus a full-tensor reduction per skip scale); here each is one launch forward and one backward:
-//   gate:      out = act(a) * b                          ga = g * b * act'(a),  gb = g * act(a)
+//   gate:      out = act(a) * b                          ga = g * b * act'(a),  gb = g * act(a)      act: SiLU | GELU | sigmoid
 //   scale_add: out = x * s[c] + o                        gx = g * s[c],  go = g,  gs[c] = sum_{b,p} g * x
 // Exact activations (expf / erff: these feed gradients judged at 1e-4 against a float64 truth).
 #pragma once
@@ -22,6 +22,11 @@ template <> __device__ __forceinline__ void act_and_grad<2>(float v, float& f, f
     const float c = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
     f = v * c;
     df = c + v * 0.39894228040143267794f * expf(-0.5f * v * v);
+}
+
+template <> __device__ __forceinline__ void act_and_grad<3>(float v, float& f, float& df) {       // sigmoid (PAConv's pixel gate, :697-699)
+    f = 1.0f / (1.0f + expf(-v));
+    df = f * (1.0f - f);
 }
 
 struct GateArgs {

@@ -1626,7 +1626,7 @@ int wm_plane_sums(const float* x, float* sums, int B, int C, int H, int W, void*
 int wm_gate_fwd(const float* a, const float* b, float* out, int act, int B, int64_t per_b, int64_t stride_a, int64_t stride_b,
                 int64_t stride_out, void* stream) {
     if (B < 0 || per_b < 0) return WM_EINVAL;
-    if (act != 1 && act != 2) return WM_EUNSUPPORTED;
+    if (act < 1 || act > 3) return WM_EUNSUPPORTED;
     if (B == 0 || per_b == 0) return WM_OK;
     if (!a || !b || !out) return WM_ENULL;
     if (B > 65535) return WM_EUNSUPPORTED;
@@ -1637,7 +1637,7 @@ int wm_gate_fwd(const float* a, const float* b, float* out, int act, int B, int6
     hipStream_t st = (hipStream_t)stream;
 #define WM_GATE(ACT) do { if (vec) hipLaunchKernelGGL((gate_kernel<ACT, false, true>), grid, block, 0, st, p);          \
                           else hipLaunchKernelGGL((gate_kernel<ACT, false, false>), grid, block, 0, st, p); } while (0)
-    if (act == 1) WM_GATE(1); else WM_GATE(2);
+    if (act == 1) WM_GATE(1); else if (act == 2) WM_GATE(2); else WM_GATE(3);
 #undef WM_GATE
     return launch_status();
 }
@@ -1645,7 +1645,7 @@ int wm_gate_fwd(const float* a, const float* b, float* out, int act, int B, int6
 int wm_gate_bwd(const float* a, const float* b, const float* g, float* ga, float* gb, int act, int B, int64_t per_b,
                 int64_t stride_a, int64_t stride_b, int64_t stride_g, int64_t stride_ga, int64_t stride_gb, void* stream) {
     if (B < 0 || per_b < 0) return WM_EINVAL;
-    if (act != 1 && act != 2) return WM_EUNSUPPORTED;
+    if (act < 1 || act > 3) return WM_EUNSUPPORTED;
     if (B == 0 || per_b == 0) return WM_OK;
     if (!a || !b || !g || !ga || !gb) return WM_ENULL;
     if (B > 65535) return WM_EUNSUPPORTED;
@@ -1656,7 +1656,7 @@ int wm_gate_bwd(const float* a, const float* b, const float* g, float* ga, float
     hipStream_t st = (hipStream_t)stream;
 #define WM_GATE(ACT) do { if (vec) hipLaunchKernelGGL((gate_kernel<ACT, true, true>), grid, block, 0, st, p);           \
                           else hipLaunchKernelGGL((gate_kernel<ACT, true, false>), grid, block, 0, st, p); } while (0)
-    if (act == 1) WM_GATE(1); else WM_GATE(2);
+    if (act == 1) WM_GATE(1); else if (act == 2) WM_GATE(2); else WM_GATE(3);
 #undef WM_GATE
     return launch_status();
 }

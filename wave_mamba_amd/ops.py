@@ -665,7 +665,7 @@ class _NoCtx:
 # ------------------------------------------------------------------------------------------------
 # element-wise gates and scaled skips of the LFSSBlock training path (forward + backward in HIP)
 # ------------------------------------------------------------------------------------------------
-_ACTS = {"silu": 1, "gelu": 2}
+_ACTS = {"silu": 1, "gelu": 2, "sigmoid": 3}
 
 
 def _batch_strided(t):
@@ -753,7 +753,7 @@ def gate_supported(a, b):
 
 
 def gate_act(a, b, act):
-    """act(a) * b with act in {"silu", "gelu"} (exact erf GELU), differentiable; see _Gate."""
+    """act(a) * b with act in {"silu", "gelu", "sigmoid"} (exact erf GELU), differentiable; see _Gate."""
     _lib.load()
     _require_cuda("gate_act", a, b)
     if not gate_supported(a, b):
