@@ -369,15 +369,18 @@ def _ss2d_core_prepared(params):
     return buf
 
 
-def _ss2d_core_fwd(f, merged, prepared=None):
+def _ss2d_core_fwd(f, merged, prepared=None, separate=False):
     """f[0] = x (fp32 or bf16 planes: the outputs take the same storage type), f[1:] fp32 parameters; `prepared`: the
-    buffer of _ss2d_core_prepared for these parameters, or None."""
+    buffer of _ss2d_core_prepared for these parameters, or None.  separate: four allocations instead of one (4, B, D, L)
+    block (torch.library ops must not return tensors that share a storage)."""
     lib = _lib.load()
     x = f[0]
     B, D, H, W, N, R = _ss2d_core_shapes(x, f[1], f[2], f[4])
     L = H * W
     if merged:
         outs = [torch.empty((B, D, L), dtype=x.dtype, device=x.device)]
+    elif separate:
+        outs = [torch.empty((B, D, L), dtype=x.dtype, device=x.device) for _ in range(4)]
     else:       # one allocation, reference return order: a consumer can add the four with one base pointer + stride
         outs = list(torch.empty((4, B, D, L), dtype=x.dtype, device=x.device).unbind(0))
     ws_bytes = lib.wm_ss2d_core_fwd_workspace_bytes(B, D, H, W, N, R, int(bool(merged)))

@@ -120,7 +120,7 @@ def _selective_scan_backward_fake(u, delta, A, B, C, D, delta_bias, dout, delta_
 def _ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds):
     f = [x.detach().contiguous().float()] + [t.detach().contiguous().float()
                                                for t in (x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)]
-    return tuple(ops._ss2d_core_fwd(f, False))
+    return tuple(ops._ss2d_core_fwd(f, False, separate=True))
 
 
 def _ss2d_core_fake(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds):
