@@ -181,6 +181,15 @@ int wm_dwconv3x3_fwd(const void* x, const float* weight, const float* bias, void
  * mode); token tensors are always fp32. */
 int wm_lfss_in_fwd(const float* tok, int tok_nchw, const float* ln_w, const float* ln_b, float ln_eps,
                    const float* in_proj_weight, void* x, void* z, int B, int64_t L, int C, int plane_dtype, void* stream);
+/* wm_lfss_in_fwd + wm_dwconv3x3_fwd(act = SiLU) in ONE kernel (reference :483-487: in_proj, chunk, NHWC -> NCHW, depth-wise 3x3,
+ * SiLU): xc = silu(conv2d(x) + conv_bias) (B, D, H, W) and z (B, D, H W); x itself never reaches HBM (the 3x3's one-pixel halo of
+ * the projection output is recomputed per 62-column strip and row band).  C == 32 only (WM_EUNSUPPORTED otherwise: use the
+ * two calls).  conv_weight (D, 1, 3, 3), conv_bias (D) or NULL.  Same values of x as wm_lfss_in_fwd; the convolution sums
+ * its taps row by row (differs from wm_dwconv3x3_fwd in the last bits). */
+int wm_lfss_in_conv_fwd(const float* tok, int tok_nchw, const float* ln_w, const float* ln_b, float ln_eps,
+                        const float* in_proj_weight, const float* conv_weight, const float* conv_bias, void* xc, void* z,
+                        int B, int H, int W, int C, int plane_dtype, void* stream);
+
 int wm_lfss_mid_fwd(const void* ysum, int ny, int64_t ystride, const void* z, const float* tok, int tok_nchw,
                     const float* out_norm_w, const float* out_norm_b, float out_norm_eps,
                     const float* out_proj_weight, const float* skip_scale,

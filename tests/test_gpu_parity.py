@@ -713,6 +713,36 @@ def test_lfss_out_with_depthwise_conv_folded_in(B, H, W, nchw):
                                     int(nchw), B, H, W - 4, C, 0, _stream()) == -5       # W % 32 != 0: WM_EUNSUPPORTED
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 40, 96), (2, 3, 32), (1, 1, 64), (1, 17, 130), (1, 64, 62), (1, 5, 63), (1, 9, 125),
+                                   (1, 2, 8), (2, 272, 480), (1, 70, 1920)])
+@pytest.mark.parametrize("nchw", [False, True])
+def test_lfss_prologue_one_kernel_vs_two_and_fp64(B, H, W, nchw):
+    """wm_lfss_in_conv_fwd (ln_1 -> in_proj -> depth-wise 3x3 -> SiLU in one kernel, x never in HBM; reference :524, :483-487)
+    against wm_lfss_in_fwd + wm_dwconv3x3_fwd (z BIT-equal: the same projection code; the convolution sums its taps in
+    another order) and against the float64 composition of the reference's lines: strips of 62 columns with recomputed
+    halos (W < 62, = 62, 63, 125, 130, 1920), row bands (H = 1 .. 272), image borders, batch > 1, token and NCHW inputs."""
+    torch.manual_seed(H * 1000 + W)
+    blk = arch.LFSSBlock(32, expand=2.0).to(DEV).eval()
+    with torch.no_grad():
+        blk.ln_1.weight.add_(0.3 * torch.randn_like(blk.ln_1.weight)); blk.ln_1.bias.add_(0.2 * torch.randn_like(blk.ln_1.bias))
+    ss = blk.self_attention
+    x_map = torch.randn(B, 32, H, W, device=DEV)
+    tok = x_map if nchw else x_map.flatten(2).transpose(1, 2).contiguous()
+    xc1, z1 = wm.ops.lfss_prologue(tok, (H, W), blk, tok_nchw=nchw, fused=True)
+    xc2, z2 = wm.ops.lfss_prologue(tok, (H, W), blk, tok_nchw=nchw, fused=False)
+    assert torch.equal(z1, z2), "z differs from wm_lfss_in_fwd's"
+    assert_close(xc1, xc2, 2e-6, "fused prologue vs two kernels")
+    t64 = x_map.double().flatten(2).transpose(1, 2)
+    xz = F.linear(F.layer_norm(t64, (32,), blk.ln_1.weight.double(), blk.ln_1.bias.double(), blk.ln_1.eps), ss.in_proj.weight.double())
+    x64, z64 = xz.chunk(2, dim=-1)
+    x64 = x64.transpose(1, 2).reshape(B, 64, H, W)
+    ref = F.silu(F.conv2d(x64, ss.conv2d.weight.double(), ss.conv2d.bias.double(), padding=1, groups=64))
+    assert_close(xc1, ref.float(), 5e-6, "fused prologue vs float64")
+    assert_close(z1, z64.transpose(1, 2).float().contiguous(), 5e-6, "z vs float64")
+    again, _ = wm.ops.lfss_prologue(tok, (H, W), blk, tok_nchw=nchw, fused=True)
+    assert torch.equal(again, xc1)
+
+
 @pytest.mark.parametrize("B,L", [(1, 64), (2, 1000), (3, 37), (1, 4097)])
 @pytest.mark.parametrize("nchw", [False, True])
 def test_lfss_glue_kernels_c32_vs_fp64(B, L, nchw):

@@ -222,7 +222,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 19; }
+int wm_abi_version(void) { return 20; }
 
 #ifndef WM_BUILD_ID
 #define WM_BUILD_ID "unknown"
@@ -1241,6 +1241,47 @@ int wm_lfss_in_fwd(const float* tok, int tok_nchw, const float* ln_w, const floa
         return launch_status();
     }
     WM_LFSS_DISPATCH(5, lfss_in_kernel, tok, tok_nchw, ln_w, ln_b, ln_eps, in_proj_weight, x, z, B, (long long)L);
+}
+
+int wm_lfss_in_conv_fwd(const float* tok, int tok_nchw, const float* ln_w, const float* ln_b, float ln_eps,
+                        const float* in_proj_weight, const float* conv_weight, const float* conv_bias, void* xc_, void* z_,
+                        int B, int H, int W, int C, int plane_dtype, void* stream) {
+    if (B < 0 || H < 0 || W < 0) return WM_EINVAL;
+    if (C != 32) return WM_EUNSUPPORTED;                        // callers fall back to wm_lfss_in_fwd + wm_dwconv3x3_fwd
+    if (plane_dtype != WM_F32 && plane_dtype != WM_BF16) return WM_EUNSUPPORTED;
+    if (B == 0 || H == 0 || W == 0) return WM_OK;
+    if ((long long)H * W * 64 > 0x7fffffffLL) return WM_EUNSUPPORTED;
+    if (!tok || !ln_w || !ln_b || !in_proj_weight || !conv_weight || !xc_ || !z_) return WM_ENULL;
+    if (!tok_nchw && !aligned16(tok)) return WM_EALIGN;
+    const int nstrips = (W + kIcCols - 1) / kIcCols;
+    // rows per band: the largest of 32 .. 4 that still gives the chip >= 1024 wave pairs (two per 256-thread workgroup); every
+    // band recomputes two halo rows, so short bands cost in_proj work and token re-reads (first / second-level cache hits)
+    // rows per band.  A 4-wave workgroup (two strips x two channel halves) holds two waves per SIMD, so the chip takes 512
+    // workgroups at a time and a launch lasts rounds x (rb + 2 row groups + ~1 of prologue); every band recomputes two
+    // halo rows.  (rb = 32 at UHD level 1 gave 527 workgroups: a second round for 15 of them, 0.885 ms against 0.62 for the
+    // two kernels this one replaces.)
+    int rb = 1;
+    {
+        double best = 1e300;
+        for (int cand = 1; cand <= 128 && cand <= H + 1; ++cand) {
+            const long long nb = (H + cand - 1) / cand;
+            const long long wgs = ((long long)B * nstrips * nb + 1) / 2;
+            const double cost = (double)((wgs + 511) / 512) * (cand + 3);
+            if (cost < best) { best = cost; rb = cand; }
+        }
+    }
+    const int nbands = (H + rb - 1) / rb;
+    const long long pairs = (long long)B * nstrips * nbands;
+    if (pairs > 0x3fffffffLL) return WM_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(5, st);
+    if (plane_dtype == WM_F32)
+        hipLaunchKernelGGL(lfss_in_conv_mfma_kernel<float>, dim3((unsigned)((pairs + 1) / 2)), dim3(256), 0, st, tok, tok_nchw, ln_w, ln_b,
+                           ln_eps, in_proj_weight, conv_weight, conv_bias, (float*)xc_, (float*)z_, B, H, W, nstrips, nbands, rb);
+    else
+        hipLaunchKernelGGL(lfss_in_conv_mfma_kernel<bf16_t>, dim3((unsigned)((pairs + 1) / 2)), dim3(256), 0, st, tok, tok_nchw, ln_w,
+                           ln_b, ln_eps, in_proj_weight, conv_weight, conv_bias, (bf16_t*)xc_, (bf16_t*)z_, B, H, W, nstrips, nbands, rb);
+    return launch_status();
 }
 
 int wm_lfss_mid_fwd(const void* ysum_, int ny, int64_t ystride, const void* z_, const float* tok, int tok_nchw, const float* out_norm_w,

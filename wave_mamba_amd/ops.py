@@ -459,6 +459,40 @@ def _w(t):
 
 
 _FUSE_OUT_CONV = True      # tests / tools: False takes wm_dwconv3x3_fwd + wm_lfss_out_fwd (bit-identical on fp32 planes)
+# ln_1 -> in_proj -> depth-wise 3x3 -> SiLU as ONE kernel (wm_lfss_in_conv_fwd, round 4): built, parity-green
+# (tests: test_lfss_prologue_one_kernel_vs_two_and_fp64) and MEASURED SLOWER than the two streaming kernels it would replace -
+# 0.888 / 0.248 / 0.082 ms against 0.618 / 0.173 / 0.046 ms at UHD levels 1 / 2 / 3 (tools/bench_lfss_in.py,
+# profiles/r04/lfss_prologue_one_kernel.txt): the recomputed halo and the row-by-row walk leave two long-running waves per
+# SIMD waiting on their own loads and stores (VALU active 0.19 of a wave's life, PMC in the same file), where the two
+# kernels keep 13-16 short waves per SIMD streaming at 3.9 TB/s.  Off by default; WM_FUSE_IN_CONV=1 takes it.
+_FUSE_IN_CONV = os.environ.get("WM_FUSE_IN_CONV", "0") == "1"
+
+
+def lfss_prologue(tok, x_size, blk, tok_nchw=False, fused=True):
+    """SS2D's prologue alone (reference :483-487 behind ln_1, :524): tok -> (silu(conv2d(x)), z) as (B, D, H, W) / (B, D, L)
+    fp32 planes.  fused: wm_lfss_in_conv_fwd (one kernel), else wm_lfss_in_fwd + wm_dwconv3x3_fwd.  Forward only (tests, tools)."""
+    lib = _lib.load()
+    _require_cuda("lfss_prologue", tok)
+    H, W = x_size
+    L = H * W
+    ss = blk.self_attention
+    C, D = ss.d_model, ss.d_inner
+    B = tok.shape[0]
+    tok = tok.contiguous().float()
+    z = torch.empty((B, D, L), dtype=torch.float32, device=tok.device)
+    with torch.cuda.device(tok.device):
+        if fused:
+            xc = torch.empty((B, D, H, W), dtype=torch.float32, device=tok.device)
+            check(lib.wm_lfss_in_conv_fwd(_ptr(tok), int(tok_nchw), _ptr(_w(blk.ln_1.weight)), _ptr(_w(blk.ln_1.bias)),
+                                          float(blk.ln_1.eps), _ptr(_w(ss.in_proj.weight)), _ptr(_w(ss.conv2d.weight)),
+                                          None if ss.conv2d.bias is None else _ptr(_w(ss.conv2d.bias)), _ptr(xc), _ptr(z),
+                                          B, H, W, C, WM_F32, _stream()), "wm_lfss_in_conv_fwd")
+            return xc, z
+        x = torch.empty((B, D, H, W), dtype=torch.float32, device=tok.device)
+        check(lib.wm_lfss_in_fwd(_ptr(tok), int(tok_nchw), _ptr(_w(blk.ln_1.weight)), _ptr(_w(blk.ln_1.bias)),
+                                 float(blk.ln_1.eps), _ptr(_w(ss.in_proj.weight)), _ptr(x), _ptr(z), B, L, C, WM_F32, _stream()),
+              "wm_lfss_in_fwd")
+    return dwconv3x3(x, ss.conv2d.weight, ss.conv2d.bias, "silu"), z
 
 
 def lfss_block_forward(tok, x_size, blk, tok_nchw=False, out_nchw=False):
@@ -479,13 +513,22 @@ def lfss_block_forward(tok, x_size, blk, tok_nchw=False, out_nchw=False):
     # bf16 planes: the C = 32 kernels on maps with 16-byte tile accesses (W % 4 == 0); else fp32 planes
     pd = _PLANE_DTYPE if (C == 32 and W % 4 == 0) else torch.float32
     code = WM_F32 if pd == torch.float32 else WM_BF16
-    x = torch.empty((B, D, H, W), dtype=pd, device=dev)
     z = torch.empty((B, D, L), dtype=pd, device=dev)
-    with torch.cuda.device(dev):
-        check(lib.wm_lfss_in_fwd(_ptr(tok), int(tok_nchw), _ptr(_w(blk.ln_1.weight)), _ptr(_w(blk.ln_1.bias)),
-                                 float(blk.ln_1.eps), _ptr(_w(ss.in_proj.weight)), _ptr(x), _ptr(z), B, L, C, code, st),
-              "wm_lfss_in_fwd")
-    xc = dwconv3x3(x, ss.conv2d.weight, ss.conv2d.bias, "silu")
+    if C == 32 and _FUSE_IN_CONV:
+        # ln_1 -> in_proj -> depth-wise 3x3 -> SiLU in one kernel: x (in_proj's first half) never reaches HBM
+        xc = torch.empty((B, D, H, W), dtype=pd, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.wm_lfss_in_conv_fwd(_ptr(tok), int(tok_nchw), _ptr(_w(blk.ln_1.weight)), _ptr(_w(blk.ln_1.bias)),
+                                          float(blk.ln_1.eps), _ptr(_w(ss.in_proj.weight)), _ptr(_w(ss.conv2d.weight)),
+                                          None if ss.conv2d.bias is None else _ptr(_w(ss.conv2d.bias)), _ptr(xc), _ptr(z),
+                                          B, H, W, C, code, st), "wm_lfss_in_conv_fwd")
+    else:
+        x = torch.empty((B, D, H, W), dtype=pd, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.wm_lfss_in_fwd(_ptr(tok), int(tok_nchw), _ptr(_w(blk.ln_1.weight)), _ptr(_w(blk.ln_1.bias)),
+                                     float(blk.ln_1.eps), _ptr(_w(ss.in_proj.weight)), _ptr(x), _ptr(z), B, L, C, code, st),
+                  "wm_lfss_in_fwd")
+        xc = dwconv3x3(x, ss.conv2d.weight, ss.conv2d.bias, "silu")
     # the four directions' outputs stay separate (one (4, B, D, L) allocation); lfss_mid adds them as it loads (:490)
     core_params = (ss.x_proj_weight, ss.dt_projs_weight, ss.dt_projs_bias, ss.A_logs, ss.Ds)
     y4 = _ss2d_core_fwd([xc] + [_w(t) for t in core_params], merged=False, prepared=_ss2d_core_prepared(core_params))
