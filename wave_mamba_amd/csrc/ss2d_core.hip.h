@@ -43,6 +43,9 @@
 #ifndef WM_CORE_ABLATE
 #define WM_CORE_ABLATE 0          // timing experiments only (wrong results): 1 = no MFMA, 2 = no scan steps, 4 = no y store
 #endif
+#ifndef WM_CORE_RANK1_MFMA
+#define WM_CORE_RANK1_MFMA 0      // the steps' rank-1 update h[n][ch] += B_t[n] (dt u)[ch] on v_mfma_f32_4x4x1_16b_f32 (see core_body)
+#endif
 #ifndef WM_CORE_STAMP
 #define WM_CORE_STAMP 0           // diagnostics: per-wave s_memtime phase totals into CoreArgs::stamps (tools/core_stamps.py)
 #endif
@@ -123,8 +126,11 @@ template <int NP> struct CoreCfg {
     static constexpr int P_LC = P_A2 + NP * 64;
     static constexpr int PREP = P_LC + 6 * 64;
 };
+#ifndef WM_CORE_LDS_PAD
+#define WM_CORE_LDS_PAD 0         // experiments: extra dynamic LDS per workgroup (bytes), e.g. to keep a second workgroup off the compute unit
+#endif
 template <int NP, int NW> constexpr int core_lds_bytes() {
-    return (CoreCfg<NP>::WF + NW * CoreCfg<NP>::XT + NW * 16 * CoreCfg<NP>::RS + 4 /* row-chunk counter */) * 4;
+    return (CoreCfg<NP>::WF + NW * CoreCfg<NP>::XT + NW * 16 * CoreCfg<NP>::RS + 4 /* row-chunk counter */) * 4 + WM_CORE_LDS_PAD;
 }
 
 typedef __bf16 core_bf2 __attribute__((ext_vector_type(2)));
@@ -520,7 +526,18 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
                 float* rc = srec + c16 * RS;
                 if (g4 == 0) *reinterpret_cast<core_f4*>(rc) = acc[0];
 #pragma unroll
-                for (int t = 1; t < NT; ++t) *reinterpret_cast<core_f4*>(rc + 4 + 16 * (t - 1) + 4 * g4) = acc[t];
+                for (int t = 1; t < NT; ++t) {
+#if WM_CORE_RANK1_MFMA
+                    // B rows as the matrix instruction's A operand wants them: state n = 16 tb + 4 g + m at slot
+                    // 16 tb + 4 m + g, so that lane (m = lane & 3) reads its four operands (g = 0..3) as one float4
+                    if (t <= NTB) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) rc[4 + 16 * (t - 1) + 4 * i + g4] = acc[t][i];
+                        continue;
+                    }
+#endif
+                    *reinterpret_cast<core_f4*>(rc + 4 + 16 * (t - 1) + 4 * g4) = acc[t];
+                }
             }
             core_lds_fence();
             WM_STAMP(2)                                  // projection + record write
@@ -538,6 +555,10 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
                 int roff = 4 * cq * RS;                                   // records of tile columns 4 cq .. 4 cq + 3
                 asm volatile("" : "+v"(roff));                            // (an opaque OFFSET: the pointer stays an LDS pointer)
                 const float* rq = srec + roff;
+#if WM_CORE_RANK1_MFMA
+                int l4x4 = 4 * (lane & 3);                                // the lane's slot group in the transposed B rows
+                asm volatile("" : "+v"(l4x4));
+#endif
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {                          // two steps at a time (softplus on a float pair)
                     float dtr[2];
@@ -563,13 +584,37 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
                         if (PHASE == 1) sum_dt += dt;
                         v2f y2 = splat(0.0f);
                         const float* rc = rq + (REV ? 3 - j : j) * RS + 4;
+#if WM_CORE_RANK1_MFMA
+                        // h[n][ch] <- a h + B_t[n] (dt u)[ch]: the rank-1 term of four states is ONE v_mfma_f32_4x4x1_16b_f32
+                        // in this layout (block = lane / 4, column = lane % 4 = the lane's own channel, row i = register =
+                        // state 4 g + i: D[i][j] = A[i] B[j] + C[i][j] with A from lane 4 (lane / 4) + i = B_t[4 g + i],
+                        // B = the lane's dt u, C = a h): 8 of the 32 packed operations of a step leave the VALU - the unit
+                        // that bounds this kernel - for four 2-pass instructions on the idle matrix pipe
+                        // (tools/ubench_rank1_mfma.hip).
+                        float bA[NP / 4];
+#pragma unroll
+                        for (int tb = 0; tb < NTB; ++tb) {
+                            const float4 bq = *reinterpret_cast<const float4*>(rc + l4x4 + 16 * tb);
+                            bA[4 * tb] = bq.x; bA[4 * tb + 1] = bq.y; bA[4 * tb + 2] = bq.z; bA[4 * tb + 3] = bq.w;
+                        }
+                        const float du1 = dt * ut;
+#endif
 #pragma unroll
                         for (int r = 0; r < NP / 4; ++r) {
-                            const float4 bv = *reinterpret_cast<const float4*>(rc + 4 * r);
                             const v2f a0 = exp2_2(dt2 * WM_A2(2 * r));
                             const v2f a1 = exp2_2(dt2 * WM_A2(2 * r + 1));
+#if WM_CORE_RANK1_MFMA
+                            {
+                                const v2f m0 = a0 * h[2 * r], m1 = a1 * h[2 * r + 1];
+                                const core_f4 hn = __builtin_amdgcn_mfma_f32_4x4x1f32(bA[r], du1, (core_f4){m0.x, m0.y, m1.x, m1.y},
+                                                                                      0, 0, 0);
+                                h[2 * r] = (v2f){hn[0], hn[1]}; h[2 * r + 1] = (v2f){hn[2], hn[3]};
+                            }
+#else
+                            const float4 bv = *reinterpret_cast<const float4*>(rc + 4 * r);
                             h[2 * r] = a0 * h[2 * r] + du2 * (v2f){bv.x, bv.y};
                             h[2 * r + 1] = a1 * h[2 * r + 1] + du2 * (v2f){bv.z, bv.w};
+#endif
                             if (PHASE == 3) {
                                 const float4 cv = *reinterpret_cast<const float4*>(rc + NP + 4 * r);
                                 y2 = (v2f){cv.x, cv.y} * h[2 * r] + y2;
