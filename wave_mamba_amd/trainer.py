@@ -31,13 +31,17 @@ def make_optimizer(net, lr=5e-4, weight_decay=1e-3, betas=(0.9, 0.99)):
     return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, betas=betas, fused=fused)
 
 
-def wrap_ddp(net, device=None, find_unused_parameters=False):
+def wrap_ddp(net, device=None, find_unused_parameters=False, force=False):
     """DDP wrap like base_model.py:111-114.  find_unused_parameters defaults to False: every one of
-    the 591 parameter tensors receives a gradient, so the graph walk is wasted work."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    the 591 parameter tensors receives a gradient, so the graph walk is wasted work.
+    `force`: wrap at world size 1 as well (one-GPU self-tests of the RCCL path: the reducer then runs its bucketed
+    all-reduce over a one-rank communicator)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return net
     ids = [device.index] if device is not None and device.type == "cuda" else None
-    return torch.nn.parallel.DistributedDataParallel(net, device_ids=ids,
+    # gradient_as_bucket_view: the 591 gradients are views of the reducer's flat bucket instead of being copied into it
+    # one small kernel at a time (measured over a one-rank RCCL communicator, config 3: see DESIGN.md section 6)
+    return torch.nn.parallel.DistributedDataParallel(net, device_ids=ids, gradient_as_bucket_view=True,
                                                      find_unused_parameters=find_unused_parameters)
 
 
