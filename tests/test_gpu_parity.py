@@ -929,6 +929,24 @@ def test_gram_vs_torch(B, C, L):
     assert_close(ny, y.double().pow(2).sum(-1).float(), 2e-5, "|y|^2")
 
 
+@pytest.mark.parametrize("B,C,L", [(2, 32, 4096), (8, 32, 65536), (3, 16, 1000)])
+def test_gram_train_gradients_vs_normalize_path_fp64(B, C, L):
+    """The training form of the transposed attention's logits - gram_train + division by the norms on the (B, C, C) result -
+    against the reference's F.normalize(q) @ F.normalize(k)^T (:783-786) under autograd in float64: value and both gradients."""
+    q = (torch.randn(B, C, L, generator=gen(L)) + 0.1).to(DEV).requires_grad_(True)
+    k = (torch.randn(B, C, L, generator=gen(L + 7)) - 0.2).to(DEV).requires_grad_(True)
+    wgt = torch.randn(B, C, C, generator=gen(5)).to(DEV)
+    G, nq, nk = wm.ops.gram_train(q, k)
+    attn = G / (nq.sqrt().clamp_min(1e-12).unsqueeze(2) * nk.sqrt().clamp_min(1e-12).unsqueeze(1))
+    (attn * wgt).sum().backward()
+    q64, k64 = q.detach().double().requires_grad_(True), k.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.normalize(q64, dim=-1) @ torch.nn.functional.normalize(k64, dim=-1).transpose(1, 2)
+    (ref * wgt.double()).sum().backward()
+    assert_close(attn.detach(), ref.detach().float(), 2e-5, "normalized gram")
+    assert_close(q.grad, q64.grad.float(), 5e-5, "d q")
+    assert_close(k.grad, k64.grad.float(), 5e-5, "d k")
+
+
 def test_hfe_block_hip_helpers_vs_module_path():
     """HFEBlock with the HIP helpers (Gram-based matching + attention, LayerNorm2d, depth-wise conv) vs the
     same block evaluated with the plain PyTorch ops on the GPU."""

@@ -403,11 +403,13 @@ class LayerNorm2d(nn.Module):
         return self.weight.view(1, -1, 1, 1) * y + self.bias.view(1, -1, 1, 1)
 
 
-def _gram_ok(a, b):
+def _gram_ok(a, b, differentiable=True):
+    """The HIP Gram kernel serves (a, b); `differentiable=False`: the caller takes nothing differentiable from it (the
+    channel matching keeps indices only), so tensors under autograd qualify too."""
     ops = _OpsBackend.impl
     return (hasattr(ops, "gram") and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32
             and a.shape == b.shape and a.shape[1] <= 32
-            and not (torch.is_grad_enabled() and (a.requires_grad or b.requires_grad)))
+            and not (differentiable and torch.is_grad_enabled() and (a.requires_grad or b.requires_grad)))
 
 
 def nearest_candidate_index(maps, candidates, num_matches):
@@ -415,9 +417,10 @@ def nearest_candidate_index(maps, candidates, num_matches):
     channel of `candidates`; keeps the `num_matches` channels whose nearest distance is smallest (original
     channel order).  -> (B, num_matches) int64 channel indices into `candidates`."""
     ops = _OpsBackend.impl
-    if _gram_ok(maps, candidates):
-        # d^2 = |x|^2 + |y|^2 - 2 x.y, the same expansion torch.cdist uses for C > 25 (mm mode)
-        G, nx, ny = ops.gram(maps, candidates)
+    if _gram_ok(maps, candidates, differentiable=False):
+        # d^2 = |x|^2 + |y|^2 - 2 x.y, the same expansion torch.cdist uses for C > 25 (mm mode).  Indices only leave this
+        # function (topk indices are not differentiable in the reference either): training takes the same kernel
+        G, nx, ny = ops.gram(maps.detach(), candidates.detach())
         if hasattr(ops, "match_index") and (num_matches is None or num_matches == -1 or num_matches >= maps.size(1)):
             return ops.match_index(G, nx, ny)                       # every channel kept: one argmin kernel
         dist = (nx.unsqueeze(2) + ny.unsqueeze(1) - 2.0 * G).clamp_min(1e-30).sqrt()
@@ -550,9 +553,11 @@ class CMTAttention(nn.Module):
         k = k.reshape(b * heads, c // heads, h * w)
         v = v.reshape(b, heads, c // heads, h * w)
         ops = _OpsBackend.impl
-        if _gram_ok(q, k):
+        train_gram = (hasattr(ops, "gram_train") and _gram_ok(q, k, differentiable=False)
+                      and torch.is_grad_enabled() and (q.requires_grad or k.requires_grad))
+        if train_gram or _gram_ok(q, k):
             # normalize(q) @ normalize(k)^T == (q @ k^T) / (max(|q|, eps) max(|k|, eps)): one pass over q, k
-            G, nq, nk = ops.gram(q.contiguous(), k.contiguous())
+            G, nq, nk = ops.gram_train(q, k) if train_gram else ops.gram(q.contiguous(), k.contiguous())
             if (hasattr(ops, "attn_fold") and c <= 64 and ops.conv2d_supported(x, self.project_out.weight)
                     and not (torch.is_grad_enabled() and any(t.requires_grad for t in self.parameters()))):
                 # project_out(softmax(...) @ v) = (W_po @ blockdiag(attn)) @ v: a tiny kernel folds the (c/heads)^2

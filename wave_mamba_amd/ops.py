@@ -598,6 +598,39 @@ def gram(x, y):
     return G, nx, ny
 
 
+class _GramTrain(torch.autograd.Function):
+    """gram() under autograd: (G, |x|^2, |y|^2) of x, y (B, C, L).  Backward: dx = dG y + 2 d|x|^2 x, dy = dG^T x + 2 d|y|^2 y
+    (two batched GEMMs and two scaled adds).  The training-side form of the transposed attention's
+    normalize(q) @ normalize(k)^T (reference :783-786): one pass over q and k instead of two normalisations and a batched
+    product, and the division by the norms happens on the (B, C, C) result."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = x.contiguous(), y.contiguous()
+        ctx.save_for_backward(x, y)
+        G, nx, ny = gram(x, y)
+        return G, nx, ny
+
+    @staticmethod
+    def backward(ctx, dG, dnx, dny):
+        x, y = ctx.saved_tensors
+        dx = dy = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.bmm(dG, y) if dG is not None else torch.zeros_like(x)
+            if dnx is not None:
+                dx.addcmul_(x, dnx.unsqueeze(2), value=2.0)
+        if ctx.needs_input_grad[1]:
+            dy = torch.bmm(dG.transpose(1, 2), x) if dG is not None else torch.zeros_like(y)
+            if dny is not None:
+                dy.addcmul_(y, dny.unsqueeze(2), value=2.0)
+        return dx, dy
+
+
+def gram_train(x, y):
+    """gram(x, y) with gradients (x, y (B, C <= 32, L) fp32 HIP tensors)."""
+    return _GramTrain.apply(x, y)
+
+
 class _DWConvTrain(torch.autograd.Function):
     """Depth-wise 3x3 conv (+bias) with HIP forward, input gradient (the same kernel on the flipped weight) and
     weight / bias gradient (strip reduction).  Training-side replacement of MIOpen's naive depth-wise kernels."""
