@@ -266,6 +266,24 @@ int wm_layernorm2d_bwd(const float* x, const float* weight, const float* gy, flo
 int wm_conv2d_select(int mode);
 size_t wm_conv2d_wfrag_bytes(int Cout, int Cin, int ks);
 int wm_conv2d_prep(const float* weight, void* wfrag, int Cout, int Cin, int ks, void* stream);
+/* The training form of the same convolutions (the F.conv2d calls of wavemamba_arch.py under autograd, femasr_model.py:170-181:
+ * forward, and - on the transposed, flipped weight - the input gradient): fp16 matrix cores, two-term split of both operands
+ * (22 significant bits, fp32-class: ~1e-7 relative to an fp64 convolution instead of the bf16 form's 3-4e-6, which the
+ * parameter gradients of the deepest blocks do not tolerate), each tensor scaled by a power of two taken from its largest
+ * magnitude so that fp16's exponent range is never the limit.  `amax`: TWO device floats {max |x|, max |weight|} written by
+ * the caller on the same stream (no host synchronisation); wm_conv2d_prep_f16 reads amax[1], wm_conv2d_fwd_f16 both - the same
+ * buffer must be passed to both calls.  `wfrag`: wm_conv2d_wfrag_bytes(Cout, Cin, ks) bytes, 16-byte aligned.  y = conv(x) + bias
+ * (bias may be NULL).  Same kernels, tilings and limits as wm_conv2d_fwd; no concatenated / gathered second input, no gate. */
+/* amax[0] = max |x[0..nx)|, amax[1] = max |weight[0..nw)| (device floats; one memset + one launch on `stream`). */
+int wm_conv2d_amax(const float* x, int64_t nx, const float* weight, int64_t nw, float* amax, void* stream);
+int wm_conv2d_prep_f16(const float* weight, const float* amax, void* wfrag, int Cout, int Cin, int ks, void* stream);
+int wm_conv2d_fwd_f16(const float* x, const void* wfrag, const float* amax, const float* bias, float* y, int B, int Cin, int Cout,
+                      int H, int W, int ks, void* stream);
+/* The three steps above in one call (what ops.conv2d_f16 uses: one binding call per convolution): workspace =
+ * wm_conv2d_f16_workspace_bytes(Cout, Cin, ks) bytes, 16-byte aligned, caller-owned, holds the two magnitudes and the fragments. */
+size_t wm_conv2d_f16_workspace_bytes(int Cout, int Cin, int ks);
+int wm_conv2d_f16(const float* x, const float* weight, const float* bias, float* y, void* workspace, size_t workspace_bytes,
+                  int B, int Cin, int Cout, int H, int W, int ks, void* stream);
 int wm_conv2d_fwd(const float* xa, const float* xb, const int* xb_index, const void* wfrag, const float* bias,
                   const float* gate, const float* residual, float* y, int B, int Ca, int Cb, int Cb_src, int Cout,
                   int H, int W, int ks, void* stream);

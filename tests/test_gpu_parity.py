@@ -1627,10 +1627,11 @@ def test_uint8_pipeline_matches_sequential(golden):
 
 @pytest.mark.parametrize("ks,B,Cin,Cout,H,W,bias", [(3, 2, 32, 64, 24, 40, True), (1, 1, 64, 32, 17, 33, True),
                                                     (3, 1, 3, 32, 16, 32, False), (1, 2, 12, 32, 9, 20, True)])
-@pytest.mark.parametrize("fast", [False, True])
-def test_conv2d_train_gradients_vs_torch_autograd(ks, B, Cin, Cout, H, W, bias, fast):
-    """Both training modes of the dense convolutions against the fp64 convolution: the default (ATen fp32, bar 2e-6) and
-    the opt-in split-bf16 matrix-core kernel for forward and input gradient (bars 2e-5 / 5e-5)."""
+@pytest.mark.parametrize("mode", ["auto", "f16", "aten", "bf16x3"])
+def test_conv2d_train_gradients_vs_torch_autograd(ks, B, Cin, Cout, H, W, bias, mode):
+    """The three training modes of the dense convolutions against the fp64 convolution: the default (fp16 split on the matrix
+    cores) and ATen's fp32 at the same bar (2e-6), the split-bf16 inference kernels at 2e-5 / 5e-5."""
+    fast = mode == "bf16x3"
     gg = gen(ks * 10 + Cin)
     x = torch.randn(B, Cin, H, W, generator=gg)
     w = torch.randn(Cout, Cin, ks, ks, generator=gg) / (ks * Cin ** 0.5)
@@ -1640,17 +1641,58 @@ def test_conv2d_train_gradients_vs_torch_autograd(ks, B, Cin, Cout, H, W, bias, 
     ref = F.conv2d(ps[0], ps[1], ps[2] if bias else None, padding=ks // 2)
     gref = torch.autograd.grad(ref, ps, gy.double())
     qs = [t.to(DEV).requires_grad_(True) for t in (x, w)] + ([b.to(DEV).requires_grad_(True)] if bias else [])
-    prev = wm.ops.set_train_conv_bf16x3(fast)
+    prev = wm.ops.set_train_conv_mode(mode)
     try:
         got = wm.ops.conv2d_train(qs[0], qs[1], qs[2] if bias else None)
         ggot = torch.autograd.grad(got, qs, gy.to(DEV))
     finally:
-        wm.ops.set_train_conv_bf16x3(prev)
+        wm.ops.set_train_conv_mode(prev)
     assert_close(got.detach(), ref.detach().float(), 2e-5 if fast else 2e-6, "conv2d_train forward")
     hip_gw = wm.ops.conv2d_wgrad_supported(qs[0], qs[1])     # W % 32 == 0: the weight gradient is the split-bf16 HIP kernel's
     for a, r, nm in zip(ggot, gref, ("gx", "gw", "gb")):
         bar = 5e-5 if fast else (2e-5 if (nm == "gw" and hip_gw) else 2e-6)
         assert_close(a, r.float(), bar, f"conv2d_train {nm} ks={ks}")
+
+
+@pytest.mark.parametrize("ks,B,Cin,Cout,H,W,bias", [
+    (3, 8, 64, 64, 256, 256, False),     # BASELINE config 3, level 1: the wave-specialised kernel, two row tiles
+    (3, 8, 64, 32, 256, 256, True),      # ... one row tile
+    (3, 2, 32, 96, 128, 128, True),      # h_out_conv: three row tiles (2 + 1)
+    (3, 8, 64, 64, 64, 64, False),       # level 3: the first-generation kernel
+    (3, 1, 3, 32, 70, 50, True), (3, 2, 32, 3, 33, 65, True),
+    (1, 8, 32, 96, 256, 256, True), (1, 2, 64, 32, 17, 33, True), (1, 1, 96, 64, 40, 56, False), (1, 3, 12, 20, 9, 20, True),
+])
+@pytest.mark.parametrize("scale", [1.0, 3e-7, 2e4])
+def test_conv2d_f16_vs_float64(ks, B, Cin, Cout, H, W, bias, scale):
+    """The training form of the dense convolutions (fp16 split, per-tensor power-of-two scales) against the float64 convolution,
+    next to ATen's fp32 on the same inputs: activations of magnitude `scale` (3e-7: a gradient map - far below fp16's range
+    without the scale) with a heavy-tailed distribution (a few entries 1e3 x the typical one), weights of magnitude 1 / sqrt(K)."""
+    gg = gen(ks + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=gg)
+    x = x * torch.where(torch.rand(x.shape, generator=gg) < 1e-3, 1e3, 1.0) * scale
+    w = torch.randn(Cout, Cin, ks, ks, generator=gg) / (ks * Cin ** 0.5)
+    b = (torch.randn(Cout, generator=gg) * scale) if bias else None
+    xd, wd = x.to(DEV), w.to(DEV)
+    ref = F.conv2d(xd.double(), wd.double(), None if b is None else b.to(DEV).double(), padding=ks // 2)
+    got = wm.ops.conv2d_f16(xd, wd, None if b is None else b.to(DEV))
+    aten = F.conv2d(xd, wd, None if b is None else b.to(DEV), padding=ks // 2)
+    e_got, e_aten = rel_err(got, ref.float()), rel_err(aten, ref.float())
+    print(f"conv2d_f16 ks={ks} {B}x{Cin}->{Cout} {H}x{W} scale {scale:g}: rel l2 / max {e_got[0]:.2e} / {e_got[1]:.2e} "
+          f"(ATen fp32: {e_aten[0]:.2e} / {e_aten[1]:.2e})")
+    assert_close(got, ref.float(), 1e-6, "conv2d_f16")
+    assert torch.equal(wm.ops.conv2d_f16(xd, wd, None if b is None else b.to(DEV)), got), "conv2d_f16: not reproducible run to run"
+
+
+def test_conv2d_f16_degenerate_inputs():
+    """all-zero input (scale falls back to 1), a single non-zero element, a constant map: exact / fp32-class results"""
+    w = torch.randn(32, 16, 3, 3, generator=gen(1)).to(DEV)
+    z = torch.zeros(1, 16, 8, 32, device=DEV)
+    assert float(wm.ops.conv2d_f16(z, w).abs().max()) == 0.0
+    one = z.clone(); one[0, 5, 3, 7] = 1.0e-20
+    ref = F.conv2d(one.double(), w.double(), padding=1)
+    assert_close(wm.ops.conv2d_f16(one, w), ref.float(), 1e-6, "single tiny element")
+    c = torch.full((2, 16, 8, 32), 7.25, device=DEV)
+    assert_close(wm.ops.conv2d_f16(c, w), F.conv2d(c.double(), w.double(), padding=1).float(), 1e-6, "constant map")
 
 
 @pytest.mark.parametrize("ks,B,Cin,Cout,H,W", [

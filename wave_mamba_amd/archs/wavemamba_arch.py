@@ -100,7 +100,7 @@ def _conv(conv, x, x2=None, x2_index=None, gate=None, residual=None):
         return ops.conv2d(x, conv.weight, conv.bias, x2, x2_index, gate, residual)
     x = _cat_gathered(x, x2, x2_index)
     if hasattr(ops, "conv2d_train") and ops.conv2d_supported(x, conv.weight) and torch.is_grad_enabled():
-        y = ops.conv2d_train(x, conv.weight, conv.bias)             # fp32 (ATen) by default, split-bf16 HIP as a fast mode
+        y = ops.conv2d_train(x, conv.weight, conv.bias)             # ops.set_train_conv_mode(): fp16-split HIP kernels by default
     else:
         y = conv(x)
     if gate is not None:

@@ -40,6 +40,7 @@
 namespace wm {
 
 using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8_t = __attribute__((ext_vector_type(8))) _Float16;
 using f32x16_t = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kCvTW = 32;             // tile width in pixels = one MFMA column tile
@@ -59,18 +60,92 @@ struct Conv2dArgs {
     int nch;                          // ceil((Ca + Cb) / 16) input-channel chunks
     int mtot;                         // ceil(Cout / 32) row tiles in wfrag
     int mbase;                        // first row tile of this launch
+    const float* amax;                // F16 kernels: device floats {max |input|, max |weight|} (the power-of-two operand scales), else null
 };
 
 union Frag16 {
     bf16x8_t v;
+    f16x8_t h;
     uint4 u;
 };
+
+// ---- the fp16 form (training): x = x_hi + x_lo with x_hi = fp16(s x), x_lo = fp16(s x - x_hi) carries 22 significant bits per
+// operand (bf16: 16) on the same three matrix instructions per product (v_mfma_f32_32x32x16_f16 runs at the bf16 rate).  fp16's
+// narrow exponent is met by a power-of-two scale per TENSOR taken from its largest magnitude (a device float: no host
+// synchronisation): s max|x| lies in [2^14, 2^15), elements down to 2^-28 of the largest keep a normal hi part, smaller ones
+// lose bits gradually (absolute error <= 2^-39 of the largest element).  Products are exact in the fp32 accumulator; the
+// epilogue multiplies by 1 / (s_x s_w) - exact.
+__device__ __forceinline__ float cv_pow2_scale(float amax) {
+    if (!(amax > 0.0f) || !(amax < 3.0e38f)) return 1.0f;
+    int e;
+    (void)frexpf(amax, &e);                       // amax = m 2^e, m in [0.5, 1)
+    e = 15 - e;
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    return ldexpf(1.0f, e);
+}
+// amax[0] = max |x|, amax[1] = max |w| (non-negative floats order like their bit patterns: atomicMax on the words; the caller
+// zeroes the two words first).  NaNs are skipped (the convolution then produces them where they belong).  One atomic per
+// workgroup and at most 512 workgroups: 8,192 wave-level atomics on one address cost 70 us of a 106-us launch over 134 MB.
+__global__ __launch_bounds__(256) void cv_amax2_kernel(const float* __restrict__ x, long long nx, const float* __restrict__ w,
+                                                       long long nw, unsigned* __restrict__ amax) {
+    __shared__ float s_m[4];
+    const bool second = blockIdx.y == 1;
+    const float* p = second ? w : x;
+    const long long n = second ? nw : nx;
+    float m = 0.0f;
+    const long long stride = (long long)gridDim.x * 256;
+    const bool vec = (reinterpret_cast<size_t>(p) & 15) == 0;
+    const long long nq = vec ? n >> 2 : 0;
+    const float4* q = reinterpret_cast<const float4*>(p);
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < nq; i += 4 * stride) {                   // four loads in flight per thread
+        const float4 a = q[i], b = q[i + stride], c = q[i + 2 * stride], d = q[i + 3 * stride];
+        m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                           fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
+        m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))),
+                           fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)))));
+    }
+    for (; i < nq; i += stride) {
+        const float4 v = q[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (long long e = 4 * nq + (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) m = fmaxf(m, fabsf(p[e]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        if (m > 0.0f) atomicMax(amax + (second ? 1 : 0), __float_as_uint(m));
+    }
+}
+
+template <bool F16>
+__device__ __forceinline__ void cv_split(float v, Frag16& hi, Frag16& lo, int j) {
+    if constexpr (F16) {
+        const _Float16 hv = (_Float16)v;
+        hi.h[j] = hv;
+        lo.h[j] = (_Float16)(v - (float)hv);
+    } else {
+        const __bf16 hv = (__bf16)v;
+        hi.v[j] = hv;
+        lo.v[j] = (__bf16)(v - (float)hv);
+    }
+}
+template <bool F16>
+__device__ __forceinline__ f32x16_t cv_mfma(const Frag16& A, const Frag16& B, f32x16_t c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(A.h, B.h, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, B.v, c, 0, 0, 0);
+}
 
 // w (Cout, Cin, KS, KS) fp32 -> wfrag[chunk][tap][m][split][lane] x 8 bf16: lane l of fragment (chunk, tap, m)
 // holds w[32 m + (l & 31)][16 chunk + 8 (l >> 5) + j][tap], j = 0..7 (the A-operand layout of
 // v_mfma_f32_32x32x16_bf16); channels beyond Cout / Cin are zero.
+template <bool F16 = false>
 __global__ __launch_bounds__(256) void conv2d_prep_kernel(const float* __restrict__ w, uint4* __restrict__ wfrag,
-                                                          int Cout, int Cin, int taps, int nch, int mtot) {
+                                                          int Cout, int Cin, int taps, int nch, int mtot,
+                                                          const float* __restrict__ amax = nullptr) {
+    const float sw = F16 ? cv_pow2_scale(amax[1]) : 1.0f;
     const long long total = (long long)nch * taps * mtot * 2 * 64;
     for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int lane = (int)(idx & 63), split = (int)((idx >> 6) & 1);
@@ -84,8 +159,10 @@ __global__ __launch_bounds__(256) void conv2d_prep_kernel(const float* __restric
         for (int j = 0; j < 8; ++j) {
             const int ci = ci0 + j;
             const float v = (co < Cout && ci < Cin) ? w[((long long)co * Cin + ci) * taps + tap] : 0.0f;
-            const __bf16 hi = (__bf16)v;
-            f.v[j] = split ? (__bf16)(v - (float)hi) : hi;
+            Frag16 hi, lo;
+            cv_split<F16>(F16 ? v * sw : v, hi, lo, j);
+            if constexpr (F16) f.h[j] = split ? lo.h[j] : hi.h[j];
+            else f.v[j] = split ? lo.v[j] : hi.v[j];
         }
         wfrag[idx] = f.u;
     }
@@ -94,8 +171,11 @@ __global__ __launch_bounds__(256) void conv2d_prep_kernel(const float* __restric
 // G1X1 (3x3 only): a second, 1x1 convolution of the same input (its own prepared weights a.wfrag1 / a.bias1) rides on
 // the centre tap's B fragments into a second accumulator set and gates the output: y = conv3x3(X) * sigmoid(conv1x1(X) +
 // b1) - PAConv's k3(x) * sigmoid(k2(x)) (reference :694-697) without the gate tensor ever existing.
-template <int KS /*1 or 3*/, int RW /*rows per wave*/, int MT /*32-channel row tiles per launch*/, bool G1X1 = false>
+template <int KS /*1 or 3*/, int RW /*rows per wave*/, int MT /*32-channel row tiles per launch*/, bool G1X1 = false, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a) {
+    static_assert(!(F16 && G1X1), "the fp16 form serves the plain convolutions of the training step");
+    const float sx = F16 ? cv_pow2_scale(a.amax[0]) : 1.0f;
+    const float osc = F16 ? 1.0f / (sx * cv_pow2_scale(a.amax[1])) : 1.0f;
     extern __shared__ __attribute__((aligned(16))) unsigned char cv_smem[];
     constexpr int PAD = KS / 2, TAPS = KS * KS;
     constexpr int PW = kCvTW + 2 * PAD;              // staged row pitch in pixels
@@ -200,9 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float v = (j < cn && pok[it]) ? pin[half][it][j] : 0.0f;
-                        const __bf16 hv = (__bf16)v;
-                        hi.v[j] = hv;
-                        lo.v[j] = (__bf16)(v - (float)hv);
+                        cv_split<F16>(F16 ? v * sx : v, hi, lo, j);
                     }
                     s_in[half * NPIX + p] = hi.u;
                     s_in[(2 + half) * NPIX + p] = lo.u;
@@ -248,8 +326,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
                         if (r < 0 || r >= RW) continue;
 #pragma unroll
                         for (int m = 0; m < MT; ++m)
-                            acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                term == 2 ? Al[ky][m].v : Ah[ky][m].v, term == 1 ? Bl.v : Bh.v, acc[m][r], 0, 0, 0);
+                            acc[m][r] = cv_mfma<F16>(term == 2 ? Al[ky][m] : Ah[ky][m], term == 1 ? Bl : Bh, acc[m][r]);
                     }
                 if constexpr (G1X1) {
                     if (kx == PAD && j >= PAD && j < RW + PAD) {       // centre tap: staged row j is output row j - PAD
@@ -259,9 +336,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
                             Wh.u = s_w1[(m * 2 + 0) * 64 + lane];
                             Wl.u = s_w1[(m * 2 + 1) * 64 + lane];
                             f32x16_t c1 = acc1[m][j - PAD];
-                            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wh.v, Bh.v, c1, 0, 0, 0);
-                            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wh.v, Bl.v, c1, 0, 0, 0);
-                            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wl.v, Bh.v, c1, 0, 0, 0);
+                            c1 = cv_mfma<false>(Wh, Bh, c1);
+                            c1 = cv_mfma<false>(Wh, Bl, c1);
+                            c1 = cv_mfma<false>(Wl, Bh, c1);
                             acc1[m][j - PAD] = c1;
                         }
                     }
@@ -347,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int dc = (i & 3) + 8 * (i >> 2);
-                float v = acc[m][r][i] + bv[i];
+                float v = (F16 ? acc[m][r][i] * osc : acc[m][r][i]) + bv[i];
                 if constexpr (G1X1) v = v / (1.0f + __expf(-(acc1[m][r][i] + b1v[i])));
                 if (a.gate) v = v / (1.0f + __expf(-gv[i]));
                 if (a.res) v += rv[i];

@@ -82,9 +82,12 @@ __device__ __forceinline__ void ws_lds_store16(unsigned addr, const uint4& v) {
 
 __device__ __forceinline__ void ws_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int RW, int MT, bool G1X1, bool EPI, int NPW = 4>
+template <int RW, int MT, bool G1X1, bool EPI, int NPW = 4, bool F16 = false>
 __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void conv3x3_ws_kernel(const Conv2dArgs a, const int B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cv_smem[];
+    static_assert(!(F16 && G1X1), "the fp16 form (conv2d.hip.h) serves the plain convolutions of the training step");
+    const float sx = F16 ? cv_pow2_scale(a.amax[0]) : 1.0f;
+    const float osc = F16 ? 1.0f / (sx * cv_pow2_scale(a.amax[1])) : 1.0f;
     using Cfg = ConvWsCfg<RW, MT, G1X1, NPW>;
     constexpr int PW = Cfg::PW, TH = Cfg::TH, NPIX = Cfg::NPIX, PIT = Cfg::PIT, NPT = Cfg::NPT;
     constexpr int W_ITEMS = Cfg::W_ITEMS, W1_ITEMS = Cfg::W1_ITEMS, BUF = Cfg::BUF_ITEMS;
@@ -220,9 +223,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void conv3x3_ws_kern
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float v = j < cn ? __builtin_bit_cast(float, __builtin_bit_cast(unsigned, pin[S][half][it][j]) & okm[S][it]) : 0.0f;
-                        const __bf16 hv = (__bf16)v;
-                        hi.v[j] = hv;
-                        lo.v[j] = (__bf16)(v - (float)hv);
+                        cv_split<F16>(F16 ? v * sx : v, hi, lo, j);
                     }
                     ws_lds_store16<0>(s_in + it * (NPT * 16u), hi.u);
                     ws_lds_store16<2 * NPIX * 16>(s_in + it * (NPT * 16u), lo.u);
@@ -321,8 +322,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void conv3x3_ws_kern
                         if (r < 0 || r >= RW) continue;
 #pragma unroll
                         for (int m = 0; m < MT; ++m)
-                            acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                term == 2 ? Al[ky][m].v : Ah[ky][m].v, term == 1 ? Bl.v : Bh.v, acc[m][r], 0, 0, 0);
+                            acc[m][r] = cv_mfma<F16>(term == 2 ? Al[ky][m] : Ah[ky][m], term == 1 ? Bl : Bh, acc[m][r]);
                     }
                 if constexpr (G1X1) {
                     if (kx == 1 && j >= 1 && j < RW + 1) {             // centre tap: staged row j is output row j - 1
@@ -332,9 +332,9 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void conv3x3_ws_kern
                             Wh.u = s_w1[(m * 2 + 0) * 64 + lane];
                             Wl.u = s_w1[(m * 2 + 1) * 64 + lane];
                             f32x16_t c1 = acc1[m][j - 1];
-                            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wh.v, Bh.v, c1, 0, 0, 0);
-                            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wh.v, Bl.v, c1, 0, 0, 0);
-                            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wl.v, Bh.v, c1, 0, 0, 0);
+                            c1 = cv_mfma<false>(Wh, Bh, c1);
+                            c1 = cv_mfma<false>(Wh, Bl, c1);
+                            c1 = cv_mfma<false>(Wl, Bh, c1);
                             acc1[m][j - 1] = c1;
                         }
                     }
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void conv3x3_ws_kern
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const unsigned o = o0 + (unsigned)(r * W) * 4u + (unsigned)((i & 3) + 8 * (i >> 2)) * HWb;
-                        float v = acc[m][r][i] + bv[i];
+                        float v = (F16 ? acc[m][r][i] * osc : acc[m][r][i]) + bv[i];
                         if constexpr (G1X1) v = v / (1.0f + __expf(-(acc1[m][r][i] + b1v[i])));
                         if constexpr (EPI) v = is_gate ? v / (1.0f + __expf(-ev[r][i])) : v + ev[r][i];
                         *reinterpret_cast<float*>(yb + (size_t)o) = v;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void conv3x3_ws_kern
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int dc = (i & 3) + 8 * (i >> 2);
-                    float v = acc[m][r][i] + bv[i];
+                    float v = (F16 ? acc[m][r][i] * osc : acc[m][r][i]) + bv[i];
                     if constexpr (G1X1) v = v / (1.0f + __expf(-(acc1[m][r][i] + b1v[i])));
                     if constexpr (EPI) v = is_gate ? v / (1.0f + __expf(-ev[r][i])) : v + ev[r][i];
                     if (full || chb + dc < a.Cout) a.y[o + dc * HW] = v;

@@ -222,7 +222,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 20; }
+int wm_abi_version(void) { return 21; }
 
 #ifndef WM_BUILD_ID
 #define WM_BUILD_ID "unknown"
@@ -1801,25 +1801,50 @@ int wm_conv2d_prep(const float* weight, void* wfrag, int Cout, int Cin, int ks, 
     if (!aligned16(wfrag)) return WM_EALIGN;
     const int nch = (Cin + 15) / 16, mtot = (Cout + 31) / 32;
     const long long total = (long long)nch * ks * ks * mtot * 128;
-    hipLaunchKernelGGL(conv2d_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       weight, (uint4*)wfrag, Cout, Cin, ks * ks, nch, mtot);
+    hipLaunchKernelGGL(conv2d_prep_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       weight, (uint4*)wfrag, Cout, Cin, ks * ks, nch, mtot, (const float*)nullptr);
+    return launch_status();
+}
+
+int wm_conv2d_amax(const float* x, int64_t nx, const float* weight, int64_t nw, float* amax, void* stream) {
+    if (nx < 0 || nw < 0) return WM_EINVAL;
+    if (!amax || (nx > 0 && !x) || (nw > 0 && !weight)) return WM_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(amax, 0, 2 * sizeof(float), st) != hipSuccess) return WM_EHIP;
+    const long long big = (long long)(nx > nw ? nx : nw);
+    if (big == 0) return WM_OK;
+    long long blocks = (big / 4 + 256 * 8 - 1) / (256 * 8);          // >= 8 float4 per thread
+    blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+    hipLaunchKernelGGL(cv_amax2_kernel, dim3((unsigned)blocks, 2), dim3(256), 0, st, x, (long long)nx, weight, (long long)nw, (unsigned*)amax);
+    return launch_status();
+}
+
+int wm_conv2d_prep_f16(const float* weight, const float* amax, void* wfrag, int Cout, int Cin, int ks, void* stream) {
+    if (Cout <= 0 || Cin <= 0) return WM_EINVAL;
+    if (ks != 1 && ks != 3) return WM_EUNSUPPORTED;
+    if (!weight || !wfrag || !amax) return WM_ENULL;
+    if (!aligned16(wfrag)) return WM_EALIGN;
+    const int nch = (Cin + 15) / 16, mtot = (Cout + 31) / 32;
+    const long long total = (long long)nch * ks * ks * mtot * 128;
+    hipLaunchKernelGGL(conv2d_prep_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       weight, (uint4*)wfrag, Cout, Cin, ks * ks, nch, mtot, amax);
     return launch_status();
 }
 
 }  // extern "C"
 
-template <int KS, int RW, int MT, bool G1X1 = false>
+template <int KS, int RW, int MT, bool G1X1 = false, bool F16 = false>
 static int conv2d_launch(const wm::Conv2dArgs& a, int B, hipStream_t st) {
     constexpr int PAD = KS / 2;
     constexpr int smem = ((4 * RW + 2 * PAD) * (wm::kCvTW + 2 * PAD) * 4 + (KS * KS + (G1X1 ? 1 : 0)) * MT * 2 * 64) * 16;   // input planes + weights
     static bool configured[64] = {};
     if (smem > 65536) {
-        const int rc = wm::lds_optin((const void*)wm::conv2d_mfma_kernel<KS, RW, MT, G1X1>, smem, configured);
+        const int rc = wm::lds_optin((const void*)wm::conv2d_mfma_kernel<KS, RW, MT, G1X1, F16>, smem, configured);
         if (rc) return rc;
     }
     const int ntiles = ((a.W + wm::kCvTW - 1) / wm::kCvTW) * ((a.H + 4 * RW - 1) / (4 * RW));
     const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8), (unsigned)B);
-    hipLaunchKernelGGL((wm::conv2d_mfma_kernel<KS, RW, MT, G1X1>), grid, dim3(256), smem, st, a);
+    hipLaunchKernelGGL((wm::conv2d_mfma_kernel<KS, RW, MT, G1X1, F16>), grid, dim3(256), smem, st, a);
     return launch_status();
 }
 
@@ -1867,7 +1892,7 @@ static bool conv_ws_enabled(const wm::Conv2dArgs& a, int B, int th) {
     return ntiles >= 768;
 }
 
-template <int RW, int MT, bool G1X1 = false, bool EPI = false, int NPW = 4>
+template <int RW, int MT, bool G1X1 = false, bool EPI = false, int NPW = 4, bool F16 = false>
 static int conv2d_ws_launch(const wm::Conv2dArgs& a, int B, hipStream_t st) {
     using Cfg = wm::ConvWsCfg<RW, MT, G1X1, NPW>;
     static bool configured[64] = {};
@@ -1878,7 +1903,7 @@ static int conv2d_ws_launch(const wm::Conv2dArgs& a, int B, hipStream_t st) {
     {
         std::lock_guard<std::mutex> lk(mu);
         if (!configured[dev]) {
-            if (hipFuncSetAttribute((const void*)wm::conv3x3_ws_kernel<RW, MT, G1X1, EPI, NPW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute((const void*)wm::conv3x3_ws_kernel<RW, MT, G1X1, EPI, NPW, F16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     Cfg::LDS_BYTES) != hipSuccess) return WM_EHIP;
             if (hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return WM_EHIP;
             configured[dev] = true;
@@ -1888,7 +1913,7 @@ static int conv2d_ws_launch(const wm::Conv2dArgs& a, int B, hipStream_t st) {
     if (ntiles >= (1ll << 31)) return WM_EUNSUPPORTED;
     const int cus = std::max(8, ncu[dev] & ~7);
     const int G = (int)std::min<long long>(cus, ((ntiles + 7) / 8) * 8);
-    hipLaunchKernelGGL((wm::conv3x3_ws_kernel<RW, MT, G1X1, EPI, NPW>), dim3((unsigned)G), dim3(256 + 64 * NPW), Cfg::LDS_BYTES, st, a, B);
+    hipLaunchKernelGGL((wm::conv3x3_ws_kernel<RW, MT, G1X1, EPI, NPW, F16>), dim3((unsigned)G), dim3(256 + 64 * NPW), Cfg::LDS_BYTES, st, a, B);
     return launch_status();
 }
 
@@ -1910,7 +1935,7 @@ int wm_conv2d_fwd(const float* xa, const float* xb, const int* xb_index, const v
     a.xa = xa; a.xb = Cb > 0 ? xb : nullptr; a.xb_idx = Cb > 0 ? xb_index : nullptr; a.wfrag = (const uint4*)wfrag;
     a.bias = bias; a.gate = gate; a.res = residual; a.y = y; a.wfrag1 = nullptr; a.bias1 = nullptr;
     a.Ca = Ca; a.Cb = Cb; a.Cbsrc = Cb_src; a.Cout = Cout; a.H = H; a.W = W;
-    a.nch = (Ca + Cb + 15) / 16; a.mtot = (Cout + 31) / 32;
+    a.nch = (Ca + Cb + 15) / 16; a.mtot = (Cout + 31) / 32; a.amax = nullptr;
     ProfScope ps(ks == 3 ? 13 : 14, st);
     for (int mb = 0; mb < a.mtot;) {
         a.mbase = mb;
@@ -1939,6 +1964,66 @@ int wm_conv2d_fwd(const float* xa, const float* xb, const int* xb_index, const v
     return WM_OK;
 }
 
+// The training form (conv2d.hip.h, fp16 split with per-tensor power-of-two scales): y = conv(x, w) + bias, ks in {1, 3}; wfrag from
+// wm_conv2d_prep_f16 with the SAME amax buffer {max |x|, max |w|} (device floats).
+int wm_conv2d_fwd_f16(const float* x, const void* wfrag, const float* amax, const float* bias, float* y, int B, int Cin, int Cout,
+                      int H, int W, int ks, void* stream) {
+    if (B < 0 || Cin <= 0 || Cout <= 0 || H < 0 || W < 0) return WM_EINVAL;
+    if (ks != 1 && ks != 3) return WM_EUNSUPPORTED;
+    if (B == 0 || H == 0 || W == 0) return WM_OK;
+    if (!x || !wfrag || !y || !amax) return WM_ENULL;
+    if (B > 65535 || (long long)H * W >= (1ll << 31)) return WM_EUNSUPPORTED;
+    if (!aligned16(wfrag)) return WM_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    Conv2dArgs a;
+    a.xa = x; a.xb = nullptr; a.xb_idx = nullptr; a.wfrag = (const uint4*)wfrag;
+    a.bias = bias; a.gate = nullptr; a.res = nullptr; a.y = y; a.wfrag1 = nullptr; a.bias1 = nullptr;
+    a.Ca = Cin; a.Cb = 0; a.Cbsrc = 0; a.Cout = Cout; a.H = H; a.W = W;
+    a.nch = (Cin + 15) / 16; a.mtot = (Cout + 31) / 32; a.amax = amax;
+    ProfScope ps(ks == 3 ? 13 : 14, st);
+    for (int mb = 0; mb < a.mtot;) {
+        a.mbase = mb;
+        const int left = a.mtot - mb;
+        int rc;
+        if (ks == 3) {
+            if (conv_ws_enabled(a, B, 8)) {
+                if (left >= 2) { rc = conv2d_ws_launch<WM_CONV_WS_RW2, 2, false, false, 4, true>(a, B, st); mb += 2; }
+                else { rc = conv2d_ws_launch<WM_CONV_WS_RW1, 1, false, false, WM_CONV_WS_NPW1, true>(a, B, st); mb += 1; }
+            } else if (left >= 2) { rc = conv2d_launch<3, 4, 2, false, true>(a, B, st); mb += 2; }
+            else { rc = conv2d_launch<3, WM_CONV_RW1, 1, false, true>(a, B, st); mb += 1; }
+        } else {
+            if (left >= 3) { rc = conv2d_launch<1, 2, 3, false, true>(a, B, st); mb += 3; }
+            else if (left == 2) { rc = conv2d_launch<1, 4, 2, false, true>(a, B, st); mb += 2; }
+            else { rc = conv2d_launch<1, 4, 1, false, true>(a, B, st); mb += 1; }
+        }
+        if (rc) return rc;
+    }
+    return WM_OK;
+}
+
+// amax + weight fragments + convolution in one call: workspace = [amax (256 B) | wfrag]
+size_t wm_conv2d_f16_workspace_bytes(int Cout, int Cin, int ks) {
+    const size_t f = wm_conv2d_wfrag_bytes(Cout, Cin, ks);
+    return f ? f + 256 : 0;
+}
+
+int wm_conv2d_f16(const float* x, const float* weight, const float* bias, float* y, void* workspace, size_t workspace_bytes,
+                  int B, int Cin, int Cout, int H, int W, int ks, void* stream) {
+    if (B < 0 || Cin <= 0 || Cout <= 0 || H < 0 || W < 0) return WM_EINVAL;
+    if (ks != 1 && ks != 3) return WM_EUNSUPPORTED;
+    if (B == 0 || H == 0 || W == 0) return WM_OK;
+    if (!x || !weight || !y || !workspace) return WM_ENULL;
+    if (!aligned16(workspace)) return WM_EALIGN;
+    if (workspace_bytes < wm_conv2d_f16_workspace_bytes(Cout, Cin, ks)) return WM_EWORKSPACE;
+    float* amax = (float*)workspace;
+    void* wfrag = (char*)workspace + 256;
+    int rc = wm_conv2d_amax(x, (int64_t)B * Cin * H * W, weight, (int64_t)Cout * Cin * ks * ks, amax, stream);
+    if (rc) return rc;
+    rc = wm_conv2d_prep_f16(weight, amax, wfrag, Cout, Cin, ks, stream);
+    if (rc) return rc;
+    return wm_conv2d_fwd_f16(x, wfrag, amax, bias, y, B, Cin, Cout, H, W, ks, stream);
+}
+
 int wm_conv2d_gated_fwd(const float* xa, const float* xb, const int* xb_index, const void* wfrag3, const void* wfrag1,
                         const float* bias1, float* y, int B, int Ca, int Cb, int Cb_src, int Cout, int H, int W,
                         void* stream) {
@@ -1954,7 +2039,7 @@ int wm_conv2d_gated_fwd(const float* xa, const float* xb, const int* xb_index, c
     a.xa = xa; a.xb = Cb > 0 ? xb : nullptr; a.xb_idx = Cb > 0 ? xb_index : nullptr; a.wfrag = (const uint4*)wfrag3;
     a.bias = nullptr; a.gate = nullptr; a.res = nullptr; a.y = y; a.wfrag1 = (const uint4*)wfrag1; a.bias1 = bias1;
     a.Ca = Ca; a.Cb = Cb; a.Cbsrc = Cb_src; a.Cout = Cout; a.H = H; a.W = W;
-    a.nch = (Ca + Cb + 15) / 16; a.mtot = (Cout + 31) / 32;
+    a.nch = (Ca + Cb + 15) / 16; a.mtot = (Cout + 31) / 32; a.amax = nullptr;
     ProfScope ps(13, st);
     for (int mb = 0; mb < a.mtot;) {
         // two accumulator sets per wave: 64 channels x 8-row tiles read the input once (0.79 ms against 0.90 ms for

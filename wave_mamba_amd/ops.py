@@ -1076,6 +1076,41 @@ def conv2d(x, weight, bias=None, x2=None, x2_index=None, gate=None, residual=Non
     return y
 
 
+_F16_WS = {}
+
+
+def _f16_ws_bytes(lib, cout, cin, ks):
+    key = (cout, cin, ks)
+    n = _F16_WS.get(key)
+    if n is None:
+        n = _F16_WS[key] = int(lib.wm_conv2d_f16_workspace_bytes(cout, cin, ks))
+    return n
+
+
+def conv2d_f16(x, weight, bias=None):
+    """y = F.conv2d(x, weight, bias, stride=1, padding=ks // 2), ks in {1, 3}, NCHW fp32, on the fp16 matrix cores with a
+    two-term split of both operands and per-tensor power-of-two scales (csrc/conv2d.hip.h): ~1e-7 relative to the fp64
+    result - the training step's form (forward, and the input gradient on the transposed, flipped weight).  Four launches:
+    memset + the two largest magnitudes, weight fragments, convolution; nothing synchronises the host.  Forward only."""
+    lib = _lib.load()
+    _require_cuda("conv2d_f16", x, weight, bias)
+    B, Cin, H, W = x.shape
+    cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
+    if weight.dim() != 4 or weight.shape[3] != ks or ks not in (1, 3) or cin != Cin:
+        raise RuntimeError(f"conv2d_f16: weight {tuple(weight.shape)} does not fit x {tuple(x.shape)} (ks in (1, 3))")
+    if x.dtype != torch.float32 or weight.dtype != torch.float32:
+        raise RuntimeError("conv2d_f16: float32 only")
+    x = x.contiguous()
+    w = weight.detach().contiguous()
+    nws = _f16_ws_bytes(lib, cout, cin, ks)
+    ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+    y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.wm_conv2d_f16(_ptr(x), _ptr(w), _ptr(None if bias is None else bias.detach().contiguous()), _ptr(y), _ptr(ws), nws,
+                                B, cin, cout, H, W, ks, _stream()), "wm_conv2d_f16")
+    return y
+
+
 def conv2d_gated(x, weight3, weight1, bias1=None, x2=None, x2_index=None):
     """conv3x3(X; weight3) * sigmoid(conv1x1(X; weight1) + bias1) with X as in `conv2d` - PAConv's k3(x) * sigmoid(k2(x))
     (reference wavemamba_arch.py:694-697) in one kernel.  weight3 (Cout, Cin, 3, 3) without bias, weight1
@@ -1163,13 +1198,16 @@ def plane_sums(x):
 
 class _Conv2dTrain(torch.autograd.Function):
     """Dense 3x3 / 1x1 convolution (stride 1, 'same' padding) for training: forward and input gradient on the
-    matrix-core kernel (the input gradient is the same convolution with the weight transposed and flipped), weight and
-    bias gradients from ATen's convolution_backward (MIOpen / hipBLASLt)."""
+    matrix-core kernels (the input gradient is the same convolution with the weight transposed and flipped) - the fp16 form
+    (f16, conv2d_f16) or the inference kernels' split-bf16 form; weight and bias gradients from _conv_weight_grad / plane_sums."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, f16):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.f16 = f16
+        if f16:
+            return conv2d_f16(x.detach(), weight.detach(), None if bias is None else bias.detach())
         return conv2d(x.detach(), weight.detach(), None if bias is None else bias.detach())
 
     @staticmethod
@@ -1179,12 +1217,12 @@ class _Conv2dTrain(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wt = weight.detach().transpose(0, 1).flip(2, 3).contiguous()          # (Cin, Cout, ks, ks)
-            gx = conv2d(gy, wt, None, dynamic_weight=True)
+            gx = conv2d_f16(gy, wt) if ctx.f16 else conv2d(gy, wt, None, dynamic_weight=True)
         if ctx.needs_input_grad[1]:
             gw = _conv_weight_grad(gy, x, weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = plane_sums(gy)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 # Weight gradients of the dense convolutions in training: the HIP kernel (conv_wgrad.hip.h: K = positions on the bf16 matrix
@@ -1273,36 +1311,51 @@ class _Conv2dAten(torch.autograd.Function):
         return gx, gw, gb
 
 
-# Training convolutions.  The split-bf16 matrix-core kernel carries 16 significant bits per operand (3-4e-6 relative on an
-# output): right for inference (the contract's bar is 1e-4 on outputs), but in the training step those 3e-6 on the
-# activations become ~1e-4 on the parameter gradients of the deepest block, whose 8 x 8 maps make every gradient a short
-# cancelling sum - measured against the float64 evaluation of the reference (tools/grad_localize.py): prediction 2.8e-6 /
-# worst gradient tensor 1.1e-4 with it, 7.7e-8 / 1.4e-5 with fp32 convolutions (the reference's own fp32: 9.7e-8 / 6e-6).
-# So autograd takes ATen's fp32 convolutions (MIOpen) unless the fast mode is asked for.
-_TRAIN_CONV_BF16X3 = os.environ.get("WM_TRAIN_CONV_BF16X3", "0") == "1"
+# Training convolutions (forward + input gradient; weight / bias gradients: _conv_weight_grad, plane_sums).  Modes:
+#   "auto"    (default) per call, whichever of the next two is faster at that shape (tools/bench_conv_train.py on MI355X,
+#             profiles/r04/bench_conv_train.txt): the fp16 form for 3x3 convolutions over >= 2^17 positions and 1x1 over >= 2^19
+#             (BASELINE config 3's level-1 / level-2 and full-resolution maps: 3x3 64 -> 64 at 8 x 256 x 256 0.137 against
+#             0.371 ms, 32 -> 96 0.130 / 0.306, 64 -> 64 at 128 x 128 0.066 / 0.099, 1x1 32 -> 64 0.066 / 0.119), ATen below that
+#             (8 x 64 x 64 maps: three launches cost more than MIOpen's one: 0.055 against 0.032 ms);
+#   "f16"     always the fp16 form of the matrix-core kernels: two-term split, per-tensor power-of-two scales - 22 significant
+#             bits per operand, fp32-class (conv2d_f16): a training step without MIOpen / hipBLASLt in it;
+#   "aten"    always ATen's fp32 convolutions (MIOpen Winograd / hipBLASLt): the mode of rounds 3-4a, kept as the cross-check;
+#   "bf16x3"  the inference kernels' split-bf16 form: 16 significant bits per operand (3-4e-6 on an output) - right for
+#             inference (the contract's bar is 1e-4 on outputs), but in the training step those 3e-6 on the activations become
+#             ~1e-4 on the parameter gradients of the deepest block, whose 8 x 8 maps make every gradient a short cancelling sum
+#             (tools/grad_localize.py: prediction 2.8e-6 / worst gradient tensor 1.1e-4 with it, 7.7e-8 / 1.4e-5 with fp32
+#             convolutions; the reference's own fp32: 9.7e-8 / 6e-6).  Never the default.
+# WM_TRAIN_CONV=<mode> in the environment, or set_train_conv_mode().
+_TRAIN_CONV_MODES = ("auto", "f16", "aten", "bf16x3")
+_TRAIN_CONV_MODE = os.environ.get("WM_TRAIN_CONV", "bf16x3" if os.environ.get("WM_TRAIN_CONV_BF16X3", "0") == "1" else "auto")
+if _TRAIN_CONV_MODE not in _TRAIN_CONV_MODES:
+    raise RuntimeError(f"WM_TRAIN_CONV={_TRAIN_CONV_MODE!r}: one of {_TRAIN_CONV_MODES}")
 
 
-def set_train_conv_bf16x3(on):
-    """True: forward and input gradient of the dense convolutions on the split-bf16 matrix-core kernel in training too
-    (8 ms of a 110-ms step at 8 x 512 x 512 faster, parameter gradients to ~1e-4 instead of ~1e-5).  Returns the old value."""
-    global _TRAIN_CONV_BF16X3
-    prev, _TRAIN_CONV_BF16X3 = _TRAIN_CONV_BF16X3, bool(on)
+def set_train_conv_mode(mode):
+    """Select how autograd's dense convolutions run (see above).  Returns the previous mode."""
+    global _TRAIN_CONV_MODE
+    if mode not in _TRAIN_CONV_MODES:
+        raise ValueError(f"set_train_conv_mode: {mode!r} is not one of {_TRAIN_CONV_MODES}")
+    prev, _TRAIN_CONV_MODE = _TRAIN_CONV_MODE, mode
     return prev
 
 
-def conv2d_train_enabled():
-    return _TRAIN_CONV_BF16X3
+def train_conv_mode():
+    return _TRAIN_CONV_MODE
 
 
 def conv2d_train(x, weight, bias=None):
-    """F.conv2d(x, weight, bias, stride=1, padding=ks // 2) with autograd: ATen's fp32 convolution, or - fast mode,
-    set_train_conv_bf16x3(True) - the split-bf16 matrix-core kernel for forward and input gradient (_Conv2dTrain)."""
+    """F.conv2d(x, weight, bias, stride=1, padding=ks // 2) with autograd, in the mode set_train_conv_mode() selects."""
     _require_cuda("conv2d_train", x, weight, bias)
-    if not _TRAIN_CONV_BF16X3:
+    mode = _TRAIN_CONV_MODE
+    if mode == "auto":
+        mode = "f16" if x.shape[0] * x.shape[2] * x.shape[3] >= ((1 << 17) if weight.shape[2] == 3 else (1 << 19)) else "aten"
+    if mode == "aten":
         if not ((bias is not None and bias.requires_grad) or weight.requires_grad):
             return F.conv2d(x.float(), weight, bias, stride=1, padding=weight.shape[2] // 2)
         return _Conv2dAten.apply(x.float(), weight, bias)
-    return _Conv2dTrain.apply(x.contiguous().float(), weight, bias)
+    return _Conv2dTrain.apply(x.contiguous().float(), weight, bias, mode == "f16")
 
 
 def conv2d_supported(x, weight, x2=None):
