@@ -196,6 +196,16 @@ int wm_lfss_mid_fwd(const void* ysum, int ny, int64_t ystride, const void* z, co
                     const float* ln2_w, const float* ln2_b, float ln2_eps,
                     const float* conv1_weight, const float* conv1_bias,
                     float* tok1, void* f, int B, int64_t L, int C, int plane_dtype, void* stream);
+/* wm_lfss_mid_fwd with the gate RECOMPUTED from `tok` instead of read: z = in_proj(ln_1(tok))[..., D:2D] (:485-486) on the
+ * matrix cores, in the matrix-instruction order of wm_lfss_in_fwd (fp32 planes: bit-identical results).  With it
+ * wm_lfss_in_fwd is called with z = NULL (the gate half is never written): 512 fewer bytes per position of the block's 3456.
+ * C == 32 only (WM_EUNSUPPORTED otherwise). */
+int wm_lfss_mid_rz_fwd(const void* ysum, int ny, int64_t ystride, const float* tok, int tok_nchw, const float* ln1_w,
+                       const float* ln1_b, float ln1_eps, const float* in_proj_weight, const float* out_norm_w,
+                       const float* out_norm_b, float out_norm_eps, const float* out_proj_weight,
+                       const float* skip_scale, const float* ln2_w, const float* ln2_b, float ln2_eps,
+                       const float* conv1_weight, const float* conv1_bias, float* tok1, void* f, int B, int64_t L,
+                       int C, int plane_dtype, void* stream);
 int wm_lfss_out_fwd(const void* fc, const float* tok1, const float* conv3_weight, const float* conv3_bias,
                     const float* skip_scale2, float* out, int out_nchw, int B, int64_t L, int C, int plane_dtype,
                     void* stream);

@@ -651,6 +651,36 @@ def test_lfss_block_golden(golden):
     assert_close(y, g["y"], TOL, "LFSSBlock (fused HIP path)")
 
 
+@pytest.mark.parametrize("B,H,W,nchw", [(1, 40, 96, True), (2, 33, 32, False), (1, 272, 480, True), (2, 5, 64, False), (1, 1, 32, True)])
+def test_lfss_block_recomputed_gate_bit_identical(B, H, W, nchw):
+    """The block with the gate z recomputed inside lfss_mid from the tokens (wm_lfss_mid_rz_fwd; lfss_in writes the x half only)
+    against the block with z written by lfss_in and read back: the same matrix instructions in the same order - equal bit for bit
+    on fp32 planes; bf16 planes: the recomputed gate skips one bf16 rounding (compared at the bf16-storage bar)."""
+    torch.manual_seed(H)
+    blk = arch.LFSSBlock(32, expand=2.0).eval().to(DEV)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+        x = torch.randn(B, 32, H, W, device=DEV) if nchw else torch.randn(B, H * W, 32, device=DEV)
+        outs = {}
+        for rz in (True, False):
+            prev, wm.ops._RECOMPUTE_Z = wm.ops._RECOMPUTE_Z, rz
+            try:
+                outs[rz] = wm.ops.lfss_block_forward(x, (H, W), blk, tok_nchw=nchw, out_nchw=nchw)
+                if W % 4 == 0:
+                    pd = wm.ops.set_plane_dtype(torch.bfloat16)
+                    try:
+                        outs[(rz, "bf16")] = wm.ops.lfss_block_forward(x, (H, W), blk, tok_nchw=nchw, out_nchw=nchw)
+                    finally:
+                        wm.ops.set_plane_dtype(pd)
+            finally:
+                wm.ops._RECOMPUTE_Z = prev
+    assert torch.equal(outs[True], outs[False]), f"recomputed gate: max abs difference {float((outs[True] - outs[False]).abs().max()):.3e}"
+    if (True, "bf16") in outs:
+        assert_close(outs[(True, "bf16")], outs[False], 2e-2, "bf16 planes, recomputed gate vs fp32")
+        assert_close(outs[(True, "bf16")], outs[(False, "bf16")], 1e-2, "bf16 planes, recomputed vs stored gate")
+
+
 @pytest.mark.parametrize("C,H,W", [(32, 40, 72), (32, 33, 31), (32, 5, 7), (16, 17, 23), (8, 64, 64)])
 def test_lfss_block_fused_vs_module_path(C, H, W):
     """fused block kernels vs the same block evaluated through the PyTorch modules + HIP scan."""

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("WAVEMAMBA_HIP_LIB") or os.path.join(HERE, "libwavemam
 WM_F32, WM_BF16 = 0, 1
 WM_OK, WM_EINVAL, WM_ENULL, WM_EALIGN, WM_EWORKSPACE, WM_EUNSUPPORTED, WM_EHIP = 0, -1, -2, -3, -4, -5, -6
 WM_PROF_NKERNELS = 20
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _c = ctypes
 _p, _i, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
@@ -38,6 +38,8 @@ SIGNATURES = {
     "wm_ss2d_core_bwd": (_i, [_p] * 16 + [_p, _sz] + [_i] * 6 + [_p]),
     "wm_lfss_in_fwd": (_i, [_p, _i, _p, _p, _c.c_float, _p, _p, _p, _i, _i64, _i, _i, _p]),
     "wm_lfss_in_conv_fwd": (_i, [_p, _i, _p, _p, _c.c_float, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "wm_lfss_mid_rz_fwd": (_i, [_p, _i, _i64, _p, _i, _p, _p, _c.c_float, _p, _p, _p, _c.c_float, _p, _p, _p, _p, _c.c_float, _p, _p,
+                               _p, _p, _i, _i64, _i, _i, _p]),
     "wm_lfss_mid_fwd": (_i, [_p, _i, _i64, _p, _p, _i, _p, _p, _c.c_float, _p, _p, _p, _p, _c.c_float, _p, _p, _p, _p,
                              _i, _i64, _i, _i, _p]),
     "wm_lfss_out_fwd": (_i, [_p] * 6 + [_i, _i, _i64, _i, _i, _p]),

@@ -117,21 +117,45 @@ __device__ __forceinline__ void store_rows64(TP* __restrict__ plane0 /* channel 
 // ---- lfss_mid: ysum, z, tok -> tok1 (B, L, C), f (B, D, L) -------------------------------------------
 // NY = 1: merged core output; NY = 4: the four directions' outputs, added here (:490).  TP: storage type of the y / z / f
 // planes (float, or bf16_t in the bf16-storage mode)
-template <int NY, typename TP = float>
+// RZ: the gate z = in_proj(ln_1(tok))[D:2D] (:485-486) is RECOMPUTED here from the token tile this kernel reads anyway for
+// the skip connection, instead of being written by lfss_in and read back (512 B per position of the block's 3456): the same
+// A operands (W_in rows D.. x ln_1.weight), the same normalised tile as B operands, the same matrix-instruction order and bias
+// start as lfss_in_mfma_kernel - bit-identical z in fp32 storage - with the output ROWS permuted so that accumulator
+// register i of row block mt IS channel 2 (16 mt + i) + h: the layout the out_norm'ed y has after its half-wave swap.
+template <int NY, typename TP = float, bool RZ = false>
 __global__ __launch_bounds__(256, WM_LFSS_MID_WAVES) void lfss_mid_mfma_kernel(
     const TP* __restrict__ ysum, long long ystride, const TP* __restrict__ z, const float* __restrict__ tok, int tok_nchw,
     const float* __restrict__ on_w, const float* __restrict__ on_b, float on_eps,
     const float* __restrict__ W_out /*(C, D)*/, const float* __restrict__ skip1,
     const float* __restrict__ ln2_w, const float* __restrict__ ln2_b, float ln2_eps,
     const float* __restrict__ W1 /*(D, C)*/, const float* __restrict__ b1,
-    float* __restrict__ tok1, TP* __restrict__ f, int B, long long L, int ngl, long long ngroups, int gpw) {
+    float* __restrict__ tok1, TP* __restrict__ f, int B, long long L, int ngl, long long ngroups, int gpw,
+    const float* __restrict__ ln1_w = nullptr, const float* __restrict__ ln1_b = nullptr, float ln1_eps = 0.0f,
+    const float* __restrict__ W_in = nullptr /*(2D, C)*/) {
     constexpr int C = 32, D = 64;
     __shared__ __attribute__((aligned(16))) float s_skip[C];
     __shared__ __attribute__((aligned(16))) float s_b1[D];
     __shared__ __attribute__((aligned(16))) float s_Aout[(D / 2) * 64];          // 32 operands x 64 lanes
     __shared__ __attribute__((aligned(16))) float s_A1[2 * (C / 2) * 64];        // 2 row blocks x 16 operands
+    __shared__ __attribute__((aligned(16))) float s_Az[RZ ? 2 * (C / 2) * 64 : 4];   // RZ: the gate's 2 row blocks x 16 operands
+    __shared__ __attribute__((aligned(16))) float s_bz[RZ ? D : 4];             // RZ: [half h][row block][register]
     const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (RZ) {
+        for (int e = threadIdx.x; e < 2 * (C / 2) * 64; e += 256) {
+            const int mt = e >> 10, j = (e >> 6) & 15, l = e & 63;
+            const int k = acc_chan(j, l >> 5), r = l & 31;
+            const int c = 2 * (16 * mt + (r & 3) + 4 * (r >> 3)) + ((r >> 2) & 1);   // the gate channel MFMA row r of block mt computes
+            s_Az[aop_slot(mt * 16 + j, l)] = W_in[(D + c) * C + k] * ln1_w[k];
+        }
+        if (threadIdx.x >= 128 && threadIdx.x < 128 + D) {
+            const int m = threadIdx.x - 128, hh = m >> 5, mt = (m >> 4) & 1, i = m & 15;
+            const int c = 2 * (16 * mt + i) + hh;
+            float acc = 0.0f;
+            for (int k = 0; k < C; ++k) acc = fmaf(W_in[(D + c) * C + k], ln1_b[k], acc);
+            s_bz[m] = acc;
+        }
+    }
     if (threadIdx.x < C) s_skip[threadIdx.x] = skip1[threadIdx.x];
     if (threadIdx.x >= 64 && threadIdx.x < 64 + D) {
         const int m = threadIdx.x - 64;
@@ -189,6 +213,14 @@ __global__ __launch_bounds__(256, WM_LFSS_MID_WAVES) void lfss_mid_mfma_kernel(
 #pragma unroll
         for (int d = 0; d < D; ++d) { const float q = y[d] - mean; var = fmaf(q, q, var); }
         const float rstd = rsqrtf(var * (1.0f / D) + on_eps);
+        if constexpr (RZ) {
+#pragma unroll
+            for (int d0 = 0; d0 < D; d0 += 8) {          // (eight channels' scalar weights at a time: all 128 at once spill)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) y[d0 + i] = fmaf((y[d0 + i] - mean) * rstd, on_w[d0 + i], on_b[d0 + i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
         // z in explicit double-buffered batches: left to itself the compiler issues the 64 loads one at a time, each
         // followed by its wait (64 serialised round trips per group)
         constexpr int ZB = 8;
@@ -206,6 +238,7 @@ __global__ __launch_bounds__(256, WM_LFSS_MID_WAVES) void lfss_mid_mfma_kernel(
             for (int i = 0; i < ZB; ++i)
                 y[d0 + i] = fmaf((y[d0 + i] - mean) * rstd, on_w[d0 + i], on_b[d0 + i]) * silu_fast(zb[cur][i]);
         }
+        }
         // ---- B operands of the two tiles ----
 #pragma unroll
         for (int j = 0; j < D / 2; ++j) {
@@ -213,6 +246,36 @@ __global__ __launch_bounds__(256, WM_LFSS_MID_WAVES) void lfss_mid_mfma_kernel(
                                                             false, false);
             y[2 * j] = __uint_as_float(r[0]);           // tile 0: positions p0 + n,      channels 2j + h
             y[2 * j + 1] = __uint_as_float(r[1]);       // tile 1: positions p0 + 32 + n, channels 2j + h
+        }
+        if constexpr (RZ) {
+            // ---- the gate, recomputed in the layout y now has: y[2 j + t] *= silu(z[channel 2 j + h] at tile t's position).
+            // One tile at a time (16 + 16 live registers beside y's 64; both tiles at once spilled 22)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                __builtin_amdgcn_sched_barrier(0);       // the tile's loads stay here (hoisted above out_norm they spill)
+                float nt[16];
+                load_tile32(tok, tok_nchw != 0, b, min(p0 + 32 * t + n, L - 1), L, h, nt);
+                tile_normalise(nt, ln1_eps);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    lfss_v16f za;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const float4 bb = *reinterpret_cast<const float4*>(&s_bz[(h * 2 + mt) * 16 + 4 * gq]);
+                        za[4 * gq] = bb.x; za[4 * gq + 1] = bb.y; za[4 * gq + 2] = bb.z; za[4 * gq + 3] = bb.w;
+                    }
+#pragma unroll
+                    for (int j4 = 0; j4 < C / 8; ++j4) {
+                        const float4 a4 = *reinterpret_cast<const float4*>(&s_Az[((mt * 4 + j4) * 64 + lane) * 4]);
+                        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+                            za = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], nt[4 * j4 + jj], za, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) y[2 * (16 * mt + i) + t] *= silu_fast(za[i]);
+                }
+            }
         }
         lfss_v16f acc[2];
 #pragma unroll
@@ -318,6 +381,7 @@ __global__ __launch_bounds__(256, WM_LFSS_IN_WAVES) void lfss_in_mfma_kernel(
         if (gi + 1 < gpw && g + 4 < ngroups) load_tok(g + 4);       // ahead of this group's 128 stores
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
+            if (mt >= 2 && !z) break;                    // z == nullptr: the consumer recomputes the gate (lfss_mid, RZ)
             lfss_v16f acc[2];
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {

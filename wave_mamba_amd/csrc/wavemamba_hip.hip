@@ -222,7 +222,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 21; }
+int wm_abi_version(void) { return 22; }
 
 #ifndef WM_BUILD_ID
 #define WM_BUILD_ID "unknown"
@@ -1223,7 +1223,8 @@ int wm_lfss_in_fwd(const float* tok, int tok_nchw, const float* ln_w, const floa
     if (B < 0 || L < 0) return WM_EINVAL;
     if (plane_dtype != WM_F32 && !(plane_dtype == WM_BF16 && C == 32)) return WM_EUNSUPPORTED;    // bf16 planes: C = 32 kernels
     float* x = (float*)x_; float* z = (float*)z_;
-    if (B && L && (!tok || !ln_w || !ln_b || !in_proj_weight || !x || !z)) return WM_ENULL;
+    // z == NULL (C == 32 only): the gate half is not written - the block's wm_lfss_mid_rz_fwd recomputes it
+    if (B && L && (!tok || !ln_w || !ln_b || !in_proj_weight || !x || (!z && C != 32))) return WM_ENULL;
     if (!tok_nchw && !aligned16(tok)) return WM_EALIGN;
     if (C == 32 && B && L) {
         const int ngl = (int)((L + 63) / 64);
@@ -1313,6 +1314,37 @@ int wm_lfss_mid_fwd(const void* ysum_, int ny, int64_t ystride, const void* z_, 
     }
     WM_LFSS_DISPATCH(9, lfss_mid_kernel, ysum, ny, (long long)ystride, z, tok, tok_nchw, out_norm_w, out_norm_b, out_norm_eps, out_proj_weight,
                      skip_scale, ln2_w, ln2_b, ln2_eps, conv1_weight, conv1_bias, tok1, f, B, (long long)L);
+}
+
+// wm_lfss_mid_fwd with the gate z RECOMPUTED from `tok` (ln_1 + in_proj rows [D, 2D) on the matrix cores, bit-identical to
+// wm_lfss_in_fwd's z in fp32 planes) instead of read: C == 32 only (WM_EUNSUPPORTED otherwise: callers keep z and wm_lfss_mid_fwd).
+int wm_lfss_mid_rz_fwd(const void* ysum_, int ny, int64_t ystride, const float* tok, int tok_nchw, const float* ln1_w,
+                       const float* ln1_b, float ln1_eps, const float* in_proj_weight, const float* out_norm_w,
+                       const float* out_norm_b, float out_norm_eps, const float* out_proj_weight,
+                       const float* skip_scale, const float* ln2_w, const float* ln2_b, float ln2_eps,
+                       const float* conv1_weight, const float* conv1_bias, float* tok1, void* f_, int B, int64_t L,
+                       int C, int plane_dtype, void* stream) {
+    if (B < 0 || L < 0 || (ny != 1 && ny != 4)) return WM_EINVAL;
+    if (C != 32 || (plane_dtype != WM_F32 && plane_dtype != WM_BF16)) return WM_EUNSUPPORTED;
+    if (B == 0 || L == 0) return WM_OK;
+    if (!ysum_ || !tok || !ln1_w || !ln1_b || !in_proj_weight || !out_norm_w || !out_norm_b || !out_proj_weight || !skip_scale ||
+        !ln2_w || !ln2_b || !conv1_weight || !conv1_bias || !tok1 || !f_) return WM_ENULL;
+    if ((!tok_nchw && !aligned16(tok)) || !aligned16(tok1)) return WM_EALIGN;
+    const int ngl = (int)((L + 63) / 64);
+    const long long ngroups = (long long)B * ngl;
+    const int gpw = lfss_groups_per_wave(ngroups, 1024 * WM_LFSS_MID_WAVES);
+    const long long waves = (ngroups + gpw - 1) / gpw;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(9, st);
+#define WM_MIDZ(NY, TP) hipLaunchKernelGGL((lfss_mid_mfma_kernel<NY, TP, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, \
+                           (const TP*)ysum_, (long long)ystride, (const TP*)nullptr, tok, tok_nchw,                                  \
+                           out_norm_w, out_norm_b, out_norm_eps, out_proj_weight, skip_scale, ln2_w, ln2_b, ln2_eps,                 \
+                           conv1_weight, conv1_bias, tok1, (TP*)f_, B, (long long)L, ngl, ngroups, gpw, ln1_w, ln1_b, ln1_eps,       \
+                           in_proj_weight)
+    if (plane_dtype == WM_F32) { if (ny == 4) WM_MIDZ(4, float); else WM_MIDZ(1, float); }
+    else { if (ny == 4) WM_MIDZ(4, bf16_t); else WM_MIDZ(1, bf16_t); }
+#undef WM_MIDZ
+    return launch_status();
 }
 
 int wm_lfss_out_fwd(const void* fc_, const float* tok1, const float* conv3_weight, const float* conv3_bias,

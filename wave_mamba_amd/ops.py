@@ -466,6 +466,9 @@ _FUSE_OUT_CONV = True      # tests / tools: False takes wm_dwconv3x3_fwd + wm_lf
 # SIMD waiting on their own loads and stores (VALU active 0.19 of a wave's life, PMC in the same file), where the two
 # kernels keep 13-16 short waves per SIMD streaming at 3.9 TB/s.  Off by default; WM_FUSE_IN_CONV=1 takes it.
 _FUSE_IN_CONV = os.environ.get("WM_FUSE_IN_CONV", "0") == "1"
+# The gate z = in_proj(ln_1(x))[D:] recomputed by lfss_mid from the tokens instead of written by lfss_in and read back
+# (512 of the block's 3456 B per position; bit-identical in fp32 planes: tests/test_gpu_parity.py).  0: round-3 data flow.
+_RECOMPUTE_Z = os.environ.get("WM_LFSS_RECOMPUTE_Z", "1") == "1"
 
 
 def lfss_prologue(tok, x_size, blk, tok_nchw=False, fused=True):
@@ -513,7 +516,10 @@ def lfss_block_forward(tok, x_size, blk, tok_nchw=False, out_nchw=False):
     # bf16 planes: the C = 32 kernels on maps with 16-byte tile accesses (W % 4 == 0); else fp32 planes
     pd = _PLANE_DTYPE if (C == 32 and W % 4 == 0) else torch.float32
     code = WM_F32 if pd == torch.float32 else WM_BF16
-    z = torch.empty((B, D, L), dtype=pd, device=dev)
+    # C == 32: the gate z is recomputed by the block's middle kernel from the tokens it reads anyway (wm_lfss_mid_rz_fwd, bit-identical
+    # in fp32 planes) - lfss_in writes the x half only; WM_LFSS_RECOMPUTE_Z=0 keeps the written / re-read z
+    rz = C == 32 and _RECOMPUTE_Z and not _FUSE_IN_CONV
+    z = None if rz else torch.empty((B, D, L), dtype=pd, device=dev)
     if C == 32 and _FUSE_IN_CONV:
         # ln_1 -> in_proj -> depth-wise 3x3 -> SiLU in one kernel: x (in_proj's first half) never reaches HBM
         xc = torch.empty((B, D, H, W), dtype=pd, device=dev)
@@ -535,11 +541,19 @@ def lfss_block_forward(tok, x_size, blk, tok_nchw=False, out_nchw=False):
     tok1 = torch.empty((B, L, C), dtype=torch.float32, device=dev)
     f = torch.empty((B, D, H, W), dtype=pd, device=dev)
     with torch.cuda.device(dev):
-        check(lib.wm_lfss_mid_fwd(_ptr(y4[0]), 4, B * D * L, _ptr(z), _ptr(tok), int(tok_nchw), _ptr(_w(ss.out_norm.weight)),
-                                  _ptr(_w(ss.out_norm.bias)), float(ss.out_norm.eps), _ptr(_w(ss.out_proj.weight)),
-                                  _ptr(_w(blk.skip_scale)), _ptr(_w(blk.ln_2.weight)), _ptr(_w(blk.ln_2.bias)),
-                                  float(blk.ln_2.eps), _ptr(_w(ff.conv1.weight)), _ptr(_w(ff.conv1.bias)),
-                                  _ptr(tok1), _ptr(f), B, L, C, code, st), "wm_lfss_mid_fwd")
+        if rz:
+            check(lib.wm_lfss_mid_rz_fwd(_ptr(y4[0]), 4, B * D * L, _ptr(tok), int(tok_nchw), _ptr(_w(blk.ln_1.weight)),
+                                         _ptr(_w(blk.ln_1.bias)), float(blk.ln_1.eps), _ptr(_w(ss.in_proj.weight)),
+                                         _ptr(_w(ss.out_norm.weight)), _ptr(_w(ss.out_norm.bias)), float(ss.out_norm.eps),
+                                         _ptr(_w(ss.out_proj.weight)), _ptr(_w(blk.skip_scale)), _ptr(_w(blk.ln_2.weight)),
+                                         _ptr(_w(blk.ln_2.bias)), float(blk.ln_2.eps), _ptr(_w(ff.conv1.weight)),
+                                         _ptr(_w(ff.conv1.bias)), _ptr(tok1), _ptr(f), B, L, C, code, st), "wm_lfss_mid_rz_fwd")
+        else:
+            check(lib.wm_lfss_mid_fwd(_ptr(y4[0]), 4, B * D * L, _ptr(z), _ptr(tok), int(tok_nchw), _ptr(_w(ss.out_norm.weight)),
+                                      _ptr(_w(ss.out_norm.bias)), float(ss.out_norm.eps), _ptr(_w(ss.out_proj.weight)),
+                                      _ptr(_w(blk.skip_scale)), _ptr(_w(blk.ln_2.weight)), _ptr(_w(blk.ln_2.bias)),
+                                      float(blk.ln_2.eps), _ptr(_w(ff.conv1.weight)), _ptr(_w(ff.conv1.bias)),
+                                      _ptr(tok1), _ptr(f), B, L, C, code, st), "wm_lfss_mid_fwd")
     out = torch.empty((B, C, H, W) if out_nchw else (B, L, C), dtype=torch.float32, device=dev)
     if C == 32 and W % 32 == 0 and _FUSE_OUT_CONV:
         # the ffn's depth-wise 3x3 inside the closing kernel: fc (conv2's output) never reaches HBM
