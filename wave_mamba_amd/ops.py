@@ -662,8 +662,9 @@ class _DWConvTrain(torch.autograd.Function):
         gy = gy.contiguous().float()
         B, C, H, W = x.shape
         gx = dwconv3x3(gy, weight.detach().flip(2, 3).contiguous(), None, "none")
-        dW = torch.empty_like(weight, dtype=torch.float32)
-        db = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        buf = torch.empty(10 * C, dtype=torch.float32, device=x.device)         # dW | db back to back: one memset in the library
+        dW = buf[:9 * C].view(weight.shape)
+        db = buf[9 * C:] if ctx.has_bias else None
         with torch.cuda.device(x.device):
             check(lib.wm_dwconv3x3_wgrad(_ptr(x.contiguous()), _ptr(gy), _ptr(dW), _ptr(db), B, C, H, W, _stream()),
                   "wm_dwconv3x3_wgrad")
@@ -692,8 +693,8 @@ class _LayerNorm2dTrain(torch.autograd.Function):
         B, C, H, W = x.shape
         gy = gy.contiguous().float()
         gx = torch.empty_like(x)
-        dw = torch.empty(C, dtype=torch.float32, device=x.device)
-        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        buf = torch.empty(2 * C, dtype=torch.float32, device=x.device)          # dweight | dbias back to back: one memset
+        dw, db = buf[:C], buf[C:]
         with torch.cuda.device(x.device):
             check(lib.wm_layernorm2d_bwd(_ptr(x), _ptr(_w(weight)), _ptr(gy), ctx.eps, _ptr(gx), _ptr(dw), _ptr(db),
                                          B, H * W, C, _stream()), "wm_layernorm2d_bwd")
