@@ -33,7 +33,20 @@
 #define WM_BWD_DX_LATE 0         // experiment: keep the dx product in registers across one more workgroup barrier before adding it
 #endif
 
+#ifndef WM_BWD_STAMP
+#define WM_BWD_STAMP 0           // diagnostics: cycle totals per phase of core_bwd_chunk_kernel (tools/core_bwd_stamps.py)
+#endif
+
 namespace wm {
+
+#if WM_BWD_STAMP
+// [REV][wave (2)][phase (10) | chunks]: cycle totals summed over workgroups (one set of atomics per wave and workgroup - one
+// atomic per stamp serialises the chip: 1.3 M atomics on 40 words made a chunk look like 175 k cycles)
+__device__ unsigned long long g_bwd_stamps[2 * 2 * 11];
+#define BWD_STAMP(ph) do { const unsigned long long now_ = __builtin_readcyclecounter(); st_acc[ph] += now_ - st_prev; st_prev = now_; } while (0)
+#else
+#define BWD_STAMP(ph) do { } while (0)
+#endif
 
 // The accumulator of a v_mfma chain, about to be read by a VALU / LDS instruction.  The compiler's own wait (s_nop 6 behind
 // v_mfma_f32_16x16x32_bf16) left the lanes 48..63 of the dx product stale now and then on MI355X (tools/debug_core_bwd.py:
@@ -376,10 +389,19 @@ __global__ __launch_bounds__(64 * BwdCfg<NP>::NW, 2) void core_bwd_chunk_kernel(
 #pragma unroll
     for (int i = 0; i < NT3 * (4 / NW); ++i) wacc[i] = (core_f4){0.f, 0.f, 0.f, 0.f};
 
+#if WM_BWD_STAMP
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_prev = __builtin_readcyclecounter();
+#endif
     for (int chunk = c_end - 1; chunk >= c_first; --chunk) {
-        if (chunk != c_end - 1) __syncthreads();         // the previous chunk's tiles are consumed
+        // LDS-only barrier: __syncthreads() also drains the vector-memory counter, i.e. waits here for the dx stores of the chunk
+        // just finished (3.3 k cycles per chunk, 5.9 k where dx is read-modify-write: tools/core_bwd_stamps.py) BEFORE the next
+        // chunk's tile loads are even issued; now the two round trips overlap (nothing here hands global data between waves)
+        if (chunk != c_end - 1) core_barrier();          // the previous chunk's tiles are consumed
+        BWD_STAMP(0);                                    // barrier between chunks (+ the dx store's tail)
         const int t0 = chunk * kBT, tl = min((int)p.L, t0 + kBT) - t0;
         const FusedTile<REV> ft(L, t0, tl);
+
         // ---- operand tiles: x and dy, eight quads of 16 rows shared out among the waves
 #pragma unroll
         for (int it = 0; it < 8 / NW; ++it) {
@@ -390,6 +412,7 @@ __global__ __launch_bounds__(64 * BwdCfg<NP>::NW, 2) void core_bwd_chunk_kernel(
         if (tl < kBT)                                     // a ragged last chunk: no stale gradient columns
             for (int e = tid; e < Cfg::NRED * kBRow; e += 64 * NW) s_red[e] = 0.0f;
         __syncthreads();
+        BWD_STAMP(1);                                    // tile loads + barrier
         // ---- records: every wave computes the dt_r tile (and from it dt of the 16 steps) for itself - identical values, so
         // the shared copies in s_dtr / s_d may be written by all of them - and ONE of the B / C tiles (NW = 2 NTB)
         {
@@ -410,10 +433,16 @@ __global__ __launch_bounds__(64 * BwdCfg<NP>::NW, 2) void core_bwd_chunk_kernel(
             const v2f da = softplus2((v2f){xr[0], xr[1]}), db = softplus2((v2f){xr[2], xr[3]});
             *reinterpret_cast<float4*>(&s_d[lane * kBRow + 4 * q]) = make_float4(da.x, da.y, db.x, db.y);
         }
+        BWD_STAMP(2);                                    // projection + dt
         __syncthreads();                                 // B and C tiles of the other waves
+        BWD_STAMP(3);                                    // barrier
         // ---- state at the chunk's start = (state from zero at the block's start) + (decay since the block's start) x H_in
         v2f h[4];
         {
+            // (requesting this record earlier does not pay, measured with tools/core_bwd_stamps.py: the memory counter returns in
+            // order, so the next consumer of ANY vector-memory load - the operand tiles, the projection's or the products' weight
+            // fragments, a spill reload - pays the round trip instead: with the tiles 46.9 k cycles per chunk, behind the tile
+            // barrier 47.1 k, one chunk ahead 49.3 k, against 46.6 k here)
             float Sc = 0.0f;
             float4 hv[2];
             if (p.nchunks > 1) {
@@ -437,24 +466,31 @@ __global__ __launch_bounds__(64 * BwdCfg<NP>::NW, 2) void core_bwd_chunk_kernel(
 #pragma unroll
             for (int i = 0; i < 4; ++i) { hs[(st * 8 + 2 * i) * 64] = h[i].x; hs[(st * 8 + 2 * i + 1) * 64] = h[i].y; }
             if (st < NSUB - 1) {
+                // branch-free (a step past the chunk's end is dt = 0: a = 1, b = 0 - the forward kernels' mask): with a branch
+                // per step the B reads of a step were issued behind the previous step's arithmetic; now the sub-tile's ten
+                // reads are in flight together and the sixteen exponentials do not wait for the recurrence
                 const float4 dt4 = *reinterpret_cast<const float4*>(&s_d[lane * kBRow + 4 * st]);
                 const float4 u4 = *reinterpret_cast<const float4*>(&s_u[lane * kBRow + 4 * st]);
                 const float dtv[4] = {dt4.x, dt4.y, dt4.z, dt4.w}, uv[4] = {u4.x, u4.y, u4.z, u4.w};
+                float4 bvv[kBS][2];
+#pragma unroll
+                for (int j = 0; j < kBS; ++j)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) bvv[j][q] = *reinterpret_cast<const float4*>(&s_B[(st * kBS + j) * NP + 8 * w + 4 * q]);
 #pragma unroll
                 for (int j = 0; j < kBS; ++j) {
-                    const int tt = st * kBS + j;
-                    if (tt < tl) {
-                        const v2f dt2 = splat(dtv[j]), du2 = splat(dtv[j] * uv[j]);
+                    const float dtm = (st * kBS + j < tl) ? dtv[j] : 0.0f;          // tl is wave-uniform: a scalar compare + select
+                    const v2f dt2 = splat(dtm), du2 = splat(dtm * uv[j]);
 #pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const float4 bv = *reinterpret_cast<const float4*>(&s_B[tt * NP + 8 * w + 4 * q]);
-                            h[2 * q] = exp2_2(dt2 * A2[2 * q]) * h[2 * q] + du2 * (v2f){bv.x, bv.y};
-                            h[2 * q + 1] = exp2_2(dt2 * A2[2 * q + 1]) * h[2 * q + 1] + du2 * (v2f){bv.z, bv.w};
-                        }
+                    for (int q = 0; q < 2; ++q) {
+                        const float4 bv = bvv[j][q];
+                        h[2 * q] = exp2_2(dt2 * A2[2 * q]) * h[2 * q] + du2 * (v2f){bv.x, bv.y};
+                        h[2 * q + 1] = exp2_2(dt2 * A2[2 * q + 1]) * h[2 * q + 1] + du2 * (v2f){bv.z, bv.w};
                     }
                 }
             }
         }
+        BWD_STAMP(4);                                    // start state + forward sweep
         // ---- the four sub-tiles, last first
 #pragma unroll 1
         for (int st = NSUB - 1; st >= 0; --st) {
@@ -530,7 +566,9 @@ __global__ __launch_bounds__(64 * BwdCfg<NP>::NW, 2) void core_bwd_chunk_kernel(
 #pragma unroll
             for (int j = 0; j < kBS; ++j) { hs[(st * 8 + 2 * j) * 64] = psb[j]; hs[(st * 8 + 2 * j + 1) * 64] = psd[j]; }
         }
+        BWD_STAMP(5);                                    // the four sub-tiles in reverse
         __syncthreads();
+        BWD_STAMP(6);                                    // barrier
         // ---- closing the steps: du_t, ddelta_t from the waves' shares; wave w closes steps SPW w .. SPW w + SPW - 1 and
         // reduces their d dt_r[r][tt] = sum over channels of ddelta[d][tt] Wdt[d][r]
         {
@@ -580,6 +618,7 @@ __global__ __launch_bounds__(64 * BwdCfg<NP>::NW, 2) void core_bwd_chunk_kernel(
             }
         }
         __syncthreads();
+        BWD_STAMP(7);                                    // closing + barrier
         // ---- dx tile (in s_dy) += Wx^T [dB | dC] on the matrix cores; D layout: lane (c16 = step, g4) holds channels
         // 16 t + 4 g4 .. + 3 - every element of the tile has exactly one owner (the dt_r part of dx is added by the store)
 #if WM_BWD_DX_LATE
@@ -671,6 +710,7 @@ __global__ __launch_bounds__(64 * BwdCfg<NP>::NW, 2) void core_bwd_chunk_kernel(
             }
         }
         __syncthreads();
+        BWD_STAMP(8);                                    // dx and dWx products + barrier
         // ---- dx (+)= du: four quads of 16 rows shared out among the waves (LDS column = scan time)
         {
             const int trow = lane >> 2, tq = lane & 3, c = 4 * tq;
@@ -713,7 +753,14 @@ __global__ __launch_bounds__(64 * BwdCfg<NP>::NW, 2) void core_bwd_chunk_kernel(
                 }
             }
         }
+        BWD_STAMP(9);                                    // dx store (issue)
     }                                                    // next chunk of the block (in reverse)
+#if WM_BWD_STAMP
+    if (lane == 0 && w < 2) {
+        for (int k = 0; k < 10; ++k) atomicAdd(&g_bwd_stamps[((REV ? 1 : 0) * 2 + w) * 11 + k], st_acc[k]);
+        atomicAdd(&g_bwd_stamps[((REV ? 1 : 0) * 2 + w) * 11 + 10], (unsigned long long)(c_end - c_first));
+    }
+#endif
 
     // ---- one partial record per block: [b * dim + d][block][NP + 8] = dA | dD, dbias, dWdt[0..3], 0, 0
     __syncthreads();

@@ -2101,6 +2101,17 @@ int wm_conv2d_select(int mode) {
     return WM_OK;
 }
 
+#if WM_BWD_STAMP
+int wm_debug_bwd_stamps(unsigned long long* out, int reset) {      // host buffer of 44 values
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wm::g_bwd_stamps), sizeof(unsigned long long) * 44);
+    if (rc == 0 && reset) {
+        unsigned long long z[44] = {};
+        rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(wm::g_bwd_stamps), z, sizeof(z));
+    }
+    return rc;
+}
+#endif
+
 #if WM_CV_STAMP
 int wm_debug_conv_stamps(unsigned long long* out) {      // host buffer of 2 * 128 * 8 values
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wm::g_cv_stamps), sizeof(unsigned long long) * 2 * 128 * 8);
