@@ -81,3 +81,38 @@ def test_library_ops_equal_the_python_surface_and_pass_opcheck():
     torch.library.opcheck(ns.idwt2d.default, (torch.randn(1, 8, 4, 8, device=dev, requires_grad=True),), test_utils=utils)
     torch.library.opcheck(ns.selective_scan.default, tuple(l1) + (True,), test_utils=utils)
     torch.library.opcheck(ns.ss2d_core.default, tuple(c1), test_utils=utils)
+
+
+@pytest.mark.gpu
+def test_ops_trace_through_torch_compile_aot_eager():
+    """A function built from the registered ops compiled with torch.compile(backend="aot_eager", fullgraph=True): Dynamo and AOT
+    autograd trace forward AND backward through the fake implementations and the registered autograd formulas (the ops stay
+    opaque nodes; no kernel runs while tracing), then the traced graphs run the HIP kernels - values and gradients equal eager's."""
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(3)
+    ns = torch.ops.wavemamba_hip
+
+    def f(x, u, delta, A, Bm, Cm, D, bias):
+        ll, hl, lh, hh = ns.dwt2d(x)
+        y = ns.idwt2d(torch.cat([ll * 1.5, hl, lh - hh, hh], 1))
+        s = ns.selective_scan(u, delta, A, Bm, Cm, D, bias, True)
+        return y.square().mean() + s.square().mean()
+
+    x = torch.randn(2, 4, 16, 24, device=dev, generator=g)
+    u, delta = torch.randn(2, 64, 200, device=dev, generator=g), torch.randn(2, 64, 200, device=dev, generator=g) * 0.3
+    A = -torch.rand(64, 16, device=dev, generator=g) - 0.1
+    Bm, Cm = torch.randn(2, 1, 16, 200, device=dev, generator=g), torch.randn(2, 1, 16, 200, device=dev, generator=g)
+    D, bias = torch.randn(64, device=dev, generator=g), torch.randn(64, device=dev, generator=g) * 0.1
+
+    def run(fn):
+        ins = [t.clone().requires_grad_(True) for t in (x, u, delta, A, Bm, Cm, D, bias)]
+        out = fn(*ins)
+        out.backward()
+        return out.detach(), [t.grad for t in ins]
+
+    torch._dynamo.reset()
+    o_e, g_e = run(f)
+    o_c, g_c = run(torch.compile(f, backend="aot_eager", fullgraph=True))
+    assert torch.equal(o_e, o_c)
+    for a, b in zip(g_e, g_c):
+        assert a is not None and b is not None and torch.equal(a, b)
