@@ -15,4 +15,8 @@ bash tools/pmc_core_bwd.sh $O/pmc_core_bwd > /dev/null 2>&1
 python tools/pmc_summary.py $O/pmc_core_bwd core_bwd > $O/pmc_core_bwd_summary.txt 2>&1
 python tools/train_breakdown.py --steps 3 --detail core_bwd_chunk,core_bwd_reduce > $O/train_step_kernel_breakdown.txt 2>&1
 WM_CORE_BWD_V1=1 python tools/train_breakdown.py --steps 3 > $O/train_step_kernel_breakdown_first_generation_backward.txt 2>&1
+bash tools/pmc_conv.sh $O/pmc_conv > /dev/null 2>&1
+python tools/pmc_summary.py $O/pmc_conv conv > $O/pmc_conv_summary.txt 2>&1
+python tools/bench_conv_train.py > $O/bench_conv_train.txt 2>&1
+python tools/bench_lfss_rz.py > $O/bench_lfss_rz.txt 2>&1
 cat $O/build_id.txt; cat $O/pmc_traffic.log; head -12 $O/multi/bench_rocprofv3_kernel_stats.csv; head -20 $O/single/bench_per_step_kernel_breakdown.txt; cat $O/bench_core_bwd.txt; ls -la $O $O/multi $O/single | head -40
