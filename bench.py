@@ -44,12 +44,21 @@ CORE_CLASSES = ("ss2d_core_reduce", "selscan_carry", "ss2d_core_scan")
 EXP_PEAK = 18.5e12               # v_exp_f32 lane-ops/s chip-wide, tools/microbench.hip on MI355X
 # The LFSSBlock kernels around the scan.  SURVEY 8d gives bytes for the wavelets and the scan
 # only; for these the algorithmic bytes are what each kernel must move at the shipped width (C = 32, D = 64, fp32 planes):
-#   lfss_in   reads tokens (4C) and writes x, z (2 x 4D)                                   = 640 B / position
+#   lfss_in   reads tokens (4C) and writes x (4D) - and z (4D) unless the gate is recomputed downstream     = 384 (640) B / position
 #   dwconv3x3 reads x and writes conv(x) (2 x 4D)                                          = 512
-#   lfss_mid  reads the scan's `LFSS_MID_NY` y buffers, z and the tokens, writes tok1 and f (4 D NY + 4D + 4C + 4C + 4D)
+#   lfss_mid  reads the scan's `LFSS_MID_NY` y buffers and the tokens - and z unless it recomputes the gate from the tokens
+#             (round 4, ops._RECOMPUTE_Z) -, writes tok1 and f (4 D NY [+ 4D] + 4C + 4C + 4D)  = 1536 (1792)
 #   lfss_out  reads f (4D) and tok1 (4C), writes the block's output (4C)                   = 512
+# The table quotes what the kernels the run actually used must move (never the larger figure for the smaller data flow).
 LFSS_MID_NY = 4
-LFSS_BYTES_PER_POS = {"lfss_in": 640, "dwconv3x3": 512, "lfss_mid": 256 * LFSS_MID_NY + 256 + 128 + 128 + 256, "lfss_out": 512}
+
+
+def lfss_bytes_per_pos():
+    z = 0 if getattr(wm.ops, "_RECOMPUTE_Z", False) and not getattr(wm.ops, "_FUSE_IN_CONV", False) else 256
+    return {"lfss_in": 128 + 256 + z, "dwconv3x3": 512, "lfss_mid": 256 * LFSS_MID_NY + z + 128 + 128 + 256, "lfss_out": 512}
+
+
+LFSS_BYTES_PER_POS = lfss_bytes_per_pos()
 
 
 def pad_to(x, mult=128):
