@@ -276,6 +276,13 @@ int wm_layernorm2d_bwd(const float* x, const float* weight, const float* gy, flo
 int wm_conv2d_select(int mode);
 size_t wm_conv2d_wfrag_bytes(int Cout, int Cin, int ks);
 int wm_conv2d_prep(const float* weight, void* wfrag, int Cout, int Cin, int ks, void* stream);
+/* y = conv1x1(LayerNorm2d(x; ln_weight, ln_bias, ln_eps)) + bias (+ residual): HFEBlock's norm1 -> attn.qkv and norm2 ->
+ * ffn.project_in[0] (wavemamba_arch.py:843-851 over LayerNorm2d :532-569) as ONE kernel - the normalisation happens in the registers
+ * the 1x1 kernel stages its pixels through (same arithmetic as wm_layernorm2d_fwd + wm_conv2d_fwd: bit-identical results), the
+ * LayerNorm launch and its 256 B per position are gone.  Cin == 32 only (WM_EUNSUPPORTED otherwise); `wfrag` from
+ * wm_conv2d_prep(weight (Cout, 32, 1, 1)); bias, residual may be NULL. */
+int wm_conv2d_ln_fwd(const float* x, const float* ln_weight, const float* ln_bias, float ln_eps, const void* wfrag, const float* bias,
+                     const float* residual, float* y, int B, int Cin, int Cout, int H, int W, void* stream);
 /* The training form of the same convolutions (the F.conv2d calls of wavemamba_arch.py under autograd, femasr_model.py:170-181:
  * forward, and - on the transposed, flipped weight - the input gradient): fp16 matrix cores, two-term split of both operands
  * (22 significant bits, fp32-class: ~1e-7 relative to an fp64 convolution instead of the bf16 form's 3-4e-6, which the

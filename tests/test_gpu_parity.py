@@ -1713,6 +1713,27 @@ def test_conv2d_f16_vs_float64(ks, B, Cin, Cout, H, W, bias, scale):
     assert torch.equal(wm.ops.conv2d_f16(xd, wd, None if b is None else b.to(DEV)), got), "conv2d_f16: not reproducible run to run"
 
 
+@pytest.mark.parametrize("B,Cout,H,W,res", [(1, 96, 40, 56, False), (2, 32, 33, 65, True), (1, 64, 272, 480, False), (1, 32, 5, 7, True),
+                                            (1, 96, 1088, 1920, False)])
+def test_conv2d_ln_bit_identical_to_two_launches(B, Cout, H, W, res):
+    """conv1x1(LayerNorm2d(x)) in one kernel (the normalisation in the 1x1 kernel's staging registers) against
+    wm_layernorm2d_fwd + wm_conv2d_fwd: the same arithmetic on the same values - equal bit for bit; and against float64."""
+    gg = gen(Cout + H)
+    x = (torch.randn(B, 32, H, W, generator=gg) * 1.7 + 0.3).to(DEV)
+    lw, lb = (torch.randn(32, generator=gg) * 0.2 + 1.0).to(DEV), (torch.randn(32, generator=gg) * 0.1).to(DEV)
+    w, b = (torch.randn(Cout, 32, 1, 1, generator=gg) / 32 ** 0.5).to(DEV), torch.randn(Cout, generator=gg).to(DEV)
+    r = torch.randn(B, Cout, H, W, generator=gg).to(DEV) if res else None
+    one = wm.ops.conv2d_ln(x, lw, lb, 1e-6, w, b, r)
+    two = wm.ops.conv2d(wm.ops.layernorm2d(x, lw, lb, 1e-6), w, b, residual=r)
+    assert torch.equal(one, two), f"max abs difference {float((one - two).abs().max()):.3e}"
+    if H * W <= 200000:
+        xd = x.double()
+        mu = xd.mean(1, keepdim=True)
+        ln = (xd - mu) / ((xd - mu).pow(2).mean(1, keepdim=True) + 1e-6).sqrt() * lw.double().view(1, -1, 1, 1) + lb.double().view(1, -1, 1, 1)
+        ref = F.conv2d(ln, w.double(), b.double()) + (0 if r is None else r.double())
+        assert_close(one, ref.float(), 2e-5, "conv2d_ln vs float64")
+
+
 def test_conv2d_f16_degenerate_inputs():
     """all-zero input (scale falls back to 1), a single non-zero element, a constant map: exact / fp32-class results"""
     w = torch.randn(32, 16, 3, 3, generator=gen(1)).to(DEV)

@@ -114,6 +114,19 @@ def _conv(conv, x, x2=None, x2_index=None, gate=None, residual=None):
     return y
 
 
+def _ln_conv(norm, conv, x):
+    """conv(norm(x)) for a LayerNorm2d `norm` (or None) and a 1x1 nn.Conv2d: HFEBlock's norm1 -> attn.qkv and norm2 ->
+    ffn.project_in[0] (reference :843-851).  Inference on the HIP backend: ONE kernel (the normalisation happens in the 1x1
+    kernel's staging registers - bit-identical to the two launches, 256 B per position less); otherwise the two modules."""
+    if norm is None:
+        return _conv(conv, x)
+    ops = _OpsBackend.impl
+    if (hasattr(ops, "conv2d_ln") and ops.conv2d_ln_supported(x, conv.weight) and not _needs_grad(conv, x)
+            and not _needs_grad(norm, x)):
+        return ops.conv2d_ln(x, norm.weight, norm.bias, norm.eps, conv.weight, conv.bias)
+    return _conv(conv, norm(x))
+
+
 def _cat_gathered(x, x2=None, x2_index=None):
     """cat([x, gather(x2, 1, x2_index)], 1) (x2_index None: cat([x, x2], 1); x2 None: x)."""
     if x2 is None:
@@ -513,8 +526,9 @@ class FeedForward(nn.Module):
             nn.GELU(),
             nn.Conv2d(hidden, dim, 1, bias=bias))
 
-    def forward(self, x, perception, residual=None):
-        y = _dwconv(self.project_in[1], _conv(self.project_in[0], x))
+    def forward(self, x, perception, residual=None, norm=None):
+        """`norm`: the block's norm2, applied to `x` here (so that it can ride in project_in's 1x1 kernel)"""
+        y = _dwconv(self.project_in[1], _ln_conv(norm, self.project_in[0], x))
         if perception is not None:
             y = self.matching_transformation(y, perception)
         # project_out = [depth-wise 3x3, GELU, 1x1]: the GELU rides in the depth-wise kernel
@@ -538,12 +552,13 @@ class CMTAttention(nn.Module):
             self.matching_transformation = Matching_transformation(
                 dim=dim, match_factor=match_factor, ffn_expansion_factor=ffn_expansion_factor, bias=bias)
 
-    def qkv_of(self, x):
-        """The part of `forward` that needs `x` alone (UNet.forward runs it ahead of time on a side stream)."""
-        return _dwconv(self.qkv_dwconv, _conv(self.qkv, x))
+    def qkv_of(self, x, norm=None):
+        """The part of `forward` that needs `x` alone (UNet.forward runs it ahead of time on a side stream).  `norm`: the
+        block's norm1, applied to `x` here (it rides in the qkv 1x1 kernel)."""
+        return _dwconv(self.qkv_dwconv, _ln_conv(norm, self.qkv, x))
 
-    def forward(self, x, perception, residual=None, qkv=None):
-        q, k, v = (self.qkv_of(x) if qkv is None else qkv).chunk(3, dim=1)
+    def forward(self, x, perception, residual=None, qkv=None, norm=None):
+        q, k, v = (self.qkv_of(x, norm) if qkv is None else qkv).chunk(3, dim=1)
         x = v                                              # from here on only shape / device / dtype of `x` matter
         b, c, h, w = x.shape
         if self.matching is True:
@@ -599,12 +614,12 @@ class HFEBlock(nn.Module):
 
     def qkv_of(self, x):
         """dwconv(qkv(norm1(x))): everything of the block that does not need `perception`."""
-        return self.attn.qkv_of(self.norm1(x))
+        return self.attn.qkv_of(x, self.norm1)
 
     def forward(self, x, perception, qkv=None):
         p = self.LayerNorm(perception)
-        x = self.attn(self.norm1(x) if qkv is None else None, p, residual=x, qkv=qkv)   # x + attn(...): the add rides in the 1x1 epilogue
-        return self.ffn(self.norm2(x), p, residual=x)
+        x = self.attn(x if qkv is None else None, p, residual=x, qkv=qkv, norm=self.norm1)   # x + attn(norm1(x)): the add rides in the 1x1 epilogue
+        return self.ffn(x, p, residual=x, norm=self.norm2)
 
 
 class SKFF(nn.Module):

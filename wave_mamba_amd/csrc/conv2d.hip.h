@@ -61,6 +61,9 @@ struct Conv2dArgs {
     int mtot;                         // ceil(Cout / 32) row tiles in wfrag
     int mbase;                        // first row tile of this launch
     const float* amax;                // F16 kernels: device floats {max |input|, max |weight|} (the power-of-two operand scales), else null
+    const float* ln_w;                // LNIN kernels (1x1, Ca == 32, no second input): LayerNorm2d over the 32 input channels of a pixel
+    const float* ln_b;                //   applied while the pixel is staged: y = conv1x1(weight * (x - mean) / sqrt(var + eps) + bias)
+    float ln_eps;
 };
 
 union Frag16 {
@@ -171,9 +174,16 @@ __global__ __launch_bounds__(256) void conv2d_prep_kernel(const float* __restric
 // G1X1 (3x3 only): a second, 1x1 convolution of the same input (its own prepared weights a.wfrag1 / a.bias1) rides on
 // the centre tap's B fragments into a second accumulator set and gates the output: y = conv3x3(X) * sigmoid(conv1x1(X) +
 // b1) - PAConv's k3(x) * sigmoid(k2(x)) (reference :694-697) without the gate tensor ever existing.
-template <int KS /*1 or 3*/, int RW /*rows per wave*/, int MT /*32-channel row tiles per launch*/, bool G1X1 = false, bool F16 = false>
+// LNIN (1x1 only): the convolution's input is LayerNorm2d(x) (reference LayerNorm2d, :532-569: per pixel over the channels, biased
+// variance) of a 32-channel map - HFEBlock's norm1 -> attn.qkv and norm2 -> ffn.project_in[0] (:843-851).  A thread stages whole
+// pixels (all channels of its PIT pixels pass through its registers chunk by chunk), so the statistics need no other thread:
+// both 16-channel chunks are fetched up front, normalised in registers, and the chunk loop stages from them - the LayerNorm
+// launch and its 256 B per position (written, read back) are gone.
+template <int KS /*1 or 3*/, int RW /*rows per wave*/, int MT /*32-channel row tiles per launch*/, bool G1X1 = false, bool F16 = false,
+          bool LNIN = false>
 __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a) {
     static_assert(!(F16 && G1X1), "the fp16 form serves the plain convolutions of the training step");
+    static_assert(!LNIN || (KS == 1 && !G1X1 && !F16), "LayerNorm2d rides on the inference 1x1");
     const float sx = F16 ? cv_pow2_scale(a.amax[0]) : 1.0f;
     const float osc = F16 ? 1.0f / (sx * cv_pow2_scale(a.amax[1])) : 1.0f;
     extern __shared__ __attribute__((aligned(16))) unsigned char cv_smem[];
@@ -351,7 +361,54 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
     // The two-tile and gated forms fit it too (244 / 208 VGPRs) but lose more to the registers than they gain
     // (-0.4 % on the whole step); the 64-channel x 16-row form spills with it.
     constexpr bool PIPE = (MT == 1) && !G1X1;
-    if constexpr (PIPE) {
+    if constexpr (LNIN) {
+        // host contract: Ca == 32, Cb == 0 (nch == 2)
+        float xin[2][2][PIT][8];
+        fetch_in(0);
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int it = 0; it < PIT; ++it)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xin[0][half][it][j] = pin[half][it][j];
+        fetch_in(1);
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int it = 0; it < PIT; ++it)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xin[1][half][it][j] = pin[half][it][j];
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) {
+            float mean = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) mean += xin[c >> 4][(c >> 3) & 1][it][c & 7];
+            mean *= (1.0f / 32.0f);
+            float var = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) { const float q = xin[c >> 4][(c >> 3) & 1][it][c & 7] - mean; var = fmaf(q, q, var); }
+            const float rstd = 1.0f / sqrtf(var * (1.0f / 32.0f) + a.ln_eps);
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                float& v = xin[c >> 4][(c >> 3) & 1][it][c & 7];
+                v = fmaf((v - mean) * rstd, a.ln_w[c], a.ln_b[c]);
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int it = 0; it < PIT; ++it)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pin[half][it][j] = xin[cc][half][it][j];
+            fetch_w(cc);
+            stage(cc);
+            __syncthreads();
+            mma();
+            __syncthreads();
+        }
+    } else if constexpr (PIPE) {
         fetch_in(0);
         fetch_w(0);
         stage(0);

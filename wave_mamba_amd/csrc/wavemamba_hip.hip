@@ -222,7 +222,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 22; }
+int wm_abi_version(void) { return 23; }
 
 #ifndef WM_BUILD_ID
 #define WM_BUILD_ID "unknown"
@@ -1871,18 +1871,18 @@ int wm_conv2d_prep_f16(const float* weight, const float* amax, void* wfrag, int 
 
 }  // extern "C"
 
-template <int KS, int RW, int MT, bool G1X1 = false, bool F16 = false>
+template <int KS, int RW, int MT, bool G1X1 = false, bool F16 = false, bool LNIN = false>
 static int conv2d_launch(const wm::Conv2dArgs& a, int B, hipStream_t st) {
     constexpr int PAD = KS / 2;
     constexpr int smem = ((4 * RW + 2 * PAD) * (wm::kCvTW + 2 * PAD) * 4 + (KS * KS + (G1X1 ? 1 : 0)) * MT * 2 * 64) * 16;   // input planes + weights
     static bool configured[64] = {};
     if (smem > 65536) {
-        const int rc = wm::lds_optin((const void*)wm::conv2d_mfma_kernel<KS, RW, MT, G1X1, F16>, smem, configured);
+        const int rc = wm::lds_optin((const void*)wm::conv2d_mfma_kernel<KS, RW, MT, G1X1, F16, LNIN>, smem, configured);
         if (rc) return rc;
     }
     const int ntiles = ((a.W + wm::kCvTW - 1) / wm::kCvTW) * ((a.H + 4 * RW - 1) / (4 * RW));
     const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8), (unsigned)B);
-    hipLaunchKernelGGL((wm::conv2d_mfma_kernel<KS, RW, MT, G1X1, F16>), grid, dim3(256), smem, st, a);
+    hipLaunchKernelGGL((wm::conv2d_mfma_kernel<KS, RW, MT, G1X1, F16, LNIN>), grid, dim3(256), smem, st, a);
     return launch_status();
 }
 
@@ -1973,7 +1973,7 @@ int wm_conv2d_fwd(const float* xa, const float* xb, const int* xb_index, const v
     a.xa = xa; a.xb = Cb > 0 ? xb : nullptr; a.xb_idx = Cb > 0 ? xb_index : nullptr; a.wfrag = (const uint4*)wfrag;
     a.bias = bias; a.gate = gate; a.res = residual; a.y = y; a.wfrag1 = nullptr; a.bias1 = nullptr;
     a.Ca = Ca; a.Cb = Cb; a.Cbsrc = Cb_src; a.Cout = Cout; a.H = H; a.W = W;
-    a.nch = (Ca + Cb + 15) / 16; a.mtot = (Cout + 31) / 32; a.amax = nullptr;
+    a.nch = (Ca + Cb + 15) / 16; a.mtot = (Cout + 31) / 32; a.amax = nullptr; a.ln_w = nullptr; a.ln_b = nullptr; a.ln_eps = 0.0f;
     ProfScope ps(ks == 3 ? 13 : 14, st);
     for (int mb = 0; mb < a.mtot;) {
         a.mbase = mb;
@@ -2002,6 +2002,34 @@ int wm_conv2d_fwd(const float* xa, const float* xb, const int* xb_index, const v
     return WM_OK;
 }
 
+// y = conv1x1(LayerNorm2d(x)) + bias (+ residual): the LayerNorm of a 32-channel map inside the 1x1 kernel's staging (conv2d.hip.h, LNIN).
+int wm_conv2d_ln_fwd(const float* x, const float* ln_weight, const float* ln_bias, float ln_eps, const void* wfrag, const float* bias,
+                     const float* residual, float* y, int B, int Cin, int Cout, int H, int W, void* stream) {
+    if (B < 0 || Cin <= 0 || Cout <= 0 || H < 0 || W < 0) return WM_EINVAL;
+    if (Cin != 32) return WM_EUNSUPPORTED;                 // callers run wm_layernorm2d_fwd + wm_conv2d_fwd
+    if (B == 0 || H == 0 || W == 0) return WM_OK;
+    if (!x || !ln_weight || !ln_bias || !wfrag || !y) return WM_ENULL;
+    if (B > 65535 || (long long)H * W >= (1ll << 31)) return WM_EUNSUPPORTED;
+    if (!aligned16(wfrag)) return WM_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    Conv2dArgs a;
+    a.xa = x; a.xb = nullptr; a.xb_idx = nullptr; a.wfrag = (const uint4*)wfrag;
+    a.bias = bias; a.gate = nullptr; a.res = residual; a.y = y; a.wfrag1 = nullptr; a.bias1 = nullptr;
+    a.Ca = Cin; a.Cb = 0; a.Cbsrc = 0; a.Cout = Cout; a.H = H; a.W = W;
+    a.nch = 2; a.mtot = (Cout + 31) / 32; a.amax = nullptr; a.ln_w = ln_weight; a.ln_b = ln_bias; a.ln_eps = ln_eps;
+    ProfScope ps(14, st);
+    for (int mb = 0; mb < a.mtot;) {
+        a.mbase = mb;
+        const int left = a.mtot - mb;
+        int rc;
+        if (left >= 3) { rc = conv2d_launch<1, 2, 3, false, false, true>(a, B, st); mb += 3; }
+        else if (left == 2) { rc = conv2d_launch<1, 4, 2, false, false, true>(a, B, st); mb += 2; }
+        else { rc = conv2d_launch<1, 4, 1, false, false, true>(a, B, st); mb += 1; }
+        if (rc) return rc;
+    }
+    return WM_OK;
+}
+
 // The training form (conv2d.hip.h, fp16 split with per-tensor power-of-two scales): y = conv(x, w) + bias, ks in {1, 3}; wfrag from
 // wm_conv2d_prep_f16 with the SAME amax buffer {max |x|, max |w|} (device floats).
 int wm_conv2d_fwd_f16(const float* x, const void* wfrag, const float* amax, const float* bias, float* y, int B, int Cin, int Cout,
@@ -2017,7 +2045,7 @@ int wm_conv2d_fwd_f16(const float* x, const void* wfrag, const float* amax, cons
     a.xa = x; a.xb = nullptr; a.xb_idx = nullptr; a.wfrag = (const uint4*)wfrag;
     a.bias = bias; a.gate = nullptr; a.res = nullptr; a.y = y; a.wfrag1 = nullptr; a.bias1 = nullptr;
     a.Ca = Cin; a.Cb = 0; a.Cbsrc = 0; a.Cout = Cout; a.H = H; a.W = W;
-    a.nch = (Cin + 15) / 16; a.mtot = (Cout + 31) / 32; a.amax = amax;
+    a.nch = (Cin + 15) / 16; a.mtot = (Cout + 31) / 32; a.amax = amax; a.ln_w = nullptr; a.ln_b = nullptr; a.ln_eps = 0.0f;
     ProfScope ps(ks == 3 ? 13 : 14, st);
     for (int mb = 0; mb < a.mtot;) {
         a.mbase = mb;
@@ -2077,7 +2105,7 @@ int wm_conv2d_gated_fwd(const float* xa, const float* xb, const int* xb_index, c
     a.xa = xa; a.xb = Cb > 0 ? xb : nullptr; a.xb_idx = Cb > 0 ? xb_index : nullptr; a.wfrag = (const uint4*)wfrag3;
     a.bias = nullptr; a.gate = nullptr; a.res = nullptr; a.y = y; a.wfrag1 = (const uint4*)wfrag1; a.bias1 = bias1;
     a.Ca = Ca; a.Cb = Cb; a.Cbsrc = Cb_src; a.Cout = Cout; a.H = H; a.W = W;
-    a.nch = (Ca + Cb + 15) / 16; a.mtot = (Cout + 31) / 32; a.amax = nullptr;
+    a.nch = (Ca + Cb + 15) / 16; a.mtot = (Cout + 31) / 32; a.amax = nullptr; a.ln_w = nullptr; a.ln_b = nullptr; a.ln_eps = 0.0f;
     ProfScope ps(13, st);
     for (int mb = 0; mb < a.mtot;) {
         // two accumulator sets per wave: 64 channels x 8-row tiles read the input once (0.79 ms against 0.90 ms for

@@ -1126,6 +1126,36 @@ def conv2d_f16(x, weight, bias=None):
     return y
 
 
+def conv2d_ln(x, ln_weight, ln_bias, ln_eps, weight, bias=None, residual=None):
+    """conv1x1(LayerNorm2d(x)) + bias (+ residual) in one kernel (wm_conv2d_ln_fwd): x (B, 32, H, W) fp32, weight (Cout, 32, 1, 1).
+    Bit-identical to layernorm2d() + conv2d().  Forward only."""
+    lib = _lib.load()
+    _require_cuda("conv2d_ln", x, ln_weight, ln_bias, weight, bias, residual)
+    B, C, H, W = x.shape
+    cout = weight.shape[0]
+    if C != 32 or tuple(weight.shape[1:]) != (32, 1, 1) or x.dtype != torch.float32:
+        raise NotImplementedError("conv2d_ln: fp32, 32 input channels, 1x1 weight")
+    if residual is not None and tuple(residual.shape) != (B, cout, H, W):
+        raise RuntimeError(f"conv2d_ln: residual must be {(B, cout, H, W)}, got {tuple(residual.shape)}")
+    x = x.contiguous()
+    frag = _conv2d_wfrag(weight)
+    y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.wm_conv2d_ln_fwd(_ptr(x), _ptr(_w(ln_weight)), _ptr(_w(ln_bias)), float(ln_eps), _ptr(frag),
+                                   _ptr(None if bias is None else bias.detach().contiguous()),
+                                   _ptr(None if residual is None else residual.contiguous()), _ptr(y), B, C, cout, H, W, _stream()),
+              "wm_conv2d_ln_fwd")
+    return y
+
+
+_FUSE_LN_CONV = os.environ.get("WM_FUSE_LN_CONV", "1") == "1"      # 0: LayerNorm2d and the 1x1 convolution as two launches (A/B runs)
+
+
+def conv2d_ln_supported(x, weight):
+    return (_FUSE_LN_CONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 32 and weight.dim() == 4
+            and tuple(weight.shape[1:]) == (32, 1, 1) and x.shape[2] * x.shape[3] < 2 ** 31)
+
+
 def conv2d_gated(x, weight3, weight1, bias1=None, x2=None, x2_index=None):
     """conv3x3(X; weight3) * sigmoid(conv1x1(X; weight1) + bias1) with X as in `conv2d` - PAConv's k3(x) * sigmoid(k2(x))
     (reference wavemamba_arch.py:694-697) in one kernel.  weight3 (Cout, Cin, 3, 3) without bias, weight1
