@@ -122,8 +122,14 @@ __device__ __forceinline__ void store_rows64(TP* __restrict__ plane0 /* channel 
 // A operands (W_in rows D.. x ln_1.weight), the same normalised tile as B operands, the same matrix-instruction order and bias
 // start as lfss_in_mfma_kernel - bit-identical z in fp32 storage - with the output ROWS permuted so that accumulator
 // register i of row block mt IS channel 2 (16 mt + i) + h: the layout the out_norm'ed y has after its half-wave swap.
+// (the recomputing form holds the normalised token tile and the gate accumulators beside y: at three waves per SIMD it spills 19
+// registers; at two - 256 registers, none spilled - it is 3-6 % faster per call, tools/bench_lfss_rz.py with -DWM_LFSS_MID_WAVES=2;
+// the reading form is 25 % slower at two)
+#ifndef WM_LFSS_MID_RZ_WAVES
+#define WM_LFSS_MID_RZ_WAVES 2
+#endif
 template <int NY, typename TP = float, bool RZ = false>
-__global__ __launch_bounds__(256, WM_LFSS_MID_WAVES) void lfss_mid_mfma_kernel(
+__global__ __launch_bounds__(256, RZ ? WM_LFSS_MID_RZ_WAVES : WM_LFSS_MID_WAVES) void lfss_mid_mfma_kernel(
     const TP* __restrict__ ysum, long long ystride, const TP* __restrict__ z, const float* __restrict__ tok, int tok_nchw,
     const float* __restrict__ on_w, const float* __restrict__ on_b, float on_eps,
     const float* __restrict__ W_out /*(C, D)*/, const float* __restrict__ skip1,

@@ -1332,7 +1332,7 @@ int wm_lfss_mid_rz_fwd(const void* ysum_, int ny, int64_t ystride, const float* 
     if ((!tok_nchw && !aligned16(tok)) || !aligned16(tok1)) return WM_EALIGN;
     const int ngl = (int)((L + 63) / 64);
     const long long ngroups = (long long)B * ngl;
-    const int gpw = lfss_groups_per_wave(ngroups, 1024 * WM_LFSS_MID_WAVES);
+    const int gpw = lfss_groups_per_wave(ngroups, 1024 * WM_LFSS_MID_RZ_WAVES);
     const long long waves = (ngroups + gpw - 1) / gpw;
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(9, st);
