@@ -61,6 +61,48 @@ def lfss_bytes_per_pos():
 LFSS_BYTES_PER_POS = lfss_bytes_per_pos()
 
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak of MI355X (MI355X_MICROARCH.md); never the 2:1-sparsity figure
+
+
+def conv_workload(net, x):
+    """Arithmetic of the dense convolutions of ONE forward (the HFE branch and the plumbing): every call of
+    ops.conv2d / conv2d_gated / conv2d_ln is counted by shape while one forward runs.  -> {"3x3": (flop, bytes, calls), "1x1": ...};
+    flop = 2 Cin Cout k^2 per output position (the fp32 convolution's; the kernels spend three bf16 products on each),
+    bytes = 4 (Cin + Cout) per position (+ 4 Cout for a gate / residual operand)."""
+    tally = {"3x3": [0.0, 0.0, 0], "1x1": [0.0, 0.0, 0]}
+    o = wm.ops
+    orig = (o.conv2d, o.conv2d_gated, o.conv2d_ln)
+
+    def count(ks, pos, cin, cout, extra=0):
+        t = tally["3x3" if ks == 3 else "1x1"]
+        t[0] += 2.0 * cin * cout * ks * ks * pos; t[1] += 4.0 * (cin + cout + extra) * pos; t[2] += 1
+
+    def conv2d(xx, weight, bias=None, x2=None, x2_index=None, gate=None, residual=None, dynamic_weight=False):
+        pos = xx.shape[0] * xx.shape[2] * xx.shape[3]
+        count(weight.shape[2], pos, weight.shape[1], weight.shape[0], weight.shape[0] * ((gate is not None) + (residual is not None)))
+        return orig[0](xx, weight, bias, x2, x2_index, gate, residual, dynamic_weight)
+
+    def conv2d_gated(xx, weight3, weight1, bias1=None, x2=None, x2_index=None):
+        pos = xx.shape[0] * xx.shape[2] * xx.shape[3]
+        count(3, pos, weight3.shape[1], weight3.shape[0])
+        tally["3x3"][0] += 2.0 * weight1.shape[1] * weight1.shape[0] * pos        # the gating 1x1 rides in the same kernel
+        return orig[1](xx, weight3, weight1, bias1, x2, x2_index)
+
+    def conv2d_ln(xx, lw, lb, eps, weight, bias=None, residual=None):
+        pos = xx.shape[0] * xx.shape[2] * xx.shape[3]
+        count(1, pos, weight.shape[1], weight.shape[0], weight.shape[0] * (residual is not None))
+        return orig[2](xx, lw, lb, eps, weight, bias, residual)
+
+    o.conv2d, o.conv2d_gated, o.conv2d_ln = conv2d, conv2d_gated, conv2d_ln
+    try:
+        with torch.no_grad():
+            net.restoration_network(x)
+        torch.cuda.synchronize()
+    finally:
+        o.conv2d, o.conv2d_gated, o.conv2d_ln = orig
+    return {k: tuple(v) for k, v in tally.items()}
+
+
 def pad_to(x, mult=128):
     """inference_wavemamba.py:28-36: reflect-pad bottom/right to a multiple of 128."""
     h, w = x.shape[-2:]
@@ -536,6 +578,22 @@ def main():
                 gbs = gb / (table[name]["ms_per_step"] * 1e-3)
                 table[name].update({"algorithmic_bytes_per_position": bpp, "algorithmic_GB_per_step": gb,
                                     "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS})
+        # the dense convolutions: 3x3 against the bf16 matrix peak (three products per fp32 product), 1x1 against HBM
+        try:
+            cw = conv_workload(net, x)
+            if "conv3x3" in table and cw["3x3"][2]:
+                fl, _, nc = cw["3x3"]
+                tf = fl / (table["conv3x3"]["ms_per_step"] * 1e-3) / 1e12
+                table["conv3x3"].update({"bound": "mfma", "algorithmic_TFLOP_per_step": fl / 1e12, "calls_counted": nc,
+                                         "achieved_TFLOPs_fp32_equivalent": tf, "bf16_products_per_fp32_product": 3,
+                                         "peak_TFLOPs_bf16_dense": MFMA_BF16_PEAK_TFLOPS, "frac": 3.0 * tf / MFMA_BF16_PEAK_TFLOPS})
+            if "conv1x1" in table and cw["1x1"][2]:
+                _, by, nc = cw["1x1"]
+                gbs = by / (table["conv1x1"]["ms_per_step"] * 1e-3) / 1e9
+                table["conv1x1"].update({"bound": "hbm", "algorithmic_GB_per_step": by / 1e9, "calls_counted": nc,
+                                         "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS})
+        except Exception as e:                             # a counting pass must never cost the line
+            table.setdefault("conv3x3", {})["workload_error"] = f"{type(e).__name__}: {e}"[:200]
         core_ms = sum(table[k]["ms_per_step"] for k in CORE_CLASSES if k in table)
         calls = table.get("ss2d_core_scan", {}).get("launches_per_step", 0)
         scan_bytes = SCAN_BYTES_PER_POS[16] * pos
