@@ -198,7 +198,13 @@ __global__ __launch_bounds__(256, RZ ? WM_LFSS_MID_RZ_WAVES : WM_LFSS_MID_WAVES)
         } else {
             // the four directions' outputs, added in the reference's order y1 + y2 + y3 + y4 (:490) =
             // [row fwd] + [row rev] + [col fwd] + [col rev]; explicit batches of 4 channels x 4 buffers in flight (8 x 4 spills at 128 registers)
-            constexpr int YB = 4;
+            // channels per batch of y loads (x 4 direction buffers in flight per lane).  The recomputing form runs two waves per SIMD
+            // with registers to spare: 16 channels = 64 loads in flight per lane, 0.71 -> 0.65 ms at UHD level 1 (4.9 TB/s on its
+            // 1536 B per position); 32 gains nothing more (tools/bench_lfss_rz.py with -DWM_LFSS_MID_YB_RZ=..)
+#ifndef WM_LFSS_MID_YB_RZ
+#define WM_LFSS_MID_YB_RZ 16
+#endif
+            constexpr int YB = RZ ? WM_LFSS_MID_YB_RZ : 4;
 #pragma unroll
             for (int d0 = 0; d0 < D; d0 += YB) {
                 float t[4][YB];
