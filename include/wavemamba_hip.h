@@ -395,6 +395,15 @@ int wm_skff_fwd(const float* x0, const float* x1, const float* x2, const float* 
                 const float* Wfc, float* out, void* workspace, size_t workspace_bytes, int B, int C, int d, int H, int W,
                 void* stream);
 
+/* The UNet's pixel-unshuffled image inputs, ps_down{1,2,3} = nn.Sequential(nn.PixelUnshuffle(r), nn.Conv2d(r*r*Cin, Cout, 1))
+ * (wavemamba_arch.py:1014-1025, applied to the input image at :1043-1045), as one r x r / stride-r convolution read straight from
+ * the image: y[b, o, yo, xo] = bias[o] + sum_{c,i,j} weight[o, (c r + i) r + j] * img[b, c, r yo + i, r xo + j].
+ *   img (B, Cin, H, W) fp32, 16-byte aligned, H and W multiples of r; weight (Cout, Cin r r) = the Conv2d's (Cout, Cin r r, 1, 1);
+ *   bias (Cout) or NULL; y (B, Cout, H / r, W / r) fp32.  r in {2, 4, 8}, Cout in {16, 32, 48, 64}, Cin r r Cout <= 16384
+ *   (else WM_EUNSUPPORTED: callers keep the two modules).  fp32 FMAs in PixelUnshuffle's (c, i, j) channel order. */
+int wm_patchify_conv_fwd(const float* img, const float* weight, const float* bias, float* y, int B, int Cin, int Cout, int H, int W,
+                         int r, void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * Profiling hooks used by bench.py (HIP events recorded on the launch stream around each kernel
  * class).  Disabled by default; when disabled the library records nothing.
@@ -404,7 +413,7 @@ int wm_skff_fwd(const float* x0, const float* x1, const float* x2, const float* 
  *               (+ the merged-output sum), 9 wm_lfss_mid_fwd, 10 ss2d core chunk-reduce (+ the parameter prep),
  *               11 wm_lfss_out_fwd / wm_lfss_out_conv_fwd, 12 selective-scan backward (all phases),
  *               13 dense 3x3 convolution, 14 1x1 convolution, 15 SKFF (all three kernels), 16 LayerNorm2d,
- *               17 depth-wise conv without SiLU (HFE branch, ffn), 18-19 unused
+ *               17 depth-wise conv without SiLU (HFE branch, ffn), 18 wm_patchify_conv_fwd, 19 unused
  * wm_prof_enable(mask): bit k of `mask` switches recording for kernel id k (0 = off, ~0u = every class);
  * a non-zero mask also clears what was recorded before.  Two hipEventRecord calls cost ~10 us of stream
  * time per launch, so a caller timing a whole step enables only the classes it needs.

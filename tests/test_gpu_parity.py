@@ -438,6 +438,84 @@ def test_ss2d_core_vs_oracle(B, D, H, W, N, R):
     assert_close(wm.ops.ss2d_core(*cu(*case), merged=True), sum(want), TOL, "merged")
 
 
+@pytest.mark.parametrize("B,D,H,W,N,R", [
+    (1, 64, 64, 64, 16, 2), (2, 64, 24, 40, 16, 2), (1, 64, 40, 136, 16, 2), (1, 48, 9, 7, 8, 3), (1, 64, 128, 128, 16, 2),
+    (1, 16, 16, 2048, 16, 2), (1, 64, 48, 40, 32, 2), (2, 64, 33, 71, 16, 2), (1, 64, 65, 33, 16, 2), (1, 8, 1, 1, 16, 1),
+    (1, 64, 1, 37, 16, 2), (1, 64, 272, 480, 16, 2),
+])
+def test_ss2d_core_paired_planes(B, D, H, W, N, R):
+    """Paired mode (merged = 2): two output planes, each reversed direction's launch ADDS into the plane its forward twin's
+    launch stored.  fp32 planes: bit-equal to the pairwise sums of the four-plane outputs (one fp32 addition either way)."""
+    case = cu(*random_core_case(B, D, H, W, N, R, seed=H * 100 + W))
+    y4 = wm.ops.ss2d_core(*case)
+    y2 = wm.ops.ss2d_core(*case, merged=2)
+    assert len(y2) == 2
+    assert torch.equal(y2[0], y4[0] + y4[1]), "row pair"
+    assert torch.equal(y2[1], y4[2] + y4[3]), "column pair"
+
+
+def test_ss2d_core_paired_planes_bf16():
+    """bf16 planes: the forward twin's output is rounded to bf16 when stored, the sum once more."""
+    case = cu(*random_core_case(1, 64, 40, 136, 16, 2, seed=11))
+    xb = case[0].bfloat16()
+    y4 = wm.ops.ss2d_core(xb.float(), *case[1:])
+    y2 = wm.ops.ss2d_core(xb, *case[1:], merged=2)
+    for i in range(2):
+        want = (y4[2 * i].bfloat16().float() + y4[2 * i + 1]).bfloat16()
+        assert y2[i].dtype == torch.bfloat16 and torch.equal(y2[i], want), f"pair {i}"
+
+
+def test_lfss_block_paired_core(monkeypatch):
+    """LFSSBlock inference with the core's paired mode (lfss_mid reads two planes): same block output as with four planes up to
+    the order of three fp32 additions ((y1 + y2) + (y3 + y4) instead of ((y1 + y2) + y3) + y4, :490)."""
+    torch.manual_seed(5)
+    blk = arch.LFSSBlock(32, expand=2.0).eval().to(DEV)
+    for hw in ((64, 96), (33, 72)):
+        x = torch.randn(2, hw[0] * hw[1], 32, generator=gen(9)).to(DEV)
+        with torch.no_grad():
+            monkeypatch.setattr(wm.ops, "_CORE_PAIRED", False)
+            a = wm.ops.lfss_block_forward(x, hw, blk)
+            monkeypatch.setattr(wm.ops, "_CORE_PAIRED", True)
+            b = wm.ops.lfss_block_forward(x, hw, blk)
+        assert_close(b, a, 2e-6, f"paired block {hw}")
+
+
+@pytest.mark.parametrize("B,Cin,H,W,r,Cout", [
+    (1, 3, 64, 96, 2, 32), (2, 3, 64, 96, 4, 32), (1, 3, 64, 96, 8, 32), (1, 3, 272, 520, 2, 32), (1, 3, 40, 1048, 8, 32),
+    (2, 3, 16, 24, 8, 16), (1, 3, 32, 48, 4, 48), (1, 4, 24, 40, 2, 64), (1, 1, 8, 8, 8, 16), (1, 3, 2160, 3840, 8, 32),
+])
+def test_patchify_conv_vs_float64(B, Cin, H, W, r, Cout):
+    """wm_patchify_conv_fwd = nn.PixelUnshuffle(r) + 1x1 nn.Conv2d (reference :1014-1025) against the float64 composition of the two
+    PyTorch ops; the fp32 composition's own error is printed beside it."""
+    g = gen(H + W + r)
+    img = torch.rand(B, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin * r * r, 1, 1, generator=g) / (Cin * r * r) ** 0.5).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    assert wm.ops.patchify_conv_supported(img, w, r)
+    got = wm.ops.patchify_conv(img, w, b, r)
+    want = F.conv2d(F.pixel_unshuffle(img.double(), r), w.double(), b.double())
+    assert_close(got.double(), want, 2e-6, f"patchify r={r}")
+    nob = wm.ops.patchify_conv(img, w, None, r)
+    assert_close(nob.double(), want - b.double().view(1, -1, 1, 1), 2e-6, f"patchify r={r} no bias")
+
+
+def test_patchify_conv_in_network(golden):
+    """The UNet takes the fused kernel for ps_down1..3 in inference: same output as with the two modules (PixelUnshuffle copy +
+    1x1 matrix-core convolution) within the convolutions' own accuracy."""
+    torch.manual_seed(0)
+    net = wm.WaveMamba(in_chn=3, wf=32, n_l_blocks=[1, 1, 1], n_h_blocks=[1, 1, 1], ffn_scale=2.0).eval().to(DEV)
+    img = torch.rand(1, 3, 128, 192, generator=gen(3)).to(DEV)
+    with torch.no_grad():
+        a = net(img)
+        orig = wm.ops.patchify_conv_supported
+        try:
+            wm.ops.patchify_conv_supported = lambda *args: False
+            b = net(img)
+        finally:
+            wm.ops.patchify_conv_supported = orig
+    assert_close(a, b, 2e-5, "network with / without the fused patch embedding")
+
+
 def test_ss2d_core_unaligned_planes():
     """x at a 4-byte-aligned address that is not 16-byte aligned (a view into a larger buffer): the core takes its
     element-wise tile accesses instead of refusing the call; same results as from an aligned copy."""

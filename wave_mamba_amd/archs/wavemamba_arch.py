@@ -114,6 +114,16 @@ def _conv(conv, x, x2=None, x2_index=None, gate=None, residual=None):
     return y
 
 
+def _ps_conv(ps, img):
+    """ps = nn.Sequential(nn.PixelUnshuffle(r), 1x1 nn.Conv2d) on the input image (reference :1014-1025, :1043-1045).  Inference
+    on the HIP backend: one r x r / stride-r kernel reading the image itself (no unshuffled copy); otherwise the two modules."""
+    ops = _OpsBackend.impl
+    r, conv = ps[0].downscale_factor, ps[1]
+    if (hasattr(ops, "patchify_conv") and ops.patchify_conv_supported(img, conv.weight, r) and not _needs_grad(conv, img)):
+        return ops.patchify_conv(img, conv.weight, conv.bias, r)
+    return _conv(conv, ps[0](img))
+
+
 def _ln_conv(norm, conv, x):
     """conv(norm(x)) for a LayerNorm2d `norm` (or None) and a 1x1 nn.Conv2d: HFEBlock's norm1 -> attn.qkv and norm2 ->
     ffn.project_in[0] (reference :843-851).  Inference on the HIP backend: ONE kernel (the normalisation happens in the 1x1
@@ -802,14 +812,14 @@ class UNet(nn.Module):
         sides = _side_streams(x, 3) if self.two_streams and not _needs_grad(self, x) else (None, None, None)
         pss = (self.ps_down1, self.ps_down2, self.ps_down3)
         if sides[0] is None:
-            d, d_ready = [_conv(ps[1], ps[0](img)) for ps in pss], (None, None, None)
+            d, d_ready = [_ps_conv(ps, img) for ps in pss], (None, None, None)
         else:                                          # the pixel-unshuffled inputs of the three l_convs: off the main chain too
             main = torch.cuda.current_stream(x.device)
             d, d_ready = [], []
             for ps, side in zip(pss, sides):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    d.append(_conv(ps[1], ps[0](img)))
+                    d.append(_ps_conv(ps, img))
                     d_ready.append(side.record_event())
             img.record_stream(sides[0]); img.record_stream(sides[1]); img.record_stream(sides[2])
         low, high1 = self.down_group1(_conv(self.conv_01, img), d[0], sides[0], d_ready[0])

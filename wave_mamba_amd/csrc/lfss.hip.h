@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void lfss_mid_kernel(
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         const float* q = ysum + (b * D + d) * L + p;
-        y[d] = ny == 1 ? q[0] : ((q[0] + q[ystride]) + q[2 * ystride]) + q[3 * ystride];     // y1 + y2 + y3 + y4 (:490)
+        y[d] = ny == 1 ? q[0] : ny == 2 ? q[0] + q[ystride] : ((q[0] + q[ystride]) + q[2 * ystride]) + q[3 * ystride];     // y1 + y2 + y3 + y4 (:490)
     }
     layer_norm<D>(y, on_w, on_b, on_eps);
 #pragma unroll

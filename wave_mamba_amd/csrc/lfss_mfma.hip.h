@@ -204,16 +204,20 @@ __global__ __launch_bounds__(256, RZ ? WM_LFSS_MID_RZ_WAVES : WM_LFSS_MID_WAVES)
 #ifndef WM_LFSS_MID_YB_RZ
 #define WM_LFSS_MID_YB_RZ 16
 #endif
-            constexpr int YB = RZ ? WM_LFSS_MID_YB_RZ : 4;
+            // NY = 2 (paired core output): [row fwd + row rev] + [col fwd + col rev], twice the channels per batch = the same loads in flight
+            constexpr int YB = (RZ ? WM_LFSS_MID_YB_RZ : 4) * (NY == 2 ? 2 : 1);
 #pragma unroll
             for (int d0 = 0; d0 < D; d0 += YB) {
-                float t[4][YB];
+                float t[NY][YB];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < NY; ++q)
 #pragma unroll
                     for (int i = 0; i < YB; ++i) t[q][i] = ld1(yp + q * ystride + (long long)(d0 + i) * L);
 #pragma unroll
-                for (int i = 0; i < YB; ++i) y[d0 + i] = ((t[0][i] + t[1][i]) + t[2][i]) + t[3][i];
+                for (int i = 0; i < YB; ++i) {
+                    if constexpr (NY == 2) y[d0 + i] = t[0][i] + t[1][i];
+                    else y[d0 + i] = ((t[0][i] + t[1][i]) + t[2][i]) + t[3][i];
+                }
                 __builtin_amdgcn_sched_barrier(0);       // one batch of loads in flight, not all 256 (spills)
             }
         }

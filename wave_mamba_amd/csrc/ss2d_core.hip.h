@@ -102,6 +102,9 @@ struct CoreArgs {
     int row_cpw;                                // row chunks per workgroup (handed to its waves on demand)
     unsigned long long* stamps;                 // WM_CORE_STAMP builds: [workgroup][wave][12] cycle totals / stamps, else unused
     int dirmask;                                // bit k set: direction k runs (tools: time one direction alone)
+    int col_wgs16;                              // col_tiles * col_nseg rounded up to 16 (paired mode's half grids)
+    int pairsel;                                // -1: all four directions in one grid; 0 / 1: the grid holds the forward / the reversed
+                                                // directions' slots only (paired mode: consecutive workgroup ids = consecutive XCDs)
     const float* prep;                          // ss2d_core_prep_kernel's output: 4 x CoreCfg<NP>::PREP floats
     int col_seg, col_nseg, col_tiles, col_wgs;  // rows per column segment (multiple of 16), segments, column tiles,
                                                 // workgroup slots per direction (col_tiles * col_nseg rounded up to 8)
@@ -216,7 +219,9 @@ __device__ __forceinline__ void core_lds_fence() {       // LDS hand-off between
 // RHI: dt_rank > 2 (the dt projection reads four record slots instead of two).
 // VEC: 16-byte tile accesses (W % 4 == 0, 16-byte aligned planes) or element-wise ones with per-element masks (any W, fp32
 // planes: odd map widths are rare - the network pads its input to multiples of 8 - and take the same kernel, slower).
-template <int NP, int NW, int PHASE, bool RHI, typename TP, bool COL, bool REV, bool VEC>
+// RMW (scan pass of the PAIRED mode, reversed directions only): y is ADDED to what the mirrored forward direction's
+// launch stored at the same positions (p.y[k] == p.y[k - 2]) - two output planes per call instead of four.
+template <int NP, int NW, int PHASE, bool RHI, typename TP, bool COL, bool REV, bool VEC, bool RMW = false>
 __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const int b, const int wg, float* smem) {
     using Cfg = CoreCfg<NP>;
     constexpr int NTB = Cfg::NTB, NQ = Cfg::NQ, RS = Cfg::RS, ROW = Cfg::ROW, XT = Cfg::XT;
@@ -426,7 +431,27 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
             const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (elem_ok(ti, i, j)) st1(yb + (tile_off(ti, i) + (unsigned)j), v[j]);
+                if (elem_ok(ti, i, j)) {
+                    TP* q = yb + (tile_off(ti, i) + (unsigned)j);
+                    st1(q, RMW ? ld1(q) + v[j] : v[j]);
+                }
+        }
+    };
+    // paired mode: the quads this thread is about to overwrite, as the forward direction's launch left them (clamped
+    // offsets like fetch(): invalid quads are loaded from offset 0 and never stored)
+    typename IO::raw yo[4];
+    auto fetch_y = [&](int ti) {
+        if constexpr (RMW && VEC) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) yo[i] = IO::load(yb + (tile_ok(ti, i) ? tile_off(ti, i) : 0u));
+        }
+    };
+    auto add_y = [&](int i, float4 v4) -> float4 {
+        if constexpr (RMW && VEC) {
+            const float4 o = IO::cvt(yo[i]);
+            return make_float4(o.x + v4.x, o.y + v4.y, o.z + v4.z, o.w + v4.w);
+        } else {
+            return v4;
         }
     };
 
@@ -635,10 +660,11 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
 
         WM_STAMP(3)                                      // 16 scan steps
         if (PHASE == 3 && !(WM_CORE_ABLATE & 4)) {
+            fetch_y(ti);                                 // (paired mode) in flight across the fence / barrier + LDS reads below
             if (!COL) {
                 core_lds_fence();
 #pragma unroll
-                for (int i = 0; i < 4; ++i) put(ti, i, *reinterpret_cast<const float4*>(&sx[(16 * i + trow) * ROW + 4 * tq]));
+                for (int i = 0; i < 4; ++i) put(ti, i, add_y(i, *reinterpret_cast<const float4*>(&sx[(16 * i + trow) * ROW + 4 * tq])));
                 core_lds_fence();                        // the y tile is read before the next stage() overwrites it
             } else {
                 core_barrier();
@@ -660,10 +686,10 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
                 if (full) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        IO::store(yb + tile_off(ti, i), make_float4(v[i][0], v[i][1], v[i][2], v[i][3]));
+                        IO::store(yb + tile_off(ti, i), add_y(i, make_float4(v[i][0], v[i][1], v[i][2], v[i][3])));
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) put(ti, i, make_float4(v[i][0], v[i][1], v[i][2], v[i][3]));
+                    for (int i = 0; i < 4; ++i) put(ti, i, add_y(i, make_float4(v[i][0], v[i][1], v[i][2], v[i][3])));
                 }
                 core_barrier();
             }
@@ -722,12 +748,16 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
 // same XCD (workgroup id -> XCD id % 8), whose L2 then holds the line.
 // second launch-bound: minimum waves per SIMD (N <= 16: four, i.e. <= 128 registers - one 16-wave or two 8-wave
 // workgroups per compute unit; N = 32: two)
-template <int NP, int NW, int PHASE, bool RHI, typename TP = float, bool VEC = true>
+// RMW: the second scan launch of the paired mode - reversed directions only, adding into the forward directions' planes.
+template <int NP, int NW, int PHASE, bool RHI, typename TP = float, bool VEC = true, bool RMW = false>
 __global__ __launch_bounds__(64 * NW, NP == 16 ? 4 : 2) void ss2d_core_kernel(CoreArgs p) {
     extern __shared__ __attribute__((aligned(16))) float core_smem[];
-    const int per_b = 2 * p.row_wgs + 2 * p.col_wgs;
+    // paired mode's half grids: col_wgs16 column slots (a multiple of 16) + row_wgs row slots of ONE direction each
+    const int ncol = p.pairsel < 0 ? p.col_wgs : p.col_wgs16;
+    const int per_b = p.pairsel < 0 ? 2 * (p.row_wgs + ncol) : p.row_wgs + ncol;
     const int b = blockIdx.x / per_b;
     int r = blockIdx.x - b * per_b;
+    if (p.pairsel >= 0) r = 2 * r + p.pairsel;          // slot ids alternate forward / reversed
     bool col;
 #if WM_CORE_INTERLEAVE
     // experiment: column and row slots alternate in blocks of WM_CORE_INTERLEAVE workgroup ids (= one dispatch round of
@@ -741,20 +771,22 @@ __global__ __launch_bounds__(64 * NW, NP == 16 ? 4 : 2) void ss2d_core_kernel(Co
         else { r -= 2 * m; col = r < nc - m; r = m + (col ? r : r - (nc - m)); }
     }
 #else
-    col = r < 2 * p.col_wgs;
-    if (!col) r -= 2 * p.col_wgs;
+    col = r < 2 * ncol;
+    if (!col) r -= 2 * ncol;
 #endif
     if (col) {
         const int idx = r >> 1;
-        const int wg = (((idx >> 3) << 2) + (idx & 3)) * 2 + ((idx >> 2) & 1);
+        // (half grid: the two tiles of a line pair sit 8 workgroup ids apart there too)
+        const int wg = p.pairsel < 0 ? (((idx >> 3) << 2) + (idx & 3)) * 2 + ((idx >> 2) & 1)
+                                     : (((idx >> 4) << 3) + (idx & 7)) * 2 + ((idx >> 3) & 1);
         if (wg >= p.col_tiles * p.col_nseg || !((p.dirmask >> ((r & 1) * 2 + 1)) & 1)) return;
-        if (r & 1) core_body<NP, NW, PHASE, RHI, TP, true, true, VEC>(p, 3, b, wg, core_smem);
-        else core_body<NP, NW, PHASE, RHI, TP, true, false, VEC>(p, 1, b, wg, core_smem);
+        if (r & 1) core_body<NP, NW, PHASE, RHI, TP, true, true, VEC, RMW>(p, 3, b, wg, core_smem);
+        else if constexpr (!RMW) core_body<NP, NW, PHASE, RHI, TP, true, false, VEC>(p, 1, b, wg, core_smem);
     } else {
         const int wg = r >> 1;
         if (!((p.dirmask >> ((r & 1) * 2)) & 1)) return;
-        if (r & 1) core_body<NP, NW, PHASE, RHI, TP, false, true, VEC>(p, 2, b, wg, core_smem);
-        else core_body<NP, NW, PHASE, RHI, TP, false, false, VEC>(p, 0, b, wg, core_smem);
+        if (r & 1) core_body<NP, NW, PHASE, RHI, TP, false, true, VEC, RMW>(p, 2, b, wg, core_smem);
+        else if constexpr (!RMW) core_body<NP, NW, PHASE, RHI, TP, false, false, VEC>(p, 0, b, wg, core_smem);
     }
 }
 

@@ -29,6 +29,7 @@
 #include "imageio.hip.h"
 #include "gates.hip.h"
 #include "conv_wgrad.hip.h"
+#include "patchify.hip.h"
 
 namespace wm {
 
@@ -222,7 +223,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 23; }
+int wm_abi_version(void) { return 24; }
 
 #ifndef WM_BUILD_ID
 #define WM_BUILD_ID "unknown"
@@ -684,7 +685,7 @@ static int core_plan(CorePlan& pl, int B, int D, int H, int W, int N, int R, int
 }
 
 template <int NP, int NW, bool RHI, typename TP, bool VEC>
-static int core_launch(const CoreArgs& a, const CorePlan& pl, bool do_prep, hipStream_t st) {
+static int core_launch(const CoreArgs& a, const CorePlan& pl, bool do_prep, bool paired, hipStream_t st) {
     constexpr int lds = core_lds_bytes<NP, NW>();
     // > 64 KB of dynamic LDS is an opt-in per function AND per device
     static bool configured[64] = {};
@@ -698,6 +699,9 @@ static int core_launch(const CoreArgs& a, const CorePlan& pl, bool do_prep, hipS
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)ss2d_core_kernel<NP, NW, 3, RHI, TP, VEC>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)ss2d_core_kernel<NP, NW, 3, RHI, TP, VEC, true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) return WM_EHIP;
             if (dev >= 0 && dev < 64) configured[dev] = true;
@@ -726,9 +730,19 @@ static int core_launch(const CoreArgs& a, const CorePlan& pl, bool do_prep, hipS
         hipLaunchKernelGGL((selscan_carry_kernel<false>), dim3((unsigned)((nchains + 15) / 16), 1, 4), dim3(1024), 0,
                            st, cb, nchains);
     }
-    {
+    if (!paired) {
         ProfScope ps(8, st);
         hipLaunchKernelGGL((ss2d_core_kernel<NP, NW, 3, RHI, TP, VEC>), grid, block, lds, st, a);
+    } else {
+        // paired mode: the forward directions store y[0] (rows) / y[1] (columns); a second launch runs the reversed
+        // directions, which ADD their outputs to the same planes (stream order is the only ordering the two need)
+        ProfScope ps(8, st);
+        CoreArgs f = a, r = a;
+        f.pairsel = 0;
+        r.pairsel = 1; r.y[2] = a.y[0]; r.y[3] = a.y[1];
+        const dim3 half((unsigned)(a.B * (pl.row_wgs + a.col_wgs16)));
+        hipLaunchKernelGGL((ss2d_core_kernel<NP, NW, 3, RHI, TP, VEC>), half, block, lds, st, f);
+        hipLaunchKernelGGL((ss2d_core_kernel<NP, NW, 3, RHI, TP, VEC, true>), half, block, lds, st, r);
     }
     return launch_status();
 }
@@ -738,7 +752,7 @@ extern "C" {
 size_t wm_ss2d_core_fwd_workspace_bytes(int B, int D, int H, int W, int N, int R, int merged) {
     // (sized for fp32 planes; bf16 planes need less for the merged mode's temporaries)
     CorePlan pl;
-    if (core_plan(pl, B, D, H, W, N, R, merged) != WM_OK) return 0;
+    if (core_plan(pl, B, D, H, W, N, R, merged == 1) != WM_OK) return 0;
     return pl.total;
 }
 
@@ -783,15 +797,20 @@ int wm_ss2d_core_fwd(const void* x, const float* x_proj_weight, const float* dt_
     if (B == 0 || D == 0 || H == 0 || W == 0) return (B < 0 || D < 0 || H < 0 || W < 0) ? WM_EINVAL : WM_OK;
     if (plane_dtype != WM_F32 && plane_dtype != WM_BF16) return WM_EUNSUPPORTED;
     CorePlan pl;
-    int rc = core_plan(pl, B, D, H, W, N, R, merged);
+    int rc = core_plan(pl, B, D, H, W, N, R, merged == 1);
     if (rc) return rc;
     if (!x || !x_proj_weight || !dt_projs_weight || !dt_projs_bias || !A_logs || !Ds || !y_row_fwd) return WM_ENULL;
-    if (!merged && (!y_row_rev || !y_col_fwd || !y_col_rev)) return WM_ENULL;
+    if (merged < 0 || merged > 2) return WM_EINVAL;
+    const bool paired = merged == 2;      // two planes: y_row_fwd <- row forward + row reversed, y_col_fwd <- column forward + reversed
+    if (merged == 0 && (!y_row_rev || !y_col_fwd || !y_col_rev)) return WM_ENULL;
+    if (paired && !y_col_fwd) return WM_ENULL;
+    if (paired) merged = 0;
     if (!workspace) return WM_ENULL;
     if (workspace_bytes < pl.total) return WM_EWORKSPACE;
     if (!aligned16(workspace)) return WM_EALIGN;
     // 16-byte tile accesses when the map width allows them (every size the network itself produces: it pads its input
     // to multiples of 8); otherwise the same kernels with element-wise tile accesses (fp32 planes only).
+    if (paired) { y_row_rev = y_row_fwd; y_col_rev = y_col_fwd; }
     const bool planes16 = aligned16(x) && aligned16(y_row_fwd) &&
                           (merged || (aligned16(y_row_rev) && aligned16(y_col_fwd) && aligned16(y_col_rev)));
     const bool vec = (W % 4 == 0) && planes16;
@@ -829,6 +848,7 @@ int wm_ss2d_core_fwd(const void* x, const float* x_proj_weight, const float* dt_
         static const int mask = [] { const char* e = getenv("WM_CORE_DIRMASK"); return e ? atoi(e) : 15; }();
         a.dirmask = mask;
     }
+    a.pairsel = -1; a.col_wgs16 = ((pl.col_tiles * pl.col_nseg + 15) / 16) * 16;
     a.col_seg = pl.col_seg; a.col_nseg = pl.col_nseg; a.col_tiles = pl.col_tiles; a.col_wgs = pl.col_wgs;
 #ifndef WM_CORE_NW
 #define WM_CORE_NW 16
@@ -836,8 +856,8 @@ int wm_ss2d_core_fwd(const void* x, const float* x_proj_weight, const float* dt_
 #define WM_CORE_GO(TP, VEC)                                                                                                   \
     do {                                                                                                                      \
         const bool dp = prepared == nullptr;                                                                                  \
-        if (pl.NP == 16) rc = R > 2 ? core_launch<16, WM_CORE_NW, true, TP, VEC>(a, pl, dp, st) : core_launch<16, WM_CORE_NW, false, TP, VEC>(a, pl, dp, st); \
-        else rc = R > 2 ? core_launch<32, 8, true, TP, VEC>(a, pl, dp, st) : core_launch<32, 8, false, TP, VEC>(a, pl, dp, st); \
+        if (pl.NP == 16) rc = R > 2 ? core_launch<16, WM_CORE_NW, true, TP, VEC>(a, pl, dp, paired, st) : core_launch<16, WM_CORE_NW, false, TP, VEC>(a, pl, dp, paired, st); \
+        else rc = R > 2 ? core_launch<32, 8, true, TP, VEC>(a, pl, dp, paired, st) : core_launch<32, 8, false, TP, VEC>(a, pl, dp, paired, st); \
     } while (0)
     if (!vec) WM_CORE_GO(float, false);
     else if (plane_dtype == WM_F32) WM_CORE_GO(float, true);
@@ -1290,7 +1310,7 @@ int wm_lfss_mid_fwd(const void* ysum_, int ny, int64_t ystride, const void* z_, 
                     const float* skip_scale, const float* ln2_w, const float* ln2_b, float ln2_eps,
                     const float* conv1_weight, const float* conv1_bias, float* tok1, void* f_, int B, int64_t L,
                     int C, int plane_dtype, void* stream) {
-    if (B < 0 || L < 0 || (ny != 1 && ny != 4)) return WM_EINVAL;
+    if (B < 0 || L < 0 || (ny != 1 && ny != 2 && ny != 4)) return WM_EINVAL;
     if (plane_dtype != WM_F32 && !(plane_dtype == WM_BF16 && C == 32)) return WM_EUNSUPPORTED;
     const float* ysum = (const float*)ysum_; const float* z = (const float*)z_; float* f = (float*)f_;
     if (B && L && (!ysum || !z || !tok || !out_norm_w || !out_norm_b || !out_proj_weight || !skip_scale || !ln2_w ||
@@ -1307,8 +1327,8 @@ int wm_lfss_mid_fwd(const void* ysum_, int ny, int64_t ystride, const void* z_, 
                            (const TP*)ysum_, (long long)ystride, (const TP*)z_, tok, tok_nchw,                                     \
                            out_norm_w, out_norm_b, out_norm_eps, out_proj_weight, skip_scale, ln2_w, ln2_b, ln2_eps,               \
                            conv1_weight, conv1_bias, tok1, (TP*)f_, B, (long long)L, ngl, ngroups, gpw)
-        if (plane_dtype == WM_F32) { if (ny == 4) WM_MID(4, float); else WM_MID(1, float); }
-        else { if (ny == 4) WM_MID(4, bf16_t); else WM_MID(1, bf16_t); }
+        if (plane_dtype == WM_F32) { if (ny == 4) WM_MID(4, float); else if (ny == 2) WM_MID(2, float); else WM_MID(1, float); }
+        else { if (ny == 4) WM_MID(4, bf16_t); else if (ny == 2) WM_MID(2, bf16_t); else WM_MID(1, bf16_t); }
 #undef WM_MID
         return launch_status();
     }
@@ -1324,7 +1344,7 @@ int wm_lfss_mid_rz_fwd(const void* ysum_, int ny, int64_t ystride, const float* 
                        const float* skip_scale, const float* ln2_w, const float* ln2_b, float ln2_eps,
                        const float* conv1_weight, const float* conv1_bias, float* tok1, void* f_, int B, int64_t L,
                        int C, int plane_dtype, void* stream) {
-    if (B < 0 || L < 0 || (ny != 1 && ny != 4)) return WM_EINVAL;
+    if (B < 0 || L < 0 || (ny != 1 && ny != 2 && ny != 4)) return WM_EINVAL;
     if (C != 32 || (plane_dtype != WM_F32 && plane_dtype != WM_BF16)) return WM_EUNSUPPORTED;
     if (B == 0 || L == 0) return WM_OK;
     if (!ysum_ || !tok || !ln1_w || !ln1_b || !in_proj_weight || !out_norm_w || !out_norm_b || !out_proj_weight || !skip_scale ||
@@ -1341,8 +1361,8 @@ int wm_lfss_mid_rz_fwd(const void* ysum_, int ny, int64_t ystride, const float* 
                            out_norm_w, out_norm_b, out_norm_eps, out_proj_weight, skip_scale, ln2_w, ln2_b, ln2_eps,                 \
                            conv1_weight, conv1_bias, tok1, (TP*)f_, B, (long long)L, ngl, ngroups, gpw, ln1_w, ln1_b, ln1_eps,       \
                            in_proj_weight)
-    if (plane_dtype == WM_F32) { if (ny == 4) WM_MIDZ(4, float); else WM_MIDZ(1, float); }
-    else { if (ny == 4) WM_MIDZ(4, bf16_t); else WM_MIDZ(1, bf16_t); }
+    if (plane_dtype == WM_F32) { if (ny == 4) WM_MIDZ(4, float); else if (ny == 2) WM_MIDZ(2, float); else WM_MIDZ(1, float); }
+    else { if (ny == 4) WM_MIDZ(4, bf16_t); else if (ny == 2) WM_MIDZ(2, bf16_t); else WM_MIDZ(1, bf16_t); }
 #undef WM_MIDZ
     return launch_status();
 }
@@ -1397,6 +1417,36 @@ int wm_lfss_out_conv_fwd(const void* f_, const float* conv2_weight, const float*
         hipLaunchKernelGGL(lfss_out_conv_mfma_kernel<bf16_t>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
                            (const bf16_t*)f_, conv2_weight, conv2_bias, tok1, conv3_weight, conv3_bias, skip_scale2, out, out_nchw,
                            B, H, W, ngl, ngroups, gpw);
+    return launch_status();
+}
+
+// nn.Sequential(nn.PixelUnshuffle(r), nn.Conv2d(r r Cin, Cout, 1)) of the UNet's image inputs (reference :1014-1025, :1043-1045) in one
+// kernel: an r x r / stride r convolution read straight from the image (patchify.hip.h).
+int wm_patchify_conv_fwd(const float* img, const float* weight, const float* bias, float* y, int B, int Cin, int Cout, int H, int W,
+                         int r, void* stream) {
+    if (B < 0 || Cin <= 0 || Cout <= 0 || H < 0 || W < 0) return WM_EINVAL;
+    if (r != 2 && r != 4 && r != 8) return WM_EUNSUPPORTED;
+    if (H % r || W % r) return WM_EINVAL;
+    if (Cout != 16 && Cout != 32 && Cout != 48 && Cout != 64) return WM_EUNSUPPORTED;
+    const size_t lds = (size_t)Cin * r * r * Cout * sizeof(float);
+    if (lds > 64 * 1024) return WM_EUNSUPPORTED;
+    if (B == 0 || H == 0 || W == 0) return WM_OK;
+    if (!img || !weight || !y) return WM_ENULL;
+    if (!aligned16(img)) return WM_EALIGN;
+    if ((long long)B * Cin * H * W >= (1ll << 40)) return WM_EUNSUPPORTED;
+    const int Ho = H / r, Wo = W / r;
+    const int spr = (Wo + 255) / 256;
+    const long long nsegs = (long long)B * Ho * spr;
+    const int spb = (int)((nsegs + 4095) / 4096);
+    const long long blocks = (nsegs + spb - 1) / spb;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(18, st);
+#define WM_PF(R, CO) hipLaunchKernelGGL((patchify_conv_kernel<R, CO>), dim3((unsigned)blocks), dim3(256), lds, st, img, weight, bias, y, \
+                                        B, Cin, H, W, spr, nsegs, spb)
+#define WM_PFR(R) do { if (Cout == 16) WM_PF(R, 16); else if (Cout == 32) WM_PF(R, 32); else if (Cout == 48) WM_PF(R, 48); else WM_PF(R, 64); } while (0)
+    if (r == 2) WM_PFR(2); else if (r == 4) WM_PFR(4); else WM_PFR(8);
+#undef WM_PFR
+#undef WM_PF
     return launch_status();
 }
 

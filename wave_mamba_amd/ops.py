@@ -377,17 +377,22 @@ def _ss2d_core_fwd(f, merged, prepared=None, separate=False):
     x = f[0]
     B, D, H, W, N, R = _ss2d_core_shapes(x, f[1], f[2], f[4])
     L = H * W
-    if merged:
+    if merged == 2:     # paired: [row forward + row reversed, column forward + column reversed] in one (2, B, D, L) block
+        outs = list(torch.empty((2, B, D, L), dtype=x.dtype, device=x.device).unbind(0))
+    elif merged:
         outs = [torch.empty((B, D, L), dtype=x.dtype, device=x.device)]
     elif separate:
         outs = [torch.empty((B, D, L), dtype=x.dtype, device=x.device) for _ in range(4)]
     else:       # one allocation, reference return order: a consumer can add the four with one base pointer + stride
         outs = list(torch.empty((4, B, D, L), dtype=x.dtype, device=x.device).unbind(0))
-    ws_bytes = lib.wm_ss2d_core_fwd_workspace_bytes(B, D, H, W, N, R, int(bool(merged)))
+    ws_bytes = lib.wm_ss2d_core_fwd_workspace_bytes(B, D, H, W, N, R, int(merged))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
-    ptrs = [_ptr(o) for o in outs] + [None] * (4 - len(outs))
+    if merged == 2:     # C argument order: y_row_fwd, y_row_rev, y_col_fwd, y_col_rev
+        ptrs = [_ptr(outs[0]), None, _ptr(outs[1]), None]
+    else:
+        ptrs = [_ptr(o) for o in outs] + [None] * (4 - len(outs))
     with torch.cuda.device(x.device):
-        check(lib.wm_ss2d_core_fwd(*[_ptr(t) for t in f], *ptrs, int(bool(merged)), _ptr(ws), ws_bytes,
+        check(lib.wm_ss2d_core_fwd(*[_ptr(t) for t in f], *ptrs, int(merged), _ptr(ws), ws_bytes,
                                    None if prepared is None else _ptr(prepared),
                                    B, D, H, W, N, R, _dtype_code(x, "ss2d_core"), _stream()), "wm_ss2d_core_fwd")
     return outs
@@ -430,20 +435,25 @@ class _SS2DCoreFn(torch.autograd.Function):
 def ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, merged=False):
     """SS2D.forward_core (reference wavemamba_arch.py:446-478) in one call.
     x (B, D, H, W) fp32 -> (y_row_fwd, y_row_rev, y_col_fwd, y_col_rev), each (B, D, H*W) in
-    row-major l - the reference's return order; merged=True returns their sum (what :490 computes).
+    row-major l - the reference's return order; merged=True returns their sum (what :490 computes); merged=2 (paired mode)
+    returns (y_row_fwd + y_row_rev, y_col_fwd + y_col_rev): each reversed direction adds into its forward twin's plane.
     Differentiable w.r.t. x and the five parameters (HIP backward, wm_ss2d_core_bwd)."""
     _lib.load()
     _require_cuda("ss2d_core", x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
     _ss2d_core_shapes(x, x_proj_weight, dt_projs_weight, A_logs)
     args = (x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
+    paired = merged == 2 and merged is not True
     if torch.is_grad_enabled() and any(t.requires_grad for t in args):
+        if paired:
+            y = _SS2DCoreFn.apply(False, *args)
+            return y[0] + y[1], y[2] + y[3]
         return _SS2DCoreFn.apply(bool(merged), *args)
     xin = x.detach().contiguous()
     if xin.dtype != torch.bfloat16:                # bf16 planes stay bf16 (outputs too); anything else computes in fp32
         xin = xin.float()
-    outs = _ss2d_core_fwd([xin] + [t.detach().contiguous().float() for t in args[1:]], merged,
+    outs = _ss2d_core_fwd([xin] + [t.detach().contiguous().float() for t in args[1:]], 2 if paired else int(bool(merged)),
                           _ss2d_core_prepared(args[1:]))
-    return outs[0] if merged else tuple(outs)
+    return outs[0] if (merged and not paired) else tuple(outs)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -469,6 +479,8 @@ _FUSE_IN_CONV = os.environ.get("WM_FUSE_IN_CONV", "0") == "1"
 # The gate z = in_proj(ln_1(x))[D:] recomputed by lfss_mid from the tokens instead of written by lfss_in and read back
 # (512 of the block's 3456 B per position; bit-identical in fp32 planes: tests/test_gpu_parity.py).  0: round-3 data flow.
 _RECOMPUTE_Z = os.environ.get("WM_LFSS_RECOMPUTE_Z", "1") == "1"
+# the core's paired mode (two output planes: each reversed direction adds into its forward twin's plane) in LFSSBlock inference
+_CORE_PAIRED = os.environ.get("WM_CORE_PAIRED", "0") == "1"
 
 
 def lfss_prologue(tok, x_size, blk, tok_nchw=False, fused=True):
@@ -537,19 +549,21 @@ def lfss_block_forward(tok, x_size, blk, tok_nchw=False, out_nchw=False):
         xc = dwconv3x3(x, ss.conv2d.weight, ss.conv2d.bias, "silu")
     # the four directions' outputs stay separate (one (4, B, D, L) allocation); lfss_mid adds them as it loads (:490)
     core_params = (ss.x_proj_weight, ss.dt_projs_weight, ss.dt_projs_bias, ss.A_logs, ss.Ds)
-    y4 = _ss2d_core_fwd([xc] + [_w(t) for t in core_params], merged=False, prepared=_ss2d_core_prepared(core_params))
+    ny = 2 if _CORE_PAIRED else 4
+    y4 = _ss2d_core_fwd([xc] + [_w(t) for t in core_params], merged=2 if _CORE_PAIRED else 0,
+                        prepared=_ss2d_core_prepared(core_params))
     tok1 = torch.empty((B, L, C), dtype=torch.float32, device=dev)
     f = torch.empty((B, D, H, W), dtype=pd, device=dev)
     with torch.cuda.device(dev):
         if rz:
-            check(lib.wm_lfss_mid_rz_fwd(_ptr(y4[0]), 4, B * D * L, _ptr(tok), int(tok_nchw), _ptr(_w(blk.ln_1.weight)),
+            check(lib.wm_lfss_mid_rz_fwd(_ptr(y4[0]), ny, B * D * L, _ptr(tok), int(tok_nchw), _ptr(_w(blk.ln_1.weight)),
                                          _ptr(_w(blk.ln_1.bias)), float(blk.ln_1.eps), _ptr(_w(ss.in_proj.weight)),
                                          _ptr(_w(ss.out_norm.weight)), _ptr(_w(ss.out_norm.bias)), float(ss.out_norm.eps),
                                          _ptr(_w(ss.out_proj.weight)), _ptr(_w(blk.skip_scale)), _ptr(_w(blk.ln_2.weight)),
                                          _ptr(_w(blk.ln_2.bias)), float(blk.ln_2.eps), _ptr(_w(ff.conv1.weight)),
                                          _ptr(_w(ff.conv1.bias)), _ptr(tok1), _ptr(f), B, L, C, code, st), "wm_lfss_mid_rz_fwd")
         else:
-            check(lib.wm_lfss_mid_fwd(_ptr(y4[0]), 4, B * D * L, _ptr(z), _ptr(tok), int(tok_nchw), _ptr(_w(ss.out_norm.weight)),
+            check(lib.wm_lfss_mid_fwd(_ptr(y4[0]), ny, B * D * L, _ptr(z), _ptr(tok), int(tok_nchw), _ptr(_w(ss.out_norm.weight)),
                                       _ptr(_w(ss.out_norm.bias)), float(ss.out_norm.eps), _ptr(_w(ss.out_proj.weight)),
                                       _ptr(_w(blk.skip_scale)), _ptr(_w(blk.ln_2.weight)), _ptr(_w(blk.ln_2.bias)),
                                       float(blk.ln_2.eps), _ptr(_w(ff.conv1.weight)), _ptr(_w(ff.conv1.bias)),
@@ -1151,6 +1165,31 @@ def conv2d_ln(x, ln_weight, ln_bias, ln_eps, weight, bias=None, residual=None):
 _FUSE_LN_CONV = os.environ.get("WM_FUSE_LN_CONV", "1") == "1"      # 0: LayerNorm2d and the 1x1 convolution as two launches (A/B runs)
 
 
+def patchify_conv_supported(img, weight, r):
+    """Shapes wm_patchify_conv_fwd covers: nn.PixelUnshuffle(r) + 1x1 nn.Conv2d on an fp32 NCHW image."""
+    return (img.is_cuda and img.dtype == torch.float32 and img.dim() == 4 and weight.dim() == 4 and r in (2, 4, 8)
+            and tuple(weight.shape[2:]) == (1, 1) and weight.shape[1] == img.shape[1] * r * r and weight.shape[0] in (16, 32, 48, 64)
+            and img.shape[2] % r == 0 and img.shape[3] % r == 0 and weight.shape[0] * weight.shape[1] <= 16384)
+
+
+def patchify_conv(img, weight, bias, r):
+    """conv1x1(pixel_unshuffle(img, r)) (the UNet's ps_down1..3, reference wavemamba_arch.py:1014-1025 / :1043-1045) as one
+    r x r / stride-r convolution read straight from the image: the unshuffled tensor is never materialised.  Forward only.
+    img (B, Cin, H, W) fp32; weight (Cout, Cin r r, 1, 1); bias (Cout) or None -> (B, Cout, H / r, W / r) fp32."""
+    lib = _lib.load()
+    _require_cuda("patchify_conv", img, weight)
+    if not patchify_conv_supported(img, weight, r):
+        raise ValueError("patchify_conv: unsupported shapes (see patchify_conv_supported)")
+    img = img.contiguous()
+    B, Cin, H, W = img.shape
+    Cout = weight.shape[0]
+    y = torch.empty((B, Cout, H // r, W // r), dtype=torch.float32, device=img.device)
+    with torch.cuda.device(img.device):
+        check(lib.wm_patchify_conv_fwd(_ptr(img), _ptr(_w(weight)), None if bias is None else _ptr(_w(bias)), _ptr(y), B, Cin, Cout,
+                                       H, W, r, _stream()), "wm_patchify_conv_fwd")
+    return y
+
+
 def conv2d_ln_supported(x, weight):
     return (_FUSE_LN_CONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 32 and weight.dim() == 4
             and tuple(weight.shape[1:]) == (32, 1, 1) and x.shape[2] * x.shape[3] < 2 ** 31)
@@ -1415,7 +1454,7 @@ def conv2d_supported(x, weight, x2=None):
 PROF_KERNELS = ("haar_analysis", "haar_synthesis", "selscan_chunk_reduce", "selscan_carry",
                 "selscan_chunk_scan", "lfss_in", "ss2d_proj", "dwconv3x3",
                 "ss2d_core_scan", "lfss_mid", "ss2d_core_reduce", "lfss_out", "selscan_bwd",
-                "conv3x3", "conv1x1", "skff", "layernorm2d", "dwconv3x3_other", "unused_18", "unused_19")
+                "conv3x3", "conv1x1", "skff", "layernorm2d", "dwconv3x3_other", "patchify_conv", "unused_19")
 
 
 def prof_enable(on=True):
