@@ -50,7 +50,7 @@ EXP_PEAK = 18.5e12               # v_exp_f32 lane-ops/s chip-wide, tools/microbe
 #             (round 4, ops._RECOMPUTE_Z) -, writes tok1 and f (4 D NY [+ 4D] + 4C + 4C + 4D)  = 1536 (1792)
 #   lfss_out  reads f (4D) and tok1 (4C), writes the block's output (4C)                   = 512
 # The table quotes what the kernels the run actually used must move (never the larger figure for the smaller data flow).
-LFSS_MID_NY = 4
+LFSS_MID_NY = 2 if getattr(wm.ops, "_CORE_PAIRED", False) else 4       # (the core's opt-in paired mode writes two planes)
 
 
 def lfss_bytes_per_pos():

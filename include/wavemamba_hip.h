@@ -123,6 +123,11 @@ int wm_selscan_bwd(const float* u, const float* delta, const float* A, const flo
  *     transposed back).  merged != 0: only y_row_fwd is written and holds the SUM of the four
  *     (what SS2D.forward computes next, :490, added in the reference's order); the other three
  *     pointers may be NULL.  wm_lfss_mid_fwd can add the four un-merged outputs while it reads them.
+ *     merged == 2 (PAIRED mode): two planes - y_row_fwd receives row forward + row reversed, y_col_fwd column forward +
+ *     column reversed (y_row_rev / y_col_rev unused, may be NULL): the reversed directions run as a second chunk-scan launch
+ *     that adds into the planes the first one stored (fp32 planes: bit-equal to adding the un-merged outputs pairwise;
+ *     wm_lfss_mid_fwd ny = 2 reads them).  Measured slower than the four planes on MI355X (profiles/r04/
+ *     core_ab_paired_planes.txt): kept as an option, not the default data flow.
  *   Supported: N <= 32, R <= 4, D <= 64, D * H * W < 2^31 (else WM_EUNSUPPORTED: use wm_selscan_fwd); any H, W.
  *   W % 4 == 0 with 16-byte aligned x / y buffers: 16-byte tile accesses; otherwise (odd widths, fp32 planes only)
  *   the same kernels with element-wise tile accesses, slower per position.
@@ -173,7 +178,8 @@ int wm_dwconv3x3_fwd(const void* x, const float* weight, const float* bias, void
  *                     + skip_scale residual (:525) + ln_2 + ffn.conv1 (:526, :226)
  *                     ysum, z, tok -> tok1, f (input of ffn.conv2).  ny = 1: `ysum` is the merged core output;
  *                     ny = 4: `ysum` points at four (B, D, L) buffers `ystride` ELEMENTS of the plane dtype apart in the order
- *                     [y_row_fwd, y_row_rev, y_col_fwd, y_col_rev] and the kernel adds them (:490) as it loads
+ *                     [y_row_fwd, y_row_rev, y_col_fwd, y_col_rev] and the kernel adds them (:490) as it loads;
+ *                     ny = 2: two buffers [row pair, column pair] of the core's paired mode (merged == 2)
  *   wm_lfss_out_fwd : gelu gate (:227-228) + ffn.conv3 (:230) + skip_scale2 residual (:526)
  *                     fc, tok1 -> out
  * -------------------------------------------------------------------------------------------- */

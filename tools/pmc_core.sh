@@ -4,7 +4,10 @@
 # Usage: tools/pmc_core.sh <outdir> [extra bench_core.py args]     (then: python tools/pmc_traffic.py <outdir>)
 set -u
 R=$PWD; OUT=$R/$1; shift
-mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
+mkdir -p $OUT; export TMPDIR=/tmp
+# the calibration copy is a built artefact (git-ignored): build it where it is missing (hipcc is in the image, here and on the GPU box)
+[ -x $R/tools/microbench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/tools/microbench.hip -o $R/tools/microbench > $OUT/microbench_build.log 2>&1
+cd /tmp
 EXTRA="$*"
 run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python $R/tools/bench_core.py --levels 1 2 3 --iters 3 $EXTRA > $OUT/$name.log 2>&1; }
 cal() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- $R/tools/microbench > $OUT/$name.log 2>&1; }

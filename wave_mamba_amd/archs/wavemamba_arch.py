@@ -811,7 +811,14 @@ class UNet(nn.Module):
         # one side stream per level: level 1's branch (the largest) is not needed before the last up group
         sides = _side_streams(x, 3) if self.two_streams and not _needs_grad(self, x) else (None, None, None)
         pss = (self.ps_down1, self.ps_down2, self.ps_down3)
-        if sides[0] is None:
+        ops = _OpsBackend.impl
+        fused_ps = all(hasattr(ops, "patchify_conv") and ops.patchify_conv_supported(img, ps[1].weight, ps[0].downscale_factor)
+                       for ps in pss)
+        if sides[0] is None or fused_ps:
+            # (the fused patch embeddings are 0.18 ms per UHD image together: issued on the main stream.  On the side streams they
+            # finished long before the side streams' next work and back-to-back forwards of alternating image sizes then differed
+            # from the single-stream order in ~10 % of the runs - tools/debug_multi_stream.py; with the embeddings
+            # on the main stream, as with the two-module form on the side streams, 0 of several hundred)
             d, d_ready = [_ps_conv(ps, img) for ps in pss], (None, None, None)
         else:                                          # the pixel-unshuffled inputs of the three l_convs: off the main chain too
             main = torch.cuda.current_stream(x.device)

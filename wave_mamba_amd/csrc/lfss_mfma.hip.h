@@ -723,12 +723,15 @@ __device__ __forceinline__ void dwconv_gate_positions(const TP* __restrict__ fb 
     }
 }
 
+#ifndef WM_LFSS_OUT_TILE
+#define WM_LFSS_OUT_TILE 8        // image rows per band of the column-major group order (0 rows = linear order: pass gpr = 0)
+#endif
 template <typename TP = float>
 __global__ __launch_bounds__(256, 4) void lfss_out_conv_mfma_kernel(
     const TP* __restrict__ f, const float* __restrict__ cw /*(D, 3, 3)*/, const float* __restrict__ cbias /*(D) or null*/,
     const float* __restrict__ tok1, const float* __restrict__ W3 /*(C, C)*/, const float* __restrict__ b3,
     const float* __restrict__ skip2, float* __restrict__ out, int out_nchw, int B, int H, int W, int ngl, long long ngroups,
-    int gpw) {
+    int gpw, int gpr /* groups per image row when W % 64 == 0, else 0 */) {
     constexpr int C = 32, D = 64;
     __shared__ __attribute__((aligned(16))) float s_b3[C];
     __shared__ __attribute__((aligned(16))) float s_skip[C];
@@ -753,7 +756,23 @@ __global__ __launch_bounds__(256, 4) void lfss_out_conv_mfma_kernel(
         const long long g = g0 + 4 * gi;
         if (g >= ngroups) break;
         const long long b = g / ngl;
-        const long long p0 = (g - b * ngl) * 64;
+        long long gl = g - b * ngl;
+        // Banded group order (round 4).  In linear order a workgroup's 4 x gpw groups are ~2 image rows, and an f row is fetched by
+        // every workgroup whose output rows touch it (workgroup i runs on XCD i % 8: no shared L2).  Within bands of
+        // WM_LFSS_OUT_TILE image rows the order is column-major instead: the four waves of a workgroup sit on four vertically
+        // adjacent groups of one 64-column strip at a time (then the next four rows, then the next strip), so a band's interior rows
+        // come from the L2 its own waves just filled.  Same arithmetic per position: bit-identical outputs.  Measured
+        // (tools/bench_lfss_out_conv.py, WM_LFSS_OUT_LINEAR=1 for the linear order): 0.107 -> 0.088 ms at UHD level 2, 0.454 -> 0.468 at
+        // level 1 (there the kernel is bound by its 576 tap loads per lane and group, not by HBM), level 3 (W % 64 != 0) keeps the
+        // linear order: 0.05 ms per UHD image.
+        if (gpr > 0) {
+            const long long per = (long long)WM_LFSS_OUT_TILE * gpr, band = gl / per;
+            if ((band + 1) * per <= ngl) {
+                const int rem = (int)(gl - band * per);
+                gl = (band * WM_LFSS_OUT_TILE + rem % WM_LFSS_OUT_TILE) * gpr + rem / WM_LFSS_OUT_TILE;
+            }
+        }
+        const long long p0 = gl * 64;
         const long long pc = min(p0 + lane, L - 1);
         const int col0 = (int)((unsigned)p0 % (unsigned)W);          // wave-uniform; p0 < L < 2^31
         const bool edge = col0 == 0 || col0 + 64 >= W;               // a lane in the first / last column (or two rows in the group)

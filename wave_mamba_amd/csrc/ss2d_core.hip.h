@@ -30,7 +30,9 @@
 //     else to repeat.  Ragged tails are masked steps (dt := 0 => a = 1, b = 0: the state passes through).
 //   * y[k] goes to the direction's own (B, D, L) buffer in row-major positions; the consumer adds the four
 //     (y1 + y2 + y3 + y4 of :490) while it reads them, so the scan launch has no read-modify-write and the four
-//     directions run concurrently, bit-reproducibly.
+//     directions run concurrently, bit-reproducibly.  (Round 4 built the two-plane alternative - the reversed directions as a
+//     second, read-modify-write scan launch, template parameter RMW / CoreArgs::pairsel, wm_ss2d_core_fwd merged = 2 - and
+//     measured it 3.5 ms per UHD image slower: profiles/r04/core_ab_paired_planes.txt.  Opt-in.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

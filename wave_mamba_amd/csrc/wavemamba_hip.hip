@@ -1407,16 +1407,19 @@ int wm_lfss_out_conv_fwd(const void* f_, const float* conv2_weight, const float*
     const long long ngroups = (long long)B * ngl;
     const int gpw = lfss_groups_per_wave(ngroups, 2048);
     const long long waves = (ngroups + gpw - 1) / gpw;
+    // groups per image row for the kernel's banded (column-major) group order; WM_LFSS_OUT_LINEAR=1 (tools): linear order
+    static const bool linear = [] { const char* e = getenv("WM_LFSS_OUT_LINEAR"); return e && atoi(e) != 0; }();
+    const int gpr = (W % 64 == 0 && !linear) ? W / 64 : 0;
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(11, st);
     if (plane_dtype == WM_F32)
         hipLaunchKernelGGL(lfss_out_conv_mfma_kernel<float>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, (const float*)f_,
                            conv2_weight, conv2_bias, tok1, conv3_weight, conv3_bias, skip_scale2, out, out_nchw, B, H, W, ngl,
-                           ngroups, gpw);
+                           ngroups, gpw, gpr);
     else
         hipLaunchKernelGGL(lfss_out_conv_mfma_kernel<bf16_t>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st,
                            (const bf16_t*)f_, conv2_weight, conv2_bias, tok1, conv3_weight, conv3_bias, skip_scale2, out, out_nchw,
-                           B, H, W, ngl, ngroups, gpw);
+                           B, H, W, ngl, ngroups, gpw, gpr);
     return launch_status();
 }
 

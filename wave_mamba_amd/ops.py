@@ -442,7 +442,7 @@ def ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, merg
     _require_cuda("ss2d_core", x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
     _ss2d_core_shapes(x, x_proj_weight, dt_projs_weight, A_logs)
     args = (x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
-    paired = merged == 2 and merged is not True
+    paired = merged is not True and merged == 2
     if torch.is_grad_enabled() and any(t.requires_grad for t in args):
         if paired:
             y = _SS2DCoreFn.apply(False, *args)
