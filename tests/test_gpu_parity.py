@@ -1163,6 +1163,42 @@ def test_conv2d_vs_torch(conv3x3_impl, ks, B, Ca, Cb, Cout, H, W, bias):
     assert_close(got, ref, 2e-5, f"conv2d ks={ks} {(B, Ca, Cb, Cout, H, W)}")
 
 
+@pytest.mark.parametrize("two_streams", [False, True])
+def test_forward_ignores_allocator_pool_contents(two_streams):
+    """No kernel of the inference forward consumes memory it does not own or has not written (uninitialised `torch.empty` outputs,
+    out-of-bounds tile reads): with every stream's allocator pool filled with NaN / 1e30 / 0 before the forward (blocks of many
+    sizes allocated, filled, freed) the output stays bit-equal - ragged map sizes included (49-, 98-, 25-column levels)."""
+    net = wm.WaveMamba(in_chn=3, wf=32, n_l_blocks=[1, 2, 4], n_h_blocks=[1, 1, 2], ffn_scale=2.0).eval().to(DEV)
+    unet = net.restoration_network
+    xs = [torch.rand(1, 3, 264, 392, generator=gen(41)).to(DEV), torch.rand(2, 3, 136, 200, generator=gen(42)).to(DEV)]
+    sizes = [2 ** k for k in range(9, 25)] + [3 * 2 ** k for k in range(9, 23)]            # 512 B .. 16 MB
+
+    def poison(value, streams):
+        for st in streams:
+            with torch.cuda.stream(st):
+                held = []
+                for n in sizes + sizes:
+                    t = torch.empty(n // 4, dtype=torch.float32, device=DEV); t.fill_(value); held.append(t)
+                del held
+        torch.cuda.synchronize()
+
+    old = unet.two_streams
+    try:
+        unet.two_streams = two_streams
+        with torch.no_grad():
+            clean = [unet(x).clone() for x in xs]
+            torch.cuda.synchronize()
+            streams = [torch.cuda.current_stream(DEV)] + (list(arch._side_streams(xs[0], 3)) if two_streams else [])
+            for value in (float("nan"), 1e30, 0.0):
+                for x, c in zip(xs, clean):
+                    poison(value, streams)
+                    o = unet(x)
+                    torch.cuda.synchronize()
+                    assert torch.equal(o, c), f"poison {value}, input {tuple(x.shape)}: the forward read memory it had not written"
+    finally:
+        unet.two_streams = old
+
+
 @pytest.mark.parametrize("ks", [3, 1])
 @pytest.mark.parametrize("B,Ca,Csrc,Cb,Cout,H,W", [(1, 32, 32, 32, 64, 24, 40), (2, 32, 32, 32, 64, 9, 33),
                                                   (2, 16, 24, 8, 32, 17, 31)])
