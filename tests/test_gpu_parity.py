@@ -778,7 +778,9 @@ def test_lfss_block_fused_vs_module_path(C, H, W):
     assert_close(fused, ref, TOL, f"LFSSBlock C={C}")
 
 
-@pytest.mark.parametrize("B,H,W", [(1, 40, 96), (2, 3, 32), (1, 1, 64), (2, 2, 32), (1, 17, 480), (1, 5, 160)])
+@pytest.mark.parametrize("B,H,W", [(1, 40, 96), (2, 3, 32), (1, 1, 64), (2, 2, 32), (1, 17, 480), (1, 5, 160),
+                                   (1, 9, 128), (2, 7, 192), (1, 2, 64), (1, 34, 960),       # W % 64 == 0: the banded one-row form
+                                   (1, 1025, 1024), (2, 513, 1088)])                          # >= 2^20 positions: the row-window form (odd H: a short last band)
 @pytest.mark.parametrize("nchw", [False, True])
 def test_lfss_out_with_depthwise_conv_folded_in(B, H, W, nchw):
     """wm_lfss_out_conv_fwd (the ffn's depth-wise 3x3 inside the closing kernel) against

@@ -818,4 +818,140 @@ __global__ __launch_bounds__(256, 4) void lfss_out_conv_mfma_kernel(
     }
 }
 
+// ---- lfss_out_conv, row-window form (round 4, end): R output rows of a 64-column strip per wave pass ------------------------
+// PMC over the UHD step (profiles/r04/pmc_step_traffic_per_kernel.txt) shows lfss_out_conv_mfma_kernel HBM-bound on 2.3 x its
+// algorithmic bytes: every wave fetches the three tap rows of its output row itself and the second-level cache does not serve the
+// re-reads (64 channel planes 8 MB apart).  Here a wave owns a strip of 64 columns and R consecutive output rows: per group of four
+// channel pairs it loads the R + 2 tap rows ONCE ((R + 2) / R of f instead of 3 x, 9 (R + 2) / R load instructions per output value
+// and channel instead of 9 ... 27) and writes the R rows' gelu(gate) * value products to R per-wave LDS tiles, from which the
+// matrix stage of lfss_out_conv_mfma_kernel runs row by row: the same operands in the same instruction order, BIT-identical
+// outputs.  Two-wave workgroups (R x 16 KB of product tiles each).  W % 64 == 0; rows past the image are masked by the
+// buffer range check (reads) and skipped (stores).
+template <int R, typename TP>
+__global__ __launch_bounds__(128, 4) void lfss_out_conv_rows_kernel(
+    const TP* __restrict__ f, const float* __restrict__ cw /*(D, 3, 3)*/, const float* __restrict__ cbias /*(D) or null*/,
+    const float* __restrict__ tok1, const float* __restrict__ W3 /*(C, C)*/, const float* __restrict__ b3,
+    const float* __restrict__ skip2, float* __restrict__ out, int out_nchw, int B, int H, int W, int nstrips, int nbands,
+    long long units, int upw) {
+    constexpr int C = 32, D = 64, E = (int)sizeof(TP);
+    __shared__ __attribute__((aligned(16))) float s_b3[C];
+    __shared__ __attribute__((aligned(16))) float s_skip[C];
+    __shared__ __attribute__((aligned(16))) float s_A3[(C / 2) * 64];
+    __shared__ __attribute__((aligned(16))) float s_cw[D * 12];
+    __shared__ __attribute__((aligned(16))) float s_g[2 * R * C * 64];           // per wave: R tiles [channel][position]
+    const long long L = (long long)H * W;
+    const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x < C) { s_b3[threadIdx.x] = b3[threadIdx.x]; s_skip[threadIdx.x] = skip2[threadIdx.x]; }
+    for (int e = threadIdx.x; e < (C / 2) * 64; e += 128) {
+        const int j = e >> 6, l = e & 63;
+        s_A3[aop_slot(j, l)] = W3[(l & 31) * C + acc_chan(j, l >> 5)];
+    }
+    for (int e = threadIdx.x; e < D * 12; e += 128) {
+        const int c = e / 12, q = e - 12 * c;
+        s_cw[e] = q < 9 ? cw[c * 9 + q] : (q == 9 && cbias ? cbias[c] : 0.0f);
+    }
+    __syncthreads();
+    float* sg = s_g + wv * (R * C * 64) + lane;
+    const long long u0 = (long long)blockIdx.x * 2 * upw + wv;       // the block's two waves walk adjacent strips together
+    for (int ui = 0; ui < upw; ++ui) {
+        const long long u = u0 + 2 * ui;
+        if (u >= units) break;
+        const int strip = (int)(u % nstrips);
+        const long long ub = u / nstrips;
+        const int band = (int)(ub % nbands);
+        const long long b = ub / nbands;
+        const int r0 = band * R;
+        const long long p = (long long)r0 * W + (long long)strip * 64 + lane;      // the lane's position in output row r0 (< L)
+        const bool ml = !(strip == 0 && lane == 0), mr = !(strip == nstrips - 1 && lane == 63);     // left / right tap inside the image
+        const TP* fb = f + b * D * L;
+        int off[R + 2];
+#pragma unroll
+        for (int dr = 0; dr < R + 2; ++dr) off[dr] = (int)((p + (long long)(dr - 1) * W) * E);     // rows r0 - 1 .. r0 + R (range check = zero rows)
+        __builtin_amdgcn_wave_barrier();                             // the previous unit's operand reads are done (in-order LDS)
+        // A ROLLED loop over groups of four channel pairs (as in dwconv_gate_positions: unrolled, every load of the strip is hoisted
+        // above its first use and a thousand registers spill)
+#pragma unroll 1
+        for (int c0 = 0; c0 < 32; c0 += 4) {
+            float t[4][2][R + 2][3];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(               // wave-uniform
+                        const_cast<TP*>(fb + (long long)(c0 + cc + 32 * v) * L), 0, (int)(L * E), 0x00020000);
+#pragma unroll
+                    for (int dr = 0; dr < R + 2; ++dr) {
+                        const float a = buf_ld<TP>(rs, off[dr] - E), bq = buf_ld<TP>(rs, off[dr]), e = buf_ld<TP>(rs, off[dr] + E);
+                        t[cc][v][dr][0] = ml ? a : 0.0f; t[cc][v][dr][1] = bq; t[cc][v][dr][2] = mr ? e : 0.0f;
+                    }
+                }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                float w[2][12];
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const float* wk = s_cw + (c0 + cc + 32 * v) * 12;                                  // [9 taps | bias | 0 0]
+                    const float4 w0 = *reinterpret_cast<const float4*>(wk), w1 = *reinterpret_cast<const float4*>(wk + 4),
+                                 w2 = *reinterpret_cast<const float4*>(wk + 8);
+                    w[v][0] = w0.x; w[v][1] = w0.y; w[v][2] = w0.z; w[v][3] = w0.w; w[v][4] = w1.x; w[v][5] = w1.y;
+                    w[v][6] = w1.z; w[v][7] = w1.w; w[v][8] = w2.x; w[v][9] = w2.y;
+                }
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    float fc[2];
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        float a = w[v][9];                           // the depth-wise kernel's order: bias, then taps row by row
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) a = fmaf(w[v][k], t[cc][v][rr + k / 3][k % 3], a);
+                        fc[v] = a;
+                    }
+                    sg[rr * (C * 64) + (c0 + cc) * 64] = gelu_erf(fc[0]) * fc[1];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+        for (int rr = 0; rr < R; ++rr) {
+            if (r0 + rr >= H) break;                     // (wave-uniform) the last band may be short
+            const float* sr = s_g + wv * (R * C * 64) + rr * (C * 64);
+            lfss_v16f acc[2];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 bb = *reinterpret_cast<const float4*>(&s_b3[8 * gq + 4 * h]);
+                acc[0][4 * gq] = bb.x; acc[0][4 * gq + 1] = bb.y; acc[0][4 * gq + 2] = bb.z; acc[0][4 * gq + 3] = bb.w;
+            }
+            acc[1] = acc[0];
+#pragma unroll
+            for (int j4 = 0; j4 < C / 8; ++j4) {
+                const float4 a4 = *reinterpret_cast<const float4*>(&s_A3[(j4 * 64 + lane) * 4]);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {        // K-step j = channels acc_chan(j, h); tile 0 = positions n, tile 1 = 32 + n
+                    const int ch = acc_chan(4 * j4 + jj, h);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], sr[ch * 64 + n], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], sr[ch * 64 + 32 + n], acc[1], 0, 0, 0);
+                }
+            }
+            const long long p0 = (long long)(r0 + rr) * W + (long long)strip * 64;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const long long pos = p0 + 32 * tt + n;
+                float tk[16], o[16];
+                load_tile32(tok1, false, b, pos, L, h, tk);
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 s4 = *reinterpret_cast<const float4*>(&s_skip[8 * gq + 4 * h]);
+                    o[4 * gq] = fmaf(tk[4 * gq], s4.x, acc[tt][4 * gq]); o[4 * gq + 1] = fmaf(tk[4 * gq + 1], s4.y, acc[tt][4 * gq + 1]);
+                    o[4 * gq + 2] = fmaf(tk[4 * gq + 2], s4.z, acc[tt][4 * gq + 2]); o[4 * gq + 3] = fmaf(tk[4 * gq + 3], s4.w, acc[tt][4 * gq + 3]);
+                }
+                store_tile32(out, out_nchw != 0, b, pos, L, h, o);
+            }
+        }
+    }
+}
+
 }  // namespace wm
