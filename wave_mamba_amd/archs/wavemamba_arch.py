@@ -785,6 +785,37 @@ def _side_streams(x, n):
     return sts[:n]
 
 
+_SERIALISE_FORWARDS = os.environ.get("WM_SERIALISE_FORWARDS", "1") != "0"      # 0: tools (the un-serialised order)
+_FORWARD_END = {}          # (device, main stream) -> event recorded behind the last multi-stream forward issued on that stream
+
+
+def _serialise_forwards(x):
+    """Multi-stream forwards issued back to back on one main stream: the HOST waits for the previous one to finish before it
+    issues the next (an event synchronisation on that stream's last forward, not a device synchronisation: forwards on other main
+    streams are not waited for; skipped under graph capture).  Why: a forward issued while its predecessor was still running could
+    change the predecessor's result when the two differ in their allocation sizes (two image sizes, fp32 / bf16 planes) - rarely
+    in the shipped stream order (one bench run in six: the fp32 reference of the bf16 leg), in ~10 % of the runs with the patch
+    embeddings on the side streams (profiles/r04/multi_stream_patchify_mismatch.txt).  Every cross-stream tensor carries its
+    record_stream and every fork / join its event, no kernel reads memory it does not own (pool-poison test): the mechanism is not
+    understood yet, a device synchronisation between forwards removed every mismatch - this is that, per main stream.  The host is
+    ~2.5 ms of launches ahead of a 30-ms UHD forward at most, so the GPU waits for the first launches of each forward only."""
+    if torch.cuda.is_current_stream_capturing() or not _SERIALISE_FORWARDS:
+        return
+    key = (x.device.index if x.device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(x.device).cuda_stream)
+    ev = _FORWARD_END.get(key)
+    if ev is not None:
+        ev.synchronize()
+
+
+def _mark_forward_end(x):
+    if torch.cuda.is_current_stream_capturing():
+        return
+    st = torch.cuda.current_stream(x.device)
+    key = (x.device.index if x.device.index is not None else torch.cuda.current_device(), st.cuda_stream)
+    _FORWARD_END[key] = st.record_event()
+
+
 class UNet(nn.Module):
     """Three-level wavelet U-Net (reference :1011-1063)."""
 
@@ -810,6 +841,8 @@ class UNet(nn.Module):
         img = x
         # one side stream per level: level 1's branch (the largest) is not needed before the last up group
         sides = _side_streams(x, 3) if self.two_streams and not _needs_grad(self, x) else (None, None, None)
+        if sides[0] is not None:
+            _serialise_forwards(x)
         pss = (self.ps_down1, self.ps_down2, self.ps_down3)
         ops = _OpsBackend.impl
         fused_ps = all(hasattr(ops, "patchify_conv") and ops.patchify_conv_supported(img, ps[1].weight, ps[0].downscale_factor)
@@ -850,7 +883,10 @@ class UNet(nn.Module):
         low = self.up_group3(low, high3, joiner(sides[2], self.up_group3, high3))
         low = self.up_group2(low, high2, joiner(sides[1], self.up_group2, high2))
         low = self.up_group1(low, high1, joiner(sides[0], self.up_group1, high1))
-        return _conv(self.last, low, residual=img)
+        out = _conv(self.last, low, residual=img)
+        if sides[0] is not None:
+            _mark_forward_end(x)
+        return out
 
 
 @ARCH_REGISTRY.register()
