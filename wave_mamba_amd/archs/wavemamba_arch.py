@@ -840,7 +840,13 @@ class UNet(nn.Module):
     def forward(self, x):
         img = x
         # one side stream per level: level 1's branch (the largest) is not needed before the last up group
-        sides = _side_streams(x, 3) if self.two_streams and not _needs_grad(self, x) else (None, None, None)
+        # (bf16 plane storage takes the single-stream order: with the side streams its UHD forward is NOT bit-reproducible - every
+        # run differs by 1e-2 .. 5e-2 at the output, tools/debug_bf16_determinism.py / debug_bf16_race.py - while the fp32-plane forward
+        # is, in both orders; the overlap that matters is each level's side-stream branch with the main stream's next levels.  Open
+        # item of DESIGN.md 7.)
+        ops_ = _OpsBackend.impl
+        bf16_planes = hasattr(ops_, "get_plane_dtype") and ops_.get_plane_dtype() == torch.bfloat16
+        sides = (_side_streams(x, 3) if self.two_streams and not bf16_planes and not _needs_grad(self, x) else (None, None, None))
         if sides[0] is not None:
             _serialise_forwards(x)
         pss = (self.ps_down1, self.ps_down2, self.ps_down3)
