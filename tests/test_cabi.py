@@ -116,3 +116,28 @@ def test_core_plan_cache_keeps_serving_new_shapes():
     warm = (time.perf_counter() - t0) / 20
     assert warm < 2e-3 and warm < 0.5 * max(cold, 4e-3), (cold, warm)           # cached: no search per call
     assert lib.wm_ss2d_core_plan(1, 64, 272, 480, 16, 2, out) == 0 and list(out) == first   # evicted and re-planned: same plan
+
+
+def test_library_isa_has_no_scalar_source_packed_f32_with_routed_halves():
+    """tools/lint_packed_f32.py on the built library: `v_pk_{fma,mul,add}_f32` with a scalar source (SGPR pair / inline constant)
+    AND a VGPR source read through op_sel = 1 returns a zero half in lanes 48..63 on MI355X while LDS-fed MFMAs of another kernel
+    share the SIMD (tools/ubench_pk_coexec.hip, profiles/r05/) - the multi-stream mismatch of rounds 4-5.  The library must not
+    contain the form; the lint's pattern matcher is checked on the instruction that did the damage."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import lint_packed_f32 as lint
+    finally:
+        sys.path.pop(0)
+    sample = ("0000000000001000 <_ZN2wm16dwconv3x3_kernelILi1ELb1EtEEvPKT1_PKfS5_PS1_iiix>:\n"
+              "\tv_pk_fma_f32 v[42:43], s[48:49], v[20:21], v[42:43] op_sel:[0,0,1] op_sel_hi:[1,1,0] // 000000001000: D3B0402A 1CAA2830\n"
+              "\tv_pk_fma_f32 v[42:43], s[76:77], v[24:25], v[42:43]\n"
+              "\tv_pk_fma_f32 v[50:51], v[26:27], v[48:49], v[50:51] op_sel:[0,0,1] op_sel_hi:[1,1,0]\n"
+              "\tv_pk_mul_f32 v[48:49], v[48:49], s[18:19] op_sel_hi:[1,0]\n"
+              "\tv_pk_fma_f32 v[6:7], v[8:9], 2.0, v[6:7] op_sel:[0,0,1] op_sel_hi:[1,0,0]\n")
+    hits = lint.offending(sample)
+    assert [h[1].split()[1] for h in hits] == ["v[42:43],", "v[6:7],"] and len(hits) == 2, hits
+    if not os.path.exists(os.path.join(lint.LLVM, "llvm-objdump")):
+        pytest.skip("llvm-objdump not available")
+    bad = lint.offending(lint.disassemble(_lib.LIB_PATH))
+    assert not bad, f"{len(bad)} vulnerable packed-fp32 instruction(s), first: {bad[0]}"

@@ -1,0 +1,300 @@
+// ubench_pk_coexec.hip - does a chain of DEPENDENT packed-fp32 VALU instructions give wrong results when another kernel's waves
+// share the SIMD?  (Round 5: the multi-stream mismatch of the inference forward was traced to compiler-generated
+// `v_pk_fma_f32` chains in dwconv3x3<bf16> reading a ZERO low half of their accumulator in lanes 48..63 while the
+// wave-specialised 3x3 convolution ran on another stream: tools/repro_pk_lanes.py, tools/repro_pk_decode.py.)
+//
+// Victim kernels (C ABI below, launched on the caller's stream): every lane runs ITER x [8 dependent accumulate steps] on small
+// integers (exact in fp32) and checks the result against integer arithmetic; per (lane, half) mismatch counts leave through
+// atomics.  Variants: GAP = independent VALU instructions between producer and consumer (0..3), weights in SGPR pairs or
+// VGPR pairs, packed (`v_pk_fma_f32`) or plain (`v_fma_f32`) arithmetic.
+// Aggressor kernels: a pure MFMA loop, a pure LDS-DMA loop, a VALU loop (controls); the library's own kernels are driven
+// from tools/repro_pk_micro.py.
+//
+//   hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/ubench_pk_coexec.hip -o build/ubench_pk_coexec.so
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef short bf8 __attribute__((ext_vector_type(8)));
+
+#define FILL0 ""
+#define FILL1 "v_mov_b32 %[t0], %[t0]\n\t"
+#define FILL2 FILL1 "v_mov_b32 %[t1], %[t1]\n\t"
+#define FILL3 FILL2 "v_mov_b32 %[t0], %[t0]\n\t"
+#define NOP1 "s_nop 0\n\t"
+
+// acc = k[i] * x[i] + acc, eight times, each consumer GAP fillers behind its producer
+#define CHAIN(FILL)                                                                                   \
+    "v_pk_fma_f32 %[acc], %[k0], %[x0], %[acc]\n\t" FILL                                               \
+    "v_pk_fma_f32 %[acc], %[k1], %[x1], %[acc]\n\t" FILL                                               \
+    "v_pk_fma_f32 %[acc], %[k2], %[x2], %[acc]\n\t" FILL                                               \
+    "v_pk_fma_f32 %[acc], %[k3], %[x3], %[acc]\n\t" FILL                                               \
+    "v_pk_fma_f32 %[acc], %[k0], %[x4], %[acc]\n\t" FILL                                               \
+    "v_pk_fma_f32 %[acc], %[k1], %[x5], %[acc]\n\t" FILL                                               \
+    "v_pk_fma_f32 %[acc], %[k2], %[x6], %[acc]\n\t" FILL                                               \
+    "v_pk_fma_f32 %[acc], %[k3], %[x7], %[acc]\n\t" FILL
+
+// the form found in dwconv3x3<bf16>: steps 4 and 8 read the accumulator with its halves SWAPPED (op_sel on src2)
+#define CHAIN_SWAP(FILL)                                                                              \
+    "v_pk_fma_f32 %[acc], %[k0], %[x0], %[acc]\n\t" FILL                                               \
+    "v_pk_fma_f32 %[acc], %[k1], %[x1], %[acc]\n\t" FILL                                               \
+    "v_pk_fma_f32 %[acc], %[k2], %[x2], %[acc]\n\t" FILL                                               \
+    "v_pk_fma_f32 %[acc], %[k3], %[x3], %[acc] op_sel:[0,0,1] op_sel_hi:[1,1,0]\n\t" FILL             \
+    "v_pk_fma_f32 %[acc], %[k0], %[x4], %[acc]\n\t" FILL                                               \
+    "v_pk_fma_f32 %[acc], %[k1], %[x5], %[acc]\n\t" FILL                                               \
+    "v_pk_fma_f32 %[acc], %[k2], %[x6], %[acc]\n\t" FILL                                               \
+    "v_pk_fma_f32 %[acc], %[k3], %[x7], %[acc] op_sel:[0,0,1] op_sel_hi:[1,1,0]\n\t" FILL
+
+// SGPR weights, src1 read as (low, low) in steps 4 and 8 (the form of the scalar-weight lfss kernels: op_sel_hi:[1,0,1])
+#define CHAIN_BCAST(FILL)                                                                             \
+    "v_pk_fma_f32 %[acc], %[k0], %[x0], %[acc]\n\t" FILL                                               \
+    "v_pk_fma_f32 %[acc], %[k1], %[x1], %[acc]\n\t" FILL                                               \
+    "v_pk_fma_f32 %[acc], %[k2], %[x2], %[acc]\n\t" FILL                                               \
+    "v_pk_fma_f32 %[acc], %[k3], %[x3], %[acc] op_sel_hi:[1,0,1]\n\t" FILL                             \
+    "v_pk_fma_f32 %[acc], %[k0], %[x4], %[acc]\n\t" FILL                                               \
+    "v_pk_fma_f32 %[acc], %[k1], %[x5], %[acc]\n\t" FILL                                               \
+    "v_pk_fma_f32 %[acc], %[k2], %[x6], %[acc]\n\t" FILL                                               \
+    "v_pk_fma_f32 %[acc], %[k3], %[x7], %[acc] op_sel_hi:[1,0,1]\n\t" FILL
+// an INLINE CONSTANT as the scalar source (2.0 for every weight), accumulator halves swapped in steps 4 and 8
+#define CHAIN_CONST(FILL)                                                                             \
+    "v_pk_fma_f32 %[acc], %[x0], 2.0, %[acc] op_sel_hi:[1,0,1]\n\t" FILL                               \
+    "v_pk_fma_f32 %[acc], %[x1], 2.0, %[acc] op_sel_hi:[1,0,1]\n\t" FILL                               \
+    "v_pk_fma_f32 %[acc], %[x2], 2.0, %[acc] op_sel_hi:[1,0,1]\n\t" FILL                               \
+    "v_pk_fma_f32 %[acc], %[x3], 2.0, %[acc] op_sel:[0,0,1] op_sel_hi:[1,0,0]\n\t" FILL               \
+    "v_pk_fma_f32 %[acc], %[x4], 2.0, %[acc] op_sel_hi:[1,0,1]\n\t" FILL                               \
+    "v_pk_fma_f32 %[acc], %[x5], 2.0, %[acc] op_sel_hi:[1,0,1]\n\t" FILL                               \
+    "v_pk_fma_f32 %[acc], %[x6], 2.0, %[acc] op_sel_hi:[1,0,1]\n\t" FILL                               \
+    "v_pk_fma_f32 %[acc], %[x7], 2.0, %[acc] op_sel:[0,0,1] op_sel_hi:[1,0,0]\n\t" FILL
+
+#define CHAIN_PLAIN(FILL)                                                                              \
+    "v_fma_f32 %[a], %[k0], %[x0], %[a]\n\t" FILL                                                       \
+    "v_fma_f32 %[a], %[k1], %[x1], %[a]\n\t" FILL                                                       \
+    "v_fma_f32 %[a], %[k2], %[x2], %[a]\n\t" FILL                                                       \
+    "v_fma_f32 %[a], %[k3], %[x3], %[a]\n\t" FILL                                                       \
+    "v_fma_f32 %[a], %[k0], %[x4], %[a]\n\t" FILL                                                       \
+    "v_fma_f32 %[a], %[k1], %[x5], %[a]\n\t" FILL                                                       \
+    "v_fma_f32 %[a], %[k2], %[x6], %[a]\n\t" FILL                                                       \
+    "v_fma_f32 %[a], %[k3], %[x7], %[a]\n\t" FILL
+
+// MODE: 0 packed, weights in SGPR pairs; 1 packed, weights in VGPR pairs; 2 plain v_fma_f32 (SGPR weights);
+//       3 packed with a v_mov_b64 of the start value right in front of the chain (the compiler's sequence in dwconv3x3<bf16>)
+//       4 / 5 / 6: mode 0 with a global_load_dwordx2 / a global_load_ushort / two ds_bpermute_b32 IN FLIGHT while the chain runs
+template <int GAP, int MODE>
+__global__ __launch_bounds__(256) void pk_victim_kernel(unsigned* __restrict__ counts, int iters, int seed,
+                                                        const unsigned* __restrict__ memsrc = nullptr) {
+    const int lane = threadIdx.x & 63;
+    unsigned bad_lo = 0, bad_hi = 0;
+    float alive = 0.0f;
+    const int wid = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 131 + seed;
+    // weights 1, 2, 4, 8 (uniform): a lost prefix of the chain is visible in the difference
+    const int kk0 = __builtin_amdgcn_readfirstlane(1 + (seed & 0)), kk1 = __builtin_amdgcn_readfirstlane(2 + (seed & 0));
+    const int kk2 = __builtin_amdgcn_readfirstlane(4 + (seed & 0)), kk3 = __builtin_amdgcn_readfirstlane(8 + (seed & 0));
+    unsigned long long ldvA = 0, ldvB = 0; unsigned lduA = 0, lduB = 0;
+    auto step = [&](int it, unsigned long long& ldv, unsigned& ldu, unsigned long long& ldv_prev, unsigned& ldu_prev) {
+        int xi[8][2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            xi[i][0] = ((lane * 7 + it * 3 + i * 5 + wid) & 15) + 1;
+            xi[i][1] = ((lane * 3 + it * 5 + i * 11 + wid) & 15) + 1;
+        }
+        const int b0 = (it & 7) + 1;
+        int e_lo = b0, e_hi = b0;
+        const int kw[4] = {1, 2, 4, 8};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if ((MODE == 10 || MODE == 11 || MODE == 13) && (i & 3) == 3) { const int t = e_lo; e_lo = e_hi; e_hi = t; }      // the swapped read
+            if (MODE == 13) { e_lo += 2 * xi[i][0]; e_hi += 2 * xi[i][1]; }
+            else if (MODE == 12 && (i & 3) == 3) { e_lo += kw[3] * xi[i][0]; e_hi += kw[3] * xi[i][0]; }          // src1 read as (low, low)
+            else { e_lo += kw[i & 3] * xi[i][0]; e_hi += kw[i & 3] * xi[i][1]; }
+        }
+        f2 x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = f2{(float)xi[i][0], (float)xi[i][1]};
+        float t0 = (float)it, t1 = (float)lane;
+        float r_lo, r_hi;
+        unsigned bp0 = 0, bp1 = 0;
+        if constexpr (MODE == 8)
+            asm volatile("global_load_dword %0, %1, off" : "+v"(ldu) : "v"(memsrc + ((size_t)(wid * 64 + lane + it * 4099) & 0xfffff) * 2) : "memory");
+        if constexpr (MODE == 9)
+            asm volatile("global_load_ushort %0, %1, off" : "+v"(ldu) : "v"(memsrc + ((size_t)(wid * 64 + lane + it * 4099) & 0xfffff) * 2) : "memory");
+        if constexpr (MODE == 4)
+            asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(ldv) : "v"(memsrc + ((size_t)(wid * 64 + lane + it * 4099) & 0xfffff) * 2) : "memory");
+        if constexpr (MODE == 5)
+            asm volatile("global_load_ushort %0, %1, off" : "+v"(ldu) : "v"(memsrc + ((size_t)(wid * 64 + lane + it * 4099) & 0xfffff) * 2) : "memory");
+        if constexpr (MODE == 6) {
+            const unsigned a0 = (unsigned)((lane + 1) & 63) * 4u, a1 = (unsigned)((lane + 63) & 63) * 4u;
+            asm volatile("ds_bpermute_b32 %0, %2, %4\n\tds_bpermute_b32 %1, %3, %4" : "=v"(bp0), "=v"(bp1) : "v"(a0), "v"(a1), "v"(it) : "memory");
+        }
+        constexpr int AM = (MODE == 9 || MODE == 11) ? 1 : MODE >= 4 ? 0 : MODE;
+        constexpr bool SWAP = MODE == 10 || MODE == 11;
+        constexpr bool BCAST = MODE == 12, CONST = MODE == 13;            // arithmetic of the mode
+        if constexpr (AM == 2) {
+            float a = (float)b0, b = (float)b0;
+            const float k0 = (float)kk0, k1 = (float)kk1, k2 = (float)kk2, k3 = (float)kk3;
+#define RUN_PLAIN(F, X)                                                                                                           \
+            asm volatile(CHAIN_PLAIN(F) : [a] "+v"(X), [t0] "+v"(t0), [t1] "+v"(t1)                                               \
+                         : [k0] "s"(k0), [k1] "s"(k1), [k2] "s"(k2), [k3] "s"(k3), [x0] "v"(x[0].SEL), [x1] "v"(x[1].SEL),        \
+                           [x2] "v"(x[2].SEL), [x3] "v"(x[3].SEL), [x4] "v"(x[4].SEL), [x5] "v"(x[5].SEL), [x6] "v"(x[6].SEL),    \
+                           [x7] "v"(x[7].SEL))
+#define SEL x
+            if constexpr (GAP == 0) RUN_PLAIN(FILL0, a); else if constexpr (GAP == 1) RUN_PLAIN(FILL1, a);
+            else if constexpr (GAP == 2) RUN_PLAIN(FILL2, a); else RUN_PLAIN(FILL3, a);
+#undef SEL
+#define SEL y
+            if constexpr (GAP == 0) RUN_PLAIN(FILL0, b); else if constexpr (GAP == 1) RUN_PLAIN(FILL1, b);
+            else if constexpr (GAP == 2) RUN_PLAIN(FILL2, b); else RUN_PLAIN(FILL3, b);
+#undef SEL
+            r_lo = a; r_hi = b;
+        } else {
+            f2 acc = f2{(float)b0, (float)b0};
+            if constexpr (AM == 3) {
+                f2 sb = f2{(float)__builtin_amdgcn_readfirstlane(b0), (float)__builtin_amdgcn_readfirstlane(b0)};
+                asm volatile("v_mov_b64 %[acc], %[sb]" : [acc] "=v"(acc) : [sb] "s"(sb));
+            }
+            if constexpr (AM == 1) {
+                const f2 k0 = f2{(float)kk0, (float)kk0}, k1 = f2{(float)kk1, (float)kk1}, k2 = f2{(float)kk2, (float)kk2},
+                         k3 = f2{(float)kk3, (float)kk3};
+#define RUN_PK(F, C)                                                                                                              \
+                if constexpr (CONST) asm volatile(CHAIN_CONST(F) : [acc] "+v"(acc), [t0] "+v"(t0), [t1] "+v"(t1)                  \
+                             : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]),                                                    \
+                               [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]), [x6] "v"(x[6]), [x7] "v"(x[7]));                   \
+                else if constexpr (BCAST) asm volatile(CHAIN_BCAST(F) : [acc] "+v"(acc), [t0] "+v"(t0), [t1] "+v"(t1)             \
+                             : [k0] C(k0), [k1] C(k1), [k2] C(k2), [k3] C(k3), [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]),    \
+                               [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]), [x6] "v"(x[6]), [x7] "v"(x[7]));                   \
+                else if constexpr (SWAP) asm volatile(CHAIN_SWAP(F) : [acc] "+v"(acc), [t0] "+v"(t0), [t1] "+v"(t1)                    \
+                             : [k0] C(k0), [k1] C(k1), [k2] C(k2), [k3] C(k3), [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]),    \
+                               [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]), [x6] "v"(x[6]), [x7] "v"(x[7]));                   \
+                else asm volatile(CHAIN(F) : [acc] "+v"(acc), [t0] "+v"(t0), [t1] "+v"(t1)                                             \
+                             : [k0] C(k0), [k1] C(k1), [k2] C(k2), [k3] C(k3), [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]),    \
+                               [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]), [x6] "v"(x[6]), [x7] "v"(x[7]))
+                if constexpr (GAP == 0) RUN_PK(FILL0, "v"); else if constexpr (GAP == 1) RUN_PK(FILL1, "v");
+                else if constexpr (GAP == 2) RUN_PK(FILL2, "v"); else if constexpr (GAP == 3) RUN_PK(FILL3, "v");
+                else RUN_PK(NOP1, "v");
+            } else {
+                const f2 k0 = f2{(float)kk0, (float)kk0}, k1 = f2{(float)kk1, (float)kk1}, k2 = f2{(float)kk2, (float)kk2},
+                         k3 = f2{(float)kk3, (float)kk3};
+                if constexpr (GAP == 0) RUN_PK(FILL0, "s"); else if constexpr (GAP == 1) RUN_PK(FILL1, "s");
+                else if constexpr (GAP == 2) RUN_PK(FILL2, "s"); else if constexpr (GAP == 3) RUN_PK(FILL3, "s");
+                else RUN_PK(NOP1, "s");
+            }
+            r_lo = acc.x; r_hi = acc.y;
+        }
+        if constexpr (MODE >= 4 && MODE <= 9) {
+            if (MODE == 6) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");      // the previous iteration's load; this one stays in flight
+            asm volatile("" : "+v"(ldv_prev), "+v"(ldu_prev), "+v"(bp0), "+v"(bp1), "+v"(ldv), "+v"(ldu));
+            t0 += (float)(unsigned)(ldv_prev >> 40) + (float)ldu_prev + (float)(bp0 ^ bp1);
+        }
+        bad_lo += (r_lo != (float)e_lo) ? 1u : 0u;
+        bad_hi += (r_hi != (float)e_hi) ? 1u : 0u;
+        asm volatile("" : "+v"(t0), "+v"(t1));
+        alive += t0;
+    };
+    for (int it = 0; it < iters; it += 2) { step(it, ldvA, lduA, ldvB, lduB); step(it + 1, ldvB, lduB, ldvA, lduA); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (alive == 1.2345e30f) atomicAdd(counts, 1u);
+    if (bad_lo) atomicAdd(counts + lane, bad_lo);
+    if (bad_hi) atomicAdd(counts + 64 + lane, bad_hi);
+}
+
+// ---- aggressors -------------------------------------------------------------------------------------------------------
+// 8-wave workgroups, one or two per compute unit, `iters` x 16 MFMAs per wave; results kept alive through a dummy store
+__global__ __launch_bounds__(512) void aggr_mfma_kernel(float* __restrict__ sink, int iters) {
+    f16v acc[4];
+    for (int m = 0; m < 4; ++m) for (int i = 0; i < 16; ++i) acc[m][i] = 0.0f;
+    bf8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (short)(0x3f80 + threadIdx.x % 7); b[i] = (short)(0x3f80 + i); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[m], 0, 0, 0);
+    }
+    float s = 0.0f;
+    for (int m = 0; m < 4; ++m) for (int i = 0; i < 16; ++i) s += acc[m][i];
+    if (s == 123.456f) sink[threadIdx.x] = s;
+}
+
+// LDS-DMA only: every wave streams `iters` x 4 KB from `src` into LDS (16 bytes per lane per instruction)
+__global__ __launch_bounds__(512) void aggr_ldsdma_kernel(const uint4* __restrict__ src, float* __restrict__ sink, int iters, int nitems) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4* s = reinterpret_cast<uint4*>(smem);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned x = 0;
+    for (int it = 0; it < iters; ++it) {
+        const int base = ((blockIdx.x * 8 + wave) * 64 * 4 + it * 977) % (nitems - 256);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + base + j * 64 + lane),
+                                             (__attribute__((address_space(3))) void*)(s + (wave * 4 + j) * 64), 16, 0, 0);
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        x += s[(wave * 4) * 64 + lane].x;
+    }
+    if (x == 0x12345678u) sink[threadIdx.x] = (float)x;
+}
+
+// ds_read_b128 + MFMA on random data (the inner loop of a convolution: operands from LDS, 16 MFMAs per 4 fragment reads)
+__global__ __launch_bounds__(512) void aggr_ldsmfma_kernel(const uint4* __restrict__ src, float* __restrict__ sink, int iters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4* s = reinterpret_cast<uint4*>(smem);
+    for (int i = threadIdx.x; i < 4096; i += 512) s[i] = src[(blockIdx.x * 4096 + i) & 0xfffff];       // 64 KB of random bf16 bit patterns
+    __syncthreads();
+    f16v acc[4];
+    for (int m = 0; m < 4; ++m) for (int i = 0; i < 16; ++i) acc[m][i] = 0.0f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int it = 0; it < iters; ++it) {
+        bf8 a[2], b[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uint4 ua = s[((it * 7 + j * 2 + wave * 64) & 63) * 64 + lane], ub = s[((it * 5 + j * 2 + 1 + wave * 64) & 63) * 64 + lane];
+            ua.x &= 0x3fff3fffu; ua.y &= 0x3fff3fffu; ua.z &= 0x3fff3fffu; ua.w &= 0x3fff3fffu;            // finite, |v| < 2
+            ub.x &= 0x3fff3fffu; ub.y &= 0x3fff3fffu; ub.z &= 0x3fff3fffu; ub.w &= 0x3fff3fffu;
+            a[j] = __builtin_bit_cast(bf8, ua); b[j] = __builtin_bit_cast(bf8, ub);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b[(j + r) & 1], acc[m], 0, 0, 0);
+    }
+    float t = 0.0f;
+    for (int m = 0; m < 4; ++m) for (int i = 0; i < 16; ++i) t += acc[m][i];
+    if (t == 123.456f) sink[threadIdx.x] = t;
+}
+
+// VALU only (control)
+__global__ __launch_bounds__(512) void aggr_valu_kernel(float* __restrict__ sink, int iters) {
+    float a = (float)threadIdx.x, b = 1.0001f;
+    for (int it = 0; it < iters * 64; ++it) { a = fmaf(a, b, 0.5f); b = fmaf(b, 0.9999f, 1e-4f); }
+    if (a == 123.456f) sink[threadIdx.x] = a + b;
+}
+
+extern "C" {
+// mode: 0 pk + SGPR weights, 1 pk + VGPR weights, 2 plain fma, 3 pk + v_mov_b64 start; gap: 0..3 independent VALU, 4 = one s_nop
+int pk_victim_launch(int mode, int gap, unsigned* counts, int blocks, int iters, int seed, void* stream, const void* memsrc) {
+    hipStream_t st = (hipStream_t)stream;
+#define GO(G, M) hipLaunchKernelGGL((pk_victim_kernel<G, M>), dim3(blocks), dim3(256), 0, st, counts, iters, seed, (const unsigned*)memsrc)
+#define GOM(M) do { if (gap == 0) GO(0, M); else if (gap == 1) GO(1, M); else if (gap == 2) GO(2, M); else if (gap == 3) GO(3, M); \
+                    else GO(4, M); } while (0)
+    if (mode == 0) GOM(0); else if (mode == 1) GOM(1); else if (mode == 3) GOM(3);
+    else if (mode == 4) GOM(4); else if (mode == 5) GOM(5); else if (mode == 6) GOM(6); else if (mode == 8) GOM(8); else if (mode == 9) GOM(9); else if (mode == 10) GOM(10); else if (mode == 11) GOM(11); else if (mode == 12) GOM(12); else if (mode == 13) GOM(13);
+    else { if (gap == 0) GO(0, 2); else if (gap == 1) GO(1, 2); else if (gap == 2) GO(2, 2); else GO(3, 2); }
+    return (int)hipGetLastError();
+}
+int aggr_launch(int kind, const void* src, int nitems, float* sink, int blocks, int iters, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == 0) hipLaunchKernelGGL(aggr_mfma_kernel, dim3(blocks), dim3(512), 0, st, sink, iters);
+    else if (kind == 1) {
+        static bool cfg = false;
+        if (!cfg) { hipFuncSetAttribute((const void*)aggr_ldsdma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32768); cfg = true; }
+        hipLaunchKernelGGL(aggr_ldsdma_kernel, dim3(blocks), dim3(512), 32768, st, (const uint4*)src, sink, iters, nitems);
+    } else if (kind == 3) {
+        static bool cfg3 = false;
+        if (!cfg3) { hipFuncSetAttribute((const void*)aggr_ldsmfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); cfg3 = true; }
+        hipLaunchKernelGGL(aggr_ldsmfma_kernel, dim3(blocks), dim3(512), 65536, st, (const uint4*)src, sink, iters);
+    } else hipLaunchKernelGGL(aggr_valu_kernel, dim3(blocks), dim3(512), 0, st, sink, iters);
+    return (int)hipGetLastError();
+}
+}

@@ -785,37 +785,6 @@ def _side_streams(x, n):
     return sts[:n]
 
 
-_SERIALISE_FORWARDS = os.environ.get("WM_SERIALISE_FORWARDS", "1") != "0"      # 0: tools (the un-serialised order)
-_FORWARD_END = {}          # (device, main stream) -> event recorded behind the last multi-stream forward issued on that stream
-
-
-def _serialise_forwards(x):
-    """Multi-stream forwards issued back to back on one main stream: the HOST waits for the previous one to finish before it
-    issues the next (an event synchronisation on that stream's last forward, not a device synchronisation: forwards on other main
-    streams are not waited for; skipped under graph capture).  Why: a forward issued while its predecessor was still running could
-    change the predecessor's result when the two differ in their allocation sizes (two image sizes, fp32 / bf16 planes) - rarely
-    in the shipped stream order (one bench run in six: the fp32 reference of the bf16 leg), in ~10 % of the runs with the patch
-    embeddings on the side streams (profiles/r04/multi_stream_patchify_mismatch.txt).  Every cross-stream tensor carries its
-    record_stream and every fork / join its event, no kernel reads memory it does not own (pool-poison test): the mechanism is not
-    understood yet, a device synchronisation between forwards removed every mismatch - this is that, per main stream.  The host is
-    ~2.5 ms of launches ahead of a 30-ms UHD forward at most, so the GPU waits for the first launches of each forward only."""
-    if torch.cuda.is_current_stream_capturing() or not _SERIALISE_FORWARDS:
-        return
-    key = (x.device.index if x.device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(x.device).cuda_stream)
-    ev = _FORWARD_END.get(key)
-    if ev is not None:
-        ev.synchronize()
-
-
-def _mark_forward_end(x):
-    if torch.cuda.is_current_stream_capturing():
-        return
-    st = torch.cuda.current_stream(x.device)
-    key = (x.device.index if x.device.index is not None else torch.cuda.current_device(), st.cuda_stream)
-    _FORWARD_END[key] = st.record_event()
-
-
 class UNet(nn.Module):
     """Three-level wavelet U-Net (reference :1011-1063)."""
 
@@ -839,25 +808,19 @@ class UNet(nn.Module):
 
     def forward(self, x):
         img = x
-        # one side stream per level: level 1's branch (the largest) is not needed before the last up group
-        # (bf16 plane storage takes the single-stream order: with the side streams its UHD forward is NOT bit-reproducible - every
-        # run differs by 1e-2 .. 5e-2 at the output, tools/debug_bf16_determinism.py / debug_bf16_race.py - while the fp32-plane forward
-        # is, in both orders; the overlap that matters is each level's side-stream branch with the main stream's next levels.  Open
-        # item of DESIGN.md 7.)
-        ops_ = _OpsBackend.impl
-        bf16_planes = hasattr(ops_, "get_plane_dtype") and ops_.get_plane_dtype() == torch.bfloat16
-        sides = (_side_streams(x, 3) if self.two_streams and not bf16_planes and not _needs_grad(self, x) else (None, None, None))
-        if sides[0] is not None:
-            _serialise_forwards(x)
+        # one side stream per level: level 1's branch (the largest) is not needed before the last up group.
+        # (Rounds 4-5: the multi-stream order gave run-to-run different results with bf16 planes.  Root cause, DESIGN.md 7 /
+        # profiles/r05/: not a missing dependency but ONE instruction form the SLP vectoriser had produced in dwconv3x3<bf16> -
+        # `v_pk_fma_f32 v, s[..], v, v op_sel:[0,0,1]`: a packed-fp32 op with a scalar source and a half-swapped VGPR source
+        # returns zero for that half in lanes 48..63 while LDS-fed MFMAs of another kernel share the SIMD (standalone reproducer:
+        # tools/ubench_pk_coexec.hip).  The library is built without that form now and tools/lint_packed_f32.py keeps it out.)
+        sides = (_side_streams(x, 3) if self.two_streams and not _needs_grad(self, x) else (None, None, None))
         pss = (self.ps_down1, self.ps_down2, self.ps_down3)
         ops = _OpsBackend.impl
         fused_ps = all(hasattr(ops, "patchify_conv") and ops.patchify_conv_supported(img, ps[1].weight, ps[0].downscale_factor)
                        for ps in pss)
         if sides[0] is None or fused_ps:
-            # (the fused patch embeddings are 0.18 ms per UHD image together: issued on the main stream.  On the side streams they
-            # finished long before the side streams' next work and back-to-back forwards of alternating image sizes then differed
-            # from the single-stream order in ~10 % of the runs - tools/debug_multi_stream.py; with the embeddings
-            # on the main stream, as with the two-module form on the side streams, 0 of several hundred)
+            # (the fused patch embeddings are 0.18 ms per UHD image together: issued on the main stream)
             d, d_ready = [_ps_conv(ps, img) for ps in pss], (None, None, None)
         else:                                          # the pixel-unshuffled inputs of the three l_convs: off the main chain too
             main = torch.cuda.current_stream(x.device)
@@ -889,10 +852,7 @@ class UNet(nn.Module):
         low = self.up_group3(low, high3, joiner(sides[2], self.up_group3, high3))
         low = self.up_group2(low, high2, joiner(sides[1], self.up_group2, high2))
         low = self.up_group1(low, high1, joiner(sides[0], self.up_group1, high1))
-        out = _conv(self.last, low, residual=img)
-        if sides[0] is not None:
-            _mark_forward_end(x)
-        return out
+        return _conv(self.last, low, residual=img)
 
 
 @ARCH_REGISTRY.register()
