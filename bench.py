@@ -304,7 +304,7 @@ def train_leg(device, steps, with_cpu_loss, batch=8, size=512):
     state = {}
 
     def step():
-        state["losses"] = wm.trainer.train_step(net, opt, lq, gt)
+        state["losses"] = wm.trainer.train_step(net, opt, lq, gt, as_float=False)
     for _ in range(2):
         step()
     torch.cuda.synchronize()
@@ -355,11 +355,11 @@ def ddp_train_leg(device, rank, world, steps, reduce_device, batch=8, size=512):
     state = {}
 
     def step():
-        state["losses"] = wm.trainer.train_step(model, opt, lq, gt)
+        state["losses"] = wm.trainer.train_step(model, opt, lq, gt, as_float=False)
 
     def step_nosync():
         with model.no_sync():
-            wm.trainer.train_step(model, opt, lq, gt)
+            wm.trainer.train_step(model, opt, lq, gt, as_float=False)
     sync, barrier = torch.cuda.synchronize, dist.barrier
     t_ddp = max_over_ranks(timed_steps(step, steps, 2, sync, barrier), world, reduce_device)
     losses = wm.trainer.loss_values(state["losses"])

@@ -1557,6 +1557,45 @@ def test_ss2d_core_backward_at_training_sizes(B, D, H, W):
           ", ".join(f"{k} {v[0]:.1e}/{v[1]:.1e}" for k, v in worst.items()))
 
 
+@pytest.mark.parametrize("B,D,H,W", [(8, 64, 256, 256), (8, 64, 64, 64)])
+def test_ss2d_core_backward_bit_reproducible_stress(B, D, H, W):
+    """round 4 saw `dx` rows of the accumulating (mirrored) launches of wm_ss2d_core_bwd zeroed in lanes 48..63 now and
+    then and attributed it to a `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` the compiler had fused.  Round 5 reproduced that
+    instruction form failing on its own (tools/ubench_pk_coexec.hip: a packed-fp32 add with one source SWAPPED returns zero halves
+    in lanes 48..63 while LDS-fed MFMAs share the SIMD - here the kernel's own projection waves): the diagnosis holds, the form
+    is linted out of the library (tools/lint_packed_f32.py).  This is the stress test asked for: 300 backward calls at the
+    config-3 map sizes, every gradient bit-equal to the first call's, with and without a 3x3 matrix-core convolution running
+    on a second stream."""
+    N, R = 16, 2
+    x, Wx, Wdt, bias, A_logs, Ds = [t.to(DEV).requires_grad_(True) for t in random_core_case(B, D, H, W, N, R, seed=3 * H + B)]
+    params = [x, Wx, Wdt, bias, A_logs, Ds]
+    dy = torch.randn(B, D, H * W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
+    xa = torch.randn(1, 64, 544, 960, generator=gen(12)).to(DEV)
+    w3 = (torch.randn(64, 64, 3, 3, generator=gen(13)) / 24).to(DEV)
+    side = torch.cuda.Stream(DEV)
+
+    def grads():
+        y = wm.ops.ss2d_core(*params, merged=True)
+        return torch.autograd.grad(y, params, dy)
+    ref = [g.clone() for g in grads()]
+    torch.cuda.synchronize()
+    names = ("dx", "dWx", "dWdt", "dbias", "dA_logs", "dDs")
+    for concurrent in (False, True):
+        cnt = [torch.zeros((), dtype=torch.int64, device=DEV) for _ in names]
+        keep = []
+        for _ in range(150):
+            if concurrent:
+                with torch.cuda.stream(side), torch.no_grad():
+                    keep.append(wm.ops.conv2d(xa, w3))
+                    if len(keep) > 6:
+                        keep.pop(0)
+            for c, g, r in zip(cnt, grads(), ref):
+                c += (g != r).sum()
+        torch.cuda.synchronize()
+        bad = {n: int(c) for n, c in zip(names, cnt) if int(c)}
+        assert not bad, f"{(B, D, H, W)} concurrent conv3x3 {concurrent}: differing gradient elements over 150 backward calls: {bad}"
+
+
 def test_trainable_lfss_block_d_state_32(golden):
     """BASELINE config 5's block in training: LFSSBlock(32, d_state=32) forward + backward on the HIP training path
     (fused core forward wm_ss2d_core_fwd, backward wm_ss2d_core_bwd at N = 32) against the REFERENCE's autograd

@@ -42,7 +42,8 @@ AGGR = {
 MODES = {0: "pk, SGPR weights", 1: "pk, VGPR weights", 3: "pk, v_mov_b64 start", 2: "plain v_fma_f32",
          4: "pk + dwordx2 load in flight", 5: "pk + ushort load in flight", 6: "pk + ds_bpermute in flight", 8: "pk + dword load in flight", 9: "pk VGPR wts + ushort load",
          10: "pk SGPR wts + op_sel swap", 11: "pk VGPR wts + op_sel swap",
-         12: "pk SGPR wts + src1 (lo,lo)", 13: "pk const 2.0 + op_sel swap"}
+         12: "pk SGPR wts + src1 (lo,lo)", 13: "pk const 2.0 + op_sel swap",
+         14: "pk_add VGPR only, src1 swapped", 15: "pk_mul VGPR only, op_sel:[1,0]"}
 if os.environ.get("MODES"):
     MODES = {int(m): MODES[int(m)] for m in os.environ["MODES"].split(",")}
 GAPS = {0: "gap 0", 1: "gap 1 VALU", 2: "gap 2 VALU", 3: "gap 3 VALU", 4: "gap s_nop 0"}

@@ -16,10 +16,10 @@ opt = wm.trainer.make_optimizer(net)
 g = torch.Generator().manual_seed(1234)
 lq, gt = torch.rand(8, 3, 512, 512, generator=g).to(dev), torch.rand(8, 3, 512, 512, generator=g).to(dev)
 for _ in range(3):
-    wm.trainer.train_step(net, opt, lq, gt)
+    wm.trainer.train_step(net, opt, lq, gt, as_float=False)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
-    wm.trainer.train_step(net, opt, lq, gt)
+    wm.trainer.train_step(net, opt, lq, gt, as_float=False)
     torch.cuda.synchronize()
 rows = prof.key_averages(group_by_input_shape=True)
 tot = 0.0

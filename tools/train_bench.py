@@ -39,7 +39,7 @@ state = {}
 
 
 def step():
-    state["losses"] = wm.trainer.train_step(ddp, opt, lq, gt)
+    state["losses"] = wm.trainer.train_step(ddp, opt, lq, gt, as_float=False)
 
 
 for _ in range(args.warmup):

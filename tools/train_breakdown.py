@@ -21,12 +21,12 @@ lq, gt = torch.rand(8, 3, 512, 512, generator=g).to(dev), torch.rand(8, 3, 512, 
 import time
 t0 = time.perf_counter()
 for _ in range(3):
-    wm.trainer.train_step(net, opt, lq, gt)
+    wm.trainer.train_step(net, opt, lq, gt, as_float=False)
 torch.cuda.synchronize()
 print(f"three warm-up steps: {time.perf_counter() - t0:.1f} s")
 t0 = time.perf_counter()
 for _ in range(5):
-    wm.trainer.train_step(net, opt, lq, gt)
+    wm.trainer.train_step(net, opt, lq, gt, as_float=False)
 torch.cuda.synchronize()
 print(f"wall clock, un-profiled: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms per step")
 if "--wall-only" in sys.argv:
@@ -34,7 +34,7 @@ if "--wall-only" in sys.argv:
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     for _ in range(args.steps):
-        wm.trainer.train_step(net, opt, lq, gt)
+        wm.trainer.train_step(net, opt, lq, gt, as_float=False)
     torch.cuda.synchronize()
 agg = collections.defaultdict(lambda: [0, 0.0])
 for e in prof.events():

@@ -13,11 +13,11 @@ opt = wm.trainer.make_optimizer(net)
 g = torch.Generator().manual_seed(1234)
 lq, gt = torch.rand(8, 3, 512, 512, generator=g).to(dev), torch.rand(8, 3, 512, 512, generator=g).to(dev)
 for _ in range(3):
-    wm.trainer.train_step(net, opt, lq, gt)
+    wm.trainer.train_step(net, opt, lq, gt, as_float=False)
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-    wm.trainer.train_step(net, opt, lq, gt)
+    wm.trainer.train_step(net, opt, lq, gt, as_float=False)
     torch.cuda.synchronize()
 rows = [(e.self_device_time_total, e.count, e.key) for e in prof.key_averages() if e.self_device_time_total > 0]
 rows.sort(reverse=True)

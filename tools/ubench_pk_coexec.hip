@@ -67,6 +67,26 @@ typedef short bf8 __attribute__((ext_vector_type(8)));
     "v_pk_fma_f32 %[acc], %[x6], 2.0, %[acc] op_sel_hi:[1,0,1]\n\t" FILL                               \
     "v_pk_fma_f32 %[acc], %[x7], 2.0, %[acc] op_sel:[0,0,1] op_sel_hi:[1,0,0]\n\t" FILL
 
+// VGPR sources only: the two other op_sel = 1 forms the library contains (scan kernels) / contained (round 4's core backward)
+#define CHAIN_ADDSWAP(FILL)                                                                           \
+    "v_pk_add_f32 %[acc], %[x0], %[acc] op_sel:[0,1] op_sel_hi:[1,0]\n\t" FILL                         \
+    "v_pk_add_f32 %[acc], %[x1], %[acc] op_sel:[0,1] op_sel_hi:[1,0]\n\t" FILL                         \
+    "v_pk_add_f32 %[acc], %[x2], %[acc] op_sel:[0,1] op_sel_hi:[1,0]\n\t" FILL                         \
+    "v_pk_add_f32 %[acc], %[x3], %[acc] op_sel:[0,1] op_sel_hi:[1,0]\n\t" FILL                         \
+    "v_pk_add_f32 %[acc], %[x4], %[acc] op_sel:[0,1] op_sel_hi:[1,0]\n\t" FILL                         \
+    "v_pk_add_f32 %[acc], %[x5], %[acc] op_sel:[0,1] op_sel_hi:[1,0]\n\t" FILL                         \
+    "v_pk_add_f32 %[acc], %[x6], %[acc] op_sel:[0,1] op_sel_hi:[1,0]\n\t" FILL                         \
+    "v_pk_add_f32 %[acc], %[x7], %[acc] op_sel:[0,1] op_sel_hi:[1,0]\n\t" FILL
+#define CHAIN_MULHI(FILL)                                                                             \
+    "v_pk_mul_f32 %[acc], %[acc], %[x0] op_sel:[1,0]\n\t" FILL                                         \
+    "v_pk_mul_f32 %[acc], %[acc], %[x1] op_sel:[1,0]\n\t" FILL                                         \
+    "v_pk_mul_f32 %[acc], %[acc], %[x2] op_sel:[1,0]\n\t" FILL                                         \
+    "v_pk_mul_f32 %[acc], %[acc], %[x3] op_sel:[1,0]\n\t" FILL                                         \
+    "v_pk_mul_f32 %[acc], %[acc], %[x4] op_sel:[1,0]\n\t" FILL                                         \
+    "v_pk_mul_f32 %[acc], %[acc], %[x5] op_sel:[1,0]\n\t" FILL                                         \
+    "v_pk_mul_f32 %[acc], %[acc], %[x6] op_sel:[1,0]\n\t" FILL                                         \
+    "v_pk_mul_f32 %[acc], %[acc], %[x7] op_sel:[1,0]\n\t" FILL
+
 #define CHAIN_PLAIN(FILL)                                                                              \
     "v_fma_f32 %[a], %[k0], %[x0], %[a]\n\t" FILL                                                       \
     "v_fma_f32 %[a], %[k1], %[x1], %[a]\n\t" FILL                                                       \
@@ -104,13 +124,15 @@ __global__ __launch_bounds__(256) void pk_victim_kernel(unsigned* __restrict__ c
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             if ((MODE == 10 || MODE == 11 || MODE == 13) && (i & 3) == 3) { const int t = e_lo; e_lo = e_hi; e_hi = t; }      // the swapped read
-            if (MODE == 13) { e_lo += 2 * xi[i][0]; e_hi += 2 * xi[i][1]; }
+            if (MODE == 14) { const int t = e_lo; e_lo = e_hi + xi[i][0]; e_hi = t + xi[i][1]; }
+            else if (MODE == 15) { const int h = e_hi; e_lo = h * ((xi[i][0] & 1) + 1); e_hi = h * ((xi[i][1] & 1) + 1); }
+            else if (MODE == 13) { e_lo += 2 * xi[i][0]; e_hi += 2 * xi[i][1]; }
             else if (MODE == 12 && (i & 3) == 3) { e_lo += kw[3] * xi[i][0]; e_hi += kw[3] * xi[i][0]; }          // src1 read as (low, low)
             else { e_lo += kw[i & 3] * xi[i][0]; e_hi += kw[i & 3] * xi[i][1]; }
         }
         f2 x[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = f2{(float)xi[i][0], (float)xi[i][1]};
+        for (int i = 0; i < 8; ++i) x[i] = MODE == 15 ? f2{(float)((xi[i][0] & 1) + 1), (float)((xi[i][1] & 1) + 1)} : f2{(float)xi[i][0], (float)xi[i][1]};
         float t0 = (float)it, t1 = (float)lane;
         float r_lo, r_hi;
         unsigned bp0 = 0, bp1 = 0;
@@ -128,7 +150,7 @@ __global__ __launch_bounds__(256) void pk_victim_kernel(unsigned* __restrict__ c
         }
         constexpr int AM = (MODE == 9 || MODE == 11) ? 1 : MODE >= 4 ? 0 : MODE;
         constexpr bool SWAP = MODE == 10 || MODE == 11;
-        constexpr bool BCAST = MODE == 12, CONST = MODE == 13;            // arithmetic of the mode
+        constexpr bool BCAST = MODE == 12, CONST = MODE == 13, ADDSW = MODE == 14, MULHI = MODE == 15;            // arithmetic of the mode
         if constexpr (AM == 2) {
             float a = (float)b0, b = (float)b0;
             const float k0 = (float)kk0, k1 = (float)kk1, k2 = (float)kk2, k3 = (float)kk3;
@@ -156,7 +178,13 @@ __global__ __launch_bounds__(256) void pk_victim_kernel(unsigned* __restrict__ c
                 const f2 k0 = f2{(float)kk0, (float)kk0}, k1 = f2{(float)kk1, (float)kk1}, k2 = f2{(float)kk2, (float)kk2},
                          k3 = f2{(float)kk3, (float)kk3};
 #define RUN_PK(F, C)                                                                                                              \
-                if constexpr (CONST) asm volatile(CHAIN_CONST(F) : [acc] "+v"(acc), [t0] "+v"(t0), [t1] "+v"(t1)                  \
+                if constexpr (ADDSW) asm volatile(CHAIN_ADDSWAP(F) : [acc] "+v"(acc), [t0] "+v"(t0), [t1] "+v"(t1)               \
+                             : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]),                                                    \
+                               [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]), [x6] "v"(x[6]), [x7] "v"(x[7]));                   \
+                else if constexpr (MULHI) asm volatile(CHAIN_MULHI(F) : [acc] "+v"(acc), [t0] "+v"(t0), [t1] "+v"(t1)             \
+                             : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]),                                                    \
+                               [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]), [x6] "v"(x[6]), [x7] "v"(x[7]));                   \
+                else if constexpr (CONST) asm volatile(CHAIN_CONST(F) : [acc] "+v"(acc), [t0] "+v"(t0), [t1] "+v"(t1)                  \
                              : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]),                                                    \
                                [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]), [x6] "v"(x[6]), [x7] "v"(x[7]));                   \
                 else if constexpr (BCAST) asm volatile(CHAIN_BCAST(F) : [acc] "+v"(acc), [t0] "+v"(t0), [t1] "+v"(t1)             \
@@ -279,7 +307,7 @@ int pk_victim_launch(int mode, int gap, unsigned* counts, int blocks, int iters,
 #define GOM(M) do { if (gap == 0) GO(0, M); else if (gap == 1) GO(1, M); else if (gap == 2) GO(2, M); else if (gap == 3) GO(3, M); \
                     else GO(4, M); } while (0)
     if (mode == 0) GOM(0); else if (mode == 1) GOM(1); else if (mode == 3) GOM(3);
-    else if (mode == 4) GOM(4); else if (mode == 5) GOM(5); else if (mode == 6) GOM(6); else if (mode == 8) GOM(8); else if (mode == 9) GOM(9); else if (mode == 10) GOM(10); else if (mode == 11) GOM(11); else if (mode == 12) GOM(12); else if (mode == 13) GOM(13);
+    else if (mode == 4) GOM(4); else if (mode == 5) GOM(5); else if (mode == 6) GOM(6); else if (mode == 8) GOM(8); else if (mode == 9) GOM(9); else if (mode == 10) GOM(10); else if (mode == 11) GOM(11); else if (mode == 12) GOM(12); else if (mode == 13) GOM(13); else if (mode == 14) GOM(14); else if (mode == 15) GOM(15);
     else { if (gap == 0) GO(0, 2); else if (gap == 1) GO(1, 2); else if (gap == 2) GO(2, 2); else GO(3, 2); }
     return (int)hipGetLastError();
 }

@@ -593,7 +593,9 @@ class CMTAttention(nn.Module):
                                    residual=None if residual is None else residual[i:i + 1], dynamic_weight=True)
                         for i in range(b)]
                 return outs[0] if b == 1 else torch.cat(outs, 0)
-            scale = nq.sqrt().clamp_min(1e-12).unsqueeze(2) * nk.sqrt().clamp_min(1e-12).unsqueeze(1)
+            # clamp BEFORE the root: sqrt'(0) is infinite, and clamp's zero gradient times it is NaN for an all-zero q / k row
+            # (F.normalize, the reference's spelling, gives a finite zero gradient there) - ADVICE r4
+            scale = nq.clamp_min(1e-24).sqrt().unsqueeze(2) * nk.clamp_min(1e-24).sqrt().unsqueeze(1)
             attn = (G / scale).reshape(b, heads, c // heads, c // heads)
         else:
             qn = F.normalize(q.reshape(b, heads, c // heads, h * w), dim=-1)

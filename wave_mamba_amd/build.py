@@ -68,7 +68,7 @@ def lint(lib=LIB):
         return None
     bad = lint_packed_f32.offending(lint_packed_f32.disassemble(lib))
     if bad:
-        raise RuntimeError(f"{lib}: {len(bad)} packed-fp32 instruction(s) with a scalar source and an op_sel-routed VGPR source "
+        raise RuntimeError(f"{lib}: {len(bad)} packed-fp32 instruction(s) with unsafe op_sel routing "
                            f"(first: {bad[0][0]}: {bad[0][1]}) - see tools/lint_packed_f32.py")
     return 0
 

@@ -86,8 +86,12 @@ __device__ __forceinline__ float cv_pow2_scale(float amax) {
     e = e < -100 ? -100 : (e > 100 ? 100 : e);
     return ldexpf(1.0f, e);
 }
-// amax[0] = max |x|, amax[1] = max |w| (non-negative floats order like their bit patterns: atomicMax on the words; the caller
-// zeroes the two words first).  NaNs are skipped (the convolution then produces them where they belong).  One atomic per
+// |v| of a FINITE v, else 0: the magnitude pass takes its maximum over the finite elements (with an Inf in the tensor
+// the scale fell back to 1 and every finite element above 65504 overflowed fp16 too).  A non-finite element itself still
+// becomes NaN in every output it touches (hi = Inf, lo = Inf - Inf), where an fp32 convolution would give Inf / NaN.
+__device__ __forceinline__ float cv_fabs_fin(float v) { const float a = fabsf(v); return a <= 3.4028234e38f ? a : 0.0f; }
+// amax[0] = max |x|, amax[1] = max |w| over the finite elements (non-negative floats order like their bit patterns: atomicMax on
+// the words; the caller zeroes the two words first).  One atomic per
 // workgroup and at most 512 workgroups: 8,192 wave-level atomics on one address cost 70 us of a 106-us launch over 134 MB.
 __global__ __launch_bounds__(256) void cv_amax2_kernel(const float* __restrict__ x, long long nx, const float* __restrict__ w,
                                                        long long nw, unsigned* __restrict__ amax) {
@@ -103,16 +107,16 @@ __global__ __launch_bounds__(256) void cv_amax2_kernel(const float* __restrict__
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     for (; i + 3 * stride < nq; i += 4 * stride) {                   // four loads in flight per thread
         const float4 a = q[i], b = q[i + stride], c = q[i + 2 * stride], d = q[i + 3 * stride];
-        m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
-                           fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
-        m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))),
-                           fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)))));
+        m = fmaxf(m, fmaxf(fmaxf(fmaxf(cv_fabs_fin(a.x), cv_fabs_fin(a.y)), fmaxf(cv_fabs_fin(a.z), cv_fabs_fin(a.w))),
+                           fmaxf(fmaxf(cv_fabs_fin(b.x), cv_fabs_fin(b.y)), fmaxf(cv_fabs_fin(b.z), cv_fabs_fin(b.w)))));
+        m = fmaxf(m, fmaxf(fmaxf(fmaxf(cv_fabs_fin(c.x), cv_fabs_fin(c.y)), fmaxf(cv_fabs_fin(c.z), cv_fabs_fin(c.w))),
+                           fmaxf(fmaxf(cv_fabs_fin(d.x), cv_fabs_fin(d.y)), fmaxf(cv_fabs_fin(d.z), cv_fabs_fin(d.w)))));
     }
     for (; i < nq; i += stride) {
         const float4 v = q[i];
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        m = fmaxf(fmaxf(m, fmaxf(cv_fabs_fin(v.x), cv_fabs_fin(v.y))), fmaxf(cv_fabs_fin(v.z), cv_fabs_fin(v.w)));
     }
-    for (long long e = 4 * nq + (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) m = fmaxf(m, fabsf(p[e]));
+    for (long long e = 4 * nq + (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) m = fmaxf(m, cv_fabs_fin(p[e]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;

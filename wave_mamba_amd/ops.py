@@ -1331,11 +1331,11 @@ def conv2d_wgrad(gy, x, ks, _refusal=RuntimeError):
     """dW (Cout, Cin, ks, ks) of a stride-1 'same' convolution from gy (B, Cout, H, W) and x (B, Cin, H, W)."""
     lib = _lib.load()
     _require_cuda("conv2d_wgrad", gy, x)
+    if x.dim() != 4 or gy.dim() != 4 or gy.shape[0] != x.shape[0] or gy.shape[2:] != x.shape[2:]:
+        raise _refusal(f"wm_conv2d_wgrad: gy {tuple(gy.shape)} does not match x {tuple(x.shape)}")
     B, Cout, H, W = gy.shape
     Cin = x.shape[1]
     gy = gy.contiguous().float(); x = x.contiguous().float()
-    if x.dim() != 4 or gy.dim() != 4 or gy.shape[0] != x.shape[0] or gy.shape[2:] != x.shape[2:]:
-        raise _refusal(f"wm_conv2d_wgrad: gy {tuple(gy.shape)} does not match x {tuple(x.shape)}")
     need = lib.wm_conv2d_wgrad_workspace_bytes(B, Cin, Cout, H, W, ks)
     if need == 0:
         raise _refusal("wm_conv2d_wgrad: unsupported shape (see conv2d_wgrad_supported)")
@@ -1435,6 +1435,8 @@ def conv2d_train(x, weight, bias=None):
     mode = _TRAIN_CONV_MODE
     if mode == "auto":
         mode = "f16" if x.shape[0] * x.shape[2] * x.shape[3] >= ((1 << 17) if weight.shape[2] == 3 else (1 << 19)) else "aten"
+        if mode == "f16" and _f16_ws_bytes(_lib.load(), weight.shape[0], weight.shape[1], weight.shape[2]) == 0:
+            mode = "aten"                        # a shape the fp16 kernels refuse: the step never dies on it
     if mode == "aten":
         if not ((bias is not None and bias.requires_grad) or weight.requires_grad):
             return F.conv2d(x.float(), weight, bias, stride=1, padding=weight.shape[2] // 2)

@@ -45,17 +45,19 @@ def wrap_ddp(net, device=None, find_unused_parameters=False, force=False):
                                                      find_unused_parameters=find_unused_parameters)
 
 
-def train_step(net, optimizer, lq, gt):
+def train_step(net, optimizer, lq, gt, as_float=True):
     """One optimize_parameters(): zero_grad, forward, L1 + 0.1*FFT, backward (DDP all-reduce), step.
-    Returns the reduced losses as 0-dim DEVICE tensors: nothing in a step waits for the GPU (the reference converts them
-    when it logs, every `print_freq` iterations - `loss_values()` is that conversion; a `float()` here was a host sync
-    per iteration, under DDP on every rank)."""
+    Returns the reduced losses {name: python float} like the reference's `reduce_loss_dict` (base_model.py:376-401: a log dict
+    of floats - callers format / json-dump it).  as_float=False returns 0-dim DEVICE tensors instead: nothing in the step then
+    waits for the GPU (a `float()` is a host synchronisation per iteration, under DDP on every rank); `loss_values()` converts
+    such a result when it is time to log (the reference logs every `print_freq` iterations).  bench.py and the tools time the
+    step with as_float=False."""
     optimizer.zero_grad(set_to_none=True)
     out = net(lq)
     l_pix, l_freq = losses(out, gt)
     (l_pix + l_freq).mean().backward()
     optimizer.step()
-    return reduce_loss_dict({"l_pix": l_pix.detach(), "l_freq": l_freq.detach()}, as_float=False)
+    return reduce_loss_dict({"l_pix": l_pix.detach(), "l_freq": l_freq.detach()}, as_float=as_float)
 
 
 def loss_values(loss_dict):
