@@ -162,6 +162,32 @@ def whole_job_value(world, steps, units_per_step, seconds):
     return world * steps * units_per_step / seconds
 
 
+def device_identity(device):
+    """What makes this rank's GPU THIS GPU: name, uuid (when the runtime reports one), PCI bus id, visible-device settings."""
+    pr = torch.cuda.get_device_properties(device)
+    ident = {"index": device.index, "name": pr.name, "uuid": str(getattr(pr, "uuid", "")) or None,
+             "pci": f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', -1):02x}:{getattr(pr, 'pci_device_id', -1):02x}",
+             "compute_units": pr.multi_processor_count, "hbm_GiB": round(pr.total_memory / 2 ** 30, 1),
+             "visible_devices": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES")),
+             "pid": os.getpid()}
+    return ident
+
+
+def gather_identities(ident, world):
+    """Every rank's device_identity() on every rank (all_gather_object over the job's process group)."""
+    if world <= 1 or not (dist.is_available() and dist.is_initialized()):
+        return [ident]
+    out = [None] * world
+    dist.all_gather_object(out, ident)
+    return out
+
+
+def distinct_devices(idents):
+    """N ranks saw N different GPUs?  Keyed by uuid when reported, else by PCI address (+ index)."""
+    keys = [(i.get("uuid") or (i.get("pci"), i.get("index"))) for i in idents]
+    return len(set(keys)) == len(keys)
+
+
 def free_port():
     import socket
     with socket.socket() as sk:
@@ -455,6 +481,16 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=device)      # RCCL on ROCm
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # who is where: every rank's GPU identity gathered over the job's own process group, so the line
+    # itself shows that RCCL saw N ranks on N distinct devices; replicas on one shared device are an error, not a number
+    idents = gather_identities(device_identity(device), world if dist.is_initialized() else 1)
+    if world > 1 and not share and not distinct_devices(idents):
+        raise SystemExit(f"bench.py: {world} ranks but the devices are not distinct: {idents}")
+    ranks_info = {"world_size": dist.get_world_size() if dist.is_initialized() else 1, "launcher_world_size": world,
+                  "backend": (dist.get_backend() if dist.is_initialized() else None),
+                  "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None),
+                  "distinct_devices": distinct_devices(idents), "devices": idents,
+                  "torch": torch.__version__, "hip": torch.version.hip}
 
     img = torch.rand(1, 3, args.height, args.width, generator=torch.Generator().manual_seed(image_seed(rank)))
     x_cpu = pad_to(img)
@@ -657,6 +693,7 @@ def main():
                                    f"init, one image per GPU per step, replicas (no collective); one forward at a time, "
                                    f"its down-path high-frequency branches on side streams: "
                                    f"{bool(getattr(net.restoration_network, 'two_streams', False))}"},
+            "ranks": ranks_info,
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
             "roofline_table": table,
             "hot_path_ms_per_step": sum(table[k]["ms_per_step"] for k in table if k in hot_names),

@@ -42,6 +42,11 @@ def _worker(rank, world, port, out_dir):
         assert syncs == [2, 8] and barriers == [2, 8]        # bracket: after the warm-up, after the K-th step
         el_max = bench.max_over_ranks(el, world, "cpu")
         value = bench.whole_job_value(world, 6, 1, el_max)
+        # the identity block of the N > 1 line: every rank's device gathered over the job's own process group
+        ident = {"index": rank, "uuid": None, "pci": f"0000:{rank:02x}:00", "pid": os.getpid()}
+        idents = bench.gather_identities(ident, world)
+        assert [i["index"] for i in idents] == list(range(world)) and bench.distinct_devices(idents)
+        assert not bench.distinct_devices(idents + [dict(idents[0])])          # two ranks on one GPU are detected
         legs_rank0_only = (rank == 0 and world == 1)         # cpu_baseline / parity / concurrent legs: N = 1 only
         torch.save({"el": el, "el_max": el_max, "value": value, "seed": bench.image_seed(rank), "legs": legs_rank0_only},
                    os.path.join(out_dir, f"r{rank}.pt"))
