@@ -42,6 +42,12 @@ FUSED_BYTES_PER_POS = 512        # SURVEY.md 8d "fused SS2D-core (stretch, repor
 # kernel classes of the selective-scan op whose HIP events are recorded in the instrumented pass
 CORE_CLASSES = ("ss2d_core_reduce", "selscan_carry", "ss2d_core_scan")
 EXP_PEAK = 18.5e12               # v_exp_f32 lane-ops/s chip-wide, tools/microbench.hip on MI355X
+# VALU issue cycles one wave (64 channels) spends per scan STEP in the innermost loops of wm::ss2d_core_kernel<16,16,1|3>, counted
+# from the ISA of the shipped build by tools/isa_valu_count.py (profiles/r05/isa_valu_count.json): 4 cycles per VALU instruction
+# (packed or not), 8 per transcendental.  Round 4's build: 289 / 325; round 5 (softplus in log2 units, constants folded): 279 / 315.
+# The arithmetic itself (per step: 16 exponentials and 24 / 32 packed operations) is 224 / 256.
+VALU_CYCLES_PER_STEP = {"reduce": 279, "scan": 315, "reduce_arithmetic_only": 224, "scan_arithmetic_only": 256}
+SIMDS, SHADER_CLOCK_HZ = 1024, 2.4e9         # 256 CUs x 4 SIMDs; the clock the scan kernels sustain (tools/ubench_active_cus)
 # The LFSSBlock kernels around the scan.  SURVEY 8d gives bytes for the wavelets and the scan
 # only; for these the algorithmic bytes are what each kernel must move at the shipped width (C = 32, D = 64, fp32 planes):
 #   lfss_in   reads tokens (4C) and writes x (4D) - and z (4D) unless the gate is recomputed downstream     = 384 (640) B / position
@@ -186,6 +192,21 @@ def distinct_devices(idents):
     """N ranks saw N different GPUs?  Keyed by uuid when reported, else by PCI address (+ index)."""
     keys = [(i.get("uuid") or (i.get("pci"), i.get("index"))) for i in idents]
     return len(set(keys)) == len(keys)
+
+
+def valu_floor(pos, core_ms, iso_ms):
+    """The op's VALU-issue floor: wave-steps x issue cycles per step of BOTH passes / (SIMDs x clock).
+    `valu_floor_ms` takes the instruction stream as compiled (ISA count), `valu_arithmetic_floor_ms` only the recurrence's own
+    arithmetic; the fractions say how much of the measured op time those floors explain (in the step as timed / alone)."""
+    wave_steps = 4 * pos                                   # four directions, one wave of 64 channels per position
+    per = VALU_CYCLES_PER_STEP
+    f = lambda cyc: cyc * wave_steps / (SIMDS * SHADER_CLOCK_HZ) * 1e3
+    floor, arith = f(per["reduce"] + per["scan"]), f(per["reduce_arithmetic_only"] + per["scan_arithmetic_only"])
+    return {"valu_cycles_per_step": per, "valu_floor_ms": floor, "valu_arithmetic_floor_ms": arith,
+            "valu_floor_frac": floor / core_ms if core_ms else None,
+            "valu_floor_frac_isolated": floor / iso_ms if iso_ms else None,
+            "valu_floor_source": "tools/isa_valu_count.py on the shipped build: innermost step loops of ss2d_core_kernel<16,16,1|3> "
+                                 "(projection, staging, y stores, prologues, tails and the carry are not in the floor)"}
 
 
 def free_port():
@@ -669,7 +690,8 @@ def main():
             "secondary_ceilings": {
                 "note": "the op is bound by VALU issue, not by HBM: KD*N = 4096 v_exp_f32 per position in each of the two "
                         "passes (chunk-reduce, chunk-scan) plus four packed fp32 operations per state-step",
-                "exp_frac": (2 * 4096 * pos / (core_ms * 1e-3) / EXP_PEAK) if core_ms else None},
+                "exp_frac": (2 * 4096 * pos / (core_ms * 1e-3) / EXP_PEAK) if core_ms else None,
+                **valu_floor(pos, core_ms, sum(iso.values()) if len(iso) == len(CORE_CLASSES) else None)},
         }
         hot_names = ("haar_analysis", "haar_synthesis", "lfss_in", "lfss_mid", "lfss_out", "dwconv3x3") + CORE_CLASSES
         # SURVEY.md 8d "for the sum": DWT + IWT + scans = 2.81 + 2.81 + 26.20 GB per UHD image over the time of EVERY

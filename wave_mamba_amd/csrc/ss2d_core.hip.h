@@ -155,7 +155,12 @@ __device__ __forceinline__ void core_split2(float a, float b, core_bf2& hi, core
 //   fragments: lane l = (r16 = l & 15, g4 = l >> 4) of (tile t, K-step s2) holds W[row(t, r16)][32 s2 + 4 j + g4],
 //   j = 0..7 - the K order of a matrix product is free, and this one lets the B operands be read from the x tile
 //   [channel][step] with the bank-conflict-free stride of the fp32 kernel (g4 -> one tile row apart).
-template <int NP>
+// L2U ("log2 units", the FORWARD kernels' form since round 5): the scan kernels work with dt' = dt / ln 2 = log2(1 + 2^x'),
+// x' = (Wdt . dt_r + bias) log2(e) - so the prepared dt weights and bias carry the factor log2(e), A is stored WITHOUT it
+// (exp(dt A) = exp2(dt' A)) and the B rows of x_proj carry ln 2 (dt u B = dt' u (ln 2 B)): the per-step softplus loses its
+// two scale multiplications and its threshold selects (core_softplus_l2), nothing else changes.  The backward kernels
+// (ss2d_core_bwd.hip.h) take the natural-unit form (L2U = false).
+template <int NP, bool L2U = false>
 __global__ __launch_bounds__(256) void ss2d_core_prep_kernel(const float* __restrict__ Wx, const float* __restrict__ Wdt,
                                                              const float* __restrict__ dtb, const float* __restrict__ A_logs,
                                                              const float* __restrict__ Ds, float* __restrict__ prep, int D, int N,
@@ -178,6 +183,7 @@ __global__ __launch_bounds__(256) void ss2d_core_prep_kernel(const float* __rest
         for (int i = 0; i < 2; ++i) {
             const int d = 32 * s2 + 4 * (2 * jp + i) + g4;
             v[i] = (row >= 0 && d < D) ? Wx[((long long)k * Cx + row) * D + d] : 0.0f;
+            if (L2U && t >= 1 && t <= NTB) v[i] *= 0.6931471805599453f;       // B rows: ln 2 (see above)
         }
         core_bf2 hi, lo;
         core_split2(v[0], v[1], hi, lo);
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(256) void ss2d_core_prep_kernel(const float* __rest
     for (int e = threadIdx.x; e < NP * 64; e += 256) {
         const int lane = e & 63, n = e >> 6;
         float a = 0.0f;
-        if (lane < D && n < N) a = -expf(A_logs[((long long)k * D + lane) * N + n]) * 1.4426950408889634f;
+        if (lane < D && n < N) a = -expf(A_logs[((long long)k * D + lane) * N + n]) * (L2U ? 1.0f : 1.4426950408889634f);
         out[Cfg::P_A2 + ((n >> 1) * 64 + lane) * 2 + (n & 1)] = a;
     }
     for (int e = threadIdx.x; e < 6 * 64; e += 256) {
@@ -198,9 +204,24 @@ __global__ __launch_bounds__(256) void ss2d_core_prep_kernel(const float* __rest
             const long long kd = (long long)k * D + lane;
             if (c < 4) v = c < R ? Wdt[kd * R + c] : 0.0f;
             else v = c == 4 ? dtb[kd] : Ds[kd];
+            if (L2U && c <= 4) v *= 1.4426950408889634f;
         }
         out[Cfg::P_LC + e] = v;
     }
+}
+
+// softplus in log2 units: x' = x log2(e) -> softplus(x) / ln 2 = log2(1 + 2^x') = max(x', 0) + log2(1 + 2^-|x'|).
+// e = 2^-|x'| <= 1, so w = fl(1 + e) <= 2 and the log1p correction of selscan.hip.h's softplus2 (d = (w - 1) - e, exact) applies
+// everywhere: log2(w - d) = log2(w) - d log2(e) / w, the 1 / w dropped as there.  No overflow for any x', hence no threshold
+// select (F.softplus's `x > 20 ? x : ...` differs from this by e^-20 = 2e-9 of x), no w < 2 select, no scale multiplications:
+// per PAIR of steps 4 transcendentals + 6 packed + 2 plain VALU operations (softplus2 + its scale: 4 + 5 + 8).
+__device__ __forceinline__ v2f core_softplus_l2(v2f x) {
+    const v2f m = (v2f){fmaxf(x.x, 0.0f), fmaxf(x.y, 0.0f)};
+    const v2f e = exp2_2(x - m * 2.0f);                                  // 2^-|x'|
+    const v2f w = e + 1.0f;
+    const v2f d = (w - 1.0f) - e;
+    const v2f lg = (v2f){__builtin_amdgcn_logf(w.x), __builtin_amdgcn_logf(w.y)};      // v_log_f32: base 2
+    return m + (lg - d * 1.4426950408889634f);
 }
 
 // Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() also drains the vector-memory counter
@@ -254,7 +275,7 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
             if (t == 0) { if (r16 < p.R) row = r16; }
             else if (t <= NTB) { const int n = 16 * (t - 1) + r16; if (n < p.N) row = p.R + n; }
             else if (t <= 2 * NTB) { const int n = 16 * (t - 1 - NTB) + r16; if (n < p.N) row = p.R + p.N + n; }
-            s_w[e] = (row >= 0 && d < D) ? p.Wx[((long long)k * Cx + row) * D + d] : 0.0f;
+            s_w[e] = ((row >= 0 && d < D) ? p.Wx[((long long)k * Cx + row) * D + d] : 0.0f) * ((t >= 1 && t <= NTB) ? 0.6931471805599453f : 1.0f);   // (log2 units: B rows x ln 2)
         }
     }
 #else
@@ -270,7 +291,7 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
     // ---- per-lane (= per-channel) constants, prepared once per call
     const bool live = lane < D;
     const int d = live ? lane : 0;
-    v2f A2r[NP / 2];                                     // A * log2(e) per state pair (in LDS instead: 4 % slower)
+    v2f A2r[NP / 2];                                     // A per state pair (log2 units: exp(dt A) = exp2(dt' A); in LDS instead: 4 % slower)
 #pragma unroll
     for (int i = 0; i < NP / 2; ++i) A2r[i] = *reinterpret_cast<const v2f*>(prep + Cfg::P_A2 + (i * 64 + lane) * 2);
 #define WM_A2(i) A2r[i]
@@ -601,7 +622,7 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
                             dtr[jj] = fmaf(wdt[1], dr.y, fmaf(wdt[0], dr.x, bias));
                         }
                     }
-                    const v2f sp = softplus2((v2f){dtr[0], dtr[1]});
+                    const v2f sp = core_softplus_l2((v2f){dtr[0], dtr[1]});             // dt / ln 2 (log2 units, see the prep kernel)
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         const int j = 2 * hf + jj;

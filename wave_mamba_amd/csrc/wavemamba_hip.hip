@@ -711,7 +711,7 @@ static int core_launch(const CoreArgs& a, const CorePlan& pl, bool do_prep, bool
     const bool split = pl.row_nchunks > 1 || pl.col_nchunks > 1;
     if (do_prep) {   // parameters -> bf16 weight fragments, A * log2(e), per-channel constants (four small blocks)
         ProfScope ps(10, st);
-        hipLaunchKernelGGL((ss2d_core_prep_kernel<NP>), dim3(4), dim3(256), 0, st, a.Wx, a.Wdt, a.dtb, a.A_logs, a.Ds,
+        hipLaunchKernelGGL((ss2d_core_prep_kernel<NP, true>), dim3(4), dim3(256), 0, st, a.Wx, a.Wdt, a.dtb, a.A_logs, a.Ds,
                            const_cast<float*>(a.prep), a.D, a.N, a.R);
     }
     if (split) {
@@ -769,10 +769,10 @@ int wm_ss2d_core_prep(const float* x_proj_weight, const float* dt_projs_weight, 
     if (!aligned16(prepared)) return WM_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     if (N <= 16)
-        hipLaunchKernelGGL((ss2d_core_prep_kernel<16>), dim3(4), dim3(256), 0, st, x_proj_weight, dt_projs_weight,
+        hipLaunchKernelGGL((ss2d_core_prep_kernel<16, true>), dim3(4), dim3(256), 0, st, x_proj_weight, dt_projs_weight,
                            dt_projs_bias, A_logs, Ds, (float*)prepared, D, N, R);
     else
-        hipLaunchKernelGGL((ss2d_core_prep_kernel<32>), dim3(4), dim3(256), 0, st, x_proj_weight, dt_projs_weight,
+        hipLaunchKernelGGL((ss2d_core_prep_kernel<32, true>), dim3(4), dim3(256), 0, st, x_proj_weight, dt_projs_weight,
                            dt_projs_bias, A_logs, Ds, (float*)prepared, D, N, R);
     return launch_status();
 }
