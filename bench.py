@@ -56,11 +56,11 @@ SIMDS, SHADER_CLOCK_HZ = 1024, 2.4e9         # 256 CUs x 4 SIMDs; the clock the 
 #             (round 4, ops._RECOMPUTE_Z) -, writes tok1 and f (4 D NY [+ 4D] + 4C + 4C + 4D)  = 1536 (1792)
 #   lfss_out  reads f (4D) and tok1 (4C), writes the block's output (4C)                   = 512
 # The table quotes what the kernels the run actually used must move (never the larger figure for the smaller data flow).
-LFSS_MID_NY = 2 if getattr(wm.ops, "_CORE_PAIRED", False) else 4       # (the core's opt-in paired mode writes two planes)
+LFSS_MID_NY = 4                                                        # the four directions' y planes, added by lfss_mid as it loads them
 
 
 def lfss_bytes_per_pos():
-    z = 0 if getattr(wm.ops, "_RECOMPUTE_Z", False) and not getattr(wm.ops, "_FUSE_IN_CONV", False) else 256
+    z = 0 if getattr(wm.ops, "_RECOMPUTE_Z", False) else 256
     return {"lfss_in": 128 + 256 + z, "dwconv3x3": 512, "lfss_mid": 256 * LFSS_MID_NY + z + 128 + 128 + 256, "lfss_out": 512}
 
 

@@ -123,11 +123,7 @@ int wm_selscan_bwd(const float* u, const float* delta, const float* A, const flo
  *     transposed back).  merged != 0: only y_row_fwd is written and holds the SUM of the four
  *     (what SS2D.forward computes next, :490, added in the reference's order); the other three
  *     pointers may be NULL.  wm_lfss_mid_fwd can add the four un-merged outputs while it reads them.
- *     merged == 2 (PAIRED mode): two planes - y_row_fwd receives row forward + row reversed, y_col_fwd column forward +
- *     column reversed (y_row_rev / y_col_rev unused, may be NULL): the reversed directions run as a second chunk-scan launch
- *     that adds into the planes the first one stored (fp32 planes: bit-equal to adding the un-merged outputs pairwise;
- *     wm_lfss_mid_fwd ny = 2 reads them).  Measured slower than the four planes on MI355X (profiles/r04/
- *     core_ab_paired_planes.txt): kept as an option, not the default data flow.
+ *     merged must be 0 or 1 (2 was round 4's two-plane mode - measured slower, profiles/r04/core_ab_paired_planes.txt - deleted).
  *   Supported: N <= 32, R <= 4, D <= 64, D * H * W < 2^31 (else WM_EUNSUPPORTED: use wm_selscan_fwd); any H, W.
  *   W % 4 == 0 with 16-byte aligned x / y buffers: 16-byte tile accesses; otherwise (odd widths, fp32 planes only)
  *   the same kernels with element-wise tile accesses, slower per position.
@@ -178,8 +174,7 @@ int wm_dwconv3x3_fwd(const void* x, const float* weight, const float* bias, void
  *                     + skip_scale residual (:525) + ln_2 + ffn.conv1 (:526, :226)
  *                     ysum, z, tok -> tok1, f (input of ffn.conv2).  ny = 1: `ysum` is the merged core output;
  *                     ny = 4: `ysum` points at four (B, D, L) buffers `ystride` ELEMENTS of the plane dtype apart in the order
- *                     [y_row_fwd, y_row_rev, y_col_fwd, y_col_rev] and the kernel adds them (:490) as it loads;
- *                     ny = 2: two buffers [row pair, column pair] of the core's paired mode (merged == 2)
+ *                     [y_row_fwd, y_row_rev, y_col_fwd, y_col_rev] and the kernel adds them (:490) as it loads
  *   wm_lfss_out_fwd : gelu gate (:227-228) + ffn.conv3 (:230) + skip_scale2 residual (:526)
  *                     fc, tok1 -> out
  * -------------------------------------------------------------------------------------------- */
@@ -187,15 +182,6 @@ int wm_dwconv3x3_fwd(const void* x, const float* weight, const float* bias, void
  * mode); token tensors are always fp32. */
 int wm_lfss_in_fwd(const float* tok, int tok_nchw, const float* ln_w, const float* ln_b, float ln_eps,
                    const float* in_proj_weight, void* x, void* z, int B, int64_t L, int C, int plane_dtype, void* stream);
-/* wm_lfss_in_fwd + wm_dwconv3x3_fwd(act = SiLU) in ONE kernel (reference :483-487: in_proj, chunk, NHWC -> NCHW, depth-wise 3x3,
- * SiLU): xc = silu(conv2d(x) + conv_bias) (B, D, H, W) and z (B, D, H W); x itself never reaches HBM (the 3x3's one-pixel halo of
- * the projection output is recomputed per 62-column strip and row band).  C == 32 only (WM_EUNSUPPORTED otherwise: use the
- * two calls).  conv_weight (D, 1, 3, 3), conv_bias (D) or NULL.  Same values of x as wm_lfss_in_fwd; the convolution sums
- * its taps row by row (differs from wm_dwconv3x3_fwd in the last bits). */
-int wm_lfss_in_conv_fwd(const float* tok, int tok_nchw, const float* ln_w, const float* ln_b, float ln_eps,
-                        const float* in_proj_weight, const float* conv_weight, const float* conv_bias, void* xc, void* z,
-                        int B, int H, int W, int C, int plane_dtype, void* stream);
-
 int wm_lfss_mid_fwd(const void* ysum, int ny, int64_t ystride, const void* z, const float* tok, int tok_nchw,
                     const float* out_norm_w, const float* out_norm_b, float out_norm_eps,
                     const float* out_proj_weight, const float* skip_scale,

@@ -438,48 +438,6 @@ def test_ss2d_core_vs_oracle(B, D, H, W, N, R):
     assert_close(wm.ops.ss2d_core(*cu(*case), merged=True), sum(want), TOL, "merged")
 
 
-@pytest.mark.parametrize("B,D,H,W,N,R", [
-    (1, 64, 64, 64, 16, 2), (2, 64, 24, 40, 16, 2), (1, 64, 40, 136, 16, 2), (1, 48, 9, 7, 8, 3), (1, 64, 128, 128, 16, 2),
-    (1, 16, 16, 2048, 16, 2), (1, 64, 48, 40, 32, 2), (2, 64, 33, 71, 16, 2), (1, 64, 65, 33, 16, 2), (1, 8, 1, 1, 16, 1),
-    (1, 64, 1, 37, 16, 2), (1, 64, 272, 480, 16, 2),
-])
-def test_ss2d_core_paired_planes(B, D, H, W, N, R):
-    """Paired mode (merged = 2): two output planes, each reversed direction's launch ADDS into the plane its forward twin's
-    launch stored.  fp32 planes: bit-equal to the pairwise sums of the four-plane outputs (one fp32 addition either way)."""
-    case = cu(*random_core_case(B, D, H, W, N, R, seed=H * 100 + W))
-    y4 = wm.ops.ss2d_core(*case)
-    y2 = wm.ops.ss2d_core(*case, merged=2)
-    assert len(y2) == 2
-    assert torch.equal(y2[0], y4[0] + y4[1]), "row pair"
-    assert torch.equal(y2[1], y4[2] + y4[3]), "column pair"
-
-
-def test_ss2d_core_paired_planes_bf16():
-    """bf16 planes: the forward twin's output is rounded to bf16 when stored, the sum once more."""
-    case = cu(*random_core_case(1, 64, 40, 136, 16, 2, seed=11))
-    xb = case[0].bfloat16()
-    y4 = wm.ops.ss2d_core(xb.float(), *case[1:])
-    y2 = wm.ops.ss2d_core(xb, *case[1:], merged=2)
-    for i in range(2):
-        want = (y4[2 * i].bfloat16().float() + y4[2 * i + 1]).bfloat16()
-        assert y2[i].dtype == torch.bfloat16 and torch.equal(y2[i], want), f"pair {i}"
-
-
-def test_lfss_block_paired_core(monkeypatch):
-    """LFSSBlock inference with the core's paired mode (lfss_mid reads two planes): same block output as with four planes up to
-    the order of three fp32 additions ((y1 + y2) + (y3 + y4) instead of ((y1 + y2) + y3) + y4, :490)."""
-    torch.manual_seed(5)
-    blk = arch.LFSSBlock(32, expand=2.0).eval().to(DEV)
-    for hw in ((64, 96), (33, 72)):
-        x = torch.randn(2, hw[0] * hw[1], 32, generator=gen(9)).to(DEV)
-        with torch.no_grad():
-            monkeypatch.setattr(wm.ops, "_CORE_PAIRED", False)
-            a = wm.ops.lfss_block_forward(x, hw, blk)
-            monkeypatch.setattr(wm.ops, "_CORE_PAIRED", True)
-            b = wm.ops.lfss_block_forward(x, hw, blk)
-        assert_close(b, a, 2e-6, f"paired block {hw}")
-
-
 @pytest.mark.parametrize("B,Cin,H,W,r,Cout", [
     (1, 3, 64, 96, 2, 32), (2, 3, 64, 96, 4, 32), (1, 3, 64, 96, 8, 32), (1, 3, 272, 520, 2, 32), (1, 3, 40, 1048, 8, 32),
     (2, 3, 16, 24, 8, 16), (1, 3, 32, 48, 4, 48), (1, 4, 24, 40, 2, 64), (1, 1, 8, 8, 8, 16), (1, 3, 2160, 3840, 8, 32),
@@ -821,36 +779,6 @@ def test_lfss_out_with_depthwise_conv_folded_in(B, H, W, nchw):
     assert_close(fused, want.float(), 1e-5, "bf16 planes, no conv2 bias")
     assert lib.wm_lfss_out_conv_fwd(_ptr(f), _ptr(w2), _ptr(b2), _ptr(tok1), _ptr(w3), _ptr(b3), _ptr(sk), _ptr(fused),
                                     int(nchw), B, H, W - 4, C, 0, _stream()) == -5       # W % 32 != 0: WM_EUNSUPPORTED
-
-
-@pytest.mark.parametrize("B,H,W", [(1, 40, 96), (2, 3, 32), (1, 1, 64), (1, 17, 130), (1, 64, 62), (1, 5, 63), (1, 9, 125),
-                                   (1, 2, 8), (2, 272, 480), (1, 70, 1920)])
-@pytest.mark.parametrize("nchw", [False, True])
-def test_lfss_prologue_one_kernel_vs_two_and_fp64(B, H, W, nchw):
-    """wm_lfss_in_conv_fwd (ln_1 -> in_proj -> depth-wise 3x3 -> SiLU in one kernel, x never in HBM; reference :524, :483-487)
-    against wm_lfss_in_fwd + wm_dwconv3x3_fwd (z BIT-equal: the same projection code; the convolution sums its taps in
-    another order) and against the float64 composition of the reference's lines: strips of 62 columns with recomputed
-    halos (W < 62, = 62, 63, 125, 130, 1920), row bands (H = 1 .. 272), image borders, batch > 1, token and NCHW inputs."""
-    torch.manual_seed(H * 1000 + W)
-    blk = arch.LFSSBlock(32, expand=2.0).to(DEV).eval()
-    with torch.no_grad():
-        blk.ln_1.weight.add_(0.3 * torch.randn_like(blk.ln_1.weight)); blk.ln_1.bias.add_(0.2 * torch.randn_like(blk.ln_1.bias))
-    ss = blk.self_attention
-    x_map = torch.randn(B, 32, H, W, device=DEV)
-    tok = x_map if nchw else x_map.flatten(2).transpose(1, 2).contiguous()
-    xc1, z1 = wm.ops.lfss_prologue(tok, (H, W), blk, tok_nchw=nchw, fused=True)
-    xc2, z2 = wm.ops.lfss_prologue(tok, (H, W), blk, tok_nchw=nchw, fused=False)
-    assert torch.equal(z1, z2), "z differs from wm_lfss_in_fwd's"
-    assert_close(xc1, xc2, 2e-6, "fused prologue vs two kernels")
-    t64 = x_map.double().flatten(2).transpose(1, 2)
-    xz = F.linear(F.layer_norm(t64, (32,), blk.ln_1.weight.double(), blk.ln_1.bias.double(), blk.ln_1.eps), ss.in_proj.weight.double())
-    x64, z64 = xz.chunk(2, dim=-1)
-    x64 = x64.transpose(1, 2).reshape(B, 64, H, W)
-    ref = F.silu(F.conv2d(x64, ss.conv2d.weight.double(), ss.conv2d.bias.double(), padding=1, groups=64))
-    assert_close(xc1, ref.float(), 5e-6, "fused prologue vs float64")
-    assert_close(z1, z64.transpose(1, 2).float().contiguous(), 5e-6, "z vs float64")
-    again, _ = wm.ops.lfss_prologue(tok, (H, W), blk, tok_nchw=nchw, fused=True)
-    assert torch.equal(again, xc1)
 
 
 @pytest.mark.parametrize("B,L", [(1, 64), (2, 1000), (3, 37), (1, 4097)])

@@ -14,7 +14,7 @@ C, D = 32, 64
 g = torch.Generator(device=dev); g.manual_seed(0)
 rn = lambda *s: torch.randn(*s, device=dev, generator=g)
 cw, cb, W3, b3, sk2 = rn(D, 1, 3, 3) / 3, rn(D) * 0.1, rn(C, C) / 6, rn(C) * 0.1, rn(C) * 0.1 + 1
-print("WM_LFSS_OUT_LINEAR =", os.environ.get("WM_LFSS_OUT_LINEAR", "0"), " WM_LFSS_OUT_ROWS =", os.environ.get("WM_LFSS_OUT_ROWS", "-1"))
+print("WM_LFSS_OUT_ROWS =", os.environ.get("WM_LFSS_OUT_ROWS", "-1"))
 for lvl in (1, 2, 3):
     H, W = 2176 >> lvl, 3840 >> lvl
     L, B = H * W, 1

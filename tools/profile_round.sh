@@ -10,11 +10,9 @@ WM_TWO_STREAMS=0 bash tools/profile_bench.sh $O/single > $O/profile_single.log 2
 bash tools/pmc_core.sh $O/pmc_core > $O/pmc_core.log 2>&1
 python tools/pmc_traffic.py $O/pmc_core $O/pmc_traffic.json > $O/pmc_traffic.log 2>&1
 python tools/bench_core_bwd.py > $O/bench_core_bwd.txt 2>&1
-WM_CORE_BWD_V1=1 python tools/bench_core_bwd.py > $O/bench_core_bwd_first_generation.txt 2>&1
 bash tools/pmc_core_bwd.sh $O/pmc_core_bwd > /dev/null 2>&1
 python tools/pmc_summary.py $O/pmc_core_bwd core_bwd > $O/pmc_core_bwd_summary.txt 2>&1
 python tools/train_breakdown.py --steps 3 --detail core_bwd_chunk,core_bwd_reduce > $O/train_step_kernel_breakdown.txt 2>&1
-WM_CORE_BWD_V1=1 python tools/train_breakdown.py --steps 3 > $O/train_step_kernel_breakdown_first_generation_backward.txt 2>&1
 bash tools/pmc_conv.sh $O/pmc_conv > /dev/null 2>&1
 python tools/pmc_summary.py $O/pmc_conv conv > $O/pmc_conv_summary.txt 2>&1
 python tools/bench_conv_train.py > $O/bench_conv_train.txt 2>&1

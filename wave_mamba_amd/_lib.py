@@ -37,7 +37,6 @@ SIGNATURES = {
     "wm_ss2d_core_bwd_workspace_bytes": (_sz, [_i] * 6),
     "wm_ss2d_core_bwd": (_i, [_p] * 16 + [_p, _sz] + [_i] * 6 + [_p]),
     "wm_lfss_in_fwd": (_i, [_p, _i, _p, _p, _c.c_float, _p, _p, _p, _i, _i64, _i, _i, _p]),
-    "wm_lfss_in_conv_fwd": (_i, [_p, _i, _p, _p, _c.c_float, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "wm_lfss_mid_rz_fwd": (_i, [_p, _i, _i64, _p, _i, _p, _p, _c.c_float, _p, _p, _p, _c.c_float, _p, _p, _p, _p, _c.c_float, _p, _p,
                                _p, _p, _i, _i64, _i, _i, _p]),
     "wm_lfss_mid_fwd": (_i, [_p, _i, _i64, _p, _p, _i, _p, _p, _c.c_float, _p, _p, _p, _p, _c.c_float, _p, _p, _p, _p,

@@ -421,173 +421,6 @@ __global__ __launch_bounds__(256, WM_LFSS_IN_WAVES) void lfss_in_mfma_kernel(
     }
 }
 
-// ---- lfss_in_conv: tok -> xc = silu(conv2d(x) + bias) (B, D, H, W), z (B, D, L) ------------------------------------
-// SS2D's prologue in ONE kernel (reference :483-487: in_proj, chunk, NHWC -> NCHW, depth-wise 3x3, SiLU):
-// x = in_proj(ln_1(tok))[:, :D] never reaches HBM (lfss_in wrote it, dwconv3x3 read it back: 512 of the pair's 1,152 B per
-// position).  The convolution needs x on a one-pixel halo, and x is a projection OUTPUT - so the halo is RECOMPUTED:
-//   * a wave owns a strip of 62 output columns (its 64 lanes are 64 consecutive columns: one halo column each side) x `rb`
-//     output rows, and 32 of the 64 x / z channels (wave & 1); the rows stream top to bottom through rb + 2 row groups;
-//   * per row group: tokens of the 64 columns -> LayerNorm in registers -> in_proj on the fp32 matrix cores (the code of
-//     lfss_in: identical x values) -> v_permlane32_swap turns the two tiles' accumulators into 32 registers with lane = column;
-//   * the 3x3 taps: horizontal neighbours are the adjacent LANES (DPP wave_shr / wave_shl, one instruction each), vertical
-//     ones are two running partial sums per channel: row r of x adds its kernel-row-2 part to output row r - 1 (complete:
-//     SiLU, store), its kernel-row-1 part to output row r and starts output row r + 1 with its kernel-row-0 part + bias.
-// Columns outside the image hold x = 0 (the convolution's zero padding), rows outside it are skipped.  Token rows are read
-// rb + 2 times per rb rows and by both waves of a channel pair (first / second-level cache hits: 128 B per position against the
-// 512 B of planes that no longer move).
-__device__ __forceinline__ float wave_shr1(float v) {      // lane i <- lane i - 1 (lane 0: 0)
-    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x138, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float wave_shl1(float v) {      // lane i <- lane i + 1 (lane 63: 0)
-    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x130, 0xf, 0xf, true));
-}
-constexpr int kIcCols = 62;                                // output columns per strip
-template <typename TP = float>
-__global__ __launch_bounds__(256, 2) void lfss_in_conv_mfma_kernel(
-    const float* __restrict__ tok, int tok_nchw, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
-    const float* __restrict__ W_in /*(2D, C)*/, const float* __restrict__ cw /*(D, 1, 3, 3)*/, const float* __restrict__ cb /*(D) or null*/,
-    TP* __restrict__ xc, TP* __restrict__ z, int B, int H, int W, int nstrips, int nbands, int rb) {
-    constexpr int C = 32, D = 64;
-    __shared__ __attribute__((aligned(16))) float s_bias[2 * D];
-    __shared__ __attribute__((aligned(16))) float s_A[4 * (C / 2) * 64];         // 4 row blocks x 16 operands
-    __shared__ __attribute__((aligned(16))) float s_cw[D * 12];                   // per channel: 9 taps, bias, 0, 0
-    const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x < 2 * D) {
-        float acc = 0.0f;
-        for (int k = 0; k < C; ++k) acc = fmaf(W_in[threadIdx.x * C + k], ln_b[k], acc);
-        s_bias[threadIdx.x] = acc;
-    }
-    for (int e = threadIdx.x; e < 4 * (C / 2) * 64; e += 256) {
-        const int mt = e >> 10, j = (e >> 6) & 15, l = e & 63;
-        const int k = acc_chan(j, l >> 5);
-        s_A[aop_slot(mt * 16 + j, l)] = W_in[(32 * mt + (l & 31)) * C + k] * ln_w[k];
-    }
-    for (int e = threadIdx.x; e < D * 12; e += 256) {
-        const int ch = e / 12, k = e - ch * 12;
-        s_cw[e] = k < 9 ? cw[ch * 9 + k] : (k == 9 && cb) ? cb[ch] : 0.0f;
-    }
-    __syncthreads();
-    const long long L = (long long)H * W;
-    const long long pair = (long long)blockIdx.x * 2 + (wv >> 1);
-    const int hb = wv & 1;                                  // channel half: x / z channels 32 hb .. 32 hb + 31
-    if (pair >= (long long)B * nbands * nstrips) return;
-    const int strip = (int)(pair % nstrips);
-    const int band = (int)((pair / nstrips) % nbands);
-    const long long b = pair / ((long long)nstrips * nbands);
-    const int col0 = strip * kIcCols - 1;                   // image column of lane 0
-    const int col = col0 + lane;
-    const bool colin = col >= 0 && col < W;
-    const float cmask = colin ? 1.0f : 0.0f;
-    const bool st_ok = lane >= 1 && lane <= kIcCols && col < W;
-    const int r0 = band * rb, r_end = min(H, r0 + rb);
-
-    float P0[32], P1[32];                                   // partial sums of output rows rho + 1 (kernel row 0 so far) and rho
-#pragma unroll
-    for (int i = 0; i < 32; ++i) { P0[i] = 0.0f; P1[i] = 0.0f; }
-    // accumulator register i of the swapped pair: channel (within the half) 8 (i >> 2) + (i & 3) [lo] and that + 4 [hi]
-    auto chan = [](int i, int half) { return 8 * (i >> 2) + (i & 3) + 4 * half; };
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-#pragma unroll
-        for (int half = 0; half < 2; ++half) P0[2 * i + half] = s_cw[(32 * hb + chan(i, half)) * 12 + 9];
-    TP* xb = xc + (b * D + 32 * hb) * L;
-    TP* zb = z + (b * D + 32 * hb) * L;
-
-    // the token tiles of a row are loaded one row ahead (a wave walks its rows one after the other: loaded when needed, every
-    // row group waited out its own global-load latency)
-    float nx[2][16];
-    auto load_row = [&](int rho) {
-        const long long prow = (long long)min(max(rho, 0), H - 1) * W;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) load_tile32(tok, tok_nchw != 0, b, prow + min(max(col0 + 32 * t + n, 0), W - 1), L, h, nx[t]);
-    };
-    load_row(r0 - 1);
-    for (int rho = r0 - 1; rho <= r_end; ++rho) {           // the x row entering the window
-        const bool rin = rho >= 0 && rho < H;
-        float xv[32];
-        float a[2][16];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) a[t][i] = nx[t][i];
-        if (rho < r_end) load_row(rho + 1);                  // (uniform)
-        if (rin) {                                           // (uniform)
-            const long long prow = (long long)rho * W;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) tile_normalise(a[t], eps);
-            const bool zrow = rho >= r0 && rho < r_end;      // an output row of this band: its z goes out too
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                if (pass == 1 && !zrow) break;
-                const int mt = 2 * pass + hb;                // row block of in_proj: x halves 0, 1; z halves 2, 3
-                lfss_v16f acc[2];
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const float4 bb = *reinterpret_cast<const float4*>(&s_bias[32 * mt + 8 * gq + 4 * h]);
-                    acc[0][4 * gq] = bb.x; acc[0][4 * gq + 1] = bb.y; acc[0][4 * gq + 2] = bb.z; acc[0][4 * gq + 3] = bb.w;
-                }
-                acc[1] = acc[0];
-#pragma unroll
-                for (int j4 = 0; j4 < C / 8; ++j4) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(&s_A[((mt * 4 + j4) * 64 + lane) * 4]);
-                    const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], a[0][4 * j4 + jj], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], a[1][4 * j4 + jj], acc[1], 0, 0, 0);
-                    }
-                }
-                if (pass == 0) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0][i]), __float_as_uint(acc[1][i]), false, false);
-                        xv[2 * i] = __uint_as_float(r[0]) * cmask;          // zero padding beyond the image's columns
-                        xv[2 * i + 1] = __uint_as_float(r[1]) * cmask;
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0][i]), __float_as_uint(acc[1][i]), false, false);
-                        if (st_ok) {
-                            TP* o = zb + (long long)chan(i, 0) * L + prow + col;
-                            st1(o, __uint_as_float(r[0]));
-                            st1(o + 4 * L, __uint_as_float(r[1]));
-                        }
-                    }
-                }
-            }
-        }
-        // the taps of this row: out[rho - 1] complete, out[rho] continued, out[rho + 1] started
-        const bool orow = rho - 1 >= r0 && rho - 1 < r_end;
-        const long long porow = (long long)(rho - 1) * W;
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int q = 2 * i + half;
-                const int ch = chan(i, half);
-                const float* wp = &s_cw[(32 * hb + ch) * 12];
-                float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f;
-                if (rin) {                                   // (uniform)
-                    const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
-                    const float w8 = wp[8];
-                    const float xm = xv[q], xl = wave_shr1(xm), xr = wave_shl1(xm);
-                    h0 = fmaf(w0.z, xr, fmaf(w0.y, xm, w0.x * xl));
-                    h1 = fmaf(w1.y, xr, fmaf(w1.x, xm, w0.w * xl));
-                    h2 = fmaf(w8, xr, fmaf(w1.w, xm, w1.z * xl));
-                }
-                const float o = P1[q] + h2;
-                if (orow && st_ok) {
-                    const float sv = o / (1.0f + __expf(-o));                   // SiLU (dwconv.hip.h: silu_f)
-                    st1(xb + (long long)ch * L + porow + col, sv);
-                }
-                P1[q] = P0[q] + h1;
-                P0[q] = wp[9] + h0;
-            }
-    }
-}
-
 // ---- lfss_out: fc (B, D, L), tok1 -> tok2 --------------------------------------------------------------
 template <typename TP = float>
 __global__ __launch_bounds__(256, 2) void lfss_out_mfma_kernel(const TP* __restrict__ fc, const float* __restrict__ tok1,
@@ -762,7 +595,7 @@ __global__ __launch_bounds__(256, 4) void lfss_out_conv_mfma_kernel(
         // WM_LFSS_OUT_TILE image rows the order is column-major instead: the four waves of a workgroup sit on four vertically
         // adjacent groups of one 64-column strip at a time (then the next four rows, then the next strip), so a band's interior rows
         // come from the L2 its own waves just filled.  Same arithmetic per position: bit-identical outputs.  Measured
-        // (tools/bench_lfss_out_conv.py, WM_LFSS_OUT_LINEAR=1 for the linear order): 0.107 -> 0.088 ms at UHD level 2, 0.454 -> 0.468 at
+        // (tools/bench_lfss_out_conv.py against the linear order of round 3): 0.107 -> 0.088 ms at UHD level 2, 0.454 -> 0.468 at
         // level 1 (there the kernel is bound by its 576 tap loads per lane and group, not by HBM), level 3 (W % 64 != 0) keeps the
         // linear order: 0.05 ms per UHD image.
         if (gpr > 0) {

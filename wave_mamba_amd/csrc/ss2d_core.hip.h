@@ -13,9 +13,9 @@
 //     bf16 terms (v = hi + lo, |v - hi - lo| <= 2^-17 |v|) and the product is accumulated in fp32 as hi*hi + hi*lo +
 //     lo*hi on v_mfma_f32_16x16x32_bf16 (two K-steps of 32 channels, 6 matrix instructions per 16-row tile): ~4e-6
 //     relative on (dt_r | B | C) against the contract's 1e-4, the same split every dense convolution of this library
-//     uses.  The fp32-input matrix instructions (v_mfma_f32_16x16x4_f32, exact products; build with
-//     -DWM_CORE_PROJ_F32=1) run at the fp32 VECTOR rate and their time ADDS to the recurrence's VALU time (round 2:
-//     2.1 of 14.1 ms per UHD step); the bf16 ones are 16x faster per FLOP and run beside the VALU.  Weight fragments
+//     uses.  The fp32-input matrix instructions (v_mfma_f32_16x16x4_f32, exact products: round 2's kernel) run at the fp32
+//     VECTOR rate and their time ADDS to the recurrence's VALU time (2.1 of 14.1 ms per UHD step); the bf16 ones are 16x
+//     faster per FLOP and run beside the VALU.  Weight fragments
 //     (pre-split, fragment-ordered), A * log2(e) and the per-channel constants come from a once-per-call prep kernel
 //     (ss2d_core_prep_kernel): a workgroup's prologue is one 12-KB copy into LDS.  x_dbl / dts / xs never exist in
 //     HBM - the first version wrote 576 B of projection records per position and re-read them in 16 launches.
@@ -31,31 +31,24 @@
 //   * y[k] goes to the direction's own (B, D, L) buffer in row-major positions; the consumer adds the four
 //     (y1 + y2 + y3 + y4 of :490) while it reads them, so the scan launch has no read-modify-write and the four
 //     directions run concurrently, bit-reproducibly.  (Round 4 built the two-plane alternative - the reversed directions as a
-//     second, read-modify-write scan launch, template parameter RMW / CoreArgs::pairsel, wm_ss2d_core_fwd merged = 2 - and
-//     measured it 3.5 ms per UHD image slower: profiles/r04/core_ab_paired_planes.txt.  Opt-in.)
+//     second, read-modify-write scan launch - and measured it 3.5 ms per UHD image slower, profiles/r04/core_ab_paired_planes.txt:
+//     launch granularity, and the bytes are the same - write + read-modify-write + two planes read = four written + four read.
+//     Round 5 built the column directions as wave-private strips of four columns (no LDS transposition, no barrier) and measured
+//     them equal at UHD level 1 and 10-13 % slower below: profiles/r05/core_column_strips_experiment.txt.  Both deleted.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "selscan.hip.h"
 #include "haar.hip.h"          // bf16_t and its conversions
 
-#ifndef WM_CORE_PROJ_F32
-#define WM_CORE_PROJ_F32 0        // 1 = x_proj on v_mfma_f32_16x16x4_f32 (exact fp32 products; round-2 kernel), 0 = bf16 x 3
-#endif
 #ifndef WM_CORE_ABLATE
 #define WM_CORE_ABLATE 0          // timing experiments only (wrong results): 1 = no MFMA, 2 = no scan steps, 4 = no y store
-#endif
-#ifndef WM_CORE_RANK1_MFMA
-#define WM_CORE_RANK1_MFMA 0      // the steps' rank-1 update h[n][ch] += B_t[n] (dt u)[ch] on v_mfma_f32_4x4x1_16b_f32 (see core_body)
 #endif
 #ifndef WM_CORE_STAMP
 #define WM_CORE_STAMP 0           // diagnostics: per-wave s_memtime phase totals into CoreArgs::stamps (tools/core_stamps.py)
 #endif
 #ifndef WM_CORE_ROW_SYNC
 #define WM_CORE_ROW_SYNC 0        // row directions: workgroup barrier every this many tiles (0 = never), see core_body
-#endif
-#ifndef WM_CORE_INTERLEAVE
-#define WM_CORE_INTERLEAVE 0      // experiment: alternate column / row workgroup slots every this many ids (0 = columns first)
 #endif
 #ifndef WM_CORE_STEP_FENCE
 #define WM_CORE_STEP_FENCE 1      // scheduling barrier after every scan step
@@ -104,9 +97,6 @@ struct CoreArgs {
     int row_cpw;                                // row chunks per workgroup (handed to its waves on demand)
     unsigned long long* stamps;                 // WM_CORE_STAMP builds: [workgroup][wave][12] cycle totals / stamps, else unused
     int dirmask;                                // bit k set: direction k runs (tools: time one direction alone)
-    int col_wgs16;                              // col_tiles * col_nseg rounded up to 16 (paired mode's half grids)
-    int pairsel;                                // -1: all four directions in one grid; 0 / 1: the grid holds the forward / the reversed
-                                                // directions' slots only (paired mode: consecutive workgroup ids = consecutive XCDs)
     const float* prep;                          // ss2d_core_prep_kernel's output: 4 x CoreCfg<NP>::PREP floats
     int col_seg, col_nseg, col_tiles, col_wgs;  // rows per column segment (multiple of 16), segments, column tiles,
                                                 // workgroup slots per direction (col_tiles * col_nseg rounded up to 8)
@@ -115,15 +105,10 @@ struct CoreArgs {
 template <int NP> struct CoreCfg {
     static constexpr int NTB = NP / 16;                  // 16-row tiles of B (and of C)
     static constexpr int NT3 = 2 * NTB + 1;              // row tiles of x_proj: dt_r | B.. | C..
-    static constexpr int NQ = (2 * NTB + 1 + 3) / 4;     // (fp32 projection) float4 of A operands per (K-step, lane)
     static constexpr int RS = 2 * NP + 4;                // record: [dt_r (4) | B (NP) | C (NP)] floats
     static constexpr int ROW = 20;                       // x tile row stride (floats): conflict-free per-lane float4
     static constexpr int XT = 64 * ROW + 4;              // x tile stride: the column scatter is 2-way at worst
-#if WM_CORE_PROJ_F32
-    static constexpr int WF = 16 * NQ * 256;             // weight fragments in LDS (floats)
-#else
     static constexpr int WF = NT3 * 1024;                // [tile][K-step (2)][hi | lo][lane] x 8 bf16 = 1 KB each
-#endif
     // prep buffer of ONE direction (floats): bf16 weight fragments | A * log2(e) as [n / 2][lane] pairs |
     // [wdt0 wdt1 wdt2 wdt3 bias D][lane]
     static constexpr int P_WF = NT3 * 1024;
@@ -242,12 +227,10 @@ __device__ __forceinline__ void core_lds_fence() {       // LDS hand-off between
 // RHI: dt_rank > 2 (the dt projection reads four record slots instead of two).
 // VEC: 16-byte tile accesses (W % 4 == 0, 16-byte aligned planes) or element-wise ones with per-element masks (any W, fp32
 // planes: odd map widths are rare - the network pads its input to multiples of 8 - and take the same kernel, slower).
-// RMW (scan pass of the PAIRED mode, reversed directions only): y is ADDED to what the mirrored forward direction's
-// launch stored at the same positions (p.y[k] == p.y[k - 2]) - two output planes per call instead of four.
-template <int NP, int NW, int PHASE, bool RHI, typename TP, bool COL, bool REV, bool VEC, bool RMW = false>
+template <int NP, int NW, int PHASE, bool RHI, typename TP, bool COL, bool REV, bool VEC>
 __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const int b, const int wg, float* smem) {
     using Cfg = CoreCfg<NP>;
-    constexpr int NTB = Cfg::NTB, NQ = Cfg::NQ, RS = Cfg::RS, ROW = Cfg::ROW, XT = Cfg::XT;
+    constexpr int NTB = Cfg::NTB, RS = Cfg::RS, ROW = Cfg::ROW, XT = Cfg::XT;
     constexpr int NT = (PHASE == 3 ? 2 * NTB : NTB) + 1;           // MFMA row tiles this phase needs: dt, B.., (C..)
     constexpr int QPR = NW / 4;                                    // float4 per tile row of a column-mode fetch
 #if WM_CORE_STAMP
@@ -263,22 +246,6 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
     const long long L = p.L;
     const float* prep = p.prep + (long long)k * Cfg::PREP;
 
-#if WM_CORE_PROJ_F32
-    // ---- x_proj_weight[k] as MFMA A operands: lane l of (K-step s, tile t) holds W[row(t, l & 15)][4 s + (l >> 4)]
-    {
-        const int Cx = p.R + 2 * p.N;
-        for (int e = tid; e < Cfg::WF; e += 64 * NW) {
-            const int t4 = e & 3, l = (e >> 2) & 63, o = e >> 8;
-            const int s = o / NQ, t = 4 * (o - s * NQ) + t4;
-            const int r16 = l & 15, d = 4 * s + (l >> 4);
-            int row = -1;
-            if (t == 0) { if (r16 < p.R) row = r16; }
-            else if (t <= NTB) { const int n = 16 * (t - 1) + r16; if (n < p.N) row = p.R + n; }
-            else if (t <= 2 * NTB) { const int n = 16 * (t - 1 - NTB) + r16; if (n < p.N) row = p.R + p.N + n; }
-            s_w[e] = ((row >= 0 && d < D) ? p.Wx[((long long)k * Cx + row) * D + d] : 0.0f) * ((t >= 1 && t <= NTB) ? 0.6931471805599453f : 1.0f);   // (log2 units: B rows x ln 2)
-        }
-    }
-#else
     // ---- the bf16 weight fragments of the row tiles this pass needs (dt_r, B.. and, in the scan pass, C..): one
     // 16-byte copy per thread
     {
@@ -286,7 +253,6 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
         uint4* sw4 = reinterpret_cast<uint4*>(s_w);
         for (int e = tid; e < NT * 256; e += 64 * NW) sw4[e] = gw[e];
     }
-#endif
 
     // ---- per-lane (= per-channel) constants, prepared once per call
     const bool live = lane < D;
@@ -456,28 +422,10 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
             for (int j = 0; j < 4; ++j)
                 if (elem_ok(ti, i, j)) {
                     TP* q = yb + (tile_off(ti, i) + (unsigned)j);
-                    st1(q, RMW ? ld1(q) + v[j] : v[j]);
+                    st1(q, v[j]);
                 }
         }
     };
-    // paired mode: the quads this thread is about to overwrite, as the forward direction's launch left them (clamped
-    // offsets like fetch(): invalid quads are loaded from offset 0 and never stored)
-    typename IO::raw yo[4];
-    auto fetch_y = [&](int ti) {
-        if constexpr (RMW && VEC) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) yo[i] = IO::load(yb + (tile_ok(ti, i) ? tile_off(ti, i) : 0u));
-        }
-    };
-    auto add_y = [&](int i, float4 v4) -> float4 {
-        if constexpr (RMW && VEC) {
-            const float4 o = IO::cvt(yo[i]);
-            return make_float4(o.x + v4.x, o.y + v4.y, o.z + v4.z, o.w + v4.w);
-        } else {
-            return v4;
-        }
-    };
-
 #if WM_CORE_STAMP == 1
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
     const unsigned long long st_kernel = st_entry;
@@ -507,39 +455,6 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = (core_f4){0.f, 0.f, 0.f, 0.f};
             const int g4 = lane >> 4, c16 = lane & 15;
-#if WM_CORE_PROJ_F32
-            // always all 16 K-steps (channels >= D carry zero weights and zero-filled tile rows): a run-time K count
-            // turns every step into its own branch and the compiler stops overlapping them
-            constexpr int KS = (WM_CORE_ABLATE & 1) ? 1 : 16;
-            // software pipeline: the operands of K-step s + 1 are read while the MFMAs of step s issue (left alone the
-            // compiler read, waited and multiplied one K-step at a time: 16 exposed LDS latencies per tile).  Two
-            // register sets, used alternately and fed to the MFMAs as they are: a VALU copy in between would cost its
-            // own issue slot plus the VALU-write -> MFMA-read wait states.
-            float xv[2];
-            float4 wq[2][NQ];
-            xv[0] = sx[g4 * ROW + c16];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-                if (4 * q < NT) wq[0][q] = *reinterpret_cast<const float4*>(&s_w[(q * 64 + lane) * 4]);
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                {
-                    if (s + 1 < KS) {
-                        xv[(s + 1) & 1] = sx[(4 * (s + 1) + g4) * ROW + c16];
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q)
-                            if (4 * q < NT)
-                                wq[(s + 1) & 1][q] = *reinterpret_cast<const float4*>(&s_w[(((s + 1) * NQ + q) * 64 + lane) * 4]);
-                    }
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const float4 w4 = wq[s & 1][t >> 2];
-                        const float wv_ = (t & 3) == 0 ? w4.x : (t & 3) == 1 ? w4.y : (t & 3) == 2 ? w4.z : w4.w;
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv_, xv[s & 1], acc[t], 0, 0, 0);
-                    }
-                }
-            }
-#else
             // B operands: lane (c16 = step, g4) of K-step s2 holds channels 32 s2 + 4 j + g4, j = 0..7 (the prep kernel's K
             // order) of tile column c16, split into bf16 hi / lo.  Channels >= D: zero-filled tile rows, zero weights.
             {
@@ -568,22 +483,12 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
                     }
                 }
             }
-#endif
             // D layout: lane holds rows 4 g4 .. 4 g4 + 3 of tile column c16
             {
                 float* rc = srec + c16 * RS;
                 if (g4 == 0) *reinterpret_cast<core_f4*>(rc) = acc[0];
 #pragma unroll
                 for (int t = 1; t < NT; ++t) {
-#if WM_CORE_RANK1_MFMA
-                    // B rows as the matrix instruction's A operand wants them: state n = 16 tb + 4 g + m at slot
-                    // 16 tb + 4 m + g, so that lane (m = lane & 3) reads its four operands (g = 0..3) as one float4
-                    if (t <= NTB) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) rc[4 + 16 * (t - 1) + 4 * i + g4] = acc[t][i];
-                        continue;
-                    }
-#endif
                     *reinterpret_cast<core_f4*>(rc + 4 + 16 * (t - 1) + 4 * g4) = acc[t];
                 }
             }
@@ -603,10 +508,6 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
                 int roff = 4 * cq * RS;                                   // records of tile columns 4 cq .. 4 cq + 3
                 asm volatile("" : "+v"(roff));                            // (an opaque OFFSET: the pointer stays an LDS pointer)
                 const float* rq = srec + roff;
-#if WM_CORE_RANK1_MFMA
-                int l4x4 = 4 * (lane & 3);                                // the lane's slot group in the transposed B rows
-                asm volatile("" : "+v"(l4x4));
-#endif
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {                          // two steps at a time (softplus on a float pair)
                     float dtr[2];
@@ -632,37 +533,13 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
                         if (PHASE == 1) sum_dt += dt;
                         v2f y2 = splat(0.0f);
                         const float* rc = rq + (REV ? 3 - j : j) * RS + 4;
-#if WM_CORE_RANK1_MFMA
-                        // h[n][ch] <- a h + B_t[n] (dt u)[ch]: the rank-1 term of four states is ONE v_mfma_f32_4x4x1_16b_f32
-                        // in this layout (block = lane / 4, column = lane % 4 = the lane's own channel, row i = register =
-                        // state 4 g + i: D[i][j] = A[i] B[j] + C[i][j] with A from lane 4 (lane / 4) + i = B_t[4 g + i],
-                        // B = the lane's dt u, C = a h): 8 of the 32 packed operations of a step leave the VALU - the unit
-                        // that bounds this kernel - for four 2-pass instructions on the idle matrix pipe
-                        // (tools/ubench_rank1_mfma.hip).
-                        float bA[NP / 4];
-#pragma unroll
-                        for (int tb = 0; tb < NTB; ++tb) {
-                            const float4 bq = *reinterpret_cast<const float4*>(rc + l4x4 + 16 * tb);
-                            bA[4 * tb] = bq.x; bA[4 * tb + 1] = bq.y; bA[4 * tb + 2] = bq.z; bA[4 * tb + 3] = bq.w;
-                        }
-                        const float du1 = dt * ut;
-#endif
 #pragma unroll
                         for (int r = 0; r < NP / 4; ++r) {
                             const v2f a0 = exp2_2(dt2 * WM_A2(2 * r));
                             const v2f a1 = exp2_2(dt2 * WM_A2(2 * r + 1));
-#if WM_CORE_RANK1_MFMA
-                            {
-                                const v2f m0 = a0 * h[2 * r], m1 = a1 * h[2 * r + 1];
-                                const core_f4 hn = __builtin_amdgcn_mfma_f32_4x4x1f32(bA[r], du1, (core_f4){m0.x, m0.y, m1.x, m1.y},
-                                                                                      0, 0, 0);
-                                h[2 * r] = (v2f){hn[0], hn[1]}; h[2 * r + 1] = (v2f){hn[2], hn[3]};
-                            }
-#else
                             const float4 bv = *reinterpret_cast<const float4*>(rc + 4 * r);
                             h[2 * r] = a0 * h[2 * r] + du2 * (v2f){bv.x, bv.y};
                             h[2 * r + 1] = a1 * h[2 * r + 1] + du2 * (v2f){bv.z, bv.w};
-#endif
                             if (PHASE == 3) {
                                 const float4 cv = *reinterpret_cast<const float4*>(rc + NP + 4 * r);
                                 y2 = (v2f){cv.x, cv.y} * h[2 * r] + y2;
@@ -683,11 +560,10 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
 
         WM_STAMP(3)                                      // 16 scan steps
         if (PHASE == 3 && !(WM_CORE_ABLATE & 4)) {
-            fetch_y(ti);                                 // (paired mode) in flight across the fence / barrier + LDS reads below
             if (!COL) {
                 core_lds_fence();
 #pragma unroll
-                for (int i = 0; i < 4; ++i) put(ti, i, add_y(i, *reinterpret_cast<const float4*>(&sx[(16 * i + trow) * ROW + 4 * tq])));
+                for (int i = 0; i < 4; ++i) put(ti, i, *reinterpret_cast<const float4*>(&sx[(16 * i + trow) * ROW + 4 * tq]));
                 core_lds_fence();                        // the y tile is read before the next stage() overwrites it
             } else {
                 core_barrier();
@@ -709,10 +585,10 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
                 if (full) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        IO::store(yb + tile_off(ti, i), add_y(i, make_float4(v[i][0], v[i][1], v[i][2], v[i][3])));
+                        IO::store(yb + tile_off(ti, i), make_float4(v[i][0], v[i][1], v[i][2], v[i][3]));
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) put(ti, i, add_y(i, make_float4(v[i][0], v[i][1], v[i][2], v[i][3])));
+                    for (int i = 0; i < 4; ++i) put(ti, i, make_float4(v[i][0], v[i][1], v[i][2], v[i][3]));
                 }
                 core_barrier();
             }
@@ -771,45 +647,26 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
 // same XCD (workgroup id -> XCD id % 8), whose L2 then holds the line.
 // second launch-bound: minimum waves per SIMD (N <= 16: four, i.e. <= 128 registers - one 16-wave or two 8-wave
 // workgroups per compute unit; N = 32: two)
-// RMW: the second scan launch of the paired mode - reversed directions only, adding into the forward directions' planes.
-template <int NP, int NW, int PHASE, bool RHI, typename TP = float, bool VEC = true, bool RMW = false>
+template <int NP, int NW, int PHASE, bool RHI, typename TP = float, bool VEC = true>
 __global__ __launch_bounds__(64 * NW, NP == 16 ? 4 : 2) void ss2d_core_kernel(CoreArgs p) {
     extern __shared__ __attribute__((aligned(16))) float core_smem[];
-    // paired mode's half grids: col_wgs16 column slots (a multiple of 16) + row_wgs row slots of ONE direction each
-    const int ncol = p.pairsel < 0 ? p.col_wgs : p.col_wgs16;
-    const int per_b = p.pairsel < 0 ? 2 * (p.row_wgs + ncol) : p.row_wgs + ncol;
+    const int ncol = p.col_wgs;
+    const int per_b = 2 * (p.row_wgs + ncol);
     const int b = blockIdx.x / per_b;
     int r = blockIdx.x - b * per_b;
-    if (p.pairsel >= 0) r = 2 * r + p.pairsel;          // slot ids alternate forward / reversed
-    bool col;
-#if WM_CORE_INTERLEAVE
-    // experiment: column and row slots alternate in blocks of WM_CORE_INTERLEAVE workgroup ids (= one dispatch round of
-    // the chip) while both last, so that with two workgroups per compute unit (NW = 8) a compute unit holds one
-    // barrier-paced column workgroup and one free-running row workgroup
-    {
-        constexpr int Q = WM_CORE_INTERLEAVE;
-        const int nc = 2 * p.col_wgs, nr = 2 * p.row_wgs;
-        const int m = (min(nc, nr) / Q) * Q;
-        if (r < 2 * m) { const int j = r / Q; col = !(j & 1); r = (j >> 1) * Q + (r - j * Q); }
-        else { r -= 2 * m; col = r < nc - m; r = m + (col ? r : r - (nc - m)); }
-    }
-#else
-    col = r < 2 * ncol;
+    const bool col = r < 2 * ncol;
     if (!col) r -= 2 * ncol;
-#endif
     if (col) {
         const int idx = r >> 1;
-        // (half grid: the two tiles of a line pair sit 8 workgroup ids apart there too)
-        const int wg = p.pairsel < 0 ? (((idx >> 3) << 2) + (idx & 3)) * 2 + ((idx >> 2) & 1)
-                                     : (((idx >> 4) << 3) + (idx & 7)) * 2 + ((idx >> 3) & 1);
+        const int wg = (((idx >> 3) << 2) + (idx & 3)) * 2 + ((idx >> 2) & 1);
         if (wg >= p.col_tiles * p.col_nseg || !((p.dirmask >> ((r & 1) * 2 + 1)) & 1)) return;
-        if (r & 1) core_body<NP, NW, PHASE, RHI, TP, true, true, VEC, RMW>(p, 3, b, wg, core_smem);
-        else if constexpr (!RMW) core_body<NP, NW, PHASE, RHI, TP, true, false, VEC>(p, 1, b, wg, core_smem);
+        if (r & 1) core_body<NP, NW, PHASE, RHI, TP, true, true, VEC>(p, 3, b, wg, core_smem);
+        else core_body<NP, NW, PHASE, RHI, TP, true, false, VEC>(p, 1, b, wg, core_smem);
     } else {
         const int wg = r >> 1;
         if (!((p.dirmask >> ((r & 1) * 2)) & 1)) return;
-        if (r & 1) core_body<NP, NW, PHASE, RHI, TP, false, true, VEC, RMW>(p, 2, b, wg, core_smem);
-        else if constexpr (!RMW) core_body<NP, NW, PHASE, RHI, TP, false, false, VEC>(p, 0, b, wg, core_smem);
+        if (r & 1) core_body<NP, NW, PHASE, RHI, TP, false, true, VEC>(p, 2, b, wg, core_smem);
+        else core_body<NP, NW, PHASE, RHI, TP, false, false, VEC>(p, 0, b, wg, core_smem);
     }
 }
 

@@ -16,7 +16,6 @@
 #include "selscan.hip.h"
 #include "selscan_bwd.hip.h"
 #include "dwconv.hip.h"
-#include "ss2d.hip.h"
 #include "ss2d_core.hip.h"
 #include "lfss.hip.h"
 #include "lfss_mfma.hip.h"
@@ -24,7 +23,7 @@
 #include "conv2d.hip.h"
 #include "conv2d_ws.hip.h"
 #include "hfe.hip.h"
-#include "ss2d_bwd.hip.h"
+#include "linear_wgrad.hip.h"
 #include "ss2d_core_bwd.hip.h"
 #include "imageio.hip.h"
 #include "gates.hip.h"
@@ -685,7 +684,7 @@ static int core_plan(CorePlan& pl, int B, int D, int H, int W, int N, int R, int
 }
 
 template <int NP, int NW, bool RHI, typename TP, bool VEC>
-static int core_launch(const CoreArgs& a, const CorePlan& pl, bool do_prep, bool paired, hipStream_t st) {
+static int core_launch(const CoreArgs& a, const CorePlan& pl, bool do_prep, hipStream_t st) {
     constexpr int lds = core_lds_bytes<NP, NW>();
     // > 64 KB of dynamic LDS is an opt-in per function AND per device
     static bool configured[64] = {};
@@ -699,9 +698,6 @@ static int core_launch(const CoreArgs& a, const CorePlan& pl, bool do_prep, bool
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)ss2d_core_kernel<NP, NW, 3, RHI, TP, VEC>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute((const void*)ss2d_core_kernel<NP, NW, 3, RHI, TP, VEC, true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) return WM_EHIP;
             if (dev >= 0 && dev < 64) configured[dev] = true;
@@ -730,19 +726,9 @@ static int core_launch(const CoreArgs& a, const CorePlan& pl, bool do_prep, bool
         hipLaunchKernelGGL((selscan_carry_kernel<false>), dim3((unsigned)((nchains + 15) / 16), 1, 4), dim3(1024), 0,
                            st, cb, nchains);
     }
-    if (!paired) {
+    {
         ProfScope ps(8, st);
         hipLaunchKernelGGL((ss2d_core_kernel<NP, NW, 3, RHI, TP, VEC>), grid, block, lds, st, a);
-    } else {
-        // paired mode: the forward directions store y[0] (rows) / y[1] (columns); a second launch runs the reversed
-        // directions, which ADD their outputs to the same planes (stream order is the only ordering the two need)
-        ProfScope ps(8, st);
-        CoreArgs f = a, r = a;
-        f.pairsel = 0;
-        r.pairsel = 1; r.y[2] = a.y[0]; r.y[3] = a.y[1];
-        const dim3 half((unsigned)(a.B * (pl.row_wgs + a.col_wgs16)));
-        hipLaunchKernelGGL((ss2d_core_kernel<NP, NW, 3, RHI, TP, VEC>), half, block, lds, st, f);
-        hipLaunchKernelGGL((ss2d_core_kernel<NP, NW, 3, RHI, TP, VEC, true>), half, block, lds, st, r);
     }
     return launch_status();
 }
@@ -800,17 +786,13 @@ int wm_ss2d_core_fwd(const void* x, const float* x_proj_weight, const float* dt_
     int rc = core_plan(pl, B, D, H, W, N, R, merged == 1);
     if (rc) return rc;
     if (!x || !x_proj_weight || !dt_projs_weight || !dt_projs_bias || !A_logs || !Ds || !y_row_fwd) return WM_ENULL;
-    if (merged < 0 || merged > 2) return WM_EINVAL;
-    const bool paired = merged == 2;      // two planes: y_row_fwd <- row forward + row reversed, y_col_fwd <- column forward + reversed
+    if (merged < 0 || merged > 1) return WM_EINVAL;       // (2 was round 4's two-plane mode: measured slower, deleted in round 5)
     if (merged == 0 && (!y_row_rev || !y_col_fwd || !y_col_rev)) return WM_ENULL;
-    if (paired && !y_col_fwd) return WM_ENULL;
-    if (paired) merged = 0;
     if (!workspace) return WM_ENULL;
     if (workspace_bytes < pl.total) return WM_EWORKSPACE;
     if (!aligned16(workspace)) return WM_EALIGN;
     // 16-byte tile accesses when the map width allows them (every size the network itself produces: it pads its input
     // to multiples of 8); otherwise the same kernels with element-wise tile accesses (fp32 planes only).
-    if (paired) { y_row_rev = y_row_fwd; y_col_rev = y_col_fwd; }
     const bool planes16 = aligned16(x) && aligned16(y_row_fwd) &&
                           (merged || (aligned16(y_row_rev) && aligned16(y_col_fwd) && aligned16(y_col_rev)));
     const bool vec = (W % 4 == 0) && planes16;
@@ -848,7 +830,6 @@ int wm_ss2d_core_fwd(const void* x, const float* x_proj_weight, const float* dt_
         static const int mask = [] { const char* e = getenv("WM_CORE_DIRMASK"); return e ? atoi(e) : 15; }();
         a.dirmask = mask;
     }
-    a.pairsel = -1; a.col_wgs16 = ((pl.col_tiles * pl.col_nseg + 15) / 16) * 16;
     a.col_seg = pl.col_seg; a.col_nseg = pl.col_nseg; a.col_tiles = pl.col_tiles; a.col_wgs = pl.col_wgs;
 #ifndef WM_CORE_NW
 #define WM_CORE_NW 16
@@ -856,8 +837,8 @@ int wm_ss2d_core_fwd(const void* x, const float* x_proj_weight, const float* dt_
 #define WM_CORE_GO(TP, VEC)                                                                                                   \
     do {                                                                                                                      \
         const bool dp = prepared == nullptr;                                                                                  \
-        if (pl.NP == 16) rc = R > 2 ? core_launch<16, WM_CORE_NW, true, TP, VEC>(a, pl, dp, paired, st) : core_launch<16, WM_CORE_NW, false, TP, VEC>(a, pl, dp, paired, st); \
-        else rc = R > 2 ? core_launch<32, 8, true, TP, VEC>(a, pl, dp, paired, st) : core_launch<32, 8, false, TP, VEC>(a, pl, dp, paired, st); \
+        if (pl.NP == 16) rc = R > 2 ? core_launch<16, WM_CORE_NW, true, TP, VEC>(a, pl, dp, st) : core_launch<16, WM_CORE_NW, false, TP, VEC>(a, pl, dp, st); \
+        else rc = R > 2 ? core_launch<32, 8, true, TP, VEC>(a, pl, dp, st) : core_launch<32, 8, false, TP, VEC>(a, pl, dp, st); \
     } while (0)
     if (!vec) WM_CORE_GO(float, false);
     else if (plane_dtype == WM_F32) WM_CORE_GO(float, true);
@@ -876,170 +857,6 @@ int wm_ss2d_core_fwd(const void* x, const float* x_proj_weight, const float* dt_
         else
             hipLaunchKernelGGL((ss2d_sum4_kernel<bf16_t, true>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (bf16_t*)a.y[0],
                                (const bf16_t*)a.y[2], (const bf16_t*)a.y[1], (const bf16_t*)a.y[3], n4);
-    }
-    return launch_status();
-}
-
-}  // extern "C"
-namespace wm {
-struct CoreBwdPlan {
-    BwdPlan scan; long long L; int CP, NP, RS, ndir;      // RS: record stride, ndir: directions per record set (4 / 2)
-    size_t rec_bytes, gpl_bytes, map_bytes, part_bytes, scan_bytes, total;
-};
-// waves of the x_proj weight-gradient kernel per (batch item, direction): >= 256 positions each, whole blocks
-static long long core_bwd_pg_waves(long long L) {
-    long long waves = (L + 255) / 256;
-    if (waves > 4096) waves = 4096;
-    return ((waves + kPgWaves - 1) / kPgWaves) * kPgWaves;
-}
-static int core_bwd_plan(CoreBwdPlan& pl, int B, int D, int H, int W, int N, int R) {
-    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || N <= 0 || R <= 0) return WM_EINVAL;
-    if (N > 32 || R > kRecPad || D > 64) return WM_EUNSUPPORTED;
-    pl.L = (long long)H * W;
-    if (pl.L > 0x7fffffffLL) return WM_EUNSUPPORTED;
-    int rc = bwd_plan(pl.scan, B, D, (int)pl.L, N, 1, kPartPadFused);
-    if (rc) return rc;
-    pl.CP = R + 2 * N;
-    pl.NP = N <= 16 ? 16 : 32;
-    pl.RS = pl.NP == 16 ? kRS : kRS32;
-    pl.ndir = pl.NP == 16 ? 4 : 2;                                // d_state 32: records of the layout's two directions only
-    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-    pl.rec_bytes = up((size_t)B * pl.ndir * pl.L * pl.RS * sizeof(float));
-    pl.gpl_bytes = up((size_t)B * 2 * pl.CP * pl.L * sizeof(float));
-    pl.map_bytes = up((size_t)B * D * pl.L * sizeof(float));
-    // block partials of the x_proj weight gradient: [2 directions][B x blocks][16 RT x 64]
-    pl.part_bytes = up((size_t)2 * B * (core_bwd_pg_waves(pl.L) / kPgWaves) * 16 * (pl.NP == 16 ? 3 : 5) * 64 * sizeof(float));
-    pl.scan_bytes = up(pl.scan.total);
-    pl.total = pl.rec_bytes + pl.gpl_bytes + 4 * pl.map_bytes + pl.scan_bytes + pl.part_bytes;
-    return WM_OK;
-}
-
-// one direction of one layout: chunked adjoint scan with fused operands, then the parameter-gradient reduction
-template <int NP, bool VEC, int MODE>
-static void core_bwd_dir(ScanBwdArgs a, const CoreBwdPlan& pl, float* seg, const float* A_logs_k, float* dA_logs_k,
-                         float* dD_k, float* dbias_k, float* dWdt_k, hipStream_t st) {
-    const dim3 grid((unsigned)pl.scan.nblocks, (unsigned)pl.scan.rows), block(64);
-    if (pl.scan.nchunks > 1) {
-        hipLaunchKernelGGL((selscan_bwd_reduce_kernel<NP, VEC, MODE>), grid, block, 0, st, a);
-        if (pl.scan.nblocks > 1) bwd_launch_carry(a, pl.scan, seg, st);
-    }
-    hipLaunchKernelGGL((selscan_bwd_chunk_kernel<NP, VEC, MODE>), grid, block, 0, st, a);
-    const int ysplit = bwd_finish_split(pl.scan.nblocks, NP + kPartPadFused);
-    hipLaunchKernelGGL(selscan_bwd_finish_kernel, dim3((unsigned)a.dim, (unsigned)ysplit), dim3(256), 0, st,
-                       (const float*)a.part, dA_logs_k, dD_k, dbias_k, a.batch, a.dim, a.N, NP + kPartPadFused,
-                       pl.scan.nblocks, A_logs_k, dWdt_k, a.R, NP);
-}
-}  // namespace wm
-extern "C" {
-
-static int core_bwd_v1(const CoreBwdPlan& pl, const float* x, const float* x_proj_weight, const float* dt_projs_weight,
-                       const float* dt_projs_bias, const float* A_logs, const float* Ds, const float* dy_row_fwd,
-                       const float* dy_row_rev, const float* dy_col_fwd, const float* dy_col_rev, float* dx,
-                       float* dx_proj_weight, float* ddt_projs_weight, float* ddt_projs_bias, float* dA_logs, float* dDs,
-                       void* workspace, int B, int D, int H, int W, int N, int R, hipStream_t st) {
-    const long long L = pl.L;
-    const int CP = pl.CP;
-    char* w = (char*)workspace;
-    float* rec = (float*)w; w += pl.rec_bytes;
-    float* gpl = (float*)w; w += pl.gpl_bytes;
-    float* xT = (float*)w; w += pl.map_bytes;
-    float* dyTa = (float*)w; w += pl.map_bytes;
-    float* dyTb = (float*)w; w += pl.map_bytes;
-    float* dxT = (float*)w; w += pl.map_bytes;
-    char* scan_ws = w; w += pl.scan_bytes;
-    float* pgpart = (float*)w;
-
-    // (dx_proj_weight: every element is written by projgrad_finish_kernel; dx and its transposed twin: the first direction
-    // of each layout writes every element, the second and the projection backward accumulate)
-    hipError_t e = hipMemsetAsync(ddt_projs_weight, 0, (size_t)4 * D * R * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(ddt_projs_bias, 0, (size_t)4 * D * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(dA_logs, 0, (size_t)4 * D * N * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(dDs, 0, (size_t)4 * D * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
-
-    ProfScope ps(12, st);
-    for (int layout = 0; layout < 2; ++layout) {
-        const int Hl = layout ? W : H, Wl = layout ? H : W;                 // the column directions see the transposed map
-        const float* xl = x; float* dxl = dx;
-        const float* dyl[2] = {dy_row_fwd, dy_row_rev};
-        if (layout) {
-            const dim3 tg((unsigned)((W + 31) / 32), (unsigned)((H + 31) / 32), (unsigned)(B * D)), tb(32, 8);
-            hipLaunchKernelGGL(transpose_planes_kernel, tg, tb, 0, st, x, xT, H, W, 0);
-            hipLaunchKernelGGL(transpose_planes_kernel, tg, tb, 0, st, dy_col_fwd, dyTa, H, W, 0);
-            if (dy_col_rev != dy_col_fwd) hipLaunchKernelGGL(transpose_planes_kernel, tg, tb, 0, st, dy_col_rev, dyTb, H, W, 0);
-            xl = xT; dxl = dxT; dyl[0] = dyTa; dyl[1] = dy_col_rev != dy_col_fwd ? dyTb : dyTa;
-        }
-        {   // records of this layout (all four directions' projections; the two of this layout are used)
-            Ss2dArgs pa;
-            pa.x = xl; pa.rec = rec; pa.Wx = x_proj_weight; pa.Wdt = dt_projs_weight; pa.dtb = dt_projs_bias;
-            pa.A_logs = A_logs; pa.Ds = Ds; pa.y = nullptr; pa.wsP = nullptr; pa.wsH = nullptr;
-            pa.B = B; pa.D = D; pa.H = Hl; pa.W = Wl; pa.L = (int)L; pa.N = N; pa.R = R; pa.k = 0;
-            pa.chunk_len = 0; pa.nchunks = 0; pa.nseg = 0; pa.accumulate = 0;
-            const int groups = (int)((L + 31) / 32);
-            long long waves = (long long)B * groups;
-            int blocks = (int)((waves + kProjWaves - 1) / kProjWaves);
-            if (blocks > 256 * 2) blocks = 256 * 2;
-            if (pl.NP == 16)
-                hipLaunchKernelGGL(ss2d_proj_kernel, dim3((unsigned)blocks), dim3(64 * kProjWaves), 0, st, pa, groups);
-            else
-                hipLaunchKernelGGL(ss2d_proj32_kernel, dim3((unsigned)blocks), dim3(64 * kProjWaves), 0, st, pa, groups,
-                                   layout ? 1 : 0, layout ? 3 : 2);
-        }
-        for (int kk = 0; kk < 2; ++kk) {
-            const int k = layout ? (kk ? 3 : 1) : (kk ? 2 : 0);
-            ScanBwdArgs a;
-            a.u = xl; a.delta = nullptr; a.A = A_logs + (size_t)k * D * N; a.Bm = nullptr; a.Cm = nullptr;
-            a.D = Ds + (size_t)k * D; a.bias = dt_projs_bias + (size_t)k * D; a.dy = dyl[kk];
-            a.du = dxl; a.ddelta = nullptr; a.dB = nullptr; a.dC = nullptr;
-            float* seg = nullptr;
-            bwd_bind_workspace(a, pl.scan, scan_ws, seg);
-            a.batch = B; a.dim = D; a.L = (int)L; a.N = N; a.G = 1; a.dpg = D; a.wpg = 1;
-            a.softplus = 1; a.atomic_bc = 0;
-            // records: (B, 4, L, 36) indexed by direction k, or (B, 2, L, 68) indexed by the layout's pair index kk
-            a.rec = rec + (size_t)(pl.NP == 16 ? k : kk) * L * pl.RS; a.rec_bstride = (long long)pl.ndir * L * pl.RS;
-            a.Wdt = dt_projs_weight + (size_t)k * D * R; a.R = R;
-            a.dplanes = gpl + (size_t)kk * CP * L; a.dpl_bstride = 2LL * CP * L;
-            a.accumulate = kk;
-            const bool vec = (L % 4 == 0) && aligned16(xl) && aligned16(dyl[kk]) && aligned16(dxl) && aligned16(gpl);
-            float* dA_k = dA_logs + (size_t)k * D * N; float* dD_k = dDs + (size_t)k * D;
-            float* db_k = ddt_projs_bias + (size_t)k * D; float* dW_k = ddt_projs_weight + (size_t)k * D * R;
-#define WM_BWD_DIR(NPV)                                                                                          \
-            do {                                                                                                 \
-                if (kk == 0) { if (vec) core_bwd_dir<NPV, true, 1>(a, pl, seg, a.A, dA_k, dD_k, db_k, dW_k, st);   \
-                               else core_bwd_dir<NPV, false, 1>(a, pl, seg, a.A, dA_k, dD_k, db_k, dW_k, st); }    \
-                else         { if (vec) core_bwd_dir<NPV, true, 2>(a, pl, seg, a.A, dA_k, dD_k, db_k, dW_k, st);   \
-                               else core_bwd_dir<NPV, false, 2>(a, pl, seg, a.A, dA_k, dD_k, db_k, dW_k, st); }    \
-            } while (0)
-            if (pl.NP == 16) WM_BWD_DIR(16); else WM_BWD_DIR(32);
-#undef WM_BWD_DIR
-        }
-        ProjBwdArgs g;
-        g.g = gpl; g.x = xl; g.dx = dxl; g.B = B; g.D = D; g.CP = CP; g.L = L;
-        const int k0 = layout ? 1 : 0, k1 = layout ? 3 : 2;
-        g.Wx0 = x_proj_weight + (size_t)k0 * CP * D; g.Wx1 = x_proj_weight + (size_t)k1 * CP * D;
-        g.dWx0 = dx_proj_weight + (size_t)k0 * CP * D; g.dWx1 = dx_proj_weight + (size_t)k1 * CP * D;
-        if (pl.NP == 16)
-            hipLaunchKernelGGL(projbwd_dx_kernel<36>, dim3((unsigned)((L + 255) / 256), (unsigned)B), dim3(256), 0, st, g);
-        else
-            hipLaunchKernelGGL(projbwd_dx_kernel<68>, dim3((unsigned)((L + 255) / 256), (unsigned)B), dim3(256), 0, st, g);
-        g.part = pgpart;
-        const long long pgwaves = core_bwd_pg_waves(L);
-        long long slice = (L + pgwaves - 1) / pgwaves;
-        slice = ((slice + 31) / 32) * 32;                                   // whole K-steps of 32 positions
-        const unsigned pgb = (unsigned)(pgwaves / kPgWaves);
-        const bool pgvec = (L % 4 == 0) && aligned16(gpl) && aligned16(xl);
-#define WM_PG(RT)                                                                                                            \
-        do {                                                                                                                 \
-            if (pgvec) hipLaunchKernelGGL((projgrad_kernel<RT, true>), dim3(pgb, (unsigned)B, 2), dim3(64 * kPgWaves), 0, st, g, slice); \
-            else hipLaunchKernelGGL((projgrad_kernel<RT, false>), dim3(pgb, (unsigned)B, 2), dim3(64 * kPgWaves), 0, st, g, slice);      \
-            hipLaunchKernelGGL(projgrad_finish_kernel<RT>, dim3(RT * 4, 2), dim3(256), 0, st, g, (int)(pgb * B));            \
-        } while (0)
-        if (pl.NP == 16) WM_PG(3); else WM_PG(5);
-#undef WM_PG
-        if (layout) {
-            const dim3 tg((unsigned)((H + 31) / 32), (unsigned)((W + 31) / 32), (unsigned)(B * D)), tb(32, 8);
-            hipLaunchKernelGGL(transpose_planes_kernel, tg, tb, 0, st, (const float*)dxT, dx, W, H, 1);   // dx += (dx^T)^T
-        }
     }
     return launch_status();
 }
@@ -1172,20 +989,10 @@ static int core_bwd_v2(const CoreBwdPlan2& pl, const float* x, const float* x_pr
     return launch_status();
 }
 
-// WM_CORE_BWD_V1=1 in the environment keeps the first-generation backward (A/B timing, tools/)
-static bool core_bwd_use_v1() {
-    static const bool v1 = [] { const char* e = getenv("WM_CORE_BWD_V1"); return e && atoi(e) != 0; }();
-    return v1;
-}
 }  // namespace wm
 extern "C" {
 
 size_t wm_ss2d_core_bwd_workspace_bytes(int B, int D, int H, int W, int N, int R) {
-    if (core_bwd_use_v1()) {
-        CoreBwdPlan pl;
-        if (core_bwd_plan(pl, B, D, H, W, N, R) != WM_OK) return 0;
-        return pl.total;
-    }
     CoreBwdPlan2 pl;
     if (core_bwd_plan2(pl, B, D, H, W, N, R) != WM_OK) return 0;
     return pl.total;
@@ -1201,16 +1008,6 @@ int wm_ss2d_core_bwd(const float* x, const float* x_proj_weight, const float* dt
     const bool nul = !x || !x_proj_weight || !dt_projs_weight || !dt_projs_bias || !A_logs || !Ds || !dy_row_fwd || !dy_row_rev ||
                      !dy_col_fwd || !dy_col_rev || !dx || !dx_proj_weight || !ddt_projs_weight || !ddt_projs_bias || !dA_logs ||
                      !dDs || !workspace;
-    if (core_bwd_use_v1()) {
-        CoreBwdPlan pl;
-        int rc = core_bwd_plan(pl, B, D, H, W, N, R);
-        if (rc) return rc;
-        if (nul) return WM_ENULL;
-        if (workspace_bytes < pl.total) return WM_EWORKSPACE;
-        if (!aligned16(workspace)) return WM_EALIGN;
-        return core_bwd_v1(pl, x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, dy_row_fwd, dy_row_rev, dy_col_fwd,
-                           dy_col_rev, dx, dx_proj_weight, ddt_projs_weight, ddt_projs_bias, dA_logs, dDs, workspace, B, D, H, W, N, R, st);
-    }
     CoreBwdPlan2 pl;
     int rc = core_bwd_plan2(pl, B, D, H, W, N, R);
     if (rc) return rc;
@@ -1264,53 +1061,12 @@ int wm_lfss_in_fwd(const float* tok, int tok_nchw, const float* ln_w, const floa
     WM_LFSS_DISPATCH(5, lfss_in_kernel, tok, tok_nchw, ln_w, ln_b, ln_eps, in_proj_weight, x, z, B, (long long)L);
 }
 
-int wm_lfss_in_conv_fwd(const float* tok, int tok_nchw, const float* ln_w, const float* ln_b, float ln_eps,
-                        const float* in_proj_weight, const float* conv_weight, const float* conv_bias, void* xc_, void* z_,
-                        int B, int H, int W, int C, int plane_dtype, void* stream) {
-    if (B < 0 || H < 0 || W < 0) return WM_EINVAL;
-    if (C != 32) return WM_EUNSUPPORTED;                        // callers fall back to wm_lfss_in_fwd + wm_dwconv3x3_fwd
-    if (plane_dtype != WM_F32 && plane_dtype != WM_BF16) return WM_EUNSUPPORTED;
-    if (B == 0 || H == 0 || W == 0) return WM_OK;
-    if ((long long)H * W * 64 > 0x7fffffffLL) return WM_EUNSUPPORTED;
-    if (!tok || !ln_w || !ln_b || !in_proj_weight || !conv_weight || !xc_ || !z_) return WM_ENULL;
-    if (!tok_nchw && !aligned16(tok)) return WM_EALIGN;
-    const int nstrips = (W + kIcCols - 1) / kIcCols;
-    // rows per band: the largest of 32 .. 4 that still gives the chip >= 1024 wave pairs (two per 256-thread workgroup); every
-    // band recomputes two halo rows, so short bands cost in_proj work and token re-reads (first / second-level cache hits)
-    // rows per band.  A 4-wave workgroup (two strips x two channel halves) holds two waves per SIMD, so the chip takes 512
-    // workgroups at a time and a launch lasts rounds x (rb + 2 row groups + ~1 of prologue); every band recomputes two
-    // halo rows.  (rb = 32 at UHD level 1 gave 527 workgroups: a second round for 15 of them, 0.885 ms against 0.62 for the
-    // two kernels this one replaces.)
-    int rb = 1;
-    {
-        double best = 1e300;
-        for (int cand = 1; cand <= 128 && cand <= H + 1; ++cand) {
-            const long long nb = (H + cand - 1) / cand;
-            const long long wgs = ((long long)B * nstrips * nb + 1) / 2;
-            const double cost = (double)((wgs + 511) / 512) * (cand + 3);
-            if (cost < best) { best = cost; rb = cand; }
-        }
-    }
-    const int nbands = (H + rb - 1) / rb;
-    const long long pairs = (long long)B * nstrips * nbands;
-    if (pairs > 0x3fffffffLL) return WM_EUNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
-    ProfScope ps(5, st);
-    if (plane_dtype == WM_F32)
-        hipLaunchKernelGGL(lfss_in_conv_mfma_kernel<float>, dim3((unsigned)((pairs + 1) / 2)), dim3(256), 0, st, tok, tok_nchw, ln_w, ln_b,
-                           ln_eps, in_proj_weight, conv_weight, conv_bias, (float*)xc_, (float*)z_, B, H, W, nstrips, nbands, rb);
-    else
-        hipLaunchKernelGGL(lfss_in_conv_mfma_kernel<bf16_t>, dim3((unsigned)((pairs + 1) / 2)), dim3(256), 0, st, tok, tok_nchw, ln_w,
-                           ln_b, ln_eps, in_proj_weight, conv_weight, conv_bias, (bf16_t*)xc_, (bf16_t*)z_, B, H, W, nstrips, nbands, rb);
-    return launch_status();
-}
-
 int wm_lfss_mid_fwd(const void* ysum_, int ny, int64_t ystride, const void* z_, const float* tok, int tok_nchw, const float* out_norm_w,
                     const float* out_norm_b, float out_norm_eps, const float* out_proj_weight,
                     const float* skip_scale, const float* ln2_w, const float* ln2_b, float ln2_eps,
                     const float* conv1_weight, const float* conv1_bias, float* tok1, void* f_, int B, int64_t L,
                     int C, int plane_dtype, void* stream) {
-    if (B < 0 || L < 0 || (ny != 1 && ny != 2 && ny != 4)) return WM_EINVAL;
+    if (B < 0 || L < 0 || (ny != 1 && ny != 4)) return WM_EINVAL;
     if (plane_dtype != WM_F32 && !(plane_dtype == WM_BF16 && C == 32)) return WM_EUNSUPPORTED;
     const float* ysum = (const float*)ysum_; const float* z = (const float*)z_; float* f = (float*)f_;
     if (B && L && (!ysum || !z || !tok || !out_norm_w || !out_norm_b || !out_proj_weight || !skip_scale || !ln2_w ||
@@ -1327,8 +1083,8 @@ int wm_lfss_mid_fwd(const void* ysum_, int ny, int64_t ystride, const void* z_, 
                            (const TP*)ysum_, (long long)ystride, (const TP*)z_, tok, tok_nchw,                                     \
                            out_norm_w, out_norm_b, out_norm_eps, out_proj_weight, skip_scale, ln2_w, ln2_b, ln2_eps,               \
                            conv1_weight, conv1_bias, tok1, (TP*)f_, B, (long long)L, ngl, ngroups, gpw)
-        if (plane_dtype == WM_F32) { if (ny == 4) WM_MID(4, float); else if (ny == 2) WM_MID(2, float); else WM_MID(1, float); }
-        else { if (ny == 4) WM_MID(4, bf16_t); else if (ny == 2) WM_MID(2, bf16_t); else WM_MID(1, bf16_t); }
+        if (plane_dtype == WM_F32) { if (ny == 4) WM_MID(4, float); else WM_MID(1, float); }
+        else { if (ny == 4) WM_MID(4, bf16_t); else WM_MID(1, bf16_t); }
 #undef WM_MID
         return launch_status();
     }
@@ -1344,7 +1100,7 @@ int wm_lfss_mid_rz_fwd(const void* ysum_, int ny, int64_t ystride, const float* 
                        const float* skip_scale, const float* ln2_w, const float* ln2_b, float ln2_eps,
                        const float* conv1_weight, const float* conv1_bias, float* tok1, void* f_, int B, int64_t L,
                        int C, int plane_dtype, void* stream) {
-    if (B < 0 || L < 0 || (ny != 1 && ny != 2 && ny != 4)) return WM_EINVAL;
+    if (B < 0 || L < 0 || (ny != 1 && ny != 4)) return WM_EINVAL;
     if (C != 32 || (plane_dtype != WM_F32 && plane_dtype != WM_BF16)) return WM_EUNSUPPORTED;
     if (B == 0 || L == 0) return WM_OK;
     if (!ysum_ || !tok || !ln1_w || !ln1_b || !in_proj_weight || !out_norm_w || !out_norm_b || !out_proj_weight || !skip_scale ||
@@ -1361,8 +1117,8 @@ int wm_lfss_mid_rz_fwd(const void* ysum_, int ny, int64_t ystride, const float* 
                            out_norm_w, out_norm_b, out_norm_eps, out_proj_weight, skip_scale, ln2_w, ln2_b, ln2_eps,                 \
                            conv1_weight, conv1_bias, tok1, (TP*)f_, B, (long long)L, ngl, ngroups, gpw, ln1_w, ln1_b, ln1_eps,       \
                            in_proj_weight)
-    if (plane_dtype == WM_F32) { if (ny == 4) WM_MIDZ(4, float); else if (ny == 2) WM_MIDZ(2, float); else WM_MIDZ(1, float); }
-    else { if (ny == 4) WM_MIDZ(4, bf16_t); else if (ny == 2) WM_MIDZ(2, bf16_t); else WM_MIDZ(1, bf16_t); }
+    if (plane_dtype == WM_F32) { if (ny == 4) WM_MIDZ(4, float); else WM_MIDZ(1, float); }
+    else { if (ny == 4) WM_MIDZ(4, bf16_t); else WM_MIDZ(1, bf16_t); }
 #undef WM_MIDZ
     return launch_status();
 }
@@ -1431,9 +1187,8 @@ int wm_lfss_out_conv_fwd(const void* f_, const float* conv2_weight, const float*
 #undef WM_ROWS
         return launch_status();
     }
-    // groups per image row for the kernel's banded (column-major) group order; WM_LFSS_OUT_LINEAR=1 (tools): linear order
-    static const bool linear = [] { const char* e = getenv("WM_LFSS_OUT_LINEAR"); return e && atoi(e) != 0; }();
-    const int gpr = (W % 64 == 0 && !linear) ? W / 64 : 0;
+    // groups per image row for the kernel's banded (column-major) group order (0: linear order, maps whose width is not a multiple of 64)
+    const int gpr = (W % 64 == 0) ? W / 64 : 0;
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(11, st);
     if (plane_dtype == WM_F32)
@@ -1968,8 +1723,7 @@ static int conv2d_launch(const wm::Conv2dArgs& a, int B, hipStream_t st) {
 // a workgroup gets one or two tiles and the first-generation kernel is 20-30 % faster), at most one epilogue operand and
 // then a single 32-channel row tile (two launches re-reading the input lose to the first-generation kernel's one) - and
 // where its 32-bit offsets hold.  wm_conv2d_select() pins the choice (parity tests run both on the same inputs: the
-// accumulation order per output element is the same, so the results are bit-identical); WM_CONV_WS=0 in the
-// environment is the same as select(1).
+// accumulation order per output element is the same, so the results are bit-identical).
 // rows per consumer wave (tile = 64 x 2 RW pixels) of the wave-specialised launches: two row tiles, one row tile, gated
 #ifndef WM_CONV_WS_RW2
 #define WM_CONV_WS_RW2 4
@@ -1983,16 +1737,8 @@ static int conv2d_launch(const wm::Conv2dArgs& a, int B, hipStream_t st) {
 #ifndef WM_CONV_WS_NPW1
 #define WM_CONV_WS_NPW1 4              // producer waves of the one-row-tile launches
 #endif
-static std::atomic<int> g_conv_select{-1};
-static int conv_select_mode() {
-    int m = g_conv_select.load(std::memory_order_relaxed);
-    if (m < 0) {
-        const char* e = getenv("WM_CONV_WS");
-        m = (e && e[0] == '0') ? 1 : 0;
-        g_conv_select.store(m, std::memory_order_relaxed);
-    }
-    return m;
-}
+static std::atomic<int> g_conv_select{0};
+static int conv_select_mode() { return g_conv_select.load(std::memory_order_relaxed); }
 // th: tile rows of the launch that would run (2 x row tiles per workgroup)
 static bool conv_ws_enabled(const wm::Conv2dArgs& a, int B, int th) {
     const int mode = conv_select_mode();

@@ -377,9 +377,7 @@ def _ss2d_core_fwd(f, merged, prepared=None, separate=False):
     x = f[0]
     B, D, H, W, N, R = _ss2d_core_shapes(x, f[1], f[2], f[4])
     L = H * W
-    if merged == 2:     # paired: [row forward + row reversed, column forward + column reversed] in one (2, B, D, L) block
-        outs = list(torch.empty((2, B, D, L), dtype=x.dtype, device=x.device).unbind(0))
-    elif merged:
+    if merged:
         outs = [torch.empty((B, D, L), dtype=x.dtype, device=x.device)]
     elif separate:
         outs = [torch.empty((B, D, L), dtype=x.dtype, device=x.device) for _ in range(4)]
@@ -387,10 +385,7 @@ def _ss2d_core_fwd(f, merged, prepared=None, separate=False):
         outs = list(torch.empty((4, B, D, L), dtype=x.dtype, device=x.device).unbind(0))
     ws_bytes = lib.wm_ss2d_core_fwd_workspace_bytes(B, D, H, W, N, R, int(merged))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
-    if merged == 2:     # C argument order: y_row_fwd, y_row_rev, y_col_fwd, y_col_rev
-        ptrs = [_ptr(outs[0]), None, _ptr(outs[1]), None]
-    else:
-        ptrs = [_ptr(o) for o in outs] + [None] * (4 - len(outs))
+    ptrs = [_ptr(o) for o in outs] + [None] * (4 - len(outs))
     with torch.cuda.device(x.device):
         check(lib.wm_ss2d_core_fwd(*[_ptr(t) for t in f], *ptrs, int(merged), _ptr(ws), ws_bytes,
                                    None if prepared is None else _ptr(prepared),
@@ -435,25 +430,20 @@ class _SS2DCoreFn(torch.autograd.Function):
 def ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, merged=False):
     """SS2D.forward_core (reference wavemamba_arch.py:446-478) in one call.
     x (B, D, H, W) fp32 -> (y_row_fwd, y_row_rev, y_col_fwd, y_col_rev), each (B, D, H*W) in
-    row-major l - the reference's return order; merged=True returns their sum (what :490 computes); merged=2 (paired mode)
-    returns (y_row_fwd + y_row_rev, y_col_fwd + y_col_rev): each reversed direction adds into its forward twin's plane.
+    row-major l - the reference's return order; merged=True returns their sum (what :490 computes).
     Differentiable w.r.t. x and the five parameters (HIP backward, wm_ss2d_core_bwd)."""
     _lib.load()
     _require_cuda("ss2d_core", x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
     _ss2d_core_shapes(x, x_proj_weight, dt_projs_weight, A_logs)
     args = (x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
-    paired = merged is not True and merged == 2
     if torch.is_grad_enabled() and any(t.requires_grad for t in args):
-        if paired:
-            y = _SS2DCoreFn.apply(False, *args)
-            return y[0] + y[1], y[2] + y[3]
         return _SS2DCoreFn.apply(bool(merged), *args)
     xin = x.detach().contiguous()
     if xin.dtype != torch.bfloat16:                # bf16 planes stay bf16 (outputs too); anything else computes in fp32
         xin = xin.float()
-    outs = _ss2d_core_fwd([xin] + [t.detach().contiguous().float() for t in args[1:]], 2 if paired else int(bool(merged)),
+    outs = _ss2d_core_fwd([xin] + [t.detach().contiguous().float() for t in args[1:]], int(bool(merged)),
                           _ss2d_core_prepared(args[1:]))
-    return outs[0] if (merged and not paired) else tuple(outs)
+    return outs[0] if merged else tuple(outs)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -469,45 +459,11 @@ def _w(t):
 
 
 _FUSE_OUT_CONV = True      # tests / tools: False takes wm_dwconv3x3_fwd + wm_lfss_out_fwd (bit-identical on fp32 planes)
-# ln_1 -> in_proj -> depth-wise 3x3 -> SiLU as ONE kernel (wm_lfss_in_conv_fwd, round 4): built, parity-green
-# (tests: test_lfss_prologue_one_kernel_vs_two_and_fp64) and MEASURED SLOWER than the two streaming kernels it would replace -
-# 0.888 / 0.248 / 0.082 ms against 0.618 / 0.173 / 0.046 ms at UHD levels 1 / 2 / 3 (tools/bench_lfss_in.py,
-# profiles/r04/lfss_prologue_one_kernel.txt): the recomputed halo and the row-by-row walk leave two long-running waves per
-# SIMD waiting on their own loads and stores (VALU active 0.19 of a wave's life, PMC in the same file), where the two
-# kernels keep 13-16 short waves per SIMD streaming at 3.9 TB/s.  Off by default; WM_FUSE_IN_CONV=1 takes it.
-_FUSE_IN_CONV = os.environ.get("WM_FUSE_IN_CONV", "0") == "1"
+# (ln_1 -> in_proj -> depth-wise 3x3 -> SiLU as ONE kernel was built in round 4 - wm_lfss_in_conv_fwd, parity-green - and measured
+# 44 % slower than the two streaming kernels, profiles/r04/lfss_prologue_one_kernel.txt; deleted in round 5.)
 # The gate z = in_proj(ln_1(x))[D:] recomputed by lfss_mid from the tokens instead of written by lfss_in and read back
 # (512 of the block's 3456 B per position; bit-identical in fp32 planes: tests/test_gpu_parity.py).  0: round-3 data flow.
-_RECOMPUTE_Z = os.environ.get("WM_LFSS_RECOMPUTE_Z", "1") == "1"
-# the core's paired mode (two output planes: each reversed direction adds into its forward twin's plane) in LFSSBlock inference
-_CORE_PAIRED = os.environ.get("WM_CORE_PAIRED", "0") == "1"
-
-
-def lfss_prologue(tok, x_size, blk, tok_nchw=False, fused=True):
-    """SS2D's prologue alone (reference :483-487 behind ln_1, :524): tok -> (silu(conv2d(x)), z) as (B, D, H, W) / (B, D, L)
-    fp32 planes.  fused: wm_lfss_in_conv_fwd (one kernel), else wm_lfss_in_fwd + wm_dwconv3x3_fwd.  Forward only (tests, tools)."""
-    lib = _lib.load()
-    _require_cuda("lfss_prologue", tok)
-    H, W = x_size
-    L = H * W
-    ss = blk.self_attention
-    C, D = ss.d_model, ss.d_inner
-    B = tok.shape[0]
-    tok = tok.contiguous().float()
-    z = torch.empty((B, D, L), dtype=torch.float32, device=tok.device)
-    with torch.cuda.device(tok.device):
-        if fused:
-            xc = torch.empty((B, D, H, W), dtype=torch.float32, device=tok.device)
-            check(lib.wm_lfss_in_conv_fwd(_ptr(tok), int(tok_nchw), _ptr(_w(blk.ln_1.weight)), _ptr(_w(blk.ln_1.bias)),
-                                          float(blk.ln_1.eps), _ptr(_w(ss.in_proj.weight)), _ptr(_w(ss.conv2d.weight)),
-                                          None if ss.conv2d.bias is None else _ptr(_w(ss.conv2d.bias)), _ptr(xc), _ptr(z),
-                                          B, H, W, C, WM_F32, _stream()), "wm_lfss_in_conv_fwd")
-            return xc, z
-        x = torch.empty((B, D, H, W), dtype=torch.float32, device=tok.device)
-        check(lib.wm_lfss_in_fwd(_ptr(tok), int(tok_nchw), _ptr(_w(blk.ln_1.weight)), _ptr(_w(blk.ln_1.bias)),
-                                 float(blk.ln_1.eps), _ptr(_w(ss.in_proj.weight)), _ptr(x), _ptr(z), B, L, C, WM_F32, _stream()),
-              "wm_lfss_in_fwd")
-    return dwconv3x3(x, ss.conv2d.weight, ss.conv2d.bias, "silu"), z
+_RECOMPUTE_Z = True
 
 
 def lfss_block_forward(tok, x_size, blk, tok_nchw=False, out_nchw=False):
@@ -529,29 +485,19 @@ def lfss_block_forward(tok, x_size, blk, tok_nchw=False, out_nchw=False):
     pd = _PLANE_DTYPE if (C == 32 and W % 4 == 0) else torch.float32
     code = WM_F32 if pd == torch.float32 else WM_BF16
     # C == 32: the gate z is recomputed by the block's middle kernel from the tokens it reads anyway (wm_lfss_mid_rz_fwd, bit-identical
-    # in fp32 planes) - lfss_in writes the x half only; WM_LFSS_RECOMPUTE_Z=0 keeps the written / re-read z
-    rz = C == 32 and _RECOMPUTE_Z and not _FUSE_IN_CONV
+    # in fp32 planes) - lfss_in writes the x half only (ops._RECOMPUTE_Z = False: the written / re-read z, tests and tools)
+    rz = C == 32 and _RECOMPUTE_Z
     z = None if rz else torch.empty((B, D, L), dtype=pd, device=dev)
-    if C == 32 and _FUSE_IN_CONV:
-        # ln_1 -> in_proj -> depth-wise 3x3 -> SiLU in one kernel: x (in_proj's first half) never reaches HBM
-        xc = torch.empty((B, D, H, W), dtype=pd, device=dev)
-        with torch.cuda.device(dev):
-            check(lib.wm_lfss_in_conv_fwd(_ptr(tok), int(tok_nchw), _ptr(_w(blk.ln_1.weight)), _ptr(_w(blk.ln_1.bias)),
-                                          float(blk.ln_1.eps), _ptr(_w(ss.in_proj.weight)), _ptr(_w(ss.conv2d.weight)),
-                                          None if ss.conv2d.bias is None else _ptr(_w(ss.conv2d.bias)), _ptr(xc), _ptr(z),
-                                          B, H, W, C, code, st), "wm_lfss_in_conv_fwd")
-    else:
-        x = torch.empty((B, D, H, W), dtype=pd, device=dev)
-        with torch.cuda.device(dev):
-            check(lib.wm_lfss_in_fwd(_ptr(tok), int(tok_nchw), _ptr(_w(blk.ln_1.weight)), _ptr(_w(blk.ln_1.bias)),
-                                     float(blk.ln_1.eps), _ptr(_w(ss.in_proj.weight)), _ptr(x), _ptr(z), B, L, C, code, st),
-                  "wm_lfss_in_fwd")
-        xc = dwconv3x3(x, ss.conv2d.weight, ss.conv2d.bias, "silu")
+    x = torch.empty((B, D, H, W), dtype=pd, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.wm_lfss_in_fwd(_ptr(tok), int(tok_nchw), _ptr(_w(blk.ln_1.weight)), _ptr(_w(blk.ln_1.bias)),
+                                 float(blk.ln_1.eps), _ptr(_w(ss.in_proj.weight)), _ptr(x), _ptr(z), B, L, C, code, st),
+              "wm_lfss_in_fwd")
+    xc = dwconv3x3(x, ss.conv2d.weight, ss.conv2d.bias, "silu")
     # the four directions' outputs stay separate (one (4, B, D, L) allocation); lfss_mid adds them as it loads (:490)
     core_params = (ss.x_proj_weight, ss.dt_projs_weight, ss.dt_projs_bias, ss.A_logs, ss.Ds)
-    ny = 2 if _CORE_PAIRED else 4
-    y4 = _ss2d_core_fwd([xc] + [_w(t) for t in core_params], merged=2 if _CORE_PAIRED else 0,
-                        prepared=_ss2d_core_prepared(core_params))
+    ny = 4
+    y4 = _ss2d_core_fwd([xc] + [_w(t) for t in core_params], merged=0, prepared=_ss2d_core_prepared(core_params))
     tok1 = torch.empty((B, L, C), dtype=torch.float32, device=dev)
     f = torch.empty((B, D, H, W), dtype=pd, device=dev)
     with torch.cuda.device(dev):
@@ -1162,7 +1108,7 @@ def conv2d_ln(x, ln_weight, ln_bias, ln_eps, weight, bias=None, residual=None):
     return y
 
 
-_FUSE_LN_CONV = os.environ.get("WM_FUSE_LN_CONV", "1") == "1"      # 0: LayerNorm2d and the 1x1 convolution as two launches (A/B runs)
+_FUSE_LN_CONV = True      # False (tests / tools): LayerNorm2d and the 1x1 convolution as two launches
 
 
 def patchify_conv_supported(img, weight, r):
@@ -1311,8 +1257,8 @@ class _Conv2dTrain(torch.autograd.Function):
 
 # Weight gradients of the dense convolutions in training: the HIP kernel (conv_wgrad.hip.h: K = positions on the bf16 matrix
 # cores, split operands) instead of MIOpen's NHWC implicit-GEMM kernels and their layout transposes / hipBLASLt for 1x1.
-# A leaf gradient - its ~4e-6 per product propagates nowhere.  WM_TRAIN_CONV_WGRAD=0 keeps ATen's.
-_TRAIN_CONV_WGRAD_HIP = os.environ.get("WM_TRAIN_CONV_WGRAD", "1") == "1"
+# A leaf gradient - its ~4e-6 per product propagates nowhere.  set_train_conv_wgrad_hip(False) keeps ATen's.
+_TRAIN_CONV_WGRAD_HIP = True
 
 
 def set_train_conv_wgrad_hip(on):
@@ -1411,7 +1357,7 @@ class _Conv2dAten(torch.autograd.Function):
 #             convolutions; the reference's own fp32: 9.7e-8 / 6e-6).  Never the default.
 # WM_TRAIN_CONV=<mode> in the environment, or set_train_conv_mode().
 _TRAIN_CONV_MODES = ("auto", "f16", "aten", "bf16x3")
-_TRAIN_CONV_MODE = os.environ.get("WM_TRAIN_CONV", "bf16x3" if os.environ.get("WM_TRAIN_CONV_BF16X3", "0") == "1" else "auto")
+_TRAIN_CONV_MODE = os.environ.get("WM_TRAIN_CONV", "auto")
 if _TRAIN_CONV_MODE not in _TRAIN_CONV_MODES:
     raise RuntimeError(f"WM_TRAIN_CONV={_TRAIN_CONV_MODE!r}: one of {_TRAIN_CONV_MODES}")
 
