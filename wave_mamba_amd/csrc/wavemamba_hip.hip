@@ -222,7 +222,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 24; }
+int wm_abi_version(void) { return 25; }
 
 #ifndef WM_BUILD_ID
 #define WM_BUILD_ID "unknown"
