@@ -544,24 +544,28 @@ def test_ss2d_core_config5_full_size():
 
 
 def test_lfss_block_config5_full_size():
-    """BASELINE config 5 as worded: LFSSBlock(32, d_state=32) on (1, 4194304, 32) with x_size [2048, 2048] - the fused
-    HIP block against the same block through the PyTorch modules + the unfused scan path, plus run-to-run bit identity."""
+    """BASELINE config 5 as worded: LFSSBlock(32, d_state=32) on (1, 4194304, 32) with x_size [2048, 2048] - the fused HIP block
+    against the SAME block on the host with the CPU oracle as hot-path backend (the pinned C restatement of SS2D.forward_core at
+    d_state 32 over the whole 2048 x 2048 map, PyTorch-CPU for the rest; about a minute on the box's host cores) - every
+    element of the output, not a self-comparison with another HIP path - plus run-to-run bit identity."""
     torch.manual_seed(0)
-    blk = arch.LFSSBlock(32, d_state=32, expand=2.0).eval().to(DEV)
-    x = torch.randn(1, 2048 * 2048, 32, generator=gen(12)).to(DEV)
+    blk_cpu = arch.LFSSBlock(32, d_state=32, expand=2.0).eval()
+    x_cpu = torch.randn(1, 2048 * 2048, 32, generator=gen(12))
+    cores = oracle.usable_cpus(cap=1 << 20)
+    torch.set_num_threads(cores); oracle.set_num_threads(cores)
+    with oracle_backend.ops_backend(oracle), torch.no_grad():
+        want = blk_cpu(x_cpu, [2048, 2048])
+    import copy
+    blk = copy.deepcopy(blk_cpu).to(DEV)
+    x = x_cpu.to(DEV)
     with torch.no_grad():
         assert blk._fused_ok(x, 2048)
         fused = blk(x, [2048, 2048])
         again = blk(x, [2048, 2048])
-        assert torch.equal(fused, again)
-        saved = (arch.LFSSBlock._fused_ok, arch.SS2D._fused_ok)
-        arch.LFSSBlock._fused_ok = lambda self, t, width=None, height=None: False
-        arch.SS2D._fused_ok = lambda self, t: False
-        try:
-            ref = blk(x, [2048, 2048])
-        finally:
-            arch.LFSSBlock._fused_ok, arch.SS2D._fused_ok = saved
-    assert_close(fused, ref, TOL, "config 5 LFSSBlock")
+    assert torch.equal(fused, again)
+    l2, mx = rel_err(fused.cpu(), want)
+    print(f"config 5 LFSSBlock vs the CPU-oracle block: rel-l2 {l2:.3e}, max-abs / max-abs {mx:.3e}")
+    assert_close(fused.cpu(), want, TOL, "config 5 LFSSBlock vs CPU oracle")
 
 
 @pytest.fixture(scope="module")
