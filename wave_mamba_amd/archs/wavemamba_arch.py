@@ -699,6 +699,8 @@ def _maps(t, h, w):    # (B, HW, C) -> (B, C, H, W)
 class DownFRG(nn.Module):
     """DWT -> low-freq LFSS stack + high-freq SKFF/HFE stack (reference :962-985)."""
 
+    early_qkv = True       # side-stream order only: the first HFEBlock's qkv head issued before the LFSS stack's result is waited for
+
     def __init__(self, dim, n_l_blocks=1, n_h_blocks=1, expand=2):
         super().__init__()
         self.dwt = DWT()
@@ -724,14 +726,17 @@ class DownFRG(nn.Module):
         side.wait_stream(main)                         # the sub-bands are ready
         with torch.cuda.stream(side):
             high = self.h_fusion([hl, lh, hh])
+            # the part of the first HFEBlock that needs `high` alone (norm1 -> qkv 1x1 -> depth-wise 3x3) runs under the main
+            # stream's LFSS stack too, not behind it (the up groups do the same with their branch, UNet.forward)
+            qkv0 = self.h_blk[0].qkv_of(high) if (len(self.h_blk) and self.early_qkv) else None
         if x_d_ready is not None:                      # x_d was computed on `side` (UNet.forward)
             main.wait_event(x_d_ready)
             x_d.record_stream(main)
         low = _run_lfss_stack(self.l_blk, _conv(self.l_conv, ll, x_d))
         side.wait_stream(main)                         # low is ready
         with torch.cuda.stream(side):
-            for blk in self.h_blk:
-                high = blk(high, low)
+            for i, blk in enumerate(self.h_blk):
+                high = blk(high, low, qkv=qkv0 if i == 0 else None)
         for t in (hl, lh, hh, low):                    # allocated on `main`, read on `side`
             t.record_stream(side)
         return low, high
