@@ -416,6 +416,14 @@ int wm_patchify_conv_fwd(const float* img, const float* weight, const float* bia
 void wm_prof_enable(unsigned mask);
 int wm_prof_collect(int* launches /*[WM_PROF_NKERNELS]*/, double* total_ms /*[WM_PROF_NKERNELS]*/);
 
+/* Host-blocking wait for `event` (a hipEvent_t recorded OUTSIDE any capture) that is legal while a stream of this
+ * thread is being captured: hipEventSynchronize under a thread-local relaxed capture mode
+ * (hipThreadExchangeStreamCaptureMode), restored before returning.  The host side uses it for a prepared-weight buffer
+ * whose preparation kernel ran on another stream before the capture began: an uncaptured event cannot be waited for by a
+ * capturing stream, and a plain hipEventSynchronize invalidates a capture in the global mode (torch.cuda.graph's
+ * default).  No reference counterpart (the reference has no graph capture). */
+int wm_event_synchronize_relaxed(void* event);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1615,6 +1615,54 @@ def test_multi_stream_uhd_bit_equal(planes):
     assert not bad, f"{planes} planes: {len(bad)} of 20 multi-stream forwards differ from the single-stream order: {bad[:5]}"
 
 
+@pytest.mark.parametrize("two_streams", [False, True], ids=["single_stream", "multi_stream"])
+def test_hip_graph_capture_after_a_multi_stream_forward(two_streams):
+    """torch.cuda.graph (global capture mode) of the forward after an eager multi-stream forward has filled the prepared-weight
+    caches from its SIDE streams: the capture stream finds buffers whose completion events were recorded outside the capture.
+    The host waits for them through wm_event_synchronize_relaxed (a plain event.synchronize() there returned
+    hipErrorStreamCaptureUnsupported and every later launch hipErrorStreamCaptureInvalidated: bench.py --graph, round 5).
+    The replay is bit-equal to the eager single-stream forward."""
+    net = wm.WaveMamba(in_chn=3, wf=32, n_l_blocks=[1, 2, 4], n_h_blocks=[1, 1, 2], ffn_scale=2.0).eval().to(DEV)
+    unet = net.restoration_network
+    x = torch.rand(1, 3, 1088, 1920, generator=gen(5)).to(DEV)
+    try:
+        with torch.no_grad():
+            unet.two_streams = True
+            unet(x)                                                  # caches filled from the side streams
+            unet.two_streams = False
+            ref = unet(x)
+            torch.cuda.synchronize()
+            unet.two_streams = two_streams
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = unet(x)
+            g.replay(); g.replay()
+            torch.cuda.synchronize()
+    finally:
+        unet.two_streams = True
+    assert torch.equal(out, ref), f"max |diff| {float((out - ref).abs().max()):.3e}"
+
+
+def test_prepared_weights_of_another_stream_under_capture():
+    """The smallest form of the case above: a convolution weight prepared on a side stream (cache entry + event), then the
+    same convolution captured on torch's capture stream."""
+    g0 = gen(3)
+    x = torch.randn(1, 32, 64, 96, generator=g0).to(DEV)
+    w = torch.nn.Parameter((torch.randn(32, 32, 3, 3, generator=g0) / 16).to(DEV), requires_grad=False)
+    side = torch.cuda.Stream(DEV)
+    side.wait_stream(torch.cuda.current_stream(DEV))
+    with torch.no_grad():
+        with torch.cuda.stream(side):
+            ref = wm.ops.conv2d(x, w)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = wm.ops.conv2d(x, w)
+        g.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+
+
 def _concurrency_victims(level_hw):
     """Operator groups of the shipped network on fixed inputs (tools/repro_victim_sweep.py): name -> callable."""
     H, W = level_hw

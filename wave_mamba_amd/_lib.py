@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("WAVEMAMBA_HIP_LIB") or os.path.join(HERE, "libwavemam
 WM_F32, WM_BF16 = 0, 1
 WM_OK, WM_EINVAL, WM_ENULL, WM_EALIGN, WM_EWORKSPACE, WM_EUNSUPPORTED, WM_EHIP = 0, -1, -2, -3, -4, -5, -6
 WM_PROF_NKERNELS = 20
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _c = ctypes
 _p, _i, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
@@ -79,6 +79,7 @@ SIGNATURES = {
     "wm_conv2d_select": (_i, [_i]),
     "wm_prof_enable": (None, [ctypes.c_uint]),
     "wm_prof_collect": (_i, [_c.POINTER(_i), _c.POINTER(_c.c_double)]),
+    "wm_event_synchronize_relaxed": (_i, [_p]),
 }
 
 _lib = None

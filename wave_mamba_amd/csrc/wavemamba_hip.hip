@@ -222,7 +222,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 25; }
+int wm_abi_version(void) { return 26; }
 
 #ifndef WM_BUILD_ID
 #define WM_BUILD_ID "unknown"
@@ -1995,6 +1995,15 @@ int wm_prof_collect(int* launches, double* total_ms) {
         total_ms[k] = tot;
     }
     return WM_OK;
+}
+
+int wm_event_synchronize_relaxed(void* event) {
+    if (!event) return WM_EINVAL;
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    if (hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) return WM_EHIP;
+    const hipError_t e = hipEventSynchronize(static_cast<hipEvent_t>(event));
+    hipThreadExchangeStreamCaptureMode(&mode);
+    return e == hipSuccess ? WM_OK : WM_EHIP;
 }
 
 }  // extern "C"

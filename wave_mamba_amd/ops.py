@@ -327,6 +327,14 @@ def _ss2d_core_shapes(x, x_proj_weight, dt_projs_weight, A_logs):
     return B, D, H, W, N, R
 
 
+def _host_wait_under_capture(event):
+    """Block the host until `event` (recorded before the capture began) has completed.  event.synchronize() is one of the
+    calls that invalidate a capture in the global capture mode (hipErrorStreamCaptureUnsupported, then
+    hipErrorStreamCaptureInvalidated at the next launch - torch.cuda.graph's default mode): the library does it under a
+    thread-local relaxed mode (wm_event_synchronize_relaxed)."""
+    check(_lib.load().wm_event_synchronize_relaxed(event.cuda_event), "wm_event_synchronize_relaxed")
+
+
 _CORE_PREP_CACHE = {}   # id(x_proj_weight) -> (weakrefs, data_ptrs, versions, prepared buffer, done event, stream)
 
 
@@ -348,7 +356,7 @@ def _ss2d_core_prepared(params):
             if torch.cuda.is_current_stream_capturing():
                 # an event recorded outside the capture cannot be waited for inside it: block the HOST until the producer
                 # (a warm-up forward on another stream that was never joined) is done, then the buffer is simply there
-                ent[3].synchronize()
+                _host_wait_under_capture(ent[3])
             else:
                 cur.wait_event(ent[3])
                 ent[2].record_stream(cur)
@@ -988,7 +996,7 @@ def _conv2d_wfrag(weight, cache=True):
             if torch.cuda.is_current_stream_capturing():
                 # an event recorded outside the capture cannot be waited for inside it: block the HOST until the producer
                 # (a warm-up forward on another stream that was never joined) is done - then the fragments are simply there
-                ent[4].synchronize()
+                _host_wait_under_capture(ent[4])
             else:
                 cur.wait_event(ent[4])
                 ent[3].record_stream(cur)
