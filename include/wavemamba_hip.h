@@ -288,7 +288,7 @@ int wm_conv2d_amax(const float* x, int64_t nx, const float* weight, int64_t nw, 
 int wm_conv2d_prep_f16(const float* weight, const float* amax, void* wfrag, int Cout, int Cin, int ks, void* stream);
 int wm_conv2d_fwd_f16(const float* x, const void* wfrag, const float* amax, const float* bias, float* y, int B, int Cin, int Cout,
                       int H, int W, int ks, void* stream);
-/* The three steps above in one call (what ops.conv2d_f16 uses: one binding call per convolution): workspace =
+/* The three steps above in one call (ops.conv2d_f16 issues the three steps itself, with `amax` in its zeroed arena): workspace =
  * wm_conv2d_f16_workspace_bytes(Cout, Cin, ks) bytes, 16-byte aligned, caller-owned, holds the two magnitudes and the fragments. */
 size_t wm_conv2d_f16_workspace_bytes(int Cout, int Cin, int ks);
 int wm_conv2d_f16(const float* x, const float* weight, const float* bias, float* y, void* workspace, size_t workspace_bytes,
@@ -342,10 +342,12 @@ int wm_linear_wgrad(const float* gy, const float* x, float* dW, int64_t T, int O
  * bf16 matrix cores with split operands (three products, ~4e-6 per product, fp32 accumulation).
  * Supported: W % 32 == 0, Cout <= 16, 32, 64 or 96 (tiles of 16: 1, 2, 4, 6); else WM_EUNSUPPORTED (workspace_bytes 0) and
  * the caller keeps ATen's gradient.
+ * db (Cout) or NULL: the BIAS gradient db[co] = sum_{b,h,w} gy[b][co][h][w] (output_mask[2]) from the same pass over gy - fp32
+ * sums in a fixed order (bit-reproducible), overwritten; wm_plane_sums is the stand-alone form.
  */
 size_t wm_conv2d_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int ks);
-int wm_conv2d_wgrad(const float* gy, const float* x, float* dW, void* workspace, size_t workspace_bytes, int B, int Cin, int Cout,
-                    int H, int W, int ks, void* stream);
+int wm_conv2d_wgrad(const float* gy, const float* x, float* dW, float* db, void* workspace, size_t workspace_bytes, int B, int Cin,
+                    int Cout, int H, int W, int ks, void* stream);
 
 /* sums (C) = sum over batch and plane of x (B, C, H, W): the bias gradient of a convolution (training). */
 int wm_plane_sums(const float* x, float* sums, int B, int C, int H, int W, void* stream);
@@ -415,6 +417,18 @@ int wm_patchify_conv_fwd(const float* img, const float* weight, const float* bia
 #define WM_PROF_NKERNELS 20
 void wm_prof_enable(unsigned mask);
 int wm_prof_collect(int* launches /*[WM_PROF_NKERNELS]*/, double* total_ms /*[WM_PROF_NKERNELS]*/);
+
+/* Zero-initialised accumulator outputs.  The entry points whose kernels ADD into an output with atomics - wm_dwconv3x3_wgrad
+ * (dW, db), wm_layernorm2d_bwd and wm_layernorm_tok_bwd (dweight, dbias), wm_linear_wgrad (dW), wm_plane_sums (sums),
+ * wm_scale_add_bwd (gscale), wm_conv2d_amax (amax) - zero that output first with a memset node on the stream.  A caller that
+ * hands these buffers out of memory it has ALREADY zeroed (one memset for many buffers: the host side's bump arena,
+ * ops._zeros_small) registers the range; a buffer lying entirely inside a registered range is then taken as zero and the node is
+ * skipped (a BASELINE config-3 training step had 323 of them, 1.4 ms of stream time).  The caller's contract: every buffer it
+ * passes from a registered range is zero at that point of the stream, and the range is unregistered before its memory is freed.
+ * register: WM_EINVAL for an empty range or one that overlaps a registered range; unregister: WM_EINVAL for an unknown base.
+ * Process-wide, thread-safe.  No reference counterpart (the reference's gradients come from ATen). */
+int wm_zero_arena_register(void* base, size_t bytes);
+int wm_zero_arena_unregister(void* base);
 
 /* Host-blocking wait for `event` (a hipEvent_t recorded OUTSIDE any capture) that is legal while a stream of this
  * thread is being captured: hipEventSynchronize under a thread-local relaxed capture mode

@@ -145,3 +145,23 @@ def test_library_isa_has_no_scalar_source_packed_f32_with_routed_halves():
         pytest.skip("llvm-objdump not available")
     bad = lint.offending(lint.disassemble(_lib.LIB_PATH))
     assert not bad, f"{len(bad)} packed-fp32 instruction(s) with unsafe op_sel routing, first: {bad[0]}"
+
+
+def test_zero_arena_registry_bookkeeping():
+    """wm_zero_arena_register / _unregister (include/wavemamba_hip.h): pure host bookkeeping, so it runs without a GPU - empty and
+    overlapping ranges and unknown bases are refused, a range can be registered again after it was unregistered."""
+    lib = _lib.load()
+    base = 0x7f0000000000
+    assert lib.wm_zero_arena_register(None, 4096) == _lib.WM_ENULL
+    assert lib.wm_zero_arena_register(base, 0) == _lib.WM_EINVAL
+    assert lib.wm_zero_arena_register(base, 4096) == _lib.WM_OK
+    try:
+        assert lib.wm_zero_arena_register(base + 4000, 4096) == _lib.WM_EINVAL          # overlaps the tail
+        assert lib.wm_zero_arena_register(base - 100, 200) == _lib.WM_EINVAL            # overlaps the head
+        assert lib.wm_zero_arena_register(base + 4096, 4096) == _lib.WM_OK              # adjacent: fine
+        assert lib.wm_zero_arena_unregister(base + 4096) == _lib.WM_OK
+        assert lib.wm_zero_arena_unregister(base + 8) == _lib.WM_EINVAL                 # not a base
+    finally:
+        assert lib.wm_zero_arena_unregister(base) == _lib.WM_OK
+    assert lib.wm_zero_arena_unregister(base) == _lib.WM_EINVAL
+    assert lib.wm_zero_arena_register(base, 64) == _lib.WM_OK and lib.wm_zero_arena_unregister(base) == _lib.WM_OK

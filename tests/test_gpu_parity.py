@@ -1663,6 +1663,64 @@ def test_prepared_weights_of_another_stream_under_capture():
     assert torch.equal(out, ref)
 
 
+def test_zero_arena_skips_the_memset_only_inside_registered_ranges():
+    """wm_plane_sums adds into its output: inside a registered range the library takes the buffer as zero (a buffer of ones comes
+    back as sums + 1 - the memset node was skipped), outside of it and after wm_zero_arena_unregister it zeroes it itself."""
+    from wave_mamba_amd.ops import _ptr, _stream
+    lib = wm._lib.load()
+    x = torch.randn(2, 8, 16, 32, generator=gen(1)).to(DEV)
+    ref = x.double().sum((0, 2, 3)).float()
+    arena = torch.ones(1024, device=DEV)
+    out_in = arena[64:72]
+    outside = torch.ones(8, device=DEV)
+    assert lib.wm_zero_arena_register(arena.data_ptr(), 4096) == 0
+    try:
+        for o in (out_in, outside):
+            assert lib.wm_plane_sums(_ptr(x), _ptr(o), 2, 8, 16, 32, _stream()) == 0
+        torch.cuda.synchronize()
+        assert_close(out_in, ref + 1.0, 1e-5, "inside a registered range: taken as zero")
+        assert_close(outside, ref, 1e-5, "outside: zeroed by the library")
+        assert lib.wm_zero_arena_unregister(arena.data_ptr()) == 0
+        assert lib.wm_zero_arena_register(arena.data_ptr(), 64 * 4 + 16) == 0  # ends in the middle of out_in: only PARTLY inside
+        arena.fill_(1.0)
+        assert lib.wm_plane_sums(_ptr(x), _ptr(out_in), 2, 8, 16, 32, _stream()) == 0
+        torch.cuda.synchronize()
+        assert_close(out_in, ref, 1e-5, "partly inside: zeroed by the library")
+    finally:
+        assert lib.wm_zero_arena_unregister(arena.data_ptr()) == 0
+    arena.fill_(1.0)
+    assert lib.wm_plane_sums(_ptr(x), _ptr(out_in), 2, 8, 16, 32, _stream()) == 0
+    torch.cuda.synchronize()
+    assert_close(out_in, ref, 1e-5, "after unregister: zeroed by the library")
+
+
+def test_zeros_small_hands_out_zeroed_distinct_slices():
+    """ops._zeros_small: slices are zero, 256-byte slots, never handed out twice - across the switch to a fresh block too - and a
+    gradient computed into one (plane_sums) matches float64."""
+    from wave_mamba_amd import ops
+    seen = set()
+    n_blocks = set()
+    for i in range(3000):                                                      # 3000 x 2 KB > one 4-MB block
+        t = ops._zeros_small(500, DEV)
+        assert t.numel() == 500 and t.data_ptr() % 256 == 0 and t.data_ptr() not in seen
+        seen.add(t.data_ptr())
+        n_blocks.add(t.untyped_storage().data_ptr())
+        if i % 500 == 0:
+            assert float(t.abs().max()) == 0.0
+            t.fill_(3.0)                                                       # dirtying a slice must not reach a later one
+    assert len(n_blocks) >= 2
+    big = ops._zeros_small(1 << 20, DEV)                                       # beyond the arena's slice limit: plain memory
+    assert big.numel() == 1 << 20
+    x = torch.randn(4, 32, 24, 40, generator=gen(2)).to(DEV)
+    assert_close(ops.plane_sums(x), x.double().sum((0, 2, 3)).float(), 1e-5, "plane_sums into an arena slice")
+    other = torch.cuda.Stream(DEV)
+    other.wait_stream(torch.cuda.current_stream(DEV))
+    with torch.cuda.stream(other):                                             # another stream: its own block
+        t2 = ops._zeros_small(16, DEV)
+        assert t2.untyped_storage().data_ptr() not in n_blocks and float(t2.abs().max()) == 0.0
+    torch.cuda.current_stream(DEV).wait_stream(other)
+
+
 def _concurrency_victims(level_hw):
     """Operator groups of the shipped network on fixed inputs (tools/repro_victim_sweep.py): name -> callable."""
     H, W = level_hw
@@ -2026,6 +2084,11 @@ def test_conv2d_wgrad_vs_float64(ks, B, Cin, Cout, H, W):
         assert_close(got, ref.float(), 1e-5, f"conv2d_wgrad ks={ks} {Cin}->{Cout} {H}x{W}")
         again = wm.ops.conv2d_wgrad(gy.to(DEV), x.to(DEV), ks)
         assert torch.equal(again, got), "conv2d_wgrad: not bit-reproducible run to run"
+        # the bias gradient from the same pass over gy (round 5): dW unchanged bit for bit, db against float64
+        got_w, got_b = wm.ops.conv2d_wgrad(gy.to(DEV), x.to(DEV), ks, with_bias=True)
+        assert torch.equal(got_w, got), "conv2d_wgrad: dW changes when the bias gradient rides along"
+        assert_close(got_b, gy.double().sum((0, 2, 3)).float(), 1e-5, f"conv2d_wgrad bias gradient ks={ks} {Cin}->{Cout} {H}x{W}")
+        assert torch.equal(wm.ops.conv2d_wgrad(gy.to(DEV), x.to(DEV), ks, with_bias=True)[1], got_b), "bias gradient: not bit-reproducible"
         # the same through autograd (conv2d_train's default mode), input and bias gradients from ATen / the plane-sum kernel
         xs = x.to(DEV).requires_grad_(True); ws = (torch.randn(Cout, Cin, ks, ks, generator=gg) * 0.1).to(DEV).requires_grad_(True)
         y = wm.ops.conv2d_train(xs, ws, None)
@@ -2244,6 +2307,12 @@ def test_conv2d_wgrad_at_training_sizes_vs_float64(ks, B, Cin, Cout, H, W):
     print(f"conv2d_wgrad ks={ks} {B}x{Cin}->{Cout} {H}x{W}: {e_got:.2e} of the float64 gradient (ATen fp32: {e_ref:.2e})")
     assert e_got <= 2e-5, f"conv2d_wgrad ks={ks} {Cin}->{Cout} {H}x{W}: {e_got:.3e} vs float64"
     assert torch.equal(wm.ops.conv2d_wgrad(gy, x, ks), got), "conv2d_wgrad: not bit-reproducible run to run"
+    got_w, got_b = wm.ops.conv2d_wgrad(gy, x, ks, with_bias=True)
+    tb = gy.double().sum((0, 2, 3))
+    # (sums of ~5e5 N(0, 1) values: |db| ~ 700 with cancellation, so the error is taken against the sum of magnitudes' scale too)
+    e_b = float((got_b.double() - tb).abs().max() / gy.double().abs().sum((0, 2, 3)).max())
+    print(f"   bias gradient: max |err| / sum |gy| = {e_b:.2e}")
+    assert torch.equal(got_w, got) and e_b <= 1e-6, f"bias gradient at training size: {e_b:.3e}"
 
 
 def test_whole_model_gradients_hip_wgrad_vs_aten_wgrad():

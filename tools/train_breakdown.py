@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import wave_mamba_amd as wm
 import bench
 ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=3); ap.add_argument("--wall-only", action="store_true")
+ap.add_argument("--top", type=int, default=45); ap.add_argument("--ops", action="store_true", help="also: host-side operators by the GPU time of their own kernels")
 ap.add_argument("--detail", default="", help="comma-separated kernel-name substrings: print every launch's duration (us) of the last profiled step")
 args = ap.parse_args()
 # (torch.backends.cudnn.benchmark = True, which the reference's train.py:129 sets, is NOT an option here: without a
@@ -32,14 +33,14 @@ print(f"wall clock, un-profiled: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms p
 if "--wall-only" in sys.argv:
     sys.exit(0)
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CUDA] + ([ProfilerActivity.CPU] if args.ops else [])) as prof:
     for _ in range(args.steps):
         wm.trainer.train_step(net, opt, lq, gt, as_float=False)
     torch.cuda.synchronize()
 agg = collections.defaultdict(lambda: [0, 0.0])
 for e in prof.events():
     if e.device_type == torch.autograd.DeviceType.CUDA:
-        k = e.name.split("(")[0][:110]
+        k = (e.name if e.name.startswith("void at::native") else e.name.split("(")[0])[:200 if e.name.startswith("void at::native") else 110]
         agg[k][0] += 1; agg[k][1] += e.device_time
 if args.detail:
     evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
@@ -49,5 +50,11 @@ if args.detail:
         print(f"# {sub}: {len(d)} launches in the last step, us: " + " ".join(f"{x:.0f}" for x in d))
 tot = sum(v[1] for v in agg.values())
 print(f"GPU kernel time per step: {tot / args.steps / 1e3:.2f} ms in {sum(v[0] for v in agg.values()) / args.steps:.0f} kernels")
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:args.top]:
     print(f"{v[0] / args.steps:7.1f} {v[1] / args.steps / 1e3:8.3f} ms  {k}")
+if args.ops:
+    print("# host-side operators by the GPU time of the kernels they launch themselves (per step)")
+    rows = sorted(prof.key_averages(), key=lambda a: -a.self_device_time_total)[:60]
+    for a in rows:
+        if a.self_device_time_total > 0:
+            print(f"{a.count / args.steps:7.1f} {a.self_device_time_total / args.steps / 1e3:8.3f} ms  {a.key[:120]}")

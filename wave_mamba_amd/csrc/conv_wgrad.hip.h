@@ -22,6 +22,10 @@
 //     the window in the row's first segment / the last in its last segment - masked per lane.
 //   * Every wave writes its accumulators as one partial; a second small kernel adds the partials of an input tile into
 //     dW (no atomics anywhere: bit-reproducible).
+//   * The BIAS gradient db[co] = sum over b, h, w of gy rides along (round 5): the wave of input tile 0 has every gy value of its
+//     position sub-range in registers anyway - eight adds per output tile and unit, one partial row per sub-range, summed by the
+//     same finish kernel.  It was a separate pass over gy before (wm_plane_sums: 87 launches + 87 memsets, 1.4 ms of a
+//     BASELINE config-3 step).
 // Needs W % 32 == 0 (every map of the network: 512 / 256 / 128 / 64 wide at the training size) - else WM_EUNSUPPORTED and
 // the caller stays on ATen.
 #pragma once
@@ -41,7 +45,10 @@ struct ConvWgradArgs {
     int nparts;                // position sub-ranges = partials per input tile
     int co0, nco;              // output channels co0 .. co0 + nco - 1 in this launch (96 = 64 + 32: the accumulators of six
                                // tiles x nine taps do not fit the registers)
+    float* bpart;              // bias gradient: [position sub-range][kCwBiasRow] partial plane sums of gy (db != nullptr)
+    float* db;                 // (Cout) or nullptr
 };
+constexpr int kCwBiasRow = 96;                                   // the most output channels a call takes
 
 typedef float cw_f4 __attribute__((ext_vector_type(4)));
 constexpr int kCwWaves = 4;
@@ -73,6 +80,10 @@ __global__ __launch_bounds__(64 * kCwWaves, WM_CW_WAVES_PER_SIMD) void conv_wgra
     for (int o = 0; o < OT; ++o)
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) acc[o][t] = (cw_f4){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = a.db != nullptr && it == 0;              // uniform: one wave per position sub-range
+    float gs[OT];
+#pragma unroll
+    for (int o = 0; o < OT; ++o) gs[o] = 0.0f;
 
     // Units in COLUMN order: u -> (image b, 32-column segment seg, row h), h fastest.  The waves of a workgroup that share a
     // position sub-range read the same gy (one first-level cache serves them), and walking DOWN a segment a wave keeps two
@@ -126,6 +137,7 @@ __global__ __launch_bounds__(64 * kCwWaves, WM_CW_WAVES_PER_SIMD) void conv_wgra
         for (int o = 0; o < OT; ++o) {
             const bool ok = 16 * o + i16 < a.nco;
             const float v[8] = {cur.g[o][0].x, cur.g[o][0].y, cur.g[o][0].z, cur.g[o][0].w, cur.g[o][1].x, cur.g[o][1].y, cur.g[o][1].z, cur.g[o][1].w};
+            if (do_bias) gs[o] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
                 core_bf2 h2, l2;
@@ -181,6 +193,15 @@ __global__ __launch_bounds__(64 * kCwWaves, WM_CW_WAVES_PER_SIMD) void conv_wgra
         for (int t = 0; t < TAPS; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[(o * TAPS + t) * 256 + (4 * kq + r) * 16 + i16] = acc[o][t][r];
+    if (do_bias) {
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {                            // the four column groups of a channel: lanes i16 + 16 kq
+            float sb = gs[o];
+            sb += __shfl_xor(sb, 16);
+            sb += __shfl_xor(sb, 32);
+            if (kq == 0 && 16 * o + i16 < a.nco) a.bpart[(long long)prange * kCwBiasRow + a.co0 + 16 * o + i16] = sb;
+        }
+    }
 }
 
 // dW[co][ci][tap] = sum over the partials of an input tile.  A block = 16 consecutive elements of a partial (one co row
@@ -209,6 +230,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_finish_kernel(const ConvWgradA
         const int c16 = f & 15, r16 = (f >> 4) & 15, tile = f >> 8, tap = tile % TAPS, o = tile / TAPS;
         const int co = 16 * o + r16, ci = 16 * it + c16;          // co: within this launch
         if (co < a.nco && ci < a.Cin) a.dW[((long long)(a.co0 + co) * a.Cin + ci) * TAPS + tap] = t;
+    }
+    if (a.db != nullptr && blockIdx.y == 0 && (int)blockIdx.x < OT) {       // uniform: block o = the bias gradient of output tile o
+        __syncthreads();
+        const int co = 16 * (int)blockIdx.x + e16;
+        float sb = 0.0f;
+        if (co < a.nco)
+            for (int q = pg; q < a.nparts; q += 16) sb += a.bpart[(long long)q * kCwBiasRow + a.co0 + co];
+        s_sum[pg][e16] = sb;
+        __syncthreads();
+        if (pg == 0 && co < a.nco) {
+            float t = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += s_sum[q][e16];
+            a.db[a.co0 + co] = t;
+        }
     }
 }
 

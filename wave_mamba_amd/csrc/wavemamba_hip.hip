@@ -222,7 +222,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 26; }
+int wm_abi_version(void) { return 27; }
 
 #ifndef WM_BUILD_ID
 #define WM_BUILD_ID "unknown"
@@ -1268,13 +1268,62 @@ static void gram_plan(int64_t L, long long& nblk, long long& slice) {
 }  // namespace wm
 extern "C" {
 
+// Zero-initialised accumulator outputs (parameter gradients that kernels add into with atomics, the two running maxima of
+// wm_conv2d_amax).  A caller that hands out such buffers from memory it has ALREADY zeroed registers that memory
+// (wm_zero_arena_register): a buffer that lies inside a registered range is taken as zero and the memset node is skipped - a
+// BASELINE config-3 training step issued 323 memsets of a few hundred bytes, 4.2 us of stream time each (round 5).
+struct ZeroArenas {
+    std::mutex mu;
+    std::atomic<int> count{0};
+    std::vector<std::pair<uintptr_t, uintptr_t>> ranges;            // [begin, end)
+};
+static ZeroArenas g_zero_arenas;
+
+static bool prezeroed(const void* p, size_t bytes) {
+    if (g_zero_arenas.count.load(std::memory_order_acquire) == 0) return false;
+    const uintptr_t b = reinterpret_cast<uintptr_t>(p), e = b + bytes;
+    std::lock_guard<std::mutex> lk(g_zero_arenas.mu);
+    for (const auto& r : g_zero_arenas.ranges)
+        if (b >= r.first && e <= r.second) return true;
+    return false;
+}
+
+static hipError_t zero_out(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0 || prezeroed(p, bytes)) return hipSuccess;
+    return hipMemsetAsync(p, 0, bytes, st);
+}
+
 // Zero two small gradient buffers: ONE memset node when the caller allocated them back to back (ops.py does: a training step
 // issued 440 memsets of a few hundred bytes, ~4 us of GPU time each).
 static hipError_t zero_pair(float* a, size_t na, float* b, size_t nb, hipStream_t st) {
-    if (b && b == a + na) return hipMemsetAsync(a, 0, (na + nb) * sizeof(float), st);
-    hipError_t e = hipMemsetAsync(a, 0, na * sizeof(float), st);
-    if (e == hipSuccess && b) e = hipMemsetAsync(b, 0, nb * sizeof(float), st);
+    if (b && b == a + na) return zero_out(a, (na + nb) * sizeof(float), st);
+    hipError_t e = zero_out(a, na * sizeof(float), st);
+    if (e == hipSuccess && b) e = zero_out(b, nb * sizeof(float), st);
     return e;
+}
+
+int wm_zero_arena_register(void* base, size_t bytes) {
+    if (!base) return WM_ENULL;
+    if (bytes == 0) return WM_EINVAL;
+    const uintptr_t b = reinterpret_cast<uintptr_t>(base);
+    std::lock_guard<std::mutex> lk(g_zero_arenas.mu);
+    for (const auto& r : g_zero_arenas.ranges)
+        if (b < r.second && b + bytes > r.first) return WM_EINVAL;  // overlaps a registered range
+    g_zero_arenas.ranges.emplace_back(b, b + bytes);
+    g_zero_arenas.count.store((int)g_zero_arenas.ranges.size(), std::memory_order_release);
+    return WM_OK;
+}
+
+int wm_zero_arena_unregister(void* base) {
+    const uintptr_t b = reinterpret_cast<uintptr_t>(base);
+    std::lock_guard<std::mutex> lk(g_zero_arenas.mu);
+    for (size_t i = 0; i < g_zero_arenas.ranges.size(); ++i)
+        if (g_zero_arenas.ranges[i].first == b) {
+            g_zero_arenas.ranges.erase(g_zero_arenas.ranges.begin() + (long)i);
+            g_zero_arenas.count.store((int)g_zero_arenas.ranges.size(), std::memory_order_release);
+            return WM_OK;
+        }
+    return WM_EINVAL;
 }
 
 size_t wm_gram_workspace_bytes(int B, int C, int64_t L) {
@@ -1429,7 +1478,7 @@ int wm_linear_wgrad(const float* gy, const float* x, float* dW, int64_t T, int O
     if (T < 0 || O <= 0 || I <= 0) return WM_EINVAL;
     if (!dW) return WM_ENULL;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(dW, 0, (size_t)O * I * sizeof(float), st);
+    hipError_t e = zero_out(dW, (size_t)O * I * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
     if (T == 0) return WM_OK;
     if (!gy || !x) return WM_ENULL;
@@ -1472,16 +1521,17 @@ size_t wm_conv2d_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, i
     if (OT > 6 || (OT != 1 && OT != 2 && OT != 4 && OT != 6)) return 0;
     int upw, blocks;
     const int np = conv_wgrad_parts((long long)B * H * (W / 32), (Cin + 15) / 16, &upw, &blocks);
-    return (size_t)((Cin + 15) / 16) * np * OT * ks * ks * 256 * sizeof(float);
+    return ((size_t)((Cin + 15) / 16) * np * OT * ks * ks * 256 + (size_t)np * kCwBiasRow) * sizeof(float);
 }
-int wm_conv2d_wgrad(const float* gy, const float* x, float* dW, void* workspace, size_t workspace_bytes, int B, int Cin, int Cout,
-                    int H, int W, int ks, void* stream) {
+int wm_conv2d_wgrad(const float* gy, const float* x, float* dW, float* db, void* workspace, size_t workspace_bytes, int B, int Cin,
+                    int Cout, int H, int W, int ks, void* stream) {
     if (B < 0 || Cin <= 0 || Cout <= 0 || H < 0 || W < 0) return WM_EINVAL;
     if (ks != 1 && ks != 3) return WM_EUNSUPPORTED;
     if (!dW) return WM_ENULL;
     hipStream_t st = (hipStream_t)stream;
     if (B == 0 || H == 0 || W == 0) {
         hipError_t e = hipMemsetAsync(dW, 0, (size_t)Cout * Cin * ks * ks * sizeof(float), st);
+        if (e == hipSuccess && db) e = hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), st);
         return e == hipSuccess ? WM_OK : (int)e;
     }
     const size_t need = wm_conv2d_wgrad_workspace_bytes(B, Cin, Cout, H, W, ks);
@@ -1496,6 +1546,8 @@ int wm_conv2d_wgrad(const float* gy, const float* x, float* dW, void* workspace,
     int blocks = 1;
     a.nparts = conv_wgrad_parts(a.nunits, (Cin + 15) / 16, &a.upw, &blocks);
     const int OT = (Cout + 15) / 16, ITN = (Cin + 15) / 16;
+    a.bpart = (float*)workspace + (size_t)ITN * a.nparts * OT * ks * ks * 256;
+    a.db = db;
     const int ygroups = (ITN + cw_tiles_per_wg(ITN) - 1) / cw_tiles_per_wg(ITN);
 #define WM_CW(KS, OTV, CO0, NCO)                                                                                         \
     do {                                                                                                                 \
@@ -1518,7 +1570,7 @@ int wm_plane_sums(const float* x, float* sums, int B, int C, int H, int W, void*
     if (C == 0) return WM_OK;
     if (!sums) return WM_ENULL;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sums, 0, (size_t)C * sizeof(float), st);
+    hipError_t e = zero_out(sums, (size_t)C * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
     const long long HW = (long long)H * W, planes = (long long)B * C;
     if (planes == 0 || HW == 0) return WM_OK;
@@ -1590,7 +1642,7 @@ int wm_scale_add_bwd(const float* g, const float* x, const float* scale, float* 
     if (C == 0) return WM_OK;
     if (!gscale) return WM_ENULL;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(gscale, 0, (size_t)C * sizeof(float), st);
+    hipError_t e = zero_out(gscale, (size_t)C * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
     if (B == 0 || L == 0) return WM_OK;
     if (!g || !x || !scale || !gx) return WM_ENULL;
@@ -1680,7 +1732,7 @@ int wm_conv2d_amax(const float* x, int64_t nx, const float* weight, int64_t nw, 
     if (nx < 0 || nw < 0) return WM_EINVAL;
     if (!amax || (nx > 0 && !x) || (nw > 0 && !weight)) return WM_ENULL;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(amax, 0, 2 * sizeof(float), st) != hipSuccess) return WM_EHIP;
+    if (zero_out(amax, 2 * sizeof(float), st) != hipSuccess) return WM_EHIP;
     const long long big = (long long)(nx > nw ? nx : nw);
     if (big == 0) return WM_OK;
     long long blocks = (big / 4 + 256 * 8 - 1) / (256 * 8);          // >= 8 float4 per thread

@@ -46,6 +46,41 @@ def _ptr(t):
 
 
 # ------------------------------------------------------------------------------------------------
+# Zeroed accumulator outputs (training): parameter gradients the kernels add into with atomics and the running maxima of the
+# fp16-split convolutions are a few hundred bytes each, and the library's memset node in front of each of them was 4.2 us of
+# stream time, 323 times per BASELINE config-3 step.  They are handed out of a 4-MB block zeroed ONCE (per device and stream,
+# bump allocation, no slice is ever handed out twice); the block is registered with the library (wm_zero_arena_register), which
+# then skips its memset for buffers inside it.  A block lives as long as any slice of it does (the slices are views of its
+# storage); it is unregistered when the next block replaces it.
+# ------------------------------------------------------------------------------------------------
+_ZERO_ARENA_FLOATS = 1 << 20
+_ZERO_ARENAS = {}            # (device index, stream handle) -> [block, floats handed out]
+_ZERO_ARENA_LOCK = __import__("threading").Lock()
+
+
+def _zeros_small(n, device):
+    """A zeroed float32 vector of n elements on `device` for an accumulate-into output of the library, valid on the current
+    stream.  Larger than 64 KB, or under graph capture: uninitialised memory (the library zeroes it itself)."""
+    if n > 16384 or torch.cuda.is_current_stream_capturing():
+        return torch.empty(n, dtype=torch.float32, device=device)
+    import weakref
+    lib = _lib.load()
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    step = (n + 63) & ~63                                  # 256-byte slots
+    with _ZERO_ARENA_LOCK:
+        ent = _ZERO_ARENAS.get(key)
+        if ent is None or ent[1] + step > _ZERO_ARENA_FLOATS:
+            block = torch.zeros(_ZERO_ARENA_FLOATS, dtype=torch.float32, device=device)
+            if ent is not None:
+                ent[2]()                                   # the exhausted block: unregistered now, freed with its last slice
+            check(lib.wm_zero_arena_register(block.data_ptr(), 4 * _ZERO_ARENA_FLOATS), "wm_zero_arena_register")
+            ent = _ZERO_ARENAS[key] = [block, 0, weakref.finalize(block, lib.wm_zero_arena_unregister, block.data_ptr())]
+        out = ent[0][ent[1]:ent[1] + n]
+        ent[1] += step
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # bf16-storage mode (BASELINE config 2 as worded): the plane tensors an LFSSBlock hands from kernel to kernel - x, z,
 # the conv outputs, the four scan outputs, f, fc - are stored as bfloat16; every kernel computes in fp32 (tiles,
 # projections, scan state, LayerNorm statistics) and the token tensors between blocks stay fp32.  Off by default:
@@ -630,7 +665,7 @@ class _DWConvTrain(torch.autograd.Function):
         gy = gy.contiguous().float()
         B, C, H, W = x.shape
         gx = dwconv3x3(gy, weight.detach().flip(2, 3).contiguous(), None, "none")
-        buf = torch.empty(10 * C, dtype=torch.float32, device=x.device)         # dW | db back to back: one memset in the library
+        buf = _zeros_small(10 * C, x.device)                                    # dW | db back to back, zeroed
         dW = buf[:9 * C].view(weight.shape)
         db = buf[9 * C:] if ctx.has_bias else None
         with torch.cuda.device(x.device):
@@ -661,7 +696,7 @@ class _LayerNorm2dTrain(torch.autograd.Function):
         B, C, H, W = x.shape
         gy = gy.contiguous().float()
         gx = torch.empty_like(x)
-        buf = torch.empty(2 * C, dtype=torch.float32, device=x.device)          # dweight | dbias back to back: one memset
+        buf = _zeros_small(2 * C, x.device)                                     # dweight | dbias back to back, zeroed
         dw, db = buf[:C], buf[C:]
         with torch.cuda.device(x.device):
             check(lib.wm_layernorm2d_bwd(_ptr(x), _ptr(_w(weight)), _ptr(gy), ctx.eps, _ptr(gx), _ptr(dw), _ptr(db),
@@ -697,8 +732,8 @@ class _LayerNormTok(torch.autograd.Function):
         C = x.shape[-1]
         gy = gy.contiguous().float()
         gx = torch.empty_like(x)
-        dw = torch.empty(C, dtype=torch.float32, device=x.device)
-        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        buf = _zeros_small(2 * C, x.device)
+        dw, db = buf[:C], buf[C:]
         with torch.cuda.device(x.device):
             check(lib.wm_layernorm_tok_bwd(_ptr(x), _ptr(w), _ptr(gy), ctx.eps, _ptr(gx), _ptr(dw), _ptr(db),
                                            x.numel() // C, C, _stream()), "wm_layernorm_tok_bwd")
@@ -846,7 +881,7 @@ class _ScaleAdd(torch.autograd.Function):
         g = g.contiguous().float()
         B, C = x.shape[:2]
         L = x[0, 0].numel()
-        gx, gs = torch.empty_like(x), torch.empty(C, dtype=torch.float32, device=x.device)
+        gx, gs = torch.empty_like(x), _zeros_small(C, x.device)
         with torch.cuda.device(x.device):
             check(lib.wm_scale_add_bwd(_ptr(g), _ptr(x), _ptr(sc), _ptr(gx), _ptr(gs), B, C, L, _stream()), "wm_scale_add_bwd")
         return gx, gs.view(ctx.scale_shape), g
@@ -1086,11 +1121,18 @@ def conv2d_f16(x, weight, bias=None):
     x = x.contiguous()
     w = weight.detach().contiguous()
     nws = _f16_ws_bytes(lib, cout, cin, ks)
-    ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+    if nws == 0:
+        check(_lib.WM_EUNSUPPORTED, "wm_conv2d_f16")
+    # the three steps of wm_conv2d_f16, with the two maxima in a slot of the zeroed arena (no memset node per convolution)
+    amax = _zeros_small(2, x.device)
+    wfrag = torch.empty(nws - 256, dtype=torch.uint8, device=x.device)
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    b = None if bias is None else bias.detach().contiguous()
     with torch.cuda.device(x.device):
-        check(lib.wm_conv2d_f16(_ptr(x), _ptr(w), _ptr(None if bias is None else bias.detach().contiguous()), _ptr(y), _ptr(ws), nws,
-                                B, cin, cout, H, W, ks, _stream()), "wm_conv2d_f16")
+        st = _stream()
+        check(lib.wm_conv2d_amax(_ptr(x), x.numel(), _ptr(w), w.numel(), _ptr(amax), st), "wm_conv2d_amax")
+        check(lib.wm_conv2d_prep_f16(_ptr(w), _ptr(amax), _ptr(wfrag), cout, cin, ks, st), "wm_conv2d_prep_f16")
+        check(lib.wm_conv2d_fwd_f16(_ptr(x), _ptr(wfrag), _ptr(amax), _ptr(b), _ptr(y), B, cin, cout, H, W, ks, st), "wm_conv2d_fwd_f16")
     return y
 
 
@@ -1205,7 +1247,7 @@ class _LinearNoBias(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             O, I = weight.shape
             g2, x2 = gy.reshape(-1, O).contiguous().float(), x.reshape(-1, I).contiguous().float()
-            gw = torch.empty((O, I), dtype=torch.float32, device=x.device)
+            gw = _zeros_small(O * I, x.device).view(O, I)
             with torch.cuda.device(x.device):
                 check(lib.wm_linear_wgrad(_ptr(g2), _ptr(x2), _ptr(gw), g2.shape[0], O, I, _stream()), "wm_linear_wgrad")
         return gx, gw
@@ -1228,7 +1270,7 @@ def plane_sums(x):
     _require_cuda("plane_sums", x)
     B, C, H, W = x.shape
     x = x.contiguous().float()
-    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    out = _zeros_small(C, x.device)
     with torch.cuda.device(x.device):
         check(lib.wm_plane_sums(_ptr(x), _ptr(out), B, C, H, W, _stream()), "wm_plane_sums")
     return out
@@ -1256,10 +1298,7 @@ class _Conv2dTrain(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = weight.detach().transpose(0, 1).flip(2, 3).contiguous()          # (Cin, Cout, ks, ks)
             gx = conv2d_f16(gy, wt) if ctx.f16 else conv2d(gy, wt, None, dynamic_weight=True)
-        if ctx.needs_input_grad[1]:
-            gw = _conv_weight_grad(gy, x, weight)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = plane_sums(gy)
+        gw, gb = _conv_param_grads(gy, x, weight, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
         return gx, gw, gb, None
 
 
@@ -1281,8 +1320,9 @@ def conv2d_wgrad_supported(x, weight):
             and (Cout + 15) // 16 in (1, 2, 4, 6) and not (ks == 3 and 64 < Cout <= 80))
 
 
-def conv2d_wgrad(gy, x, ks, _refusal=RuntimeError):
-    """dW (Cout, Cin, ks, ks) of a stride-1 'same' convolution from gy (B, Cout, H, W) and x (B, Cin, H, W)."""
+def conv2d_wgrad(gy, x, ks, _refusal=RuntimeError, with_bias=False):
+    """dW (Cout, Cin, ks, ks) of a stride-1 'same' convolution from gy (B, Cout, H, W) and x (B, Cin, H, W); with_bias: -> (dW, db),
+    db (Cout) = gy summed over batch and plane, from the same pass over gy."""
     lib = _lib.load()
     _require_cuda("conv2d_wgrad", gy, x)
     if x.dim() != 4 or gy.dim() != 4 or gy.shape[0] != x.shape[0] or gy.shape[2:] != x.shape[2:]:
@@ -1295,31 +1335,40 @@ def conv2d_wgrad(gy, x, ks, _refusal=RuntimeError):
         raise _refusal("wm_conv2d_wgrad: unsupported shape (see conv2d_wgrad_supported)")
     ws = torch.empty(need, dtype=torch.uint8, device=x.device)
     dW = torch.empty(Cout, Cin, ks, ks, dtype=torch.float32, device=x.device)
+    db = torch.empty(Cout, dtype=torch.float32, device=x.device) if with_bias else None
     with torch.cuda.device(x.device):
-        rc = lib.wm_conv2d_wgrad(_ptr(gy), _ptr(x), _ptr(dW), _ptr(ws), need, B, Cin, Cout, H, W, ks, _stream())
+        rc = lib.wm_conv2d_wgrad(_ptr(gy), _ptr(x), _ptr(dW), _ptr(db), _ptr(ws), need, B, Cin, Cout, H, W, ks, _stream())
     if rc in (_lib.WM_EUNSUPPORTED, _lib.WM_EALIGN) and _refusal is not RuntimeError:
         raise _refusal(f"wm_conv2d_wgrad refused the call (code {rc})")
     check(rc, "wm_conv2d_wgrad")
-    return dW
+    return (dW, db) if with_bias else dW
 
 
 class _WgradRefused(RuntimeError):
     pass
 
 
-def _conv_weight_grad(gy, x, weight):
+def _conv_weight_grad(gy, x, weight, with_bias=False):
     """HIP matrix-core weight gradient, or ATen's for anything the kernel refuses - by the Python predicate, by
     wm_conv2d_wgrad_workspace_bytes (its shape limits) or by the call itself (WM_EUNSUPPORTED / WM_EALIGN): a training step
-    never dies on a shape, as conv_wgrad.hip.h promises."""
+    never dies on a shape, as conv_wgrad.hip.h promises.  with_bias: -> (dW, db), the bias gradient from the same kernel (or
+    plane_sums next to ATen's weight gradient)."""
     ks = weight.shape[2]
     if _TRAIN_CONV_WGRAD_HIP and conv2d_wgrad_supported(x, weight):
         try:
-            return conv2d_wgrad(gy, x, ks, _refusal=_WgradRefused)
+            return conv2d_wgrad(gy, x, ks, _refusal=_WgradRefused, with_bias=with_bias)
         except _WgradRefused:
             pass
     _, gw, _ = torch.ops.aten.convolution_backward(
         gy, x, weight, None, [1, 1], [ks // 2, ks // 2], [1, 1], False, [0, 0], 1, [False, True, False])
-    return gw
+    return (gw, plane_sums(gy)) if with_bias else gw
+
+
+def _conv_param_grads(gy, x, weight, want_w, want_b):
+    """(dW, db) of a convolution's parameters, each None when not wanted: one kernel for both when both are."""
+    if want_w and want_b:
+        return _conv_weight_grad(gy, x, weight, with_bias=True)
+    return (_conv_weight_grad(gy, x, weight) if want_w else None), (plane_sums(gy) if want_b else None)
 
 
 class _Conv2dAten(torch.autograd.Function):
@@ -1342,10 +1391,7 @@ class _Conv2dAten(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx, _, _ = torch.ops.aten.convolution_backward(
                 gy, x, weight, None, [1, 1], [ks // 2, ks // 2], [1, 1], False, [0, 0], 1, [True, False, False])
-        if ctx.needs_input_grad[1]:
-            gw = _conv_weight_grad(gy, x, weight)
-        if ctx.needs_input_grad[2]:
-            gb = plane_sums(gy)
+        gw, gb = _conv_param_grads(gy, x, weight, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return gx, gw, gb
 
 
