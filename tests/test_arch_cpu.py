@@ -65,13 +65,12 @@ def test_state_dict_layout_and_seeded_init(meta):
         assert float(v.sum()) == s and float(v.abs().sum()) == a, f"init of {k} differs"
 
 
-def test_product_backend_refuses_cpu_tensors():
-    # no silent CPU fallback in the product path
+def test_fused_kernels_have_no_cpu_path():
+    # the fused operators are HIP-only (the three boundary operators' CPU twins: tests/test_cpu_twin.py)
     with pytest.raises(RuntimeError):
-        wm.ops.dwt_init(torch.zeros(1, 1, 4, 4))
+        wm.ops.conv2d(torch.zeros(1, 16, 4, 4), torch.zeros(16, 16, 3, 3))
     with pytest.raises(RuntimeError):
-        wm.ops.selective_scan_fn(torch.zeros(1, 4, 8), torch.zeros(1, 4, 8), -torch.ones(4, 2),
-                                 torch.zeros(1, 1, 2, 8), torch.zeros(1, 1, 2, 8))
+        wm.ops.lfss_block_forward(torch.zeros(1, 16, 32), (4, 4), arch.LFSSBlock(32, expand=2.0).eval())
 
 
 def test_tiny_model_with_reference_weights(golden, oracle_backend):

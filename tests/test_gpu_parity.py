@@ -1721,6 +1721,26 @@ def test_zeros_small_hands_out_zeroed_distinct_slices():
     torch.cuda.current_stream(DEV).wait_stream(other)
 
 
+def test_cuda_tensors_fail_loudly_without_the_library(monkeypatch):
+    """The CPU twins of dwt_init / iwt_init / selective_scan_fn (cpu_twin.py) are selected by the input's device and by nothing
+    else: with the HIP library gone, a CUDA tensor raises WaveMambaHipError - it is not quietly computed somewhere else."""
+    from wave_mamba_amd import _lib, cpu_twin
+
+    def boom(*a, **k):
+        raise AssertionError("the CPU twin was reached by a CUDA tensor")
+    for name in ("dwt_init", "iwt_init", "iwt_init_pair", "selective_scan_fn"):
+        monkeypatch.setattr(cpu_twin, name, boom)
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libwavemamba_hip.so")
+    x = torch.zeros(1, 4, 8, 8, device=DEV)
+    for call in (lambda: wm.ops.dwt_init(x), lambda: wm.ops.iwt_init(x), lambda: wm.ops.iwt_init_pair(x[:, :1], x[:, 1:]),
+                 lambda: wm.ops.selective_scan_fn(torch.zeros(1, 4, 8, device=DEV), torch.zeros(1, 4, 8, device=DEV),
+                                                  -torch.ones(4, 2, device=DEV), torch.zeros(1, 1, 2, 8, device=DEV),
+                                                  torch.zeros(1, 1, 2, 8, device=DEV))):
+        with pytest.raises(_lib.WaveMambaHipError):
+            call()
+
+
 def _concurrency_victims(level_hw):
     """Operator groups of the shipped network on fixed inputs (tools/repro_victim_sweep.py): name -> callable."""
     H, W = level_hw

@@ -30,7 +30,8 @@ def _require_cuda(name, *tensors):
         if t is not None and not t.is_cuda:
             raise RuntimeError(
                 f"{name}: expected a CUDA (ROCm) tensor, got device '{t.device}'. The Wave-Mamba hot "
-                "path is HIP-only; there is no CPU fallback in the product path.")
+                "path is HIP-only (dwt_init / iwt_init / selective_scan_fn alone have a CPU twin, for inputs that are ALL "
+                "on the CPU); nothing falls back to the CPU.")
 
 
 def _dtype_code(t, name):
@@ -202,18 +203,35 @@ class _IWT(torch.autograd.Function):
         return d_l, d_h
 
 
+# The three operators of the drop-in boundary have a CPU twin (cpu_twin.py: plain PyTorch, SURVEY.md 8b "each with CPU + HIP
+# implementations", BASELINE config 1 "CPU-only PyTorch forward").  The dispatch key is the DEVICE OF THE INPUT, as for any torch
+# operator - never the presence of the library: a CUDA tensor goes to the HIP kernels below and raises if they cannot be loaded.
+def _on_cpu(*tensors):
+    ts = [t for t in tensors if t is not None]
+    return bool(ts) and all(t.device.type == "cpu" for t in ts)
+
+
 def dwt_init(x):
     """Haar analysis of an NCHW map -> (x_LL, x_HL, x_LH, x_HH), each (B, C, H/2, W/2), dtype of x."""
+    if _on_cpu(x):
+        from . import cpu_twin
+        return cpu_twin.dwt_init(x)
     return _DWT.apply(x)
 
 
 def iwt_init(x):
     """Haar synthesis of a (B, 4C, h, w) tensor [x1|x2|x3|x4] -> (B, C, 2h, 2w), always float32."""
+    if _on_cpu(x):
+        from . import cpu_twin
+        return cpu_twin.iwt_init(x)
     return _IWT.apply(x, None)
 
 
 def iwt_init_pair(x_l, x_h):
     """iwt_init(torch.cat([x_l, x_h], dim=1)) without materialising the concatenation."""
+    if _on_cpu(x_l, x_h):
+        from . import cpu_twin
+        return cpu_twin.iwt_init_pair(x_l, x_h)
     return _IWT.apply(x_l, x_h)
 
 
@@ -311,7 +329,10 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
     wavemamba_arch.py:465-471).  u, delta: (batch, dim, L); A: (dim, N); B, C: (batch, [G,] N, L);
     D, delta_bias: (dim,).  Computes in fp32, returns `out` in u's dtype (and the fp32 last state
     (batch, dim, N) when return_last_state).  Differentiable w.r.t. u, delta, A, B, C, D, delta_bias
-    (and z, through eager gating)."""
+    (and z, through eager gating).  CPU tensors: cpu_twin.selective_scan_fn (plain PyTorch, same signature)."""
+    if _on_cpu(u, delta, A, B, C, D, z, delta_bias):
+        from . import cpu_twin
+        return cpu_twin.selective_scan_fn(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
     _require_cuda("selective_scan_fn", u, delta, A, B, C, D, z, delta_bias)
     batch, dim, L, N, G, B4, C4 = _scan_shapes(u, delta, A, B, C, D, z, delta_bias)
     squeeze_B, squeeze_C = B.dim() == 3, C.dim() == 3

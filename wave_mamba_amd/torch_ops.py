@@ -9,13 +9,15 @@ ss2d_core}").
     out = torch.ops.wavemamba_hip.selective_scan(u, delta, A, B, C, D, delta_bias, True)   # selective_scan_fn (:465-471)
     y0, y1, y2, y3 = torch.ops.wavemamba_hip.ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)  # (:446-478)
 
-Every op is a thin shell over the C ABI calls `ops.py` makes (same kernels, same checks, HIP only: a CPU tensor raises), has a
+Every op is a thin shell over the C ABI calls `ops.py` makes (same kernels, same checks) under the CUDA dispatch key, has a
 fake (meta) implementation so that tracing never launches anything, and an autograd formula whose backward is itself a
-registered op (`..._backward`), so compiled / exported graphs hold both directions as opaque nodes.
+registered op (`..._backward`), so compiled / exported graphs hold both directions as opaque nodes.  Under the CPU dispatch key
+the ops are the plain-PyTorch twins of cpu_twin.py ("each with CPU + HIP implementations"; their backward ops
+differentiate the twin with autograd) - the dispatcher picks by the tensors' device, a CUDA tensor never reaches them.
 """
 import torch
 
-from . import ops
+from . import cpu_twin, ops
 
 _NS = "wavemamba_hip"
 _lib_def = torch.library.Library(_NS, "FRAGMENT")
@@ -153,6 +155,49 @@ _define("ss2d_core", "(Tensor x, Tensor x_proj_weight, Tensor dt_projs_weight, T
 _define("ss2d_core_backward", "(Tensor x, Tensor x_proj_weight, Tensor dt_projs_weight, Tensor dt_projs_bias, Tensor A_logs, "
         "Tensor Ds, Tensor dy0, Tensor dy1, Tensor dy2, Tensor dy3) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)",
         _ss2d_core_backward, _ss2d_core_backward_fake)
+
+
+
+# ---- CPU dispatch key: the plain-PyTorch twins --------------------------------------------------------------------------
+def _twin_vjp(fn, inputs, grad_outputs):
+    """Gradients of the twin `fn` at `inputs` (None entries: absent optional arguments) for the output cotangents."""
+    with torch.enable_grad():
+        leaves = [None if t is None else t.detach().clone().requires_grad_(True) for t in inputs]
+        outs = fn(*leaves)
+        outs = outs if isinstance(outs, tuple) else (outs,)
+        have = [l for l in leaves if l is not None]
+        gs = list(torch.autograd.grad(outs, have, grad_outputs, allow_unused=True))
+    return [None if l is None else (torch.zeros_like(l) if (g := gs.pop(0)) is None else g) for l in leaves]
+
+
+def _cpu(name, impl):
+    torch.library.impl(f"{_NS}::{name}", "CPU", lib=_lib_def)(impl)
+
+
+_cpu("dwt2d", lambda x: tuple(t.contiguous() for t in cpu_twin.dwt_init(x)))
+_cpu("dwt2d_backward", lambda g_ll, g_hl, g_lh, g_hh: _twin_vjp(
+    cpu_twin.dwt_init, [g_ll.new_zeros(g_ll.shape[0], g_ll.shape[1], 2 * g_ll.shape[2], 2 * g_ll.shape[3])],
+    [g_ll, g_hl, g_lh, g_hh])[0])
+_cpu("idwt2d", cpu_twin.iwt_init)
+_cpu("idwt2d_backward", lambda g, bf16: _twin_vjp(
+    cpu_twin.iwt_init, [g.new_zeros(g.shape[0], 4 * g.shape[1], g.shape[2] // 2, g.shape[3] // 2,
+                                    dtype=torch.bfloat16 if bf16 else torch.float32)], [g])[0])
+_cpu("selective_scan", lambda u, delta, A, B, C, D, delta_bias, delta_softplus: cpu_twin.selective_scan_fn(
+    u, delta, A, B, C, D, None, delta_bias, delta_softplus))
+
+
+def _selective_scan_backward_cpu(u, delta, A, B, C, D, delta_bias, dout, delta_softplus):
+    gs = _twin_vjp(lambda u_, d_, A_, B_, C_, D_, b_: cpu_twin.selective_scan_fn(u_, d_, A_, B_, C_, D_, None, b_, delta_softplus),
+                   [u, delta, A, B, C, D, delta_bias], [dout])
+    z = u.new_zeros((0,), dtype=torch.float32)
+    return (gs[0], gs[1], gs[2].float(), gs[3].float(), gs[4].float(), z if gs[5] is None else gs[5].float(),
+            z if gs[6] is None else gs[6].float())
+
+
+_cpu("selective_scan_backward", _selective_scan_backward_cpu)
+_cpu("ss2d_core", lambda x, Wx, Wdt, bias, A_logs, Ds: tuple(t.contiguous() for t in cpu_twin.ss2d_core(x, Wx, Wdt, bias, A_logs, Ds)))
+_cpu("ss2d_core_backward", lambda x, Wx, Wdt, bias, A_logs, Ds, dy0, dy1, dy2, dy3: tuple(
+    g.float() for g in _twin_vjp(cpu_twin.ss2d_core, [x, Wx, Wdt, bias, A_logs, Ds], [dy0, dy1, dy2, dy3])))
 
 _o = torch.ops.wavemamba_hip
 
