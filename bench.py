@@ -333,7 +333,7 @@ def train_leg(device, steps, with_cpu_loss, batch=8, size=512):
     g = torch.Generator().manual_seed(image_seed(0))
     lq_cpu, gt_cpu = torch.rand(batch, 3, size, size, generator=g), torch.rand(batch, 3, size, size, generator=g)
     lq, gt = lq_cpu.to(device), gt_cpu.to(device)
-    loss_parity = None
+    loss_parity = cpu_train = None
     with torch.no_grad():
         l_pix, l_fft = wm.trainer.losses(net(lq), gt)
     first = (float(l_pix), float(l_fft))
@@ -347,7 +347,24 @@ def train_leg(device, steps, with_cpu_loss, batch=8, size=512):
         loss_parity = {"gpu": first, "cpu_oracle_network": (float(c_pix), float(c_fft)),
                        "rel_diff": max(abs(first[0] - float(c_pix)) / float(c_pix), abs(first[1] - float(c_fft)) / float(c_fft)),
                        "bar": 1e-6}
-        del net_cpu
+        # the number beside the GPU's: the same optimize_parameters() on the host cores, on a bounded sample (one pair of the batch)
+        cores = oracle.usable_cpus(cap=1 << 20)
+        torch.set_num_threads(cores)
+        oracle.set_num_threads(cores)
+        opt_cpu = wm.trainer.make_optimizer(net_cpu)
+        times = []
+        with oracle_backend.ops_backend(oracle):
+            for _ in range(2):                                              # 1 warm-up + 1 timed step
+                t0 = time.perf_counter()
+                wm.trainer.train_step(net_cpu, opt_cpu, lq_cpu[:1], gt_cpu[:1])
+                times.append(time.perf_counter() - t0)
+                if times[0] > 25.0:                                         # slow host: the first step is the sample
+                    break
+        cpu_train = {"value": 1.0 / times[-1], "unit": "images/s", "cores": cores, "kind": "port", "seconds_per_step": times,
+                     "sample": f"one optimize_parameters() on 1 of the {batch} pairs (1x3x{size}x{size}), the last of {len(times)} step(s): the same "
+                               f"network and trainer code with the C/OpenMP oracle as hot-path backend (forward and backward) + "
+                               f"PyTorch-CPU for the rest, {cores} threads"}
+        del net_cpu, opt_cpu
     state = {}
 
     def step():
@@ -382,6 +399,7 @@ def train_leg(device, steps, with_cpu_loss, batch=8, size=512):
            "selective_scan_forward": {"ms_per_step": fwd_ms,
                                       "frac": SCAN_BYTES_PER_POS[16] * pos / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fwd_ms else None},
            "losses_after_steps": wm.trainer.loss_values(state["losses"]), "first_step_loss_parity": loss_parity,
+           "cpu_baseline": cpu_train,
            "peak_mem_GB": torch.cuda.max_memory_allocated(device) / 2 ** 30}
     del net, opt
     torch.cuda.empty_cache()
