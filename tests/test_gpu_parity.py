@@ -87,8 +87,11 @@ def test_dwt_bf16_matches_reference_rounding(golden):
 def test_dwt_errors():
     with pytest.raises(RuntimeError):
         wm.ops.dwt_init(torch.zeros(1, 1, 5, 4, device=DEV))       # odd H: reference raises too
-    with pytest.raises(RuntimeError):
-        wm.ops.dwt_init(torch.zeros(1, 1, 4, 4))                   # CPU tensor: no fallback
+    xc = torch.randn(1, 3, 6, 8, generator=gen(9))                 # a CPU tensor runs the CPU twin (cpu_twin.py): same bits
+    for got, want in zip(wm.ops.dwt_init(xc), wm.ops.dwt_init(xc.to(DEV))):
+        assert got.device.type == "cpu" and torch.equal(got, want.cpu())
+    with pytest.raises(RuntimeError):                              # mixed devices: neither implementation takes them
+        wm.ops.iwt_init_pair(torch.zeros(1, 1, 4, 4), torch.zeros(1, 3, 4, 4, device=DEV))
     assert all(o.numel() == 0 for o in wm.ops.dwt_init(torch.zeros(0, 3, 4, 4, device=DEV)))
 
 
@@ -213,8 +216,10 @@ def test_scan_errors():
         wm.ops.selective_scan_fn(u, delta[:, :, :8], A, Bm, Cm)
     with pytest.raises(RuntimeError):
         wm.ops.selective_scan_fn(u, delta, A, Bm[:, :, :3], Cm)
-    with pytest.raises(RuntimeError):
-        wm.ops.selective_scan_fn(u.cpu(), delta.cpu(), A.cpu(), Bm.cpu(), Cm.cpu())
+    with pytest.raises(RuntimeError):                              # mixed devices: refused (all-CPU inputs run the CPU twin)
+        wm.ops.selective_scan_fn(u.cpu(), delta, A, Bm, Cm)
+    assert_close(wm.ops.selective_scan_fn(u.cpu(), delta.cpu(), A.cpu(), Bm.cpu(), Cm.cpu()),
+                 wm.ops.selective_scan_fn(u, delta, A, Bm, Cm).cpu(), TOL, "CPU twin vs HIP")
     with pytest.raises(NotImplementedError):
         wm.ops.selective_scan_fn(u, delta, A, A, A)
 
