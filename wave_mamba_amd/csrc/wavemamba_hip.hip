@@ -375,6 +375,25 @@ static int bwd_finish_split(int nblocks, int npp) {
     long long y = (per + 4LL * stride - 1) / (4LL * stride);
     return (int)(y < 1 ? 1 : (y > 64 ? 64 : y));
 }
+// The fused core's gradient kernel (core_bwd_chunk_kernel) is a workgroup of NP / 8 waves with 37,952 / 58,944 B of LDS and ~256
+// registers per lane: FOUR (N <= 16) / TWO (N <= 32) workgroups are resident per compute unit, 1024 / 512 on the chip, and a
+// workgroup pays a prologue (weights, carried states) of ~0.4 chunks before its first chunk.  Its block length is therefore chosen
+// per shape: the chunks per block c in [1, 32] that minimise  ceil(workgroups(c) / resident) * (c + 0.4)  - whole dispatch rounds
+// of resident workgroups - ties to the longer block (fewer summaries, shorter carry).  Round 5, BASELINE config 3 on one MI355X
+// (profiles/r05/core_bwd_block_length_ab.txt): against "at least 2048 blocks, at most 16 chunks" (two rounds at every level)
+// 3.93 -> 3.77 / 1.19 -> 1.04 / 0.514 -> 0.368 ms per call at levels 1 / 2 / 3, 59.0 -> 57.1 ms per training step; 512, 1536, 2048
+// and 4096 blocks are all slower (1536: one and a half rounds, the worst).
+static int bwd_fused_cpb(int nchunks, long long rows, int NP) {
+    const long long resident = NP == 16 ? 1024 : 512;
+    int best = 1;
+    double best_cost = 1e300;
+    for (int c = 1; c <= 32; ++c) {
+        const long long wgs = (long long)((nchunks + c - 1) / c) * rows;
+        const double cost = (double)((wgs + resident - 1) / resident) * (c + 0.4);
+        if (cost <= best_cost) { best_cost = cost; best = c; }
+    }
+    return best;
+}
 static int bwd_plan(BwdPlan& pl, int batch, int dim, int L, int N, int G, int part_pad = kPartPad) {
     if (batch <= 0 || dim <= 0 || L <= 0 || N <= 0 || G <= 0) return WM_EINVAL;
     if (N > 32) return WM_EUNSUPPORTED;
@@ -389,6 +408,7 @@ static int bwd_plan(BwdPlan& pl, int batch, int dim, int L, int N, int G, int pa
         const long long blocks1 = (long long)pl.nchunks * pl.rows;
         const int cpb = (int)(blocks1 / (long long)WM_BWD_MIN_BLOCKS);
         pl.cpb = cpb < 1 ? 1 : (cpb > WM_BWD_CPB_MAX ? WM_BWD_CPB_MAX : cpb);
+        if (part_pad == kPartPadFused) pl.cpb = bwd_fused_cpb(pl.nchunks, rows, pl.NP);     // the fused core's gradient kernel
     }
     pl.nblocks = (pl.nchunks + pl.cpb - 1) / pl.cpb;
     pl.chains = (long long)batch * dim * pl.NP;
