@@ -930,7 +930,10 @@ def test_layernorm2d_vs_torch(C, H, W):
     assert_close(got, want.detach(), 1e-5, "LayerNorm2d")
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 40, 72), (1, 5, 7, 9), (2, 96, 33, 260)])
+@pytest.mark.parametrize("shape", [(2, 64, 40, 72), (1, 5, 7, 9), (2, 96, 33, 260),
+                                   # narrow maps: 4 / 2 planes side by side in a wave (a plane count that does not fill the last group,
+                                   # widths below the lane group, one strip and several)
+                                   (8, 64, 64, 64), (3, 7, 37, 64), (1, 5, 16, 48), (2, 3, 70, 128), (1, 9, 20, 100), (2, 32, 128, 128)])
 def test_dwconv3x3_gradients_vs_torch_autograd(shape):
     import torch.nn.functional as F
     B, C, H, W = shape
@@ -1049,7 +1052,8 @@ def test_shipped_config_golden(golden, tag, hw):
 # floating-point kernel of a standard op -> PyTorch fp32 CPU conv is the reference
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(1, 64, 32, 48), (2, 5, 7, 9), (1, 3, 1, 1), (1, 8, 130, 260),
-                                   (1, 2, 33, 1030), (1, 96, 17, 64)])
+                                   (1, 2, 33, 1030), (1, 96, 17, 64),
+                                   (8, 64, 64, 64), (3, 7, 37, 64), (1, 5, 16, 8), (2, 3, 70, 128), (1, 9, 20, 100), (1, 1, 3, 4)])
 @pytest.mark.parametrize("act", ["none", "silu"])
 def test_dwconv3x3_vs_torch(shape, act):
     import torch.nn.functional as F

@@ -15,7 +15,7 @@
 
 namespace wm {
 
-constexpr int kDwRows = 16;     // output rows per thread strip
+constexpr int kDwRows = 16;     // output rows per thread strip (the kernels' `rows` argument: 16, or 8 / 4 where 16 leave the chip short of waves)
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
 
@@ -23,16 +23,25 @@ __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 // TP: storage type of the x / y planes (float, or bf16_t in the bf16-storage mode: fp32 arithmetic either way)
-template <int ACT /*0 none, 1 silu, 2 gelu*/, bool VEC, typename TP = float>
+// LPR: lanes per strip row.  64: a wave is one strip of 256 columns.  32 / 16 (maps of <= 128 / <= 64 columns - the 128 x 128 and
+// 64 x 64 maps of a BASELINE config-3 training step): a wave is 2 / 4 PLANES side by side, 32 / 16 lanes each - at 64 lanes per plane
+// three quarters of a wave were idle on a 64-column map (24 us per launch for 16 MB).  The halo shuffles cross the planes' borders
+// harmlessly: a plane's first / last lane takes its halo from memory, as the wave's first / last lane always did.
+template <int ACT /*0 none, 1 silu, 2 gelu*/, bool VEC, typename TP = float, int LPR = 64>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const TP* __restrict__ x,
                                                         const float* __restrict__ wgt,
                                                         const float* __restrict__ bias,
                                                         TP* __restrict__ y, int C, int H, int W,
-                                                        long long planes) {
-    const int lane = threadIdx.x;                        // 64 column groups = one wave per strip row
-    const int cg = blockIdx.x * 64 + lane;               // column group (4 columns)
-    const int h0 = (blockIdx.y * 4 + threadIdx.y) * kDwRows;
-    for (long long plane = blockIdx.z; plane < planes; plane += gridDim.z) {
+                                                        long long planes, int rows) {
+    constexpr int PPW = 64 / LPR;                        // planes per wave
+    const int lane = threadIdx.x;                        // LPR column groups = one strip row of one plane
+    const int cl = lane & (LPR - 1);
+    const int cg = blockIdx.x * LPR + cl;                // column group (4 columns)
+    const int h0 = (blockIdx.y * 4 + threadIdx.y) * rows;
+    for (long long pg = blockIdx.z; pg * PPW < planes; pg += gridDim.z) {
+        const long long plane_raw = pg * PPW + lane / LPR;
+        const bool pok = plane_raw < planes;             // (a last, partly filled group of planes: its spare lanes are masked)
+        const long long plane = pok ? plane_raw : planes - 1;
         const int c = (int)(plane % C);
         float k[9];
 #pragma unroll
@@ -41,7 +50,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const TP* __restrict__ x
         const TP* xp = x + plane * (long long)H * W;
         TP* yp = y + plane * (long long)H * W;
         const int w0 = cg * 4;
-        const bool colok = w0 < W;                       // whole quad in range when VEC (W % 4 == 0)
+        const bool colok = pok && w0 < W;                // whole quad in range when VEC (W % 4 == 0)
 
         // row(r): 6 values x[r][w0-1 .. w0+4], zero outside the image
         auto load_row = [&](int r, float (&v)[6]) {
@@ -61,8 +70,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const TP* __restrict__ x
                 }
             }
             float left = __shfl_up(q.w, 1), right = __shfl_down(q.x, 1);
-            if (lane == 0) left = (rowok && w0 - 1 >= 0 && w0 - 1 < W) ? ld1(xp + (long long)r * W + w0 - 1) : 0.0f;
-            if (lane == 63) right = (rowok && w0 + 4 < W) ? ld1(xp + (long long)r * W + w0 + 4) : 0.0f;
+            if (cl == 0) left = (rowok && w0 - 1 >= 0 && w0 - 1 < W) ? ld1(xp + (long long)r * W + w0 - 1) : 0.0f;
+            if (cl == LPR - 1) right = (rowok && w0 + 4 < W) ? ld1(xp + (long long)r * W + w0 + 4) : 0.0f;
             v[0] = left; v[1] = q.x; v[2] = q.y; v[3] = q.z; v[4] = q.w; v[5] = right;
         };
 
@@ -74,7 +83,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const TP* __restrict__ x
             const int rc = min(max(r, 0), H - 1);
             const TP* rowp = xp + (long long)rc * W;
             load4(rowp + (colok ? w0 : 0), q);
-            int we = lane == 0 ? w0 - 1 : w0 + 4;
+            int we = cl == 0 ? w0 - 1 : w0 + 4;
             we = min(max(we, 0), W - 1);
             e = ld1(rowp + we);
         };
@@ -82,14 +91,14 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const TP* __restrict__ x
             const bool rowok = r >= 0 && r < H, ok = rowok && colok;
             const float q0 = ok ? q[0] : 0.f, q1 = ok ? q[1] : 0.f, q2 = ok ? q[2] : 0.f, q3 = ok ? q[3] : 0.f;
             float left = __shfl_up(q3, 1), right = __shfl_down(q0, 1);
-            if (lane == 0) left = (rowok && w0 - 1 >= 0 && w0 - 1 < W) ? e : 0.0f;
-            if (lane == 63) right = (rowok && w0 + 4 < W) ? e : 0.0f;
+            if (cl == 0) left = (rowok && w0 - 1 >= 0 && w0 - 1 < W) ? e : 0.0f;
+            if (cl == LPR - 1) right = (rowok && w0 + 4 < W) ? e : 0.0f;
             v[0] = left; v[1] = q0; v[2] = q1; v[3] = q2; v[4] = q3; v[5] = right;
         };
 
         if (h0 < H) {                                     // uniform per wave (threadIdx.y, blockIdx.y)
             float r0[6], r1[6], r2[6];
-            const int hend = min(H, h0 + kDwRows);
+            const int hend = min(H, h0 + rows);
             auto body = [&](int h) {
                 float o[4];
 #pragma unroll
@@ -147,19 +156,24 @@ namespace wm {
 // dW[c][i][j] = sum_{b,h,w} gy[b,c,h,w] * x[b,c,h+i-1,w+j-1]   (zero padding),   db[c] = sum gy[b,c,h,w]
 // Same strip walk as the forward (3-row register window of x, 4 columns per thread); 10 per-thread partial
 // sums are reduced over the wave by shuffles and leave through one atomicAdd per wave and value.
-template <bool VEC>
+template <bool VEC, int LPR = 64>
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                               float* __restrict__ dW, float* __restrict__ db, int C,
-                                                              int H, int W, long long planes) {
+                                                              int H, int W, long long planes, int rows) {
+    constexpr int PPW = 64 / LPR;                        // planes per wave (dwconv3x3_kernel: narrow maps)
     const int lane = threadIdx.x;
-    const int cg = blockIdx.x * 64 + lane;
-    const int h0 = (blockIdx.y * 4 + threadIdx.y) * kDwRows;
-    for (long long plane = blockIdx.z; plane < planes; plane += gridDim.z) {
+    const int cl = lane & (LPR - 1);
+    const int cg = blockIdx.x * LPR + cl;
+    const int h0 = (blockIdx.y * 4 + threadIdx.y) * rows;
+    for (long long pg = blockIdx.z; pg * PPW < planes; pg += gridDim.z) {
+        const long long plane_raw = pg * PPW + lane / LPR;
+        const bool pok = plane_raw < planes;
+        const long long plane = pok ? plane_raw : planes - 1;
         const int c = (int)(plane % C);
         const float* xp = x + plane * (long long)H * W;
         const float* gp = gy + plane * (long long)H * W;
         const int w0 = cg * 4;
-        const bool colok = w0 < W;
+        const bool colok = pok && w0 < W;
         auto load_row = [&](int r, float (&v)[6]) {
             float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
             const bool rowok = r >= 0 && r < H;
@@ -174,8 +188,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
                 }
             }
             float left = __shfl_up(q.w, 1), right = __shfl_down(q.x, 1);
-            if (lane == 0) left = (rowok && w0 - 1 >= 0 && w0 - 1 < W) ? xp[(long long)r * W + w0 - 1] : 0.0f;
-            if (lane == 63) right = (rowok && w0 + 4 < W) ? xp[(long long)r * W + w0 + 4] : 0.0f;
+            if (cl == 0) left = (rowok && w0 - 1 >= 0 && w0 - 1 < W) ? xp[(long long)r * W + w0 - 1] : 0.0f;
+            if (cl == LPR - 1) right = (rowok && w0 + 4 < W) ? xp[(long long)r * W + w0 + 4] : 0.0f;
             v[0] = left; v[1] = q.x; v[2] = q.y; v[3] = q.z; v[4] = q.w; v[5] = right;
         };
         // 16-byte form: as in the forward kernel - unconditional loads from clamped addresses (x quad, its halo element,
@@ -184,7 +198,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
             const int rc = min(max(r, 0), H - 1), gc = min(max(r - 1, 0), H - 1);
             const float* rowp = xp + (long long)rc * W;
             q = *reinterpret_cast<const float4*>(rowp + (colok ? w0 : 0));
-            int we = lane == 0 ? w0 - 1 : w0 + 4;
+            int we = cl == 0 ? w0 - 1 : w0 + 4;
             we = min(max(we, 0), W - 1);
             e = rowp[we];
             gq = *reinterpret_cast<const float4*>(gp + (long long)gc * W + (colok ? w0 : 0));
@@ -193,8 +207,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
             const bool rowok = r >= 0 && r < H, ok = rowok && colok;
             const float q0 = ok ? q.x : 0.f, q1 = ok ? q.y : 0.f, q2 = ok ? q.z : 0.f, q3 = ok ? q.w : 0.f;
             float left = __shfl_up(q3, 1), right = __shfl_down(q0, 1);
-            if (lane == 0) left = (rowok && w0 - 1 >= 0 && w0 - 1 < W) ? e : 0.0f;
-            if (lane == 63) right = (rowok && w0 + 4 < W) ? e : 0.0f;
+            if (cl == 0) left = (rowok && w0 - 1 >= 0 && w0 - 1 < W) ? e : 0.0f;
+            if (cl == LPR - 1) right = (rowok && w0 + 4 < W) ? e : 0.0f;
             v[0] = left; v[1] = q0; v[2] = q1; v[3] = q2; v[4] = q3; v[5] = right;
         };
         float acc[10];
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
         for (int i = 0; i < 10; ++i) acc[i] = 0.0f;
         if (h0 < H) {
             float r0[6], r1[6], r2[6];
-            const int hend = min(H, h0 + kDwRows);
+            const int hend = min(H, h0 + rows);
             auto body = [&](const float (&g)[4]) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -244,16 +258,29 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
             }
             }
         }
+        // over the plane's lanes (shuffles), then over the workgroup's four strips (LDS, fixed order), then ONE atomic per value and
+        // plane: the atomics are what a launch on a small map costs (round 5: four times the strips = twice the time)
+        __shared__ float s_part[4][PPW][10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
             float v = acc[i];
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-            if (lane == 0 && v != 0.0f) {
-                if (i < 9) atomicAdd(dW + c * 9 + i, v);
-                else if (db) atomicAdd(db + c, v);
+            for (int off = LPR / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+            if (cl == 0) s_part[threadIdx.y][lane / LPR][i] = v;
+        }
+        __syncthreads();
+        if (threadIdx.y == 0 && cl == 0) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int sp = lane / LPR;
+                const float v = (s_part[0][sp][i] + s_part[1][sp][i]) + (s_part[2][sp][i] + s_part[3][sp][i]);
+                if (v != 0.0f) {
+                    if (i < 9) atomicAdd(dW + c * 9 + i, v);
+                    else if (db) atomicAdd(db + c, v);
+                }
             }
         }
+        __syncthreads();                                 // s_part is rewritten by the next group of planes
     }
 }
 

@@ -503,6 +503,16 @@ int wm_selscan_bwd(const float* u, const float* delta, const float* A, const flo
     return vec ? bwd_launch<32, true>(a, pl, seg, dA, dD, dbias, st) : bwd_launch<32, false>(a, pl, seg, dA, dD, dbias, st);
 }
 
+// lanes per strip row of the depth-wise kernels (dwconv.hip.h): narrow maps put 2 / 4 planes side by side in a wave
+static int dw_lanes_per_row(int W, bool vec) { return !vec || W > 128 ? 64 : (W > 64 ? 32 : 16); }
+// rows per strip: 16 (every input row fetched 18 / 16 times), or 8 / 4 on small problems - a strip is a chain of dependent row
+// fetches, and 16-row strips of a 64 x 64 map are 128-384 workgroups for 256 compute units (21 us per weight-gradient launch at
+// BASELINE config 3's level 3, whatever the lanes did)
+static int dw_strip_rows(int H, long long column_blocks, long long plane_groups) {
+    const long long waves16 = column_blocks * ((H + kDwRows - 1) / kDwRows) * plane_groups;
+    return waves16 >= 2048 ? kDwRows : (waves16 >= 1024 ? 8 : 4);
+}
+
 int wm_dwconv3x3_fwd(const void* x, const float* weight, const float* bias, void* y, int B, int C,
                      int H, int W, int act, int plane_dtype, void* stream) {
     if (B < 0 || C < 0 || H < 0 || W < 0) return WM_EINVAL;
@@ -511,24 +521,31 @@ int wm_dwconv3x3_fwd(const void* x, const float* weight, const float* bias, void
     if (planes == 0 || H == 0 || W == 0) return WM_OK;
     if (!x || !weight || !y) return WM_ENULL;
     const bool vec = (W % 4 == 0) && aligned16(x) && aligned16(y);      // (bf16: 8-byte accesses, covered by the same test)
+    const int lpr = dw_lanes_per_row(W, vec);
+    const long long pgroups = (planes + 64 / lpr - 1) / (64 / lpr);
     const dim3 block(64, 4);
-    const dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 4 * kDwRows - 1) / (4 * kDwRows)),
-                    (unsigned)(planes < 65535 ? planes : 65535));
+    const int rows = dw_strip_rows(H, (W + 4 * lpr - 1) / (4 * lpr), pgroups);
+    const dim3 grid((unsigned)((W + 4 * lpr - 1) / (4 * lpr)), (unsigned)((H + 4 * rows - 1) / (4 * rows)),
+                    (unsigned)(pgroups < 65535 ? pgroups : 65535));
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps(act == 1 ? 7 : 17, st);       // + SiLU: SS2D's conv2d (:486-487, hot path); the others belong to the HFE branch / the ffn
-#define WM_DW(ACT, VEC)                                                                                                  \
-    do {                                                                                                                 \
-        if (plane_dtype == WM_F32)                                                                                       \
-            hipLaunchKernelGGL((dwconv3x3_kernel<ACT, VEC, float>), grid, block, 0, st, (const float*)x, weight, bias,   \
-                               (float*)y, C, H, W, planes);                                                              \
-        else                                                                                                             \
-            hipLaunchKernelGGL((dwconv3x3_kernel<ACT, VEC, bf16_t>), grid, block, 0, st, (const bf16_t*)x, weight, bias, \
-                               (bf16_t*)y, C, H, W, planes);                                                             \
+#define WM_DW1(ACT, VEC, LPR)                                                                                                 \
+    do {                                                                                                                      \
+        if (plane_dtype == WM_F32)                                                                                            \
+            hipLaunchKernelGGL((dwconv3x3_kernel<ACT, VEC, float, LPR>), grid, block, 0, st, (const float*)x, weight, bias,   \
+                               (float*)y, C, H, W, planes, rows);                                                             \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((dwconv3x3_kernel<ACT, VEC, bf16_t, LPR>), grid, block, 0, st, (const bf16_t*)x, weight, bias, \
+                               (bf16_t*)y, C, H, W, planes, rows);                                                            \
     } while (0)
-    if (act == 1) { if (vec) WM_DW(1, true); else WM_DW(1, false); }
-    else if (act == 2) { if (vec) WM_DW(2, true); else WM_DW(2, false); }
-    else          { if (vec) WM_DW(0, true); else WM_DW(0, false); }
+#define WM_DW(ACT)                                                                                                            \
+    do {                                                                                                                      \
+        if (!vec) WM_DW1(ACT, false, 64); else if (lpr == 64) WM_DW1(ACT, true, 64);                                          \
+        else if (lpr == 32) WM_DW1(ACT, true, 32); else WM_DW1(ACT, true, 16);                                                \
+    } while (0)
+    if (act == 1) WM_DW(1); else if (act == 2) WM_DW(2); else WM_DW(0);
 #undef WM_DW
+#undef WM_DW1
     return launch_status();
 }
 
@@ -1389,11 +1406,16 @@ int wm_dwconv3x3_wgrad(const float* x, const float* gy, float* dW, float* db, in
     if (planes == 0 || H == 0 || W == 0) return WM_OK;
     if (!x || !gy) return WM_ENULL;
     const bool vec = (W % 4 == 0) && aligned16(x) && aligned16(gy);
+    const int lpr = dw_lanes_per_row(W, vec);
+    const long long pgroups = (planes + 64 / lpr - 1) / (64 / lpr);
     const dim3 block(64, 4);
-    const dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 4 * kDwRows - 1) / (4 * kDwRows)),
-                    (unsigned)(planes < 65535 ? planes : 65535));
-    if (vec) hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<true>), grid, block, 0, st, x, gy, dW, db, C, H, W, planes);
-    else hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<false>), grid, block, 0, st, x, gy, dW, db, C, H, W, planes);
+    const int rows = kDwRows;                  // (shorter strips on small maps: more atomics - twice the time at config 3's level 3)
+    const dim3 grid((unsigned)((W + 4 * lpr - 1) / (4 * lpr)), (unsigned)((H + 4 * rows - 1) / (4 * rows)),
+                    (unsigned)(pgroups < 65535 ? pgroups : 65535));
+    if (!vec) hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<false, 64>), grid, block, 0, st, x, gy, dW, db, C, H, W, planes, rows);
+    else if (lpr == 64) hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<true, 64>), grid, block, 0, st, x, gy, dW, db, C, H, W, planes, rows);
+    else if (lpr == 32) hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<true, 32>), grid, block, 0, st, x, gy, dW, db, C, H, W, planes, rows);
+    else hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<true, 16>), grid, block, 0, st, x, gy, dW, db, C, H, W, planes, rows);
     return launch_status();
 }
 
