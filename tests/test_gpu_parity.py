@@ -950,7 +950,7 @@ def test_dwconv3x3_gradients_vs_torch_autograd(shape):
         assert_close(a, r, 2e-5, f"dwconv {name}")
 
 
-@pytest.mark.parametrize("C,H,W", [(32, 33, 47), (16, 8, 8), (8, 5, 130)])
+@pytest.mark.parametrize("C,H,W", [(32, 33, 47), (16, 8, 8), (8, 5, 130), (64, 33, 47), (64, 64, 64), (32, 128, 128), (64, 1, 1), (32, 3, 5)])
 def test_layernorm2d_gradients_vs_torch_autograd(C, H, W):
     x = torch.randn(2, C, H, W, generator=gen(1)) * 2 + 0.5
     w = torch.randn(C, generator=gen(2))

@@ -107,17 +107,19 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void scale_add_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                             const float* __restrict__ s, float* __restrict__ gx,
                                                             float* __restrict__ gs, int C, long long L) {
+    // A block walks its plane in steps of gridDim.x * 1024 elements (the host launches at most 8 blocks per plane): one atomic per
+    // block - at one block per 1024 elements a 256 x 256 map was 16,384 atomics on the 32 addresses of ONE cache line, and they,
+    // not the 200 MB, were the launch (120 us; round 5).
     __shared__ float s_red[4];
-    const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     const int c = blockIdx.y % C;
-    const long long base = (long long)blockIdx.y * L + e;
     const float sc = s[c];
     float acc = 0.0f;
-    if (e < L) {
+    for (long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; e < L; e += (long long)gridDim.x * 1024) {
+        const long long base = (long long)blockIdx.y * L + e;
         if constexpr (VEC) {
             const float4 gv = *reinterpret_cast<const float4*>(g + base), xv = *reinterpret_cast<const float4*>(x + base);
             *reinterpret_cast<float4*>(gx + base) = make_float4(gv.x * sc, gv.y * sc, gv.z * sc, gv.w * sc);
-            acc = fmaf(gv.x, xv.x, fmaf(gv.y, xv.y, fmaf(gv.z, xv.z, gv.w * xv.w)));
+            acc += fmaf(gv.x, xv.x, fmaf(gv.y, xv.y, fmaf(gv.z, xv.z, gv.w * xv.w)));
         } else {
             for (int j = 0; j < 4 && e + j < L; ++j) { gx[base + j] = g[base + j] * sc; acc = fmaf(g[base + j], x[base + j], acc); }
         }

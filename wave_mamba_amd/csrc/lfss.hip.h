@@ -248,56 +248,63 @@ __global__ __launch_bounds__(256) void layernorm2d_bwd_kernel(const float* __res
     }
 }
 
-// ---- LayerNorm2d backward for wide maps (C = 64: SS2D.out_norm on (B, D, L) planes in the NCHW training path) ---------
-// The register-resident form above needs 4 C values per thread; here the channels are streamed three times (statistics,
-// the two means of the gradient, the input gradient - re-reads hit in cache) and only the 2 C parameter-gradient
-// partials stay in registers.
+// ---- LayerNorm2d backward, two lanes per pixel (C = 64: SS2D.out_norm on (B, D, L) planes in the NCHW training path; C = 32:
+// LayerNorm2d of the HFE branch) ------------------------------------------------------------------------------------------
+// Adjacent lanes (2 p, 2 p + 1) own pixel p: lane half h holds channels [h C / 2, (h + 1) C / 2) of x and gy in registers - read
+// ONCE - and the channel sums (mean, variance, the two means of the gradient) cross the pair by one shuffle each.  Round 4's form
+// for C = 64 streamed the channels three times with only the parameter-gradient partials in registers (370 us for a 134-MB map:
+// 800 MB of cache re-reads); the one-lane-per-pixel form above needs 4 C registers per thread.  Twice the threads per pixel also
+// fills the chip on the 64 x 64 maps of BASELINE config 3 (32,768 pixels).
 template <int C>
-__global__ __launch_bounds__(256) void layernorm2d_bwd_stream_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                                     const float* __restrict__ gy, float eps,
-                                                                     float* __restrict__ gx, float* __restrict__ dw,
-                                                                     float* __restrict__ db, int B, long long L) {
-    float pw[C], pb[C];
+__global__ __launch_bounds__(256) void layernorm2d_bwd_pair_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                   const float* __restrict__ gy, float eps,
+                                                                   float* __restrict__ gx, float* __restrict__ dw,
+                                                                   float* __restrict__ db, int B, long long L) {
+    constexpr int CH = C / 2;
+    const int h = threadIdx.x & 1;
+    float pw[CH], pb[CH], wv[CH];
 #pragma unroll
-    for (int c = 0; c < C; ++c) { pw[c] = 0.0f; pb[c] = 0.0f; }
+    for (int c = 0; c < CH; ++c) { pw[c] = 0.0f; pb[c] = 0.0f; wv[c] = w[h * CH + c]; }
     const long long total = (long long)B * L;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long step = ((long long)gridDim.x * blockDim.x) >> 1;
+    for (long long idx = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 1; idx < total; idx += step) {   // (the pair shares idx)
         const long long bb = idx / L, p = idx - bb * L;
-        const float* xp = x + bb * C * L + p;
-        const float* gp = gy + bb * C * L + p;
-        float* op = gx + bb * C * L + p;
+        const long long base = (bb * C + h * CH) * L + p;
+        float v[CH], g[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { v[c] = x[base + (long long)c * L]; g[c] = gy[base + (long long)c * L]; }
         float mean = 0.0f;
-#pragma unroll 16
-        for (int c = 0; c < C; ++c) mean += xp[(long long)c * L];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) mean += v[c];
+        mean += __shfl_xor(mean, 1);
         mean *= (1.0f / C);
         float var = 0.0f;
-#pragma unroll 16
-        for (int c = 0; c < C; ++c) { const float d = xp[(long long)c * L] - mean; var = fmaf(d, d, var); }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { const float d = v[c] - mean; var = fmaf(d, d, var); }
+        var += __shfl_xor(var, 1);
         const float rstd = 1.0f / sqrtf(var * (1.0f / C) + eps);
         float mg = 0.0f, mgy = 0.0f;
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const float yh = (xp[(long long)c * L] - mean) * rstd, g0 = gp[(long long)c * L];
-            pw[c] = fmaf(g0, yh, pw[c]);
-            pb[c] += g0;
-            const float g = g0 * w[c];
-            mg += g;
-            mgy = fmaf(g, yh, mgy);
+        for (int c = 0; c < CH; ++c) {
+            v[c] = (v[c] - mean) * rstd;                          // yhat
+            pw[c] = fmaf(g[c], v[c], pw[c]);
+            pb[c] += g[c];
+            g[c] *= wv[c];
+            mg += g[c];
+            mgy = fmaf(g[c], v[c], mgy);
         }
+        mg += __shfl_xor(mg, 1); mgy += __shfl_xor(mgy, 1);
         mg *= (1.0f / C); mgy *= (1.0f / C);
-#pragma unroll 16
-        for (int c = 0; c < C; ++c) {
-            const float yh = (xp[(long long)c * L] - mean) * rstd;
-            op[(long long)c * L] = rstd * (gp[(long long)c * L] * w[c] - yh * mgy - mg);
-        }
-    }
-    __shared__ float s_red[4][2 * C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
+        for (int c = 0; c < CH; ++c) gx[base + (long long)c * L] = rstd * (g[c] - v[c] * mgy - mg);
+    }
+    __shared__ float s_red[4][2 * C];                  // per-wave sums -> one atomic per block and channel
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
         float a = pw[c], bsum = pb[c];
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off); bsum += __shfl_xor(bsum, off); }
-        if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6][c] = a; s_red[threadIdx.x >> 6][C + c] = bsum; }
+        for (int off = 32; off >= 2; off >>= 1) { a += __shfl_xor(a, off); bsum += __shfl_xor(bsum, off); }   // lanes of one half
+        if ((threadIdx.x & 63) < 2) { s_red[threadIdx.x >> 6][h * CH + c] = a; s_red[threadIdx.x >> 6][C + h * CH + c] = bsum; }
     }
     __syncthreads();
     if (threadIdx.x < 2 * C) {

@@ -1430,11 +1430,12 @@ int wm_layernorm2d_bwd(const float* x, const float* weight, const float* gy, flo
     const long long total = (long long)B * L;
     if (total == 0) return WM_OK;
     if (!x || !weight || !gy || !gx) return WM_ENULL;
-    long long blocks = (total + 255) / 256;
+    const int tpp = C >= 32 ? 2 : 1;                     // threads per pixel (layernorm2d_bwd_pair_kernel)
+    long long blocks = (total * tpp + 255) / 256;
     if (blocks > 512) blocks = 512;                      // grid-stride: few blocks -> few atomics per channel
     const dim3 grid((unsigned)blocks), block(256);
-    if (C == 64) hipLaunchKernelGGL((layernorm2d_bwd_stream_kernel<64>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
-    else if (C == 32) hipLaunchKernelGGL((layernorm2d_bwd_kernel<32>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
+    if (C == 64) hipLaunchKernelGGL((layernorm2d_bwd_pair_kernel<64>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
+    else if (C == 32) hipLaunchKernelGGL((layernorm2d_bwd_pair_kernel<32>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
     else if (C == 16) hipLaunchKernelGGL((layernorm2d_bwd_kernel<16>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
     else hipLaunchKernelGGL((layernorm2d_bwd_kernel<8>), grid, block, 0, st, x, weight, gy, eps, gx, dweight, dbias, B, (long long)L);
     return launch_status();
@@ -1690,7 +1691,11 @@ int wm_scale_add_bwd(const float* g, const float* x, const float* scale, float* 
     if (!g || !x || !scale || !gx) return WM_ENULL;
     if ((long long)B * C > 65535) return WM_EUNSUPPORTED;
     const bool vec = L % 4 == 0 && aligned16(g) && aligned16(x) && aligned16(gx);
-    const dim3 grid((unsigned)((L + 1023) / 1024), (unsigned)(B * C)), block(256);
+    long long bpp = (L + 1023) / 1024;                       // blocks per plane: <= 8 (scale_add_bwd_kernel), >= ~2048 in all if the map allows
+    const long long want = (2048 + (long long)B * C - 1) / ((long long)B * C);
+    const long long cap = want > 8 ? want : 8;
+    if (bpp > cap) bpp = cap;
+    const dim3 grid((unsigned)bpp, (unsigned)(B * C)), block(256);
     if (vec) hipLaunchKernelGGL(scale_add_bwd_kernel<true>, grid, block, 0, st, g, x, scale, gx, gscale, C, (long long)L);
     else hipLaunchKernelGGL(scale_add_bwd_kernel<false>, grid, block, 0, st, g, x, scale, gx, gscale, C, (long long)L);
     return launch_status();
