@@ -158,8 +158,9 @@ int wm_ss2d_core_prep(const float* x_proj_weight, const float* dt_projs_weight, 
  * Depth-wise 3x3 convolution, stride 1, zero padding 1, + bias, + optional SiLU.
  * Replaces nn.Conv2d(groups=channels) + nn.SiLU of SS2D (wavemamba_arch.py:346-355, :487) and the
  * ffn's conv2 (:220, :226) in LFSSBlock.  x, y (B, C, H, W) fp32; weight (C, 1, 3, 3); bias (C) or
- * NULL; act: 0 = none, 1 = SiLU, 2 = GELU (exact erf form).  plane_dtype: storage type of x and y (WM_F32 / WM_BF16,
- * fp32 arithmetic).  Forward only (training keeps the autograd conv).
+ * NULL; act: 0 = none, 1 = SiLU, 2 = GELU (exact erf form), + 4: the nine taps of every channel rotated by 180 degrees
+ * (weight.flip(2, 3) without the flipped copy: the input gradient of the same convolution is act = 4 on gy).
+ * plane_dtype: storage type of x and y (WM_F32 / WM_BF16, fp32 arithmetic).  Forward only.
  * -------------------------------------------------------------------------------------------- */
 int wm_dwconv3x3_fwd(const void* x, const float* weight, const float* bias, void* y,
                      int B, int C, int H, int W, int act, int plane_dtype, void* stream);
@@ -231,7 +232,7 @@ int wm_gram_fwd(const float* X, const float* Y, float* G, float* nx, float* ny, 
 
 /* Training-side gradients of the two streaming helpers above.
  *   wm_dwconv3x3_wgrad: dW (C,1,3,3) and db (C, may be NULL) of the depth-wise conv from x and gy (B,C,H,W);
- *     the input gradient is wm_dwconv3x3_fwd(gy, flipped weight, NULL).
+ *     the input gradient is wm_dwconv3x3_fwd(gy, weight, NULL, act = 4).
  *   wm_layernorm2d_bwd: reference LayerNormFunction.backward (wavemamba_arch.py:545-557): gx, dweight, dbias. */
 int wm_dwconv3x3_wgrad(const float* x, const float* gy, float* dW, float* db, int B, int C, int H, int W,
                        void* stream);
@@ -286,6 +287,11 @@ int wm_conv2d_ln_fwd(const float* x, const float* ln_weight, const float* ln_bia
 /* amax[0] = max |x[0..nx)|, amax[1] = max |weight[0..nw)| (device floats; one memset + one launch on `stream`). */
 int wm_conv2d_amax(const float* x, int64_t nx, const float* weight, int64_t nw, float* amax, void* stream);
 int wm_conv2d_prep_f16(const float* weight, const float* amax, void* wfrag, int Cout, int Cin, int ks, void* stream);
+/* The same fragments for the INPUT-GRADIENT convolution of a forward convolution whose weight is `weight` (Cin, Cout, ks, ks):
+ * w'[co][ci][ky][kx] = weight[ci][co][ks-1-ky][ks-1-kx] (what autograd evaluates as conv(gy, weight.transpose(0, 1).flip(2, 3)))
+ * read straight from the forward weight - no flipped copy exists.  Cout / Cin are those of the gradient convolution (= the
+ * forward's Cin / Cout).  amax[1] = max |weight| as for the forward (a permutation does not change it). */
+int wm_conv2d_prep_f16_dgrad(const float* weight, const float* amax, void* wfrag, int Cout, int Cin, int ks, void* stream);
 int wm_conv2d_fwd_f16(const float* x, const void* wfrag, const float* amax, const float* bias, float* y, int B, int Cin, int Cout,
                       int H, int W, int ks, void* stream);
 /* The three steps above in one call (ops.conv2d_f16 issues the three steps itself, with `amax` in its zeroed arena): workspace =

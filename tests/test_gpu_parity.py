@@ -2073,6 +2073,36 @@ def test_conv2d_ln_bit_identical_to_two_launches(B, Cout, H, W, res):
         assert_close(one, ref.float(), 2e-5, "conv2d_ln vs float64")
 
 
+@pytest.mark.parametrize("ks,Cin,Cout", [(3, 64, 64), (1, 32, 96), (3, 3, 32), (3, 32, 3), (1, 64, 32), (3, 20, 40)])
+def test_conv2d_f16_input_gradient_from_the_forward_weight(ks, Cin, Cout):
+    """conv2d_f16(gy, weight, dgrad=True): the fragments of weight.transpose(0, 1).flip(2, 3) read from the forward weight
+    (wm_conv2d_prep_f16_dgrad) - bit-identical to preparing the materialised tensor, and the float64 input gradient of F.conv2d."""
+    gg = gen(ks * 100 + Cin + Cout)
+    w = (torch.randn(Cout, Cin, ks, ks, generator=gg) / (Cin * ks * ks) ** 0.5).to(DEV)
+    gy = torch.randn(2, Cout, 24, 40, generator=gg).to(DEV)
+    got = wm.ops.conv2d_f16(gy, w, dgrad=True)
+    want = wm.ops.conv2d_f16(gy, w.transpose(0, 1).flip(2, 3).contiguous())
+    assert torch.equal(got, want), f"max |diff| {float((got - want).abs().max()):.3e}"
+    x = torch.zeros(2, Cin, 24, 40, dtype=torch.float64, device=DEV, requires_grad=True)
+    ref, = torch.autograd.grad(F.conv2d(x, w.double(), None, padding=ks // 2), x, gy.double())
+    assert_close(got, ref.float(), 1e-6, "input gradient vs float64")
+
+
+def test_dwconv3x3_flipped_taps():
+    """wm_dwconv3x3_fwd(act + 4): the taps rotated by 180 degrees without a flipped copy of the weight - bit-identical to passing
+    weight.flip(2, 3), every activation, fp32 and bf16 planes, wide and narrow maps."""
+    gg = gen(21)
+    for shape in ((2, 16, 20, 36), (1, 8, 33, 260), (3, 5, 64, 64)):
+        x = torch.randn(*shape, generator=gg).to(DEV)
+        w = torch.randn(shape[1], 1, 3, 3, generator=gg).to(DEV)
+        b = torch.randn(shape[1], generator=gg).to(DEV)
+        for act in ("none", "silu", "gelu"):
+            assert torch.equal(wm.ops.dwconv3x3(x, w, b, act, flip=True), wm.ops.dwconv3x3(x, w.flip(2, 3).contiguous(), b, act))
+        if shape[3] % 4 == 0:
+            assert torch.equal(wm.ops.dwconv3x3(x.bfloat16(), w, None, "none", flip=True),
+                               wm.ops.dwconv3x3(x.bfloat16(), w.flip(2, 3).contiguous(), None, "none"))
+
+
 def test_conv2d_f16_degenerate_inputs():
     """all-zero input (scale falls back to 1), a single non-zero element, a constant map: exact / fp32-class results"""
     w = torch.randn(32, 16, 3, 3, generator=gen(1)).to(DEV)

@@ -151,7 +151,7 @@ __device__ __forceinline__ f32x16_t cv_mfma(const Frag16& A, const Frag16& B, f3
 template <bool F16 = false>
 __global__ __launch_bounds__(256) void conv2d_prep_kernel(const float* __restrict__ w, uint4* __restrict__ wfrag,
                                                           int Cout, int Cin, int taps, int nch, int mtot,
-                                                          const float* __restrict__ amax = nullptr) {
+                                                          const float* __restrict__ amax = nullptr, int dgrad = 0) {
     const float sw = F16 ? cv_pow2_scale(amax[1]) : 1.0f;
     const long long total = (long long)nch * taps * mtot * 2 * 64;
     for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -165,7 +165,12 @@ __global__ __launch_bounds__(256) void conv2d_prep_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int ci = ci0 + j;
-            const float v = (co < Cout && ci < Cin) ? w[((long long)co * Cin + ci) * taps + tap] : 0.0f;
+            // dgrad: `w` is the FORWARD convolution's (Cin, Cout, KS, KS) weight and the fragments are those of its transposed,
+            // 180-degree-rotated form w'[co][ci][tap] = w[ci][co][taps - 1 - tap] - the input-gradient convolution's weight, which
+            // autograd's formula materialises with a flip and a copy kernel per convolution and step
+            const float v = (co < Cout && ci < Cin)
+                                ? (dgrad ? w[((long long)ci * Cout + co) * taps + (taps - 1 - tap)] : w[((long long)co * Cin + ci) * taps + tap])
+                                : 0.0f;
             Frag16 hi, lo;
             cv_split<F16>(F16 ? v * sw : v, hi, lo, j);
             if constexpr (F16) f.h[j] = split ? lo.h[j] : hi.h[j];

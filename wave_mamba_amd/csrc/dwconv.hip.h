@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const TP* __restrict__ x
                                                         const float* __restrict__ wgt,
                                                         const float* __restrict__ bias,
                                                         TP* __restrict__ y, int C, int H, int W,
-                                                        long long planes, int rows) {
+                                                        long long planes, int rows, int flip) {
     constexpr int PPW = 64 / LPR;                        // planes per wave
     const int lane = threadIdx.x;                        // LPR column groups = one strip row of one plane
     const int cl = lane & (LPR - 1);
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const TP* __restrict__ x
         const int c = (int)(plane % C);
         float k[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) k[i] = wgt[c * 9 + i];
+        for (int i = 0; i < 9; ++i) k[i] = wgt[c * 9 + (flip ? 8 - i : i)];   // flip: the taps rotated by 180 degrees (input gradient)
         const float bv = bias ? bias[c] : 0.0f;
         const TP* xp = x + plane * (long long)H * W;
         TP* yp = y + plane * (long long)H * W;

@@ -307,12 +307,17 @@ __device__ __forceinline__ void core_bwd_reduce_body(const CoreBwdArgs& p, float
     }
 }
 
-// grid (nblocks, B, 2): blockIdx.z = the layout's forward (a0) / reversed (a1) direction
+// grid (nblocks, B, 4): blockIdx.z = direction - row layout forward (a0) / reversed (a2), column layout (the transposed copies)
+// forward (a1) / reversed (a3).  One launch for both layouts (round 5): with the gradient kernel's block length (one round of 1024
+// resident workgroups) a layout's summary pass is 2048 one-wave workgroups - two waves per SIMD where three fit.
 template <int NP, bool VEC>
-__global__ __launch_bounds__(64, NP == 16 ? 3 : 2) void core_bwd_reduce_kernel(CoreBwdArgs a0, CoreBwdArgs a1) {
+__global__ __launch_bounds__(64, NP == 16 ? 3 : 2) void core_bwd_reduce_kernel(CoreBwdArgs a0, CoreBwdArgs a1, CoreBwdArgs a2,
+                                                                               CoreBwdArgs a3) {
     __shared__ __attribute__((aligned(16))) float smem[2 * 64 * kBRow + kBT * 4 + 2 * kBT * NP];
     if (blockIdx.z == 0) core_bwd_reduce_body<NP, VEC, false>(a0, smem);
-    else core_bwd_reduce_body<NP, VEC, true>(a1, smem);
+    else if (blockIdx.z == 1) core_bwd_reduce_body<NP, VEC, false>(a1, smem);
+    else if (blockIdx.z == 2) core_bwd_reduce_body<NP, VEC, true>(a2, smem);
+    else core_bwd_reduce_body<NP, VEC, true>(a3, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

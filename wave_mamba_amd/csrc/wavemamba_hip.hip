@@ -222,7 +222,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 27; }
+int wm_abi_version(void) { return 28; }
 
 #ifndef WM_BUILD_ID
 #define WM_BUILD_ID "unknown"
@@ -516,6 +516,8 @@ static int dw_strip_rows(int H, long long column_blocks, long long plane_groups)
 int wm_dwconv3x3_fwd(const void* x, const float* weight, const float* bias, void* y, int B, int C,
                      int H, int W, int act, int plane_dtype, void* stream) {
     if (B < 0 || C < 0 || H < 0 || W < 0) return WM_EINVAL;
+    const int flip = (act >> 2) & 1;                  // act + 4: the taps rotated by 180 degrees (the input gradient's convolution)
+    act &= 3;
     if (act < 0 || act > 2 || (plane_dtype != WM_F32 && plane_dtype != WM_BF16)) return WM_EUNSUPPORTED;
     const long long planes = (long long)B * C;
     if (planes == 0 || H == 0 || W == 0) return WM_OK;
@@ -533,10 +535,10 @@ int wm_dwconv3x3_fwd(const void* x, const float* weight, const float* bias, void
     do {                                                                                                                      \
         if (plane_dtype == WM_F32)                                                                                            \
             hipLaunchKernelGGL((dwconv3x3_kernel<ACT, VEC, float, LPR>), grid, block, 0, st, (const float*)x, weight, bias,   \
-                               (float*)y, C, H, W, planes, rows);                                                             \
+                               (float*)y, C, H, W, planes, rows, flip);                                                       \
         else                                                                                                                  \
             hipLaunchKernelGGL((dwconv3x3_kernel<ACT, VEC, bf16_t, LPR>), grid, block, 0, st, (const bf16_t*)x, weight, bias, \
-                               (bf16_t*)y, C, H, W, planes, rows);                                                            \
+                               (bf16_t*)y, C, H, W, planes, rows, flip);                                                      \
     } while (0)
 #define WM_DW(ACT)                                                                                                            \
     do {                                                                                                                      \
@@ -985,11 +987,9 @@ static int core_bwd_v2(const CoreBwdPlan2& pl, const float* x, const float* x_pr
                      aligned16(xT) && aligned16(dyTa) && aligned16(dyTb) && aligned16(dxT);
     const dim3 grid((unsigned)pl.scan.nblocks, (unsigned)B);
     if (pl.scan.nchunks > 1) {
-        const dim3 g2(grid.x, grid.y, 2);
-        for (int layout = 0; layout < 2; ++layout) {
-            if (vec) hipLaunchKernelGGL((core_bwd_reduce_kernel<NP, true>), g2, dim3(64), 0, st, a[layout], a[layout + 2]);
-            else hipLaunchKernelGGL((core_bwd_reduce_kernel<NP, false>), g2, dim3(64), 0, st, a[layout], a[layout + 2]);
-        }
+        const dim3 g4(grid.x, grid.y, 4);
+        if (vec) hipLaunchKernelGGL((core_bwd_reduce_kernel<NP, true>), g4, dim3(64), 0, st, a[0], a[1], a[2], a[3]);
+        else hipLaunchKernelGGL((core_bwd_reduce_kernel<NP, false>), g4, dim3(64), 0, st, a[0], a[1], a[2], a[3]);
         if (pl.scan.nblocks > 1) {                       // all eight carries (four forward, four adjoint) in one batch
             CarryBatch cb{};
             const int nsegs = (int)carry_nsegs(pl.scan.nblocks);
@@ -1788,7 +1788,7 @@ int wm_conv2d_amax(const float* x, int64_t nx, const float* weight, int64_t nw, 
     return launch_status();
 }
 
-int wm_conv2d_prep_f16(const float* weight, const float* amax, void* wfrag, int Cout, int Cin, int ks, void* stream) {
+static int conv2d_prep_f16_impl(const float* weight, const float* amax, void* wfrag, int Cout, int Cin, int ks, int dgrad, void* stream) {
     if (Cout <= 0 || Cin <= 0) return WM_EINVAL;
     if (ks != 1 && ks != 3) return WM_EUNSUPPORTED;
     if (!weight || !wfrag || !amax) return WM_ENULL;
@@ -1796,8 +1796,14 @@ int wm_conv2d_prep_f16(const float* weight, const float* amax, void* wfrag, int 
     const int nch = (Cin + 15) / 16, mtot = (Cout + 31) / 32;
     const long long total = (long long)nch * ks * ks * mtot * 128;
     hipLaunchKernelGGL(conv2d_prep_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       weight, (uint4*)wfrag, Cout, Cin, ks * ks, nch, mtot, amax);
+                       weight, (uint4*)wfrag, Cout, Cin, ks * ks, nch, mtot, amax, dgrad);
     return launch_status();
+}
+int wm_conv2d_prep_f16(const float* weight, const float* amax, void* wfrag, int Cout, int Cin, int ks, void* stream) {
+    return conv2d_prep_f16_impl(weight, amax, wfrag, Cout, Cin, ks, 0, stream);
+}
+int wm_conv2d_prep_f16_dgrad(const float* weight, const float* amax, void* wfrag, int Cout, int Cin, int ks, void* stream) {
+    return conv2d_prep_f16_impl(weight, amax, wfrag, Cout, Cin, ks, 1, stream);
 }
 
 }  // extern "C"

@@ -685,7 +685,7 @@ class _DWConvTrain(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous().float()
         B, C, H, W = x.shape
-        gx = dwconv3x3(gy, weight.detach().flip(2, 3).contiguous(), None, "none")
+        gx = dwconv3x3(gy, weight, None, "none", flip=True)
         buf = _zeros_small(10 * C, x.device)                                    # dW | db back to back, zeroed
         dW = buf[:9 * C].view(weight.shape)
         db = buf[9 * C:] if ctx.has_bias else None
@@ -920,10 +920,10 @@ def scale_add(x, scale, o):
 # ------------------------------------------------------------------------------------------------
 # depth-wise 3x3 convolution (+ bias, + SiLU) - inference path of SS2D.conv2d / ffn.conv2
 # ------------------------------------------------------------------------------------------------
-def dwconv3x3(x, weight, bias=None, act="none"):
+def dwconv3x3(x, weight, bias=None, act="none", flip=False):
     """F.conv2d(x, weight, bias, stride=1, padding=1, groups=C) [+ SiLU / exact GELU when act == 'silu' / 'gelu'] for a
     (C, 1, 3, 3) weight, NCHW fp32 (or bf16 planes: fp32 arithmetic, bf16 storage), forward only (no autograd graph is
-    recorded)."""
+    recorded).  flip: with weight.flip(2, 3) - the convolution's input gradient - read from `weight` itself."""
     lib = _lib.load()
     _require_cuda("dwconv3x3", x, weight, bias)
     B, C, H, W = x.shape
@@ -935,7 +935,8 @@ def dwconv3x3(x, weight, bias=None, act="none"):
     with torch.cuda.device(x.device):
         check(lib.wm_dwconv3x3_fwd(_ptr(x), _ptr(weight.detach().contiguous().float()),
                                    _ptr(None if bias is None else bias.detach().contiguous().float()), _ptr(y),
-                                   B, C, H, W, {"none": 0, "silu": 1, "gelu": 2}[act], code, _stream()), "wm_dwconv3x3_fwd")
+                                   B, C, H, W, {"none": 0, "silu": 1, "gelu": 2}[act] + (4 if flip else 0), code, _stream()),
+              "wm_dwconv3x3_fwd")
     return y
 
 
@@ -1126,15 +1127,20 @@ def _f16_ws_bytes(lib, cout, cin, ks):
     return n
 
 
-def conv2d_f16(x, weight, bias=None):
+def conv2d_f16(x, weight, bias=None, dgrad=False):
     """y = F.conv2d(x, weight, bias, stride=1, padding=ks // 2), ks in {1, 3}, NCHW fp32, on the fp16 matrix cores with a
     two-term split of both operands and per-tensor power-of-two scales (csrc/conv2d.hip.h): ~1e-7 relative to the fp64
     result - the training step's form (forward, and the input gradient on the transposed, flipped weight).  Four launches:
-    memset + the two largest magnitudes, weight fragments, convolution; nothing synchronises the host.  Forward only."""
+    memset + the two largest magnitudes, weight fragments, convolution; nothing synchronises the host.  Forward only.
+    dgrad: `weight` is the (Cin, Cout, ks, ks) weight of the FORWARD convolution whose input gradient this call computes from
+    x = gy: the convolution with weight.transpose(0, 1).flip(2, 3), whose fragments wm_conv2d_prep_f16_dgrad reads from `weight`
+    itself (autograd's formula: a flip and a copy kernel per convolution and step)."""
     lib = _lib.load()
     _require_cuda("conv2d_f16", x, weight, bias)
     B, Cin, H, W = x.shape
     cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
+    if dgrad:
+        cout, cin = cin, cout
     if weight.dim() != 4 or weight.shape[3] != ks or ks not in (1, 3) or cin != Cin:
         raise RuntimeError(f"conv2d_f16: weight {tuple(weight.shape)} does not fit x {tuple(x.shape)} (ks in (1, 3))")
     if x.dtype != torch.float32 or weight.dtype != torch.float32:
@@ -1152,7 +1158,8 @@ def conv2d_f16(x, weight, bias=None):
     with torch.cuda.device(x.device):
         st = _stream()
         check(lib.wm_conv2d_amax(_ptr(x), x.numel(), _ptr(w), w.numel(), _ptr(amax), st), "wm_conv2d_amax")
-        check(lib.wm_conv2d_prep_f16(_ptr(w), _ptr(amax), _ptr(wfrag), cout, cin, ks, st), "wm_conv2d_prep_f16")
+        check((lib.wm_conv2d_prep_f16_dgrad if dgrad else lib.wm_conv2d_prep_f16)(_ptr(w), _ptr(amax), _ptr(wfrag), cout, cin, ks, st),
+              "wm_conv2d_prep_f16")
         check(lib.wm_conv2d_fwd_f16(_ptr(x), _ptr(wfrag), _ptr(amax), _ptr(b), _ptr(y), B, cin, cout, H, W, ks, st), "wm_conv2d_fwd_f16")
     return y
 
@@ -1317,8 +1324,11 @@ class _Conv2dTrain(torch.autograd.Function):
         gy = gy.contiguous().float()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            wt = weight.detach().transpose(0, 1).flip(2, 3).contiguous()          # (Cin, Cout, ks, ks)
-            gx = conv2d_f16(gy, wt) if ctx.f16 else conv2d(gy, wt, None, dynamic_weight=True)
+            if ctx.f16:
+                gx = conv2d_f16(gy, weight, dgrad=True)                           # the transposed, flipped weight is never built
+            else:
+                wt = weight.detach().transpose(0, 1).flip(2, 3).contiguous()      # (Cin, Cout, ks, ks)
+                gx = conv2d(gy, wt, None, dynamic_weight=True)
         gw, gb = _conv_param_grads(gy, x, weight, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
         return gx, gw, gb, None
 
