@@ -1750,6 +1750,34 @@ def test_cuda_tensors_fail_loudly_without_the_library(monkeypatch):
             call()
 
 
+def test_graphed_train_step_matches_the_eager_step():
+    """trainer.GraphedTrainStep: optimize_parameters() captured into a HIP graph and replayed on new batches - the same losses and
+    parameters as the eager steps on the same batches (atomics in the gradient kernels: equal to ~1e-6, not bit for bit)."""
+    cfg = dict(in_chn=3, wf=16, n_l_blocks=[1, 1, 1], n_h_blocks=[1, 1, 1], ffn_scale=2.0)
+    gg = gen(77)
+    batches = [(torch.rand(2, 3, 64, 64, generator=gg).to(DEV), torch.rand(2, 3, 64, 64, generator=gg).to(DEV)) for _ in range(3)]
+
+    def fresh():
+        torch.manual_seed(0)
+        net = wm.WaveMamba(**cfg).train().to(DEV)
+        return net, wm.trainer.make_optimizer(net, capturable=True)
+    net_e, opt_e = fresh()
+    for _ in range(3):                                             # the graphed step's warm-up, eagerly
+        wm.trainer.train_step(net_e, opt_e, *batches[0], as_float=False)
+    want = [wm.trainer.loss_values(wm.trainer.train_step(net_e, opt_e, lq, gt, as_float=False)) for lq, gt in batches]
+    net_g, opt_g = fresh()
+    step = wm.trainer.GraphedTrainStep(net_g, opt_g, *batches[0])
+    got = [wm.trainer.loss_values(step(lq, gt)) for lq, gt in batches]
+    for a, b in zip(got, want):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-5 * abs(b[k]), f"{k}: graphed {a[k]} eager {b[k]}"
+    worst = max(float((p.detach() - q.detach()).abs().max() / (q.detach().abs().max() + 1e-12))
+                for p, q in zip(net_g.parameters(), net_e.parameters()))
+    assert worst <= 1e-3, f"parameters after 3 + 3 steps differ by {worst:.2e}"
+    with pytest.raises(RuntimeError):
+        wm.trainer.GraphedTrainStep(net_e, wm.trainer.make_optimizer(net_e), *batches[0])       # not capturable
+
+
 def _concurrency_victims(level_hw):
     """Operator groups of the shipped network on fixed inputs (tools/repro_victim_sweep.py): name -> callable."""
     H, W = level_hw

@@ -22,13 +22,14 @@ def losses(output, gt, fft_weight=0.1):
     return F.l1_loss(output, gt), fft_weight * fft_l1(output, gt)
 
 
-def make_optimizer(net, lr=5e-4, weight_decay=1e-3, betas=(0.9, 0.99)):
+def make_optimizer(net, lr=5e-4, weight_decay=1e-3, betas=(0.9, 0.99), capturable=False):
     """AdamW as the reference configures it (train_wavemamba_uhdll.yml:75-79).  On a GPU the 591 small tensors are
     updated by the fused multi-tensor implementation (one launch per ~hundred tensors instead of ~10 per tensor
-    group); same arithmetic."""
+    group); same arithmetic.  capturable: step counters on the device, for GraphedTrainStep."""
     params = [p for p in net.parameters() if p.requires_grad]
     fused = bool(params) and all(p.is_cuda for p in params)
-    return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, betas=betas, fused=fused)
+    kw = {"capturable": True} if capturable else {}
+    return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, betas=betas, fused=fused, **kw)
 
 
 def wrap_ddp(net, device=None, find_unused_parameters=False, force=False):
@@ -58,6 +59,47 @@ def train_step(net, optimizer, lq, gt, as_float=True):
     (l_pix + l_freq).mean().backward()
     optimizer.step()
     return reduce_loss_dict({"l_pix": l_pix.detach(), "l_freq": l_freq.detach()}, as_float=as_float)
+
+
+class GraphedTrainStep:
+    """train_step() captured ONCE into a HIP graph (forward, both losses, backward, AdamW) and replayed: a BASELINE config-3 step is
+    ~2,500 kernel launches behind ~50 ms of Python and autograd bookkeeping - as much as the GPU needs for the kernels (54 ms), so on a
+    host with slower cores the eager step waits for the host (60.6 against 54.8 ms of kernels on one box of the pool, round 5); a
+    replay costs the host one call.  Single-process training only (a DistributedDataParallel reducer inside a capture is not
+    supported here); fixed batch shape; `optimizer` must be make_optimizer(..., capturable=True).
+
+        step = GraphedTrainStep(net, optimizer, lq0, gt0)          # 3 eager warm-up steps on (lq0, gt0), then the capture
+        losses = step(lq, gt)                                      # copies the batch into the graph's input buffers, replays
+    Returns {"l_pix", "l_freq"} as 0-dim device tensors of the step just replayed (loss_values() to log them)."""
+
+    def __init__(self, net, optimizer, lq, gt, warmup=3):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise RuntimeError("GraphedTrainStep: single-process training only")
+        if not all(g.get("capturable", False) for g in optimizer.param_groups):
+            raise RuntimeError("GraphedTrainStep: the optimizer must be capturable (make_optimizer(net, capturable=True))")
+        self.lq, self.gt = lq.clone(), gt.clone()
+        side = torch.cuda.Stream(lq.device)
+        side.wait_stream(torch.cuda.current_stream(lq.device))
+        with torch.cuda.stream(side):                              # warm-up off the capture's stream (allocator pools, library set-up)
+            for _ in range(warmup):
+                train_step(net, optimizer, self.lq, self.gt, as_float=False)
+        torch.cuda.current_stream(lq.device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            out = net(self.lq)
+            l_pix, l_freq = losses(out, self.gt)
+            (l_pix + l_freq).mean().backward()
+            optimizer.step()
+        self.losses = {"l_pix": l_pix.detach(), "l_freq": l_freq.detach()}
+
+    def __call__(self, lq=None, gt=None):
+        if lq is not None:
+            self.lq.copy_(lq)
+        if gt is not None:
+            self.gt.copy_(gt)
+        self.graph.replay()
+        return self.losses
 
 
 def loss_values(loss_dict):
