@@ -296,6 +296,12 @@ int wm_conv2d_fwd_f16(const float* x, const void* wfrag, const float* amax, cons
                       int H, int W, int ks, void* stream);
 /* The three steps above in one call (ops.conv2d_f16 issues the three steps itself, with `amax` in its zeroed arena): workspace =
  * wm_conv2d_f16_workspace_bytes(Cout, Cin, ks) bytes, 16-byte aligned, caller-owned, holds the two magnitudes and the fragments. */
+/* The training step's form: `amax` (two floats) and `wfrag` (wm_conv2d_wfrag_bytes, 16-byte aligned) are separate caller-owned
+ * buffers - amax in a registered zero arena (wm_zero_arena_register) costs no memset node - and the two magnitudes and the weight
+ * preparation are ONE launch; dgrad != 0: `weight` (Cin, Cout, ks, ks) is the forward convolution's and the call computes its input
+ * gradient from x = gy (wm_conv2d_prep_f16_dgrad).  Two launches per convolution. */
+int wm_conv2d_f16_steps(const float* x, const float* weight, const float* bias, float* y, float* amax, void* wfrag, int B, int Cin,
+                        int Cout, int H, int W, int ks, int dgrad, void* stream);
 size_t wm_conv2d_f16_workspace_bytes(int Cout, int Cin, int ks);
 int wm_conv2d_f16(const float* x, const float* weight, const float* bias, float* y, void* workspace, size_t workspace_bytes,
                   int B, int Cin, int Cout, int H, int W, int ks, void* stream);

@@ -145,6 +145,34 @@ __device__ __forceinline__ f32x16_t cv_mfma(const Frag16& A, const Frag16& B, f3
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, B.v, c, 0, 0, 0);
 }
 
+// fragment item `idx` of the prepared weights (layout: conv2d_prep_kernel)
+template <bool F16>
+__device__ __forceinline__ void cv_prep_item(const float* __restrict__ w, uint4* __restrict__ wfrag, long long idx, int Cout, int Cin,
+                                             int taps, int mtot, float sw, int dgrad) {
+    const int lane = (int)(idx & 63), split = (int)((idx >> 6) & 1);
+    long long rest = idx >> 7;
+    const int m = (int)(rest % mtot); rest /= mtot;
+    const int tap = (int)(rest % taps);
+    const int cc = (int)(rest / taps);
+    const int co = m * 32 + (lane & 31), ci0 = cc * 16 + (lane >> 5) * 8;
+    Frag16 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ci = ci0 + j;
+        // dgrad: `w` is the FORWARD convolution's (Cin, Cout, KS, KS) weight and the fragments are those of its transposed,
+        // 180-degree-rotated form w'[co][ci][tap] = w[ci][co][taps - 1 - tap] - the input-gradient convolution's weight, which
+        // autograd's formula materialises with a flip and a copy kernel per convolution and step
+        const float v = (co < Cout && ci < Cin)
+                            ? (dgrad ? w[((long long)ci * Cout + co) * taps + (taps - 1 - tap)] : w[((long long)co * Cin + ci) * taps + tap])
+                            : 0.0f;
+        Frag16 hi, lo;
+        cv_split<F16>(F16 ? v * sw : v, hi, lo, j);
+        if constexpr (F16) f.h[j] = split ? lo.h[j] : hi.h[j];
+        else f.v[j] = split ? lo.v[j] : hi.v[j];
+    }
+    wfrag[idx] = f.u;
+}
+
 // w (Cout, Cin, KS, KS) fp32 -> wfrag[chunk][tap][m][split][lane] x 8 bf16: lane l of fragment (chunk, tap, m)
 // holds w[32 m + (l & 31)][16 chunk + 8 (l >> 5) + j][tap], j = 0..7 (the A-operand layout of
 // v_mfma_f32_32x32x16_bf16); channels beyond Cout / Cin are zero.
@@ -154,30 +182,65 @@ __global__ __launch_bounds__(256) void conv2d_prep_kernel(const float* __restric
                                                           const float* __restrict__ amax = nullptr, int dgrad = 0) {
     const float sw = F16 ? cv_pow2_scale(amax[1]) : 1.0f;
     const long long total = (long long)nch * taps * mtot * 2 * 64;
-    for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int lane = (int)(idx & 63), split = (int)((idx >> 6) & 1);
-        long long rest = idx >> 7;
-        const int m = (int)(rest % mtot); rest /= mtot;
-        const int tap = (int)(rest % taps);
-        const int cc = (int)(rest / taps);
-        const int co = m * 32 + (lane & 31), ci0 = cc * 16 + (lane >> 5) * 8;
-        Frag16 f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int ci = ci0 + j;
-            // dgrad: `w` is the FORWARD convolution's (Cin, Cout, KS, KS) weight and the fragments are those of its transposed,
-            // 180-degree-rotated form w'[co][ci][tap] = w[ci][co][taps - 1 - tap] - the input-gradient convolution's weight, which
-            // autograd's formula materialises with a flip and a copy kernel per convolution and step
-            const float v = (co < Cout && ci < Cin)
-                                ? (dgrad ? w[((long long)ci * Cout + co) * taps + (taps - 1 - tap)] : w[((long long)co * Cin + ci) * taps + tap])
-                                : 0.0f;
-            Frag16 hi, lo;
-            cv_split<F16>(F16 ? v * sw : v, hi, lo, j);
-            if constexpr (F16) f.h[j] = split ? lo.h[j] : hi.h[j];
-            else f.v[j] = split ? lo.v[j] : hi.v[j];
+    for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256)
+        cv_prep_item<F16>(w, wfrag, idx, Cout, Cin, taps, mtot, sw, dgrad);
+}
+
+// wm_conv2d_amax + wm_conv2d_prep_f16 in ONE launch (the training step's fp16-split convolutions: 88 per BASELINE config-3 step):
+// the first workgroups take max |x| (one atomicMax each on amax[0], which the caller zeroed); the last
+// `nprep` workgroups each take max |w| of the whole weight for themselves (<= 96 x 96 x 9 elements, L2-resident), the first stores
+// it to amax[1], and each writes its share of the fragments with the scale it has just found - the preparation needs nothing from
+// the pass over x and runs beside it.  (ONE preparing workgroup was 40-90 us of scattered 4-byte loads for the 64 x 64 x 9 weights:
+// longer than the pass over x.)
+__global__ __launch_bounds__(256) void cv_amax_prep_kernel(const float* __restrict__ x, long long nx, const float* __restrict__ w,
+                                                           long long nw, unsigned* __restrict__ amax, uint4* __restrict__ wfrag,
+                                                           int Cout, int Cin, int taps, int nch, int mtot, int dgrad, int nprep) {
+    __shared__ float s_m[4];
+    const int nxb = (int)gridDim.x - nprep;                         // workgroups of the pass over x; the last `nprep` prepare the weights
+    const bool wblock = (int)blockIdx.x >= nxb;
+    float m = 0.0f;
+    if (!wblock) {
+        const long long stride = (long long)nxb * 256;
+        const bool vec = (reinterpret_cast<size_t>(x) & 15) == 0;
+        const long long nq = vec ? nx >> 2 : 0;
+        const float4* q = reinterpret_cast<const float4*>(x);
+        long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+        for (; i + 3 * stride < nq; i += 4 * stride) {               // four loads in flight per thread
+            const float4 a = q[i], b = q[i + stride], c = q[i + 2 * stride], d = q[i + 3 * stride];
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(cv_fabs_fin(a.x), cv_fabs_fin(a.y)), fmaxf(cv_fabs_fin(a.z), cv_fabs_fin(a.w))),
+                               fmaxf(fmaxf(cv_fabs_fin(b.x), cv_fabs_fin(b.y)), fmaxf(cv_fabs_fin(b.z), cv_fabs_fin(b.w)))));
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(cv_fabs_fin(c.x), cv_fabs_fin(c.y)), fmaxf(cv_fabs_fin(c.z), cv_fabs_fin(c.w))),
+                               fmaxf(fmaxf(cv_fabs_fin(d.x), cv_fabs_fin(d.y)), fmaxf(cv_fabs_fin(d.z), cv_fabs_fin(d.w)))));
         }
-        wfrag[idx] = f.u;
+        for (; i < nq; i += stride) {
+            const float4 v = q[i];
+            m = fmaxf(fmaxf(m, fmaxf(cv_fabs_fin(v.x), cv_fabs_fin(v.y))), fmaxf(cv_fabs_fin(v.z), cv_fabs_fin(v.w)));
+        }
+        for (long long e = 4 * nq + (long long)blockIdx.x * 256 + threadIdx.x; e < nx; e += stride) m = fmaxf(m, cv_fabs_fin(x[e]));
+    } else {                                                         // every preparing workgroup: max |w| of the WHOLE weight (L2-resident)
+        const long long nq = (reinterpret_cast<size_t>(w) & 15) == 0 ? nw >> 2 : 0;
+        const float4* q = reinterpret_cast<const float4*>(w);
+        for (long long i = threadIdx.x; i < nq; i += 256) {
+            const float4 v = q[i];
+            m = fmaxf(fmaxf(m, fmaxf(cv_fabs_fin(v.x), cv_fabs_fin(v.y))), fmaxf(cv_fabs_fin(v.z), cv_fabs_fin(v.w)));
+        }
+        for (long long e = 4 * nq + threadIdx.x; e < nw; e += 256) m = fmaxf(m, cv_fabs_fin(w[e]));
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    if (!wblock) {
+        if (threadIdx.x == 0 && m > 0.0f) atomicMax(amax, __float_as_uint(m));
+        return;
+    }
+    const int pid = (int)blockIdx.x - nxb;
+    if (pid == 0 && threadIdx.x == 0) amax[1] = __float_as_uint(m);
+    const float sw = cv_pow2_scale(m);
+    const long long total = (long long)nch * taps * mtot * 2 * 64;
+    for (long long idx = pid * 256ll + threadIdx.x; idx < total; idx += nprep * 256ll)
+        cv_prep_item<true>(w, wfrag, idx, Cout, Cin, taps, mtot, sw, dgrad);
 }
 
 // G1X1 (3x3 only): a second, 1x1 convolution of the same input (its own prepared weights a.wfrag1 / a.bias1) rides on

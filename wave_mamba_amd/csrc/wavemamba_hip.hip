@@ -222,7 +222,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 28; }
+int wm_abi_version(void) { return 29; }
 
 #ifndef WM_BUILD_ID
 #define WM_BUILD_ID "unknown"
@@ -2014,6 +2014,33 @@ int wm_conv2d_f16(const float* x, const float* weight, const float* bias, float*
     int rc = wm_conv2d_amax(x, (int64_t)B * Cin * H * W, weight, (int64_t)Cout * Cin * ks * ks, amax, stream);
     if (rc) return rc;
     rc = wm_conv2d_prep_f16(weight, amax, wfrag, Cout, Cin, ks, stream);
+    if (rc) return rc;
+    return wm_conv2d_fwd_f16(x, wfrag, amax, bias, y, B, Cin, Cout, H, W, ks, stream);
+}
+
+// The training step's form of wm_conv2d_f16: `amax` (two floats; a slot of the caller's zeroed arena skips the memset node) and the
+// fragments in separate buffers, magnitudes + weight preparation in ONE launch (cv_amax_prep_kernel), then the convolution; dgrad: the
+// input-gradient convolution of the forward weight `weight` (wm_conv2d_prep_f16_dgrad).  Two launches per convolution where round 4 had
+// four (memset, magnitudes, preparation, convolution) - and six with autograd's flipped copy of the weight.
+int wm_conv2d_f16_steps(const float* x, const float* weight, const float* bias, float* y, float* amax, void* wfrag, int B, int Cin,
+                        int Cout, int H, int W, int ks, int dgrad, void* stream) {
+    if (B < 0 || Cin <= 0 || Cout <= 0 || H < 0 || W < 0) return WM_EINVAL;
+    if (ks != 1 && ks != 3) return WM_EUNSUPPORTED;
+    if (wm_conv2d_wfrag_bytes(Cout, Cin, ks) == 0) return WM_EUNSUPPORTED;
+    if (B == 0 || H == 0 || W == 0) return WM_OK;
+    if (!x || !weight || !y || !amax || !wfrag) return WM_ENULL;
+    if (!aligned16(wfrag)) return WM_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    if (zero_out(amax, 2 * sizeof(float), st) != hipSuccess) return WM_EHIP;
+    const long long nx = (long long)B * Cin * H * W, nw = (long long)Cout * Cin * ks * ks;
+    long long blocks = (nx / 4 + 256 * 8 - 1) / (256 * 8);           // >= 8 float4 per thread
+    blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+    const int nch = (Cin + 15) / 16, mtot = (Cout + 31) / 32;
+    const long long items = (long long)nch * ks * ks * mtot * 128;
+    const int nprep = (int)(items <= 512 ? 1 : (items >= 32 * 512 ? 32 : (items + 511) / 512));   // ~2 fragment items per thread
+    hipLaunchKernelGGL(cv_amax_prep_kernel, dim3((unsigned)blocks + nprep), dim3(256), 0, st, x, nx, weight, nw, (unsigned*)amax,
+                       (uint4*)wfrag, Cout, Cin, ks * ks, nch, mtot, dgrad ? 1 : 0, nprep);
+    int rc = launch_status();
     if (rc) return rc;
     return wm_conv2d_fwd_f16(x, wfrag, amax, bias, y, B, Cin, Cout, H, W, ks, stream);
 }

@@ -1150,17 +1150,14 @@ def conv2d_f16(x, weight, bias=None, dgrad=False):
     nws = _f16_ws_bytes(lib, cout, cin, ks)
     if nws == 0:
         check(_lib.WM_EUNSUPPORTED, "wm_conv2d_f16")
-    # the three steps of wm_conv2d_f16, with the two maxima in a slot of the zeroed arena (no memset node per convolution)
+    # wm_conv2d_f16_steps: the two maxima in a slot of the zeroed arena (no memset node), magnitudes + fragments in one launch
     amax = _zeros_small(2, x.device)
     wfrag = torch.empty(nws - 256, dtype=torch.uint8, device=x.device)
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
     b = None if bias is None else bias.detach().contiguous()
     with torch.cuda.device(x.device):
-        st = _stream()
-        check(lib.wm_conv2d_amax(_ptr(x), x.numel(), _ptr(w), w.numel(), _ptr(amax), st), "wm_conv2d_amax")
-        check((lib.wm_conv2d_prep_f16_dgrad if dgrad else lib.wm_conv2d_prep_f16)(_ptr(w), _ptr(amax), _ptr(wfrag), cout, cin, ks, st),
-              "wm_conv2d_prep_f16")
-        check(lib.wm_conv2d_fwd_f16(_ptr(x), _ptr(wfrag), _ptr(amax), _ptr(b), _ptr(y), B, cin, cout, H, W, ks, st), "wm_conv2d_fwd_f16")
+        check(lib.wm_conv2d_f16_steps(_ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(amax), _ptr(wfrag), B, cin, cout, H, W, ks,
+                                      1 if dgrad else 0, _stream()), "wm_conv2d_f16_steps")
     return y
 
 
