@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const TP* __restrict__ x
     const int cg = blockIdx.x * LPR + cl;                // column group (4 columns)
     const int h0 = (blockIdx.y * 4 + threadIdx.y) * rows;
     for (long long pg = blockIdx.z; pg * PPW < planes; pg += gridDim.z) {
-        const long long plane_raw = pg * PPW + lane / LPR;
+        const long long plane_raw = pg * PPW + (LPR == 64 ? 0 : lane / LPR);   // LPR = 64: wave-uniform (weights, bias and the plane's
+                                                                                 // base address stay in scalar registers)
         const bool pok = plane_raw < planes;             // (a last, partly filled group of planes: its spare lanes are masked)
         const long long plane = pok ? plane_raw : planes - 1;
         const int c = (int)(plane % C);
@@ -166,7 +167,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
     const int cg = blockIdx.x * LPR + cl;
     const int h0 = (blockIdx.y * 4 + threadIdx.y) * rows;
     for (long long pg = blockIdx.z; pg * PPW < planes; pg += gridDim.z) {
-        const long long plane_raw = pg * PPW + lane / LPR;
+        const long long plane_raw = pg * PPW + (LPR == 64 ? 0 : lane / LPR);   // LPR = 64: wave-uniform (weights, bias and the plane's
+                                                                                 // base address stay in scalar registers)
         const bool pok = plane_raw < planes;
         const long long plane = pok ? plane_raw : planes - 1;
         const int c = (int)(plane % C);
@@ -266,13 +268,13 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
             float v = acc[i];
 #pragma unroll
             for (int off = LPR / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-            if (cl == 0) s_part[threadIdx.y][lane / LPR][i] = v;
+            if (cl == 0) s_part[threadIdx.y][LPR == 64 ? 0 : lane / LPR][i] = v;
         }
         __syncthreads();
         if (threadIdx.y == 0 && cl == 0) {
 #pragma unroll
             for (int i = 0; i < 10; ++i) {
-                const int sp = lane / LPR;
+                const int sp = LPR == 64 ? 0 : lane / LPR;
                 const float v = (s_part[0][sp][i] + s_part[1][sp][i]) + (s_part[2][sp][i] + s_part[3][sp][i]);
                 if (v != 0.0f) {
                     if (i < 9) atomicAdd(dW + c * 9 + i, v);
