@@ -280,31 +280,17 @@ int wm_conv2d_ln_fwd(const float* x, const float* ln_weight, const float* ln_bia
  * forward, and - on the transposed, flipped weight - the input gradient): fp16 matrix cores, two-term split of both operands
  * (22 significant bits, fp32-class: ~1e-7 relative to an fp64 convolution instead of the bf16 form's 3-4e-6, which the
  * parameter gradients of the deepest blocks do not tolerate), each tensor scaled by a power of two taken from its largest
- * magnitude so that fp16's exponent range is never the limit.  `amax`: TWO device floats {max |x|, max |weight|} written by
- * the caller on the same stream (no host synchronisation); wm_conv2d_prep_f16 reads amax[1], wm_conv2d_fwd_f16 both - the same
- * buffer must be passed to both calls.  `wfrag`: wm_conv2d_wfrag_bytes(Cout, Cin, ks) bytes, 16-byte aligned.  y = conv(x) + bias
- * (bias may be NULL).  Same kernels, tilings and limits as wm_conv2d_fwd; no concatenated / gathered second input, no gate. */
-/* amax[0] = max |x[0..nx)|, amax[1] = max |weight[0..nw)| (device floats; one memset + one launch on `stream`). */
-int wm_conv2d_amax(const float* x, int64_t nx, const float* weight, int64_t nw, float* amax, void* stream);
-int wm_conv2d_prep_f16(const float* weight, const float* amax, void* wfrag, int Cout, int Cin, int ks, void* stream);
-/* The same fragments for the INPUT-GRADIENT convolution of a forward convolution whose weight is `weight` (Cin, Cout, ks, ks):
- * w'[co][ci][ky][kx] = weight[ci][co][ks-1-ky][ks-1-kx] (what autograd evaluates as conv(gy, weight.transpose(0, 1).flip(2, 3)))
- * read straight from the forward weight - no flipped copy exists.  Cout / Cin are those of the gradient convolution (= the
- * forward's Cin / Cout).  amax[1] = max |weight| as for the forward (a permutation does not change it). */
-int wm_conv2d_prep_f16_dgrad(const float* weight, const float* amax, void* wfrag, int Cout, int Cin, int ks, void* stream);
-int wm_conv2d_fwd_f16(const float* x, const void* wfrag, const float* amax, const float* bias, float* y, int B, int Cin, int Cout,
-                      int H, int W, int ks, void* stream);
-/* The three steps above in one call (ops.conv2d_f16 issues the three steps itself, with `amax` in its zeroed arena): workspace =
- * wm_conv2d_f16_workspace_bytes(Cout, Cin, ks) bytes, 16-byte aligned, caller-owned, holds the two magnitudes and the fragments. */
-/* The training step's form: `amax` (two floats) and `wfrag` (wm_conv2d_wfrag_bytes, 16-byte aligned) are separate caller-owned
- * buffers - amax in a registered zero arena (wm_zero_arena_register) costs no memset node - and the two magnitudes and the weight
- * preparation are ONE launch; dgrad != 0: `weight` (Cin, Cout, ks, ks) is the forward convolution's and the call computes its input
- * gradient from x = gy (wm_conv2d_prep_f16_dgrad).  Two launches per convolution. */
+ * finite magnitude so that fp16's exponent range is never the limit.  y = conv(x, weight) + bias (bias may be NULL), ks in {1, 3}.
+ * `amax`: TWO device floats, written by the call ({max |x|, max |weight|}; in a registered zero arena - wm_zero_arena_register -
+ * the call issues no memset node); `wfrag`: wm_conv2d_wfrag_bytes(Cout, Cin, ks) bytes, 16-byte aligned; both caller-owned
+ * scratch.  dgrad != 0: `weight` (Cin, Cout, ks, ks) is the FORWARD convolution's weight and the call computes that convolution's
+ * input gradient from x = gy: the convolution with w'[co][ci][ky][kx] = weight[ci][co][ks-1-ky][ks-1-kx] (what autograd evaluates
+ * as conv(gy, weight.transpose(0, 1).flip(2, 3))), its fragments read straight from `weight` - no flipped copy exists; Cin / Cout
+ * are those of the gradient convolution (= the forward's Cout / Cin).  Two launches: magnitudes + weight preparation, convolution.
+ * Same kernels, tilings and limits as wm_conv2d_fwd; no concatenated / gathered second input, no gate; nothing synchronises the
+ * host.  (Rounds 4-5 exported the steps one by one - wm_conv2d_amax / _prep_f16 / _fwd_f16 / wm_conv2d_f16: folded into this call.) */
 int wm_conv2d_f16_steps(const float* x, const float* weight, const float* bias, float* y, float* amax, void* wfrag, int B, int Cin,
                         int Cout, int H, int W, int ks, int dgrad, void* stream);
-size_t wm_conv2d_f16_workspace_bytes(int Cout, int Cin, int ks);
-int wm_conv2d_f16(const float* x, const float* weight, const float* bias, float* y, void* workspace, size_t workspace_bytes,
-                  int B, int Cin, int Cout, int H, int W, int ks, void* stream);
 int wm_conv2d_fwd(const float* xa, const float* xb, const int* xb_index, const void* wfrag, const float* bias,
                   const float* gate, const float* residual, float* y, int B, int Ca, int Cb, int Cb_src, int Cout,
                   int H, int W, int ks, void* stream);
@@ -432,7 +418,7 @@ int wm_prof_collect(int* launches /*[WM_PROF_NKERNELS]*/, double* total_ms /*[WM
 
 /* Zero-initialised accumulator outputs.  The entry points whose kernels ADD into an output with atomics - wm_dwconv3x3_wgrad
  * (dW, db), wm_layernorm2d_bwd and wm_layernorm_tok_bwd (dweight, dbias), wm_linear_wgrad (dW), wm_plane_sums (sums),
- * wm_scale_add_bwd (gscale), wm_conv2d_amax (amax) - zero that output first with a memset node on the stream.  A caller that
+ * wm_scale_add_bwd (gscale), wm_conv2d_f16_steps (amax) - zero that output first with a memset node on the stream.  A caller that
  * hands these buffers out of memory it has ALREADY zeroed (one memset for many buffers: the host side's bump arena,
  * ops._zeros_small) registers the range; a buffer lying entirely inside a registered range is then taken as zero and the node is
  * skipped (a BASELINE config-3 training step had 323 of them, 1.4 ms of stream time).  The caller's contract: every buffer it

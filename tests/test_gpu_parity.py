@@ -2104,7 +2104,7 @@ def test_conv2d_ln_bit_identical_to_two_launches(B, Cout, H, W, res):
 @pytest.mark.parametrize("ks,Cin,Cout", [(3, 64, 64), (1, 32, 96), (3, 3, 32), (3, 32, 3), (1, 64, 32), (3, 20, 40)])
 def test_conv2d_f16_input_gradient_from_the_forward_weight(ks, Cin, Cout):
     """conv2d_f16(gy, weight, dgrad=True): the fragments of weight.transpose(0, 1).flip(2, 3) read from the forward weight
-    (wm_conv2d_prep_f16_dgrad) - bit-identical to preparing the materialised tensor, and the float64 input gradient of F.conv2d."""
+    (wm_conv2d_f16_steps, dgrad = 1) - bit-identical to preparing the materialised tensor, and the float64 input gradient of F.conv2d."""
     gg = gen(ks * 100 + Cin + Cout)
     w = (torch.randn(Cout, Cin, ks, ks, generator=gg) / (Cin * ks * ks) ** 0.5).to(DEV)
     gy = torch.randn(2, Cout, 24, 40, generator=gg).to(DEV)

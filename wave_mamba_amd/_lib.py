@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("WAVEMAMBA_HIP_LIB") or os.path.join(HERE, "libwavemam
 WM_F32, WM_BF16 = 0, 1
 WM_OK, WM_EINVAL, WM_ENULL, WM_EALIGN, WM_EWORKSPACE, WM_EUNSUPPORTED, WM_EHIP = 0, -1, -2, -3, -4, -5, -6
 WM_PROF_NKERNELS = 20
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 _c = ctypes
 _p, _i, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
@@ -70,13 +70,7 @@ SIGNATURES = {
     "wm_conv2d_fwd": (_i, [_p] * 8 + [_i] * 8 + [_p]),
     "wm_conv2d_ln_fwd": (_i, [_p, _p, _p, _c.c_float, _p, _p, _p, _p] + [_i] * 5 + [_p]),
     "wm_patchify_conv_fwd": (_i, [_p] * 4 + [_i] * 6 + [_p]),
-    "wm_conv2d_amax": (_i, [_p, _i64, _p, _i64, _p, _p]),
-    "wm_conv2d_prep_f16": (_i, [_p, _p, _p, _i, _i, _i, _p]),
-    "wm_conv2d_prep_f16_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "wm_conv2d_f16_steps": (_i, [_p] * 6 + [_i] * 7 + [_p]),
-    "wm_conv2d_fwd_f16": (_i, [_p] * 5 + [_i] * 6 + [_p]),
-    "wm_conv2d_f16_workspace_bytes": (_sz, [_i] * 3),
-    "wm_conv2d_f16": (_i, [_p] * 5 + [_sz] + [_i] * 6 + [_p]),
     "wm_conv2d_gated_fwd": (_i, [_p] * 7 + [_i] * 7 + [_p]),
     "wm_conv2d_select": (_i, [_i]),
     "wm_prof_enable": (None, [ctypes.c_uint]),

@@ -90,43 +90,6 @@ __device__ __forceinline__ float cv_pow2_scale(float amax) {
 // the scale fell back to 1 and every finite element above 65504 overflowed fp16 too).  A non-finite element itself still
 // becomes NaN in every output it touches (hi = Inf, lo = Inf - Inf), where an fp32 convolution would give Inf / NaN.
 __device__ __forceinline__ float cv_fabs_fin(float v) { const float a = fabsf(v); return a <= 3.4028234e38f ? a : 0.0f; }
-// amax[0] = max |x|, amax[1] = max |w| over the finite elements (non-negative floats order like their bit patterns: atomicMax on
-// the words; the caller zeroes the two words first).  One atomic per
-// workgroup and at most 512 workgroups: 8,192 wave-level atomics on one address cost 70 us of a 106-us launch over 134 MB.
-__global__ __launch_bounds__(256) void cv_amax2_kernel(const float* __restrict__ x, long long nx, const float* __restrict__ w,
-                                                       long long nw, unsigned* __restrict__ amax) {
-    __shared__ float s_m[4];
-    const bool second = blockIdx.y == 1;
-    const float* p = second ? w : x;
-    const long long n = second ? nw : nx;
-    float m = 0.0f;
-    const long long stride = (long long)gridDim.x * 256;
-    const bool vec = (reinterpret_cast<size_t>(p) & 15) == 0;
-    const long long nq = vec ? n >> 2 : 0;
-    const float4* q = reinterpret_cast<const float4*>(p);
-    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < nq; i += 4 * stride) {                   // four loads in flight per thread
-        const float4 a = q[i], b = q[i + stride], c = q[i + 2 * stride], d = q[i + 3 * stride];
-        m = fmaxf(m, fmaxf(fmaxf(fmaxf(cv_fabs_fin(a.x), cv_fabs_fin(a.y)), fmaxf(cv_fabs_fin(a.z), cv_fabs_fin(a.w))),
-                           fmaxf(fmaxf(cv_fabs_fin(b.x), cv_fabs_fin(b.y)), fmaxf(cv_fabs_fin(b.z), cv_fabs_fin(b.w)))));
-        m = fmaxf(m, fmaxf(fmaxf(fmaxf(cv_fabs_fin(c.x), cv_fabs_fin(c.y)), fmaxf(cv_fabs_fin(c.z), cv_fabs_fin(c.w))),
-                           fmaxf(fmaxf(cv_fabs_fin(d.x), cv_fabs_fin(d.y)), fmaxf(cv_fabs_fin(d.z), cv_fabs_fin(d.w)))));
-    }
-    for (; i < nq; i += stride) {
-        const float4 v = q[i];
-        m = fmaxf(fmaxf(m, fmaxf(cv_fabs_fin(v.x), cv_fabs_fin(v.y))), fmaxf(cv_fabs_fin(v.z), cv_fabs_fin(v.w)));
-    }
-    for (long long e = 4 * nq + (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) m = fmaxf(m, cv_fabs_fin(p[e]));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
-        if (m > 0.0f) atomicMax(amax + (second ? 1 : 0), __float_as_uint(m));
-    }
-}
-
 template <bool F16>
 __device__ __forceinline__ void cv_split(float v, Frag16& hi, Frag16& lo, int j) {
     if constexpr (F16) {
@@ -186,7 +149,9 @@ __global__ __launch_bounds__(256) void conv2d_prep_kernel(const float* __restric
         cv_prep_item<F16>(w, wfrag, idx, Cout, Cin, taps, mtot, sw, dgrad);
 }
 
-// wm_conv2d_amax + wm_conv2d_prep_f16 in ONE launch (the training step's fp16-split convolutions: 88 per BASELINE config-3 step):
+// Operand magnitudes + weight preparation of the training step's fp16-split convolutions (88 per BASELINE config-3 step) in ONE launch
+// (round 4: a memset node, a magnitude kernel - one atomic per workgroup and at most 512 workgroups: 8,192 wave-level atomics on one
+// address had cost 70 us of a 106-us launch over 134 MB - and a preparation kernel):
 // the first workgroups take max |x| (one atomicMax each on amax[0], which the caller zeroed); the last
 // `nprep` workgroups each take max |w| of the whole weight for themselves (<= 96 x 96 x 9 elements, L2-resident), the first stores
 // it to amax[1], and each writes its share of the fragments with the scale it has just found - the preparation needs nothing from

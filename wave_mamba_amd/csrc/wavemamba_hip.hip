@@ -222,7 +222,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 29; }
+int wm_abi_version(void) { return 30; }
 
 #ifndef WM_BUILD_ID
 #define WM_BUILD_ID "unknown"
@@ -1306,7 +1306,7 @@ static void gram_plan(int64_t L, long long& nblk, long long& slice) {
 extern "C" {
 
 // Zero-initialised accumulator outputs (parameter gradients that kernels add into with atomics, the two running maxima of
-// wm_conv2d_amax).  A caller that hands out such buffers from memory it has ALREADY zeroed registers that memory
+// wm_conv2d_f16_steps).  A caller that hands out such buffers from memory it has ALREADY zeroed registers that memory
 // (wm_zero_arena_register): a buffer that lies inside a registered range is taken as zero and the memset node is skipped - a
 // BASELINE config-3 training step issued 323 memsets of a few hundred bytes, 4.2 us of stream time each (round 5).
 struct ZeroArenas {
@@ -1775,37 +1775,6 @@ int wm_conv2d_prep(const float* weight, void* wfrag, int Cout, int Cin, int ks, 
     return launch_status();
 }
 
-int wm_conv2d_amax(const float* x, int64_t nx, const float* weight, int64_t nw, float* amax, void* stream) {
-    if (nx < 0 || nw < 0) return WM_EINVAL;
-    if (!amax || (nx > 0 && !x) || (nw > 0 && !weight)) return WM_ENULL;
-    hipStream_t st = (hipStream_t)stream;
-    if (zero_out(amax, 2 * sizeof(float), st) != hipSuccess) return WM_EHIP;
-    const long long big = (long long)(nx > nw ? nx : nw);
-    if (big == 0) return WM_OK;
-    long long blocks = (big / 4 + 256 * 8 - 1) / (256 * 8);          // >= 8 float4 per thread
-    blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
-    hipLaunchKernelGGL(cv_amax2_kernel, dim3((unsigned)blocks, 2), dim3(256), 0, st, x, (long long)nx, weight, (long long)nw, (unsigned*)amax);
-    return launch_status();
-}
-
-static int conv2d_prep_f16_impl(const float* weight, const float* amax, void* wfrag, int Cout, int Cin, int ks, int dgrad, void* stream) {
-    if (Cout <= 0 || Cin <= 0) return WM_EINVAL;
-    if (ks != 1 && ks != 3) return WM_EUNSUPPORTED;
-    if (!weight || !wfrag || !amax) return WM_ENULL;
-    if (!aligned16(wfrag)) return WM_EALIGN;
-    const int nch = (Cin + 15) / 16, mtot = (Cout + 31) / 32;
-    const long long total = (long long)nch * ks * ks * mtot * 128;
-    hipLaunchKernelGGL(conv2d_prep_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       weight, (uint4*)wfrag, Cout, Cin, ks * ks, nch, mtot, amax, dgrad);
-    return launch_status();
-}
-int wm_conv2d_prep_f16(const float* weight, const float* amax, void* wfrag, int Cout, int Cin, int ks, void* stream) {
-    return conv2d_prep_f16_impl(weight, amax, wfrag, Cout, Cin, ks, 0, stream);
-}
-int wm_conv2d_prep_f16_dgrad(const float* weight, const float* amax, void* wfrag, int Cout, int Cin, int ks, void* stream) {
-    return conv2d_prep_f16_impl(weight, amax, wfrag, Cout, Cin, ks, 1, stream);
-}
-
 }  // extern "C"
 
 template <int KS, int RW, int MT, bool G1X1 = false, bool F16 = false, bool LNIN = false>
@@ -1959,9 +1928,9 @@ int wm_conv2d_ln_fwd(const float* x, const float* ln_weight, const float* ln_bia
 }
 
 // The training form (conv2d.hip.h, fp16 split with per-tensor power-of-two scales): y = conv(x, w) + bias, ks in {1, 3}; wfrag from
-// wm_conv2d_prep_f16 with the SAME amax buffer {max |x|, max |w|} (device floats).
-int wm_conv2d_fwd_f16(const float* x, const void* wfrag, const float* amax, const float* bias, float* y, int B, int Cin, int Cout,
-                      int H, int W, int ks, void* stream) {
+// cv_amax_prep_kernel with the SAME amax buffer {max |x|, max |w|} (device floats).
+static int conv2d_fwd_f16(const float* x, const void* wfrag, const float* amax, const float* bias, float* y, int B, int Cin, int Cout,
+                          int H, int W, int ks, void* stream) {
     if (B < 0 || Cin <= 0 || Cout <= 0 || H < 0 || W < 0) return WM_EINVAL;
     if (ks != 1 && ks != 3) return WM_EUNSUPPORTED;
     if (B == 0 || H == 0 || W == 0) return WM_OK;
@@ -1995,32 +1964,9 @@ int wm_conv2d_fwd_f16(const float* x, const void* wfrag, const float* amax, cons
     return WM_OK;
 }
 
-// amax + weight fragments + convolution in one call: workspace = [amax (256 B) | wfrag]
-size_t wm_conv2d_f16_workspace_bytes(int Cout, int Cin, int ks) {
-    const size_t f = wm_conv2d_wfrag_bytes(Cout, Cin, ks);
-    return f ? f + 256 : 0;
-}
-
-int wm_conv2d_f16(const float* x, const float* weight, const float* bias, float* y, void* workspace, size_t workspace_bytes,
-                  int B, int Cin, int Cout, int H, int W, int ks, void* stream) {
-    if (B < 0 || Cin <= 0 || Cout <= 0 || H < 0 || W < 0) return WM_EINVAL;
-    if (ks != 1 && ks != 3) return WM_EUNSUPPORTED;
-    if (B == 0 || H == 0 || W == 0) return WM_OK;
-    if (!x || !weight || !y || !workspace) return WM_ENULL;
-    if (!aligned16(workspace)) return WM_EALIGN;
-    if (workspace_bytes < wm_conv2d_f16_workspace_bytes(Cout, Cin, ks)) return WM_EWORKSPACE;
-    float* amax = (float*)workspace;
-    void* wfrag = (char*)workspace + 256;
-    int rc = wm_conv2d_amax(x, (int64_t)B * Cin * H * W, weight, (int64_t)Cout * Cin * ks * ks, amax, stream);
-    if (rc) return rc;
-    rc = wm_conv2d_prep_f16(weight, amax, wfrag, Cout, Cin, ks, stream);
-    if (rc) return rc;
-    return wm_conv2d_fwd_f16(x, wfrag, amax, bias, y, B, Cin, Cout, H, W, ks, stream);
-}
-
-// The training step's form of wm_conv2d_f16: `amax` (two floats; a slot of the caller's zeroed arena skips the memset node) and the
+// The training step's convolution (fp16 split): `amax` (two floats; a slot of the caller's zeroed arena skips the memset node) and the
 // fragments in separate buffers, magnitudes + weight preparation in ONE launch (cv_amax_prep_kernel), then the convolution; dgrad: the
-// input-gradient convolution of the forward weight `weight` (wm_conv2d_prep_f16_dgrad).  Two launches per convolution where round 4 had
+// input-gradient convolution of the forward weight `weight` (conv2d.hip.h: cv_prep_item).  Two launches per convolution where round 4 had
 // four (memset, magnitudes, preparation, convolution) - and six with autograd's flipped copy of the weight.
 int wm_conv2d_f16_steps(const float* x, const float* weight, const float* bias, float* y, float* amax, void* wfrag, int B, int Cin,
                         int Cout, int H, int W, int ks, int dgrad, void* stream) {
@@ -2042,7 +1988,7 @@ int wm_conv2d_f16_steps(const float* x, const float* weight, const float* bias, 
                        (uint4*)wfrag, Cout, Cin, ks * ks, nch, mtot, dgrad ? 1 : 0, nprep);
     int rc = launch_status();
     if (rc) return rc;
-    return wm_conv2d_fwd_f16(x, wfrag, amax, bias, y, B, Cin, Cout, H, W, ks, stream);
+    return conv2d_fwd_f16(x, wfrag, amax, bias, y, B, Cin, Cout, H, W, ks, stream);
 }
 
 int wm_conv2d_gated_fwd(const float* xa, const float* xb, const int* xb_index, const void* wfrag3, const void* wfrag1,

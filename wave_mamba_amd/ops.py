@@ -1123,7 +1123,8 @@ def _f16_ws_bytes(lib, cout, cin, ks):
     key = (cout, cin, ks)
     n = _F16_WS.get(key)
     if n is None:
-        n = _F16_WS[key] = int(lib.wm_conv2d_f16_workspace_bytes(cout, cin, ks))
+        f = int(lib.wm_conv2d_wfrag_bytes(cout, cin, ks))
+        n = _F16_WS[key] = f + 256 if f else 0
     return n
 
 
@@ -1133,7 +1134,7 @@ def conv2d_f16(x, weight, bias=None, dgrad=False):
     result - the training step's form (forward, and the input gradient on the transposed, flipped weight).  Four launches:
     memset + the two largest magnitudes, weight fragments, convolution; nothing synchronises the host.  Forward only.
     dgrad: `weight` is the (Cin, Cout, ks, ks) weight of the FORWARD convolution whose input gradient this call computes from
-    x = gy: the convolution with weight.transpose(0, 1).flip(2, 3), whose fragments wm_conv2d_prep_f16_dgrad reads from `weight`
+    x = gy: the convolution with weight.transpose(0, 1).flip(2, 3), whose fragments the library reads from `weight`
     itself (autograd's formula: a flip and a copy kernel per convolution and step)."""
     lib = _lib.load()
     _require_cuda("conv2d_f16", x, weight, bias)
@@ -1149,7 +1150,7 @@ def conv2d_f16(x, weight, bias=None, dgrad=False):
     w = weight.detach().contiguous()
     nws = _f16_ws_bytes(lib, cout, cin, ks)
     if nws == 0:
-        check(_lib.WM_EUNSUPPORTED, "wm_conv2d_f16")
+        check(_lib.WM_EUNSUPPORTED, "wm_conv2d_f16_steps")
     # wm_conv2d_f16_steps: the two maxima in a slot of the zeroed arena (no memset node), magnitudes + fragments in one launch
     amax = _zeros_small(2, x.device)
     wfrag = torch.empty(nws - 256, dtype=torch.uint8, device=x.device)
