@@ -24,12 +24,17 @@ VARIANTS = {
     "levels 1 + 2 only": lambda: (S[0][0], S[0][1], None),
     "single stream": lambda: (None, None, None),
 }
+MAIN_HI = torch.cuda.Stream(device=dev, priority=hi)
+VARIANTS[f"three side streams (default priority), the forward itself on a stream of priority {hi}"] = lambda: tuple(S[0])
+VARIANTS[f"single stream, of priority {hi}"] = lambda: (None, None, None)
 orig = arch._side_streams
 ref = None
 for rnd in range(2):
     for name, mk in VARIANTS.items():
         arch._side_streams = lambda x_, n, mk=mk: mk()[:n]
-        with torch.no_grad():
+        main = MAIN_HI if "forward itself" in name or name.startswith("single stream, of") else torch.cuda.current_stream(dev)
+        main.wait_stream(torch.cuda.current_stream(dev))
+        with torch.no_grad(), torch.cuda.stream(main):
             for _ in range(5):
                 y = unet(x)
             torch.cuda.synchronize()
