@@ -384,10 +384,12 @@ def train_leg(device, steps, with_cpu_loss, batch=8, size=512):
     torch.cuda.synchronize()
     prof = wm.ops.prof_collect()
     wm.ops.prof_enable(False)
+    peak_eager = torch.cuda.max_memory_allocated(device) / 2 ** 30      # before the graphed leg's second network + graph pool
     graphed = None
     try:                                                            # the same step captured into a HIP graph: no host work per step
         torch.manual_seed(0)
         net_g = wm.WaveMamba(**SHIPPED).train().to(device)
+        torch.cuda.reset_peak_memory_stats(device)
         gstep = wm.trainer.GraphedTrainStep(net_g, wm.trainer.make_optimizer(net_g, capturable=True), lq, gt)
         gstep(); torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -396,6 +398,7 @@ def train_leg(device, steps, with_cpu_loss, batch=8, size=512):
         torch.cuda.synchronize()
         dg = time.perf_counter() - t0
         graphed = {"images_per_s": steps * batch / dg, "ms_per_step": 1e3 * dg / steps,
+                   "peak_mem_GB_with_the_eager_leg_resident": torch.cuda.max_memory_allocated(device) / 2 ** 30,
                    "note": "trainer.GraphedTrainStep: forward, losses, backward and AdamW captured once and replayed"}
         del net_g, gstep
     except Exception as e:                                          # best-effort leg, never fatal
@@ -416,7 +419,7 @@ def train_leg(device, steps, with_cpu_loss, batch=8, size=512):
                                       "frac": SCAN_BYTES_PER_POS[16] * pos / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fwd_ms else None},
            "losses_after_steps": wm.trainer.loss_values(state["losses"]), "first_step_loss_parity": loss_parity,
            "cpu_baseline": cpu_train, "hip_graph_replay": graphed,
-           "peak_mem_GB": torch.cuda.max_memory_allocated(device) / 2 ** 30}
+           "peak_mem_GB": peak_eager}
     del net, opt
     torch.cuda.empty_cache()
     return res

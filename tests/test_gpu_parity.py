@@ -1778,6 +1778,42 @@ def test_graphed_train_step_matches_the_eager_step():
         wm.trainer.GraphedTrainStep(net_e, wm.trainer.make_optimizer(net_e), *batches[0])       # not capturable
 
 
+def test_graphed_train_step_follows_a_learning_rate_schedule():
+    """a float lr would be frozen into the captured AdamW launch.  make_optimizer(capturable=True) keeps lr as a device
+    tensor; a torch scheduler stepped between replays fills it in place and the replayed update follows: graphed + scheduler ==
+    eager + scheduler, and the schedule visibly changes the update (lr -> 0 leaves only nothing: weight decay scales with lr too)."""
+    cfg = dict(in_chn=3, wf=8, n_l_blocks=[1, 1, 1], n_h_blocks=[1, 1, 1], ffn_scale=2.0)
+    gg = gen(78)
+    lq, gt = torch.rand(2, 3, 64, 64, generator=gg).to(DEV), torch.rand(2, 3, 64, 64, generator=gg).to(DEV)
+
+    def fresh():
+        torch.manual_seed(0)
+        net = wm.WaveMamba(**cfg).train().to(DEV)
+        opt = wm.trainer.make_optimizer(net, capturable=True)
+        return net, opt, torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.0)    # lr, 0, 0, ...
+    net_e, opt_e, sch_e = fresh()
+    assert isinstance(opt_e.param_groups[0]["lr"], torch.Tensor) and opt_e.param_groups[0]["lr"].is_cuda
+    for _ in range(3):
+        wm.trainer.train_step(net_e, opt_e, lq, gt, as_float=False)
+    wm.trainer.train_step(net_e, opt_e, lq, gt, as_float=False); sch_e.step()
+    after_first = [p.detach().clone() for p in net_e.parameters()]
+    wm.trainer.train_step(net_e, opt_e, lq, gt, as_float=False)                           # lr = 0: nothing moves
+    net_g, opt_g, sch_g = fresh()
+    step = wm.trainer.GraphedTrainStep(net_g, opt_g, lq, gt)
+    step(lq, gt); sch_g.step()
+    assert float(opt_g.param_groups[0]["lr"]) == 0.0
+    mid = [p.detach().clone() for p in net_g.parameters()]
+    step(lq, gt)
+    torch.cuda.synchronize()
+    for p, m in zip(net_g.parameters(), mid):
+        assert torch.equal(p.detach(), m), "a replay at lr = 0 moved a parameter: the captured lr is not the scheduler's"
+    worst = max(float((p.detach() - q).abs().max() / (q.abs().max() + 1e-12)) for p, q in zip(net_g.parameters(), after_first))
+    assert worst <= 1e-3, f"graphed + scheduler differs from eager + scheduler by {worst:.2e}"
+    with pytest.raises(RuntimeError):                                                     # a float lr is refused, not ignored
+        bad = torch.optim.AdamW(net_e.parameters(), lr=5e-4, capturable=True, fused=True)
+        wm.trainer.GraphedTrainStep(net_e, bad, lq, gt)
+
+
 def _concurrency_victims(level_hw):
     """Operator groups of the shipped network on fixed inputs (tools/repro_victim_sweep.py): name -> callable."""
     H, W = level_hw

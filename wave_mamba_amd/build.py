@@ -55,14 +55,12 @@ def is_stale():
 
 
 def lint(lib=LIB):
-    """tools/lint_packed_f32.py on the built library; raises when the vulnerable instruction form is present.  (Skipped, with a
+    """_lint_packed_f32.py (same directory) on the built library; raises when the vulnerable instruction form is present.  (Skipped, with a
     note, where the LLVM binutils are absent - the driver image has them.)"""
-    tools = os.path.join(HERE, "..", "tools")
-    sys.path.insert(0, tools)
-    try:
-        import lint_packed_f32
-    finally:
-        sys.path.pop(0)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("wave_mamba_amd._lint_packed_f32", os.path.join(HERE, "_lint_packed_f32.py"))
+    lint_packed_f32 = importlib.util.module_from_spec(spec)        # (by path: this file also runs as a plain script)
+    spec.loader.exec_module(lint_packed_f32)
     if not os.path.exists(os.path.join(lint_packed_f32.LLVM, "llvm-objdump")):
         print("[wave_mamba_amd] llvm-objdump not found: ISA lint skipped", file=sys.stderr)
         return None

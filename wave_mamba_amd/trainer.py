@@ -25,10 +25,15 @@ def losses(output, gt, fft_weight=0.1):
 def make_optimizer(net, lr=5e-4, weight_decay=1e-3, betas=(0.9, 0.99), capturable=False):
     """AdamW as the reference configures it (train_wavemamba_uhdll.yml:75-79).  On a GPU the 591 small tensors are
     updated by the fused multi-tensor implementation (one launch per ~hundred tensors instead of ~10 per tensor
-    group); same arithmetic.  capturable: step counters on the device, for GraphedTrainStep."""
+    group); same arithmetic.  capturable: step counters AND the learning rate on the device, for GraphedTrainStep - a
+    Python-float lr would be baked into the captured AdamW launch as a kernel scalar and a scheduler (the reference's recipe
+    uses CosineAnnealingRestartCyclicLR, train_wavemamba_uhdll.yml:86-90) would change nothing in the replays; torch's
+    schedulers `fill_()` a tensor lr in place, which the replayed kernel reads."""
     params = [p for p in net.parameters() if p.requires_grad]
     fused = bool(params) and all(p.is_cuda for p in params)
     kw = {"capturable": True} if capturable else {}
+    if capturable and fused:
+        lr = torch.tensor(float(lr), dtype=torch.float32, device=params[0].device)
     return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, betas=betas, fused=fused, **kw)
 
 
@@ -66,7 +71,9 @@ class GraphedTrainStep:
     ~2,500 kernel launches behind ~50 ms of Python and autograd bookkeeping - as much as the GPU needs for the kernels (54 ms), so on a
     host with slower cores the eager step waits for the host (60.6 against 54.8 ms of kernels on one box of the pool, round 5); a
     replay costs the host one call.  Single-process training only (a DistributedDataParallel reducer inside a capture is not
-    supported here); fixed batch shape; `optimizer` must be make_optimizer(..., capturable=True).
+    supported here); fixed batch shape; `optimizer` must be make_optimizer(..., capturable=True): its learning rate is a device
+    tensor, so a torch LR scheduler stepped between replays takes effect (it fills the tensor in place; a float lr is refused -
+    it would be frozen into the graph).  The warm-up steps are real optimizer steps at the optimizer's current lr.
 
         step = GraphedTrainStep(net, optimizer, lq0, gt0)          # 3 eager warm-up steps on (lq0, gt0), then the capture
         losses = step(lq, gt)                                      # copies the batch into the graph's input buffers, replays
@@ -77,6 +84,9 @@ class GraphedTrainStep:
             raise RuntimeError("GraphedTrainStep: single-process training only")
         if not all(g.get("capturable", False) for g in optimizer.param_groups):
             raise RuntimeError("GraphedTrainStep: the optimizer must be capturable (make_optimizer(net, capturable=True))")
+        if not all(isinstance(g["lr"], torch.Tensor) and g["lr"].is_cuda for g in optimizer.param_groups):
+            raise RuntimeError("GraphedTrainStep: the optimizer's lr must be a device tensor (make_optimizer(net, capturable=True)): "
+                               "a float lr is frozen into the captured graph and learning-rate schedules would be ignored")
         self.lq, self.gt = lq.clone(), gt.clone()
         side = torch.cuda.Stream(lq.device)
         side.wait_stream(torch.cuda.current_stream(lq.device))
