@@ -493,7 +493,7 @@ def test_ss2d_core_unaligned_planes():
         assert torch.equal(a, b), f"y{i}: element-wise and 16-byte tile accesses differ"
 
 
-def core_vs_unfused_and_oracle_subset(H, W, N, seed, channels, what):
+def core_vs_unfused_and_oracle_subset(H, W, N, seed, channels, what, full_direction=None):
     """Full-size check of the fused core (the oracle on all channels would take minutes):
     (a) all four outputs against the direction glue + the drop-in selective_scan_fn (oracle-checked on its own);
     (b) `channels` of every direction against the CPU oracle's scan, with the operands of those channels formed the
@@ -514,8 +514,9 @@ def core_vs_unfused_and_oracle_subset(H, W, N, seed, channels, what):
     del unfused
     # reference return order (:478): y_row_fwd (k=0), y_row_rev (k=2), y_col_fwd (k=1), y_col_rev (k=3)
     order = {0: 0, 2: 1, 1: 2, 3: 3}
-    sel = torch.tensor(channels, device=DEV)
     for k in range(K):
+        chs = list(range(D)) if k == full_direction else channels    # (4 of 64 channels per direction were checked)
+        sel = torch.tensor(chs, device=DEV)
         xs = x.reshape(1, D, L) if k % 2 == 0 else x.transpose(2, 3).reshape(1, D, L)      # l = h W + w | l = w H + h
         if k >= 2:
             xs = xs.flip(-1)
@@ -528,8 +529,206 @@ def core_vs_unfused_and_oracle_subset(H, W, N, seed, channels, what):
         if k >= 2:
             y = y.flip(-1)
         if k % 2 == 1:                                                                     # back to row-major l
-            y = y.reshape(1, len(channels), W, H).transpose(2, 3).reshape(1, len(channels), L)
-        assert_close(fused[order[k]][:, sel], y, TOL, f"{what} direction {k} vs oracle on channels {channels}")
+            y = y.reshape(1, len(chs), W, H).transpose(2, 3).reshape(1, len(chs), L)
+        assert_close(fused[order[k]][:, sel], y, TOL, f"{what} direction {k} vs oracle on {len(chs)} channels")
+
+
+# ------------------------------------------------------------------------------------------------
+# fused SS2D core OUTSIDE the default-init distribution (VERDICT r5 "missing" 4): trained-like / adversarial parameters
+# ------------------------------------------------------------------------------------------------
+def ood_core_case(B, D, H, W, N, R, seed, kind):
+    """SS2D.forward_core operands no default init produces (the fused core has its own log2-unit softplus without F.softplus's
+    threshold branch, a bf16-split x_proj and prepared A - reference edge: `delta_softplus=True` with threshold 20,
+    wavemamba_arch.py:465-471):
+      trained   dt_projs_bias ~ U[-8, 4], A_logs ~ U[-3, 6] (non-monotone in n: A from -0.05 to -400), Ds ~ N(0, 1), projections x3 / x4
+      dtpush    + bands of rows where x is 40x larger: the dt pre-activation runs beyond +20 (softplus's linear branch) and below
+                -40 (dt ~ 1e-18) over whole runs of positions, per channel sign
+      small / large   x scaled by 1e-3 / 1e+2
+      zeroplane one channel plane of x all zero (and one whole batch image where B > 1)
+      zeroD     Ds = 0
+      zerox     x = 0 everywhere (y must be exactly 0)"""
+    gg = gen(seed)
+    x = torch.randn(B, D, H, W, generator=gg)
+    Wx = 3.0 * torch.randn(4, R + 2 * N, D, generator=gg) / D ** 0.5
+    Wdt = 4.0 * torch.randn(4, D, R, generator=gg) * R ** -0.5
+    bias = torch.rand(4, D, generator=gg) * 12.0 - 8.0
+    A_logs = torch.rand(4 * D, N, generator=gg) * 9.0 - 3.0
+    Ds = torch.randn(4 * D, generator=gg)
+    if kind == "dtpush":
+        for r0 in range(0, H, 7):
+            x[:, :, r0:r0 + 3] *= 40.0
+        x[:, :, :, W // 2:W // 2 + 2] *= 40.0
+    elif kind == "small":
+        x *= 1e-3
+    elif kind == "large":
+        x *= 1e2
+    elif kind == "zeroplane":
+        x[:, D // 3] = 0.0
+        if B > 1:
+            x[1] = 0.0
+    elif kind == "zeroD":
+        Ds.zero_()
+    elif kind == "zerox":
+        x.zero_()
+    else:
+        assert kind == "trained"
+    return x, Wx, Wdt, bias, A_logs, Ds
+
+
+def core_eval(x, Wx, Wdt, bias, A_logs, Ds, dys, dtype):
+    """SS2D.forward_core (:446-478) with the SEQUENTIAL scan definition on the CPU through autograd, in
+    `dtype`: float64 = the truth, float32 = what the reference's own arithmetic gives.  -> (four outputs, six gradients)."""
+    leaves = [t.detach().cpu().to(dtype).requires_grad_(True) for t in (x, Wx, Wdt, bias, A_logs, Ds)]
+    x_, Wx_, Wdt_, b_, Al_, Ds_ = leaves
+    B, D, H, W = x_.shape
+    L, K = H * W, 4
+    R, N = Wdt_.shape[2], Al_.shape[1]
+    xs = torch.stack([x_.view(B, -1, L), x_.transpose(2, 3).contiguous().view(B, -1, L)], dim=1).view(B, 2, -1, L)
+    xs = torch.cat([xs, torch.flip(xs, dims=[-1])], dim=1)
+    x_dbl = torch.einsum("b k d l, k c d -> b k c l", xs, Wx_)
+    dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
+    dts = torch.einsum("b k r l, k d r -> b k d l", dts, Wdt_)
+    u = xs.reshape(B, K * D, L)
+    dt = F.softplus(dts.reshape(B, K * D, L) + b_.reshape(1, -1, 1))
+    A = -torch.exp(Al_)
+    Bf = Bs.repeat_interleave(D, dim=1)
+    Cf = Cs.repeat_interleave(D, dim=1)
+    h = torch.zeros(B, K * D, N, dtype=dtype)
+    ys = []
+    for dt_t, du_t, B_t, C_t in zip(dt.unbind(2), (dt * u).unbind(2), Bf.unbind(3), Cf.unbind(3)):
+        h = torch.exp(dt_t[..., None] * A.view(1, K * D, N)) * h + du_t[..., None] * B_t
+        ys.append((h * C_t).sum(-1))
+    out = (torch.stack(ys, 2) + u * Ds_.view(1, -1, 1)).view(B, K, -1, L)
+    inv = torch.flip(out[:, 2:4], dims=[-1]).view(B, 2, -1, L)
+    wh = out[:, 1].view(B, -1, W, H).transpose(2, 3).contiguous().view(B, -1, L)
+    invwh = inv[:, 1].view(B, -1, W, H).transpose(2, 3).contiguous().view(B, -1, L)
+    outs = (out[:, 0], inv[:, 0], wh, invwh)
+    grads = torch.autograd.grad(outs, leaves, [d.detach().cpu().to(dtype) for d in dys], allow_unused=True)
+    return [o.detach() for o in outs], grads
+
+
+def assert_vs_truth_ood(got, ref, truth, what):
+    """Out-of-distribution bar: err(got, float64 truth) <= max(1e-4, 5 err(fp32 reference arithmetic, float64 truth)), WITHOUT
+    truth_bar's 5e-4 cap: with the dt pre-activation 40x outside its trained range the reference's own fp32 gradients are up to
+    3e-3 from their float64 values (tools/core_ood_report.py, profiles/r06/core_ood_report_after.txt: cancelling sums over states
+    that differ by e^{+-1000}) - where fp32 itself loses the 1e-4, the bound is the reference's own loss times a small factor, never
+    a fixed looser number.  The factor: the build's B / C rows of x_proj are a two-term bf16 product (2^-17; the dt_r rows carry 24
+    bits since round 6) against fp32's 2^-24 - in a case that amplifies rounding 500x (reference 7e-5) the build measures 2.7e-4."""
+    e_got, e_ref = max(rel_err(got, truth)), max(rel_err(ref, truth))
+    assert e_got <= max(1e-4, 5.0 * e_ref), f"{what}: {e_got:.3e} vs float64 truth (fp32 reference arithmetic: {e_ref:.3e})"
+
+
+OOD_SHAPES = [(1, 64, 24, 40, 16, 2), (2, 64, 33, 71, 16, 2), (1, 64, 20, 36, 32, 2), (1, 16, 19, 24, 16, 1)]
+
+
+@pytest.mark.parametrize("kind", ["trained", "dtpush", "small", "large", "zeroplane", "zeroD", "zerox"])
+@pytest.mark.parametrize("B,D,H,W,N,R", OOD_SHAPES)
+def test_ss2d_core_forward_backward_out_of_distribution(B, D, H, W, N, R, kind):
+    """The kernel the network actually runs (wm_ss2d_core_fwd / _bwd) on operands outside anything a default init produces.
+    Forward: against the pinned C oracle at 1e-4; where the oracle's own fp32 arithmetic is further than 5e-5 from the float64
+    evaluation of the reference formula (cancelling sums at |A| dt ~ 1e3), the bar is the truth bar: err(build, float64) <=
+    max(1e-4, 5 err(fp32 reference arithmetic, float64)) (assert_vs_truth_ood).  Backward: every gradient on that bar."""
+    case = ood_core_case(B, D, H, W, N, R, seed=1000 + H * 7 + W + N, kind=kind)
+    L = H * W
+    dys = [torch.randn(B, D, L, generator=gen(17 + i)) for i in range(4)]
+    want = oracle.ss2d_core_raw(*case)
+    truth_y, truth_g = core_eval(*case, dys, torch.float64)
+    ref_y, ref_g = core_eval(*case, dys, torch.float32)
+    args = [t.clone().requires_grad_(True) for t in cu(*case)]
+    got = wm.ops.ss2d_core(*args)
+    for i, (a, o, tr, rf) in enumerate(zip(got, want, truth_y, ref_y)):
+        assert torch.isfinite(a).all(), f"{kind} y{i}: non-finite values"
+        if kind == "zerox":
+            assert float(a.abs().max()) == 0.0 and float(o.abs().max()) == 0.0
+            continue
+        e_o = max(rel_err(o, tr))
+        if e_o <= 5e-5:
+            assert_close(a, o, TOL, f"{kind} core y{i} vs oracle")
+        assert_vs_truth_ood(a, rf if max(rel_err(rf, tr)) > e_o else o, tr, f"{kind} core y{i}")
+    merged = wm.ops.ss2d_core(*cu(*case), merged=True)
+    if kind != "zerox":
+        assert_vs_truth_ood(merged, sum(ref_y), sum(truth_y), f"{kind} merged")
+    grads = torch.autograd.grad(got, args, cu(*dys))
+    for a, rf, tr, nm in zip(grads, ref_g, truth_g, ("dx", "dWx", "dWdt", "dbias", "dA_logs", "dDs")):
+        assert torch.isfinite(a).all(), f"{kind} {nm}: non-finite values"
+        if float(tr.abs().max()) == 0.0:
+            assert float(a.abs().max()) <= 1e-6, f"{kind} {nm}: expected zeros"
+            continue
+        assert_vs_truth_ood(a, rf, tr, f"{kind} {nm} {(B, D, H, W, N, R)}")
+
+
+def perturb_like_trained(module, seed):
+    """Every parameter of `module` off its init: SS2D's A_logs ~ U[-3, 6], dt_projs_bias ~ U[-8, 4], Ds ~ N(0, 1), x_proj x3,
+    dt_projs x4; every other tensor multiplicative and additive noise of a quarter of its own scale."""
+    g = gen(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            leaf = name.rsplit(".", 1)[-1]
+            if leaf == "A_logs":
+                p.copy_(torch.rand(p.shape, generator=g) * 9.0 - 3.0)
+            elif leaf == "dt_projs_bias":
+                p.copy_(torch.rand(p.shape, generator=g) * 12.0 - 8.0)
+            elif leaf == "Ds":
+                p.copy_(torch.randn(p.shape, generator=g))
+            elif leaf == "x_proj_weight":
+                p.mul_(3.0)
+            elif leaf == "dt_projs_weight":
+                p.mul_(4.0)
+            else:
+                scale = float(p.abs().mean()) + 1e-3
+                p.mul_(1.0 + 0.25 * torch.randn(p.shape, generator=g)).add_(0.25 * scale * torch.randn(p.shape, generator=g))
+
+
+@pytest.mark.parametrize("H,W,d_state", [(24, 40, 16), (33, 32, 16), (16, 24, 32)])
+def test_lfss_block_out_of_distribution_vs_cpu_oracle(H, W, d_state):
+    """One LFSSBlock with trained-like parameters (perturb_like_trained), inference kernels and the training path (fused core
+    forward + backward), against the SAME block on the host with the CPU oracle as hot-path backend: output at 1e-4, input and
+    parameter gradients at the truth-free bar 2e-4 (two fp32 implementations of sums over L positions)."""
+    import copy
+    torch.manual_seed(3)
+    blk_cpu = arch.LFSSBlock(32, d_state=d_state, expand=2.0)
+    perturb_like_trained(blk_cpu, seed=H + W)
+    x_cpu = (torch.randn(2, H * W, 32, generator=gen(9)) * 2.0)
+    x_cpu[:, H * W // 3:H * W // 3 + W] *= 30.0                      # one image row far outside the rest
+    blk = copy.deepcopy(blk_cpu).to(DEV)
+    with oracle_backend.ops_backend(oracle), torch.no_grad():
+        want = blk_cpu.eval()(x_cpu, [H, W])
+    with torch.no_grad():
+        got = blk.eval()(x_cpu.to(DEV), [H, W])
+    assert_close(got, want, TOL, "OOD LFSSBlock, inference kernels")
+    gy = torch.randn(want.shape, generator=gen(10))
+    xc = x_cpu.clone().requires_grad_(True)
+    with oracle_backend.ops_backend(oracle):
+        out_c = blk_cpu.train()(xc, [H, W])
+        ref = torch.autograd.grad(out_c, [xc] + list(blk_cpu.parameters()), gy)
+    xg = x_cpu.to(DEV).requires_grad_(True)
+    out_g = blk.train()(xg, [H, W])
+    assert_close(out_g, out_c, TOL, "OOD LFSSBlock, training path output")
+    grads = torch.autograd.grad(out_g, [xg] + list(blk.parameters()), gy.to(DEV))
+    names = ["dx"] + [n for n, _ in blk.named_parameters()]
+    for a, b, nm in zip(grads, ref, names):
+        assert_close(a, b, 2e-4, f"OOD LFSSBlock grad {nm}")
+
+
+def test_network_256_out_of_distribution_vs_cpu_oracle_network():
+    """BASELINE config 1's 256 x 256 input through the shipped configuration with EVERY parameter off its init (trained-like SS2D
+    parameters in all 14 LFSSBlocks) against the CPU-oracle network: rel-l2 and max-abs <= 1e-4."""
+    import copy
+    torch.manual_seed(0)
+    net_cpu = wm.WaveMamba(in_chn=3, wf=32, n_l_blocks=[1, 2, 4], n_h_blocks=[1, 1, 2], ffn_scale=2.0).eval()
+    perturb_like_trained(net_cpu, seed=5)
+    img = torch.rand(1, 3, 256, 256, generator=gen(1234))
+    cores = oracle.usable_cpus(cap=1 << 20)
+    torch.set_num_threads(cores); oracle.set_num_threads(cores)
+    with oracle_backend.ops_backend(oracle), torch.no_grad():
+        want = net_cpu(img)
+    net = copy.deepcopy(net_cpu).to(DEV)
+    with torch.no_grad():
+        got = net(img.to(DEV))
+    assert torch.isfinite(got).all()
+    l2, mx = rel_err(got.cpu(), want)
+    print(f"OOD 256 x 256 network vs CPU-oracle network: rel-l2 {l2:.3e}, max-abs / max-abs {mx:.3e}")
+    assert_close(got, want, TOL, "OOD 256 x 256 network")
 
 
 def test_ss2d_core_uhd_level2_against_unfused():
@@ -541,6 +740,13 @@ def test_ss2d_core_uhd_level1_full_size():
     """BASELINE config 2, the launch that dominates the bench: UHD level-1 map (1088 x 1920, L = 2,088,960) through the
     product path's fused core."""
     core_vs_unfused_and_oracle_subset(1088, 1920, 16, seed=4, channels=[0, 21, 42, 63], what="UHD-L1")
+
+
+def test_ss2d_core_uhd_level1_full_size_every_channel_of_a_column_direction():
+    """The same launch with ALL 64 channels of direction 3 (column-major, reversed: the direction with the most index arithmetic)
+    against the CPU oracle's scan, 4 channels of the other three."""
+    core_vs_unfused_and_oracle_subset(1088, 1920, 16, seed=6, channels=[5, 26, 47, 60], what="UHD-L1 all channels of k=3",
+                                      full_direction=3)
 
 
 def test_ss2d_core_config5_full_size():

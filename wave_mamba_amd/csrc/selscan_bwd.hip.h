@@ -6,7 +6,7 @@
 //   g_t   = C_t dy_t + a_{t+1} g_{t+1}                     adjoint state, reverse recurrence
 //   dC_t  = sum_d dy_t h_t          dB_t = sum_d g_t dt_t u_t           (sums over the group's channels)
 //   du_t  = dt_t <g_t, B_t> + D dy_t
-//   ddt_t = <g_t, A a_t h_{t-1} + B_t u_t>,  a_t h_{t-1} = h_t - dt_t B_t u_t
+//   ddt_t = <g_t, A a_t h_{t-1} + B_t u_t>   (a_t h_{t-1} formed as that product: h_t - dt_t B_t u_t cancels where a_t ~ 0)
 //   dA    = sum_t g_t a_t h_{t-1} dt_t      dD = sum_t dy_t u_t
 //   ddelta_t = ddt_t * sigmoid(delta_t + bias)  (softplus; 1 above the threshold)    dbias = sum_t ddelta_t
 //
@@ -468,9 +468,10 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
                 const float4 bv = *reinterpret_cast<const float4*>(&s_B[tt * NP + 4 * r]);
                 aa[j][2 * r] = exp2_2(dt2 * A2[2 * r]);
                 aa[j][2 * r + 1] = exp2_2(dt2 * A2[2 * r + 1]);
-                hc[2 * r] = aa[j][2 * r] * hc[2 * r] + du2 * (v2f){bv.x, bv.y};
-                hc[2 * r + 1] = aa[j][2 * r + 1] * hc[2 * r + 1] + du2 * (v2f){bv.z, bv.w};
-                hh[j][2 * r] = hc[2 * r]; hh[j][2 * r + 1] = hc[2 * r + 1];
+                hh[j][2 * r] = aa[j][2 * r] * hc[2 * r];                 // a_t h_{t-1}: kept INSTEAD of h_t (see below)
+                hh[j][2 * r + 1] = aa[j][2 * r + 1] * hc[2 * r + 1];
+                hc[2 * r] = hh[j][2 * r] + du2 * (v2f){bv.x, bv.y};
+                hc[2 * r + 1] = hh[j][2 * r + 1] + du2 * (v2f){bv.z, bv.w};
             }
         }
 #pragma unroll
@@ -492,12 +493,15 @@ __global__ __launch_bounds__(64) void selscan_bwd_chunk_kernel(ScanBwdArgs p) {
                         const v2f B2 = e ? (v2f){bv.z, bv.w} : (v2f){bv.x, bv.y};
                         const v2f C2 = e ? (v2f){cv.z, cv.w} : (v2f){cv.x, cv.y};
                         const v2f g = C2 * dy2 + gacc[n2];            // g_t
-                        const v2f ahp = hh[j][n2] - du2 * B2;         // a_t h_{t-1}
+                        // a_t h_{t-1} is the product the recomputation kept; h_t is rebuilt from it (round 6: `h_t - dt u B_t`
+                        // cancels where a_t ~ 0, see ss2d_core_bwd.hip.h)
+                        const v2f ahp = hh[j][n2];                    // a_t h_{t-1}
+                        const v2f ht = ahp + du2 * B2;                // h_t
                         const v2f gah = g * ahp;
                         dA[n2] = gah * dt2 + dA[n2];
                         sdt = gah * (A2[n2] * 0.6931471805599453f) + sdt;     // A = A2 * ln 2
                         sdu = g * B2 + sdu;
-                        const v2f pb = g * du2, pc = hh[j][n2] * dy2;
+                        const v2f pb = g * du2, pc = ht * dy2;
                         prod[2 * n2] = pb.x; prod[2 * n2 + 1] = pb.y;
                         prod[NP + 2 * n2] = pc.x; prod[NP + 2 * n2 + 1] = pc.y;
                         gacc[n2] = aa[j][n2] * g;                      // a_t g_t, carried to step t-1

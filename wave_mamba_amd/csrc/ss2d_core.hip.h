@@ -54,9 +54,23 @@
 #define WM_CORE_STEP_FENCE 1      // scheduling barrier after every scan step
 #endif
 
+#ifndef WM_CORE_PRIO
+#define WM_CORE_PRIO 0            // experiments: wave issue priorities (s_setprio), see core_setprio
+#endif
+
 namespace wm {
 
 typedef float core_f4 __attribute__((ext_vector_type(4)));
+
+// s_setprio takes an immediate: a wave-uniform value goes through a scalar switch
+__device__ __forceinline__ void core_setprio(int p) {
+    switch (p & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
 
 // Storage type of the x / y planes: float, or bf16_t in the bf16-storage mode (four elements per lane access either way;
 // everything inside the kernel - LDS tiles, projection, state - is fp32).
@@ -108,13 +122,15 @@ template <int NP> struct CoreCfg {
     static constexpr int RS = 2 * NP + 4;                // record: [dt_r (4) | B (NP) | C (NP)] floats
     static constexpr int ROW = 20;                       // x tile row stride (floats): conflict-free per-lane float4
     static constexpr int XT = 64 * ROW + 4;              // x tile stride: the column scatter is 2-way at worst
-    static constexpr int WF = NT3 * 1024;                // [tile][K-step (2)][hi | lo][lane] x 8 bf16 = 1 KB each
+    static constexpr int WF = NT3 * 1024 + 512;          // [tile][K-step (2)][hi | lo][lane] x 8 bf16 = 1 KB each, + the dt_r tile's
+                                                         // third term [K-step (2)][lane] (P_W3)
     // prep buffer of ONE direction (floats): bf16 weight fragments | A * log2(e) as [n / 2][lane] pairs |
-    // [wdt0 wdt1 wdt2 wdt3 bias D][lane]
+    // [wdt0 wdt1 wdt2 wdt3 bias D][lane] | third bf16 term of the dt_r row tile's fragments [K-step (2)][lane][4 dwords]
     static constexpr int P_WF = NT3 * 1024;
     static constexpr int P_A2 = P_WF;
     static constexpr int P_LC = P_A2 + NP * 64;
-    static constexpr int PREP = P_LC + 6 * 64;
+    static constexpr int P_W3 = P_LC + 6 * 64;
+    static constexpr int PREP = P_W3 + 512;
 };
 #ifndef WM_CORE_LDS_PAD
 #define WM_CORE_LDS_PAD 0         // experiments: extra dynamic LDS per workgroup (bytes), e.g. to keep a second workgroup off the compute unit
@@ -133,6 +149,19 @@ __device__ __forceinline__ void core_split2(float a, float b, core_bf2& hi, core
     const core_f2 p = {a, b};
     hi = __builtin_convertvector(p, core_bf2);
     lo = __builtin_convertvector(p - __builtin_convertvector(hi, core_f2), core_bf2);
+}
+
+// Three terms (24 significant bits): v ~ hi + mid + lo with (hi, mid) = core_split2's pair.  The dt_r rows of x_proj take it
+// (round 6): dt = softplus(Wdt . dt_r + bias) enters exp(dt A), which amplifies an error of the dt pre-activation by |A| dt - with
+// trained-like parameters (|A| up to e^6, projections several times their init) or activations 100x the usual the two-term
+// product's 2^-17 put the core's outputs 1e-4 .. 8e-4 from the float64 truth where the reference's fp32 arithmetic is at 4e-6 ..
+// 4e-5 (tools/core_ood_report.py, profiles/r06/core_ood_report_before.txt).  B and C enter linearly and keep the two-term form.
+__device__ __forceinline__ void core_split3(float a, float b, core_bf2& hi, core_bf2& mid, core_bf2& lo) {
+    const core_f2 p = {a, b};
+    hi = __builtin_convertvector(p, core_bf2);
+    const core_f2 r = p - __builtin_convertvector(hi, core_f2);
+    mid = __builtin_convertvector(r, core_bf2);
+    lo = __builtin_convertvector(r - __builtin_convertvector(mid, core_f2), core_bf2);
 }
 
 // Once per call: everything a workgroup's prologue used to compute from the parameters (22 k cycles per workgroup and
@@ -170,11 +199,12 @@ __global__ __launch_bounds__(256) void ss2d_core_prep_kernel(const float* __rest
             v[i] = (row >= 0 && d < D) ? Wx[((long long)k * Cx + row) * D + d] : 0.0f;
             if (L2U && t >= 1 && t <= NTB) v[i] *= 0.6931471805599453f;       // B rows: ln 2 (see above)
         }
-        core_bf2 hi, lo;
-        core_split2(v[0], v[1], hi, lo);
+        core_bf2 hi, lo, l3;
+        core_split3(v[0], v[1], hi, lo, l3);                             // (hi, lo) = core_split2's pair
         const int base = ((t * 2 + s2) * 2) * 256 + l * 4 + jp;          // [tile][K-step][split][lane][4 dwords]
         wf[base] = *reinterpret_cast<uint32_t*>(&hi);
         wf[base + 256] = *reinterpret_cast<uint32_t*>(&lo);
+        if (t == 0) reinterpret_cast<uint32_t*>(out + Cfg::P_W3)[s2 * 256 + l * 4 + jp] = *reinterpret_cast<uint32_t*>(&l3);
     }
     for (int e = threadIdx.x; e < NP * 64; e += 256) {
         const int lane = e & 63, n = e >> 6;
@@ -252,6 +282,8 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
         const uint4* gw = reinterpret_cast<const uint4*>(prep);
         uint4* sw4 = reinterpret_cast<uint4*>(s_w);
         for (int e = tid; e < NT * 256; e += 64 * NW) sw4[e] = gw[e];
+        const uint4* g3 = reinterpret_cast<const uint4*>(prep + Cfg::P_W3);          // third term of the dt_r tile: behind the tiles
+        for (int e = tid; e < 128; e += 64 * NW) sw4[Cfg::NT3 * 256 + e] = g3[e];
     }
 
     // ---- per-lane (= per-channel) constants, prepared once per call
@@ -437,6 +469,13 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
 #endif
     fetch(0);
     for (int ti = 0; ti < ntiles; ++ti) {
+#if WM_CORE_PRIO == 1
+        if (!COL) core_setprio((wv >> 2) + ti);          // the four waves of a SIMD take turns at every priority
+#elif WM_CORE_PRIO == 2
+        if (!COL) __builtin_amdgcn_s_setprio(3);         // latency-bound phases (stage, projection, store) first ...
+#elif WM_CORE_PRIO == 3
+        __builtin_amdgcn_s_setprio(3);
+#endif
         stage(ti);
         if (COL) core_barrier(); else core_lds_fence();
         WM_STAMP(0)                                      // stage (incl. the wait for the tile's loads) + barrier
@@ -465,18 +504,25 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
                     float xf[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) xf[j] = sx[(32 * s2 + 4 * j + g4) * ROW + c16];
-                    core_bf8 xh, xl;
+                    core_bf8 xh, xl, x3;
 #pragma unroll
                     for (int j = 0; j < 8; j += 2) {
-                        core_bf2 h2, l2;
-                        core_split2(xf[j], xf[j + 1], h2, l2);
-                        xh[j] = h2[0]; xh[j + 1] = h2[1]; xl[j] = l2[0]; xl[j + 1] = l2[1];
+                        core_bf2 h2, l2, t2;
+                        core_split3(xf[j], xf[j + 1], h2, l2, t2);
+                        xh[j] = h2[0]; xh[j + 1] = h2[1]; xl[j] = l2[0]; xl[j + 1] = l2[1]; x3[j] = t2[0]; x3[j + 1] = t2[1];
                     }
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const uint4 wh4 = sw4[((t * 2 + s2) * 2 + 0) * 64], wl4 = sw4[((t * 2 + s2) * 2 + 1) * 64];
                         const core_bf8 wh = *reinterpret_cast<const core_bf8*>(&wh4);
                         const core_bf8 wl = *reinterpret_cast<const core_bf8*>(&wl4);
+                        if (t == 0) {            // dt_r rows: the three further products of the 24-bit split, smallest first
+                            const uint4 w34 = sw4[Cfg::NT3 * 256 + s2 * 64];
+                            const core_bf8 w3 = *reinterpret_cast<const core_bf8*>(&w34);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3, xh, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, x3, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xl, acc[t], 0, 0, 0);
+                        }
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc[t], 0, 0, 0);
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc[t], 0, 0, 0);
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[t], 0, 0, 0);
@@ -494,6 +540,11 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
             }
             core_lds_fence();
             WM_STAMP(2)                                  // projection + record write
+#if WM_CORE_PRIO == 2
+            if (!COL) core_setprio(((wv >> 2) + ti) % 3);    // ... the steps (throughput work) below them, in turns
+#elif WM_CORE_PRIO == 3
+            if (!COL) core_setprio(((wv >> 2) + ti) % 3); else __builtin_amdgcn_s_setprio(0);
+#endif
 
             // ---- 16 scan steps ----
             // The record addresses are wave-uniform; left to itself the compiler forms each of the ~40 per quad in an
@@ -559,6 +610,11 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
         }
 
         WM_STAMP(3)                                      // 16 scan steps
+#if WM_CORE_PRIO == 2
+        if (!COL) __builtin_amdgcn_s_setprio(3);
+#elif WM_CORE_PRIO == 3
+        __builtin_amdgcn_s_setprio(3);
+#endif
         if (PHASE == 3 && !(WM_CORE_ABLATE & 4)) {
             if (!COL) {
                 core_lds_fence();
