@@ -50,3 +50,13 @@ for kk in range(4):
     m = t[:, 7] == kk
     print(f"  direction {kk}: lifetime mean {float((ext[m] - ent[m]).mean()):.1f} us (min {float((ext[m] - ent[m]).min()):.1f}, max {float((ext[m] - ent[m]).max()):.1f}); "
           f"last exit {float(ext[m].max()):.1f} us")
+# lifetime by wave index inside the workgroup (which waves are the fast ones: wave % 4 = SIMD, wave / 4 = launch order on it)
+t_all = buf.view(-1, 16, 12).cpu()
+for kk in (0, 1):
+    sel = (t_all[:, 0, 6] > 0) & (t_all[:, 0, 7] == kk)
+    if int(sel.sum()) == 0:
+        continue
+    w = t_all[sel].double()
+    life = (w[:, :, 10] - w[:, :, 8]) / 100.0
+    print(f"  direction {kk}: mean lifetime by wave index 0..15 (us): " + " ".join(f"{float(v):.0f}" for v in life.mean(0)))
+    print(f"  direction {kk}: workgroup lifetime (max over its waves) mean {float(life.max(1).values.mean()):.1f} us, mean over waves {float(life.mean()):.1f} us")

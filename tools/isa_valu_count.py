@@ -97,7 +97,7 @@ def classify(ins):
 def main():
     text = isa(sys.argv[1] if len(sys.argv) > 1 else None)
     out = {}
-    for name, lines in kernels(text, r"ss2d_core_kernelILi16ELi16ELi[13]ELb0EfLb1ELb0E"):
+    for name, lines in kernels(text, r"ss2d_core_kernelILi16ELi16ELi[13]ELb0EfLb1EEE"):
         phase = "reduce" if "ILi16ELi16ELi1E" in name else "scan"
         loops = inner_loops(lines)
         # the step loops are the innermost loops with transcendentals in them; one per direction variant (row / column x forward / reversed)
