@@ -54,23 +54,9 @@
 #define WM_CORE_STEP_FENCE 1      // scheduling barrier after every scan step
 #endif
 
-#ifndef WM_CORE_PRIO
-#define WM_CORE_PRIO 0            // experiments: wave issue priorities (s_setprio), see core_setprio
-#endif
-
 namespace wm {
 
 typedef float core_f4 __attribute__((ext_vector_type(4)));
-
-// s_setprio takes an immediate: a wave-uniform value goes through a scalar switch
-__device__ __forceinline__ void core_setprio(int p) {
-    switch (p & 3) {
-        case 0: __builtin_amdgcn_s_setprio(0); break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        default: __builtin_amdgcn_s_setprio(3); break;
-    }
-}
 
 // Storage type of the x / y planes: float, or bf16_t in the bf16-storage mode (four elements per lane access either way;
 // everything inside the kernel - LDS tiles, projection, state - is fp32).
@@ -469,13 +455,6 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
 #endif
     fetch(0);
     for (int ti = 0; ti < ntiles; ++ti) {
-#if WM_CORE_PRIO == 1
-        if (!COL) core_setprio((wv >> 2) + ti);          // the four waves of a SIMD take turns at every priority
-#elif WM_CORE_PRIO == 2
-        if (!COL) __builtin_amdgcn_s_setprio(3);         // latency-bound phases (stage, projection, store) first ...
-#elif WM_CORE_PRIO == 3
-        __builtin_amdgcn_s_setprio(3);
-#endif
         stage(ti);
         if (COL) core_barrier(); else core_lds_fence();
         WM_STAMP(0)                                      // stage (incl. the wait for the tile's loads) + barrier
@@ -540,11 +519,6 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
             }
             core_lds_fence();
             WM_STAMP(2)                                  // projection + record write
-#if WM_CORE_PRIO == 2
-            if (!COL) core_setprio(((wv >> 2) + ti) % 3);    // ... the steps (throughput work) below them, in turns
-#elif WM_CORE_PRIO == 3
-            if (!COL) core_setprio(((wv >> 2) + ti) % 3); else __builtin_amdgcn_s_setprio(0);
-#endif
 
             // ---- 16 scan steps ----
             // The record addresses are wave-uniform; left to itself the compiler forms each of the ~40 per quad in an
@@ -610,11 +584,6 @@ __device__ __forceinline__ void core_body(const CoreArgs& p, const int k, const 
         }
 
         WM_STAMP(3)                                      // 16 scan steps
-#if WM_CORE_PRIO == 2
-        if (!COL) __builtin_amdgcn_s_setprio(3);
-#elif WM_CORE_PRIO == 3
-        __builtin_amdgcn_s_setprio(3);
-#endif
         if (PHASE == 3 && !(WM_CORE_ABLATE & 4)) {
             if (!COL) {
                 core_lds_fence();
