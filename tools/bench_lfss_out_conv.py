@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """wm_lfss_out_conv_fwd (the ffn's depth-wise 3x3 + gelu gate + conv3 + scaled skip, one kernel) at the three UHD levels, ms per call
-(HIP events) and a checksum of the output.  WM_LFSS_OUT_LINEAR=1 selects the linear group order (before round 4's banded order);
-WM_LFSS_OUT_ROWS = -1 (default: the row-window form on maps of >= 2^20 positions) / 0 (never) / 2 / 3 (always, R rows per wave pass)."""
+(HIP events) and a checksum of the output.  WM_LFSS_OUT_LINEAR=1 selects the linear group order (before round 4's banded order).  The row-window form (R = 2) runs on maps of
+>= 2^20 positions; the WM_LFSS_OUT_ROWS switch and the R = 3 instantiations were deleted in round 6."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +14,6 @@ C, D = 32, 64
 g = torch.Generator(device=dev); g.manual_seed(0)
 rn = lambda *s: torch.randn(*s, device=dev, generator=g)
 cw, cb, W3, b3, sk2 = rn(D, 1, 3, 3) / 3, rn(D) * 0.1, rn(C, C) / 6, rn(C) * 0.1, rn(C) * 0.1 + 1
-print("WM_LFSS_OUT_ROWS =", os.environ.get("WM_LFSS_OUT_ROWS", "-1"))
 for lvl in (1, 2, 3):
     H, W = 2176 >> lvl, 3840 >> lvl
     L, B = H * W, 1

@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256, 4) void lfss_out_conv_mfma_kernel(
 // outputs.  Two-wave workgroups (R x 16 KB of product tiles each).  W % 64 == 0; rows past the image are masked by the
 // buffer range check (reads) and skipped (stores).
 template <int R, typename TP>
-__global__ __launch_bounds__(128, 4) void lfss_out_conv_rows_kernel(
+__global__ __launch_bounds__(128, 2) void lfss_out_conv_rows_kernel(
     const TP* __restrict__ f, const float* __restrict__ cw /*(D, 3, 3)*/, const float* __restrict__ cbias /*(D) or null*/,
     const float* __restrict__ tok1, const float* __restrict__ W3 /*(C, C)*/, const float* __restrict__ b3,
     const float* __restrict__ skip2, float* __restrict__ out, int out_nchw, int B, int H, int W, int nstrips, int nbands,

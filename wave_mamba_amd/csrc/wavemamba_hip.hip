@@ -1185,9 +1185,6 @@ int wm_lfss_out_fwd(const void* fc_, const float* tok1, const float* conv3_weigh
     WM_LFSS_DISPATCH(11, lfss_out_kernel, fc, tok1, conv3_weight, conv3_bias, skip_scale2, out, out_nchw, B, (long long)L);
 }
 
-#ifndef WM_LFSS_OUT_ROWS_DEFAULT
-#define WM_LFSS_OUT_ROWS_DEFAULT -1
-#endif
 int wm_lfss_out_conv_fwd(const void* f_, const float* conv2_weight, const float* conv2_bias, const float* tok1,
                          const float* conv3_weight, const float* conv3_bias, const float* skip_scale2, float* out,
                          int out_nchw, int B, int H, int W, int C, int plane_dtype, void* stream) {
@@ -1203,24 +1200,22 @@ int wm_lfss_out_conv_fwd(const void* f_, const float* conv2_weight, const float*
     const long long ngroups = (long long)B * ngl;
     const int gpw = lfss_groups_per_wave(ngroups, 2048);
     const long long waves = (ngroups + gpw - 1) / gpw;
-    // row-window form (lfss_out_conv_rows_kernel: R output rows per wave pass, (R + 2) / R of f instead of 3 x): W % 64 == 0.
-    // Measured (tools/bench_lfss_out_conv.py, ms per call at UHD levels 1 / 2): banded one-row form 0.464 / 0.087, R = 2 0.403 / 0.095,
-    // R = 3 0.452 / 0.128 (two-wave workgroups, one per 56 KB of product tiles: too few waves) -> R = 2 on maps of >= 2^20 positions,
-    // the one-row form below that.  WM_LFSS_OUT_ROWS = -1 (that rule) / 0 (never) / 2 / 3 (always, tools)
-    static const int rows_mode = [] { const char* e = getenv("WM_LFSS_OUT_ROWS"); return e ? atoi(e) : WM_LFSS_OUT_ROWS_DEFAULT; }();
-    if (W % 64 == 0 && (rows_mode >= 2 || (rows_mode < 0 && (long long)B * L >= (1ll << 20)))) {
-        const int R = rows_mode == 3 ? 3 : 2;
+    // row-window form (lfss_out_conv_rows_kernel: R = 2 output rows per wave pass, (R + 2) / R of f instead of 3 x): W % 64 == 0.
+    // Measured (profiles/r04, ms per call at UHD levels 1 / 2): banded one-row form 0.464 / 0.087, R = 2 0.403 / 0.095, R = 3 0.452 /
+    // 0.128 (two-wave workgroups, one per 56 KB of product tiles: too few waves; its instantiations and the environment switch
+    // were deleted in round 6) -> R = 2 on maps of >= 2^20 positions, the one-row form below that.
+    if (W % 64 == 0 && (long long)B * L >= (1ll << 20)) {
+        constexpr int R = 2;
         const int nstrips = W / 64, nbands = (H + R - 1) / R;
         const long long units = (long long)B * nbands * nstrips;
         const int upw = lfss_groups_per_wave(units, 2048);
         const long long nwaves = (units + upw - 1) / upw;
         hipStream_t st2 = (hipStream_t)stream;
         ProfScope ps2(11, st2);
-#define WM_ROWS(RR, TP) hipLaunchKernelGGL((lfss_out_conv_rows_kernel<RR, TP>), dim3((unsigned)((nwaves + 1) / 2)), dim3(128), 0, st2, \
-                                           (const TP*)f_, conv2_weight, conv2_bias, tok1, conv3_weight, conv3_bias, skip_scale2, out,      \
-                                           out_nchw, B, H, W, nstrips, nbands, units, upw)
-        if (plane_dtype == WM_F32) { if (R == 3) WM_ROWS(3, float); else WM_ROWS(2, float); }
-        else { if (R == 3) WM_ROWS(3, bf16_t); else WM_ROWS(2, bf16_t); }
+#define WM_ROWS(TP) hipLaunchKernelGGL((lfss_out_conv_rows_kernel<R, TP>), dim3((unsigned)((nwaves + 1) / 2)), dim3(128), 0, st2, \
+                                       (const TP*)f_, conv2_weight, conv2_bias, tok1, conv3_weight, conv3_bias, skip_scale2, out,   \
+                                       out_nchw, B, H, W, nstrips, nbands, units, upw)
+        if (plane_dtype == WM_F32) WM_ROWS(float); else WM_ROWS(bf16_t);
 #undef WM_ROWS
         return launch_status();
     }
