@@ -451,15 +451,45 @@ def ddp_train_leg(device, rank, world, steps, reduce_device, batch=8, size=512):
     if hasattr(model, "no_sync"):
         t_local = max_over_ranks(timed_steps(step_nosync, steps, 1, sync, barrier), world, reduce_device)
     nparam = sum(p.numel() for p in net.parameters())
+    # the same data-parallel step with the host out of it (trainer.GraphedDDPTrainStep): forward + backward + flat gradient buffer
+    # replayed from a HIP graph, ONE all-reduce, AdamW replayed.  Collective = one call, so every rank must take this leg or none:
+    # a rank that fails says so in the all-reduced flag and all ranks skip the timing
+    graphed = None
+    try:
+        del model, opt
+        torch.cuda.empty_cache()
+        # 'split' (the all-reduce is an ordinary call between two replays) unless asked otherwise: a collective INSIDE a HIP graph
+        # has only ever run on a one-rank communicator from the build sessions (tests/test_rccl_gpu.py)
+        mode = "captured" if dist.get_backend() == "nccl" and os.environ.get("WM_BENCH_DDP_GRAPH") == "captured" else "split"
+        err = None
+        try:
+            torch.manual_seed(0)
+            net_g = wm.WaveMamba(**SHIPPED).train().to(device)      # a fresh module: no reducer hooks on its parameters
+            gstep = wm.trainer.GraphedDDPTrainStep(net_g, wm.trainer.make_optimizer(net_g, capturable=True), lq, gt, collective=mode)
+        except Exception as e:
+            err = f"{type(e).__name__}: {e}"[:300]
+        bad = torch.tensor([0.0 if err is None else 1.0], device=reduce_device)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if float(bad) == 0.0:
+            t_g = max_over_ranks(timed_steps(lambda: gstep(), steps, 1, sync, barrier), world, reduce_device)
+            graphed = {"images_per_s": whole_job_value(world, steps, batch, t_g), "ms_per_step": 1e3 * t_g / steps,
+                       "collective": mode, "losses_mean_over_ranks": wm.trainer.loss_values(gstep.losses),
+                       "note": "trainer.GraphedDDPTrainStep: the bare module's forward, losses and backward + gradients into one flat "
+                               "buffer replayed from a HIP graph, one all-reduce of the buffer (inside the graph when 'captured'), "
+                               "AdamW on views of the buffer replayed"}
+        else:
+            graphed = {"error": err or "another rank failed to capture"}
+    except Exception as e:
+        graphed = {"error": f"{type(e).__name__}: {e}"[:300]}
     res = {"workload": f"BASELINE config 3: DDP over {world} ranks, batch {batch} x 3x{size}x{size} synthetic pairs per GPU, "
                        f"shipped config, L1 + 0.1 FFT-L1, AdamW; one gradient all-reduce of {4 * nparam / 1e6:.2f} MB per step "
                        f"+ the 2-scalar loss reduce (base_model.py:392)",
            "images_per_s": whole_job_value(world, steps, batch, t_ddp), "ms_per_step": 1e3 * t_ddp / steps, "steps": steps,
            "ms_per_step_without_allreduce": None if t_local is None else 1e3 * t_local / steps,
            "exposed_allreduce_ms_per_step": None if t_local is None else 1e3 * (t_ddp - t_local) / steps,
-           "scaling": "weak", "losses_rank0_mean": losses,
+           "scaling": "weak", "losses_rank0_mean": losses, "hip_graph_replay": graphed,
            "peak_mem_GB": torch.cuda.max_memory_allocated(device) / 2 ** 30}
-    del model, net, opt
+    del net
     torch.cuda.empty_cache()
     return res
 

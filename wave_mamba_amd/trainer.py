@@ -112,6 +112,118 @@ class GraphedTrainStep:
         return self.losses
 
 
+class GraphedDDPTrainStep:
+    """The data-parallel optimize_parameters() (femasr_model.py:157-185 under the DistributedDataParallel wrap of
+    base_model.py:111-114) with the host taken out of the step: every rank replays
+
+        graph A   forward, both losses, backward, the 591 gradients (pre-divided by the world size, as DDP's reducer does)
+                  and the two losses copied into ONE flat fp32 buffer
+        exchange  ONE all-reduce (sum) of that buffer - RCCL over xGMI: 6.05 MB per step for the shipped config
+        graph B   AdamW on gradients that ARE views of the buffer
+
+    instead of ~2,400 eager launches behind ~50 ms of Python, autograd and reducer bookkeeping per step and rank - with eight
+    ranks on one host that work runs on whatever cores the host has left per rank (DESIGN.md section 6 has the measured host
+    cost per step).  `net` is the BARE module (not the DDP wrap: the reducer's autograd hooks cannot run inside a capture); the
+    constructor broadcasts rank 0's parameters and buffers like DDP's does.  `collective`:
+        "split"     the all-reduce is an ordinary call between the two replays (any backend, gloo included)
+        "captured"  one graph holds A, the all-reduce and B (backend nccl = RCCL only: its collectives are stream-ordered
+                    kernels and capture like any other launch)
+    `capture=False` runs the same three phases eagerly - what the CPU / gloo tests exercise, and the cross-check of the replays.
+    Fixed batch shape; `optimizer` as for GraphedTrainStep on a GPU.  Returns {"l_pix", "l_freq"}: 0-dim tensors holding the
+    MEAN over ranks of the step just run (every rank has them - they ride in the gradient buffer; the reference's
+    reduce_loss_dict, base_model.py:376-401, leaves them on rank 0 only)."""
+
+    def __init__(self, net, optimizer, lq, gt, warmup=3, process_group=None, capture=True, collective="split"):
+        if isinstance(net, (torch.nn.parallel.DistributedDataParallel, torch.nn.DataParallel)):
+            raise RuntimeError("GraphedDDPTrainStep: pass the bare module, not its DistributedDataParallel wrap")
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("GraphedDDPTrainStep: torch.distributed is not initialised (single process: GraphedTrainStep)")
+        if collective not in ("split", "captured"):
+            raise ValueError("collective: 'split' or 'captured'")
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.net, self.optimizer, self.capture, self.collective = net, optimizer, capture, collective
+        self.params = [p for g in optimizer.param_groups for p in g["params"]]
+        if capture:
+            if not all(p.is_cuda for p in self.params):
+                raise RuntimeError("GraphedDDPTrainStep: capture needs the network on a GPU (capture=False runs eagerly)")
+            if not all(g.get("capturable", False) and isinstance(g["lr"], torch.Tensor) and g["lr"].is_cuda
+                       for g in optimizer.param_groups):
+                raise RuntimeError("GraphedDDPTrainStep: the optimizer must be make_optimizer(net, capturable=True)")
+            if collective == "captured" and dist.get_backend(process_group) != "nccl":
+                raise RuntimeError("GraphedDDPTrainStep: collective='captured' needs the nccl (RCCL) backend")
+        # DDP's constructor: every rank starts from rank 0's parameters and buffers
+        with torch.no_grad():
+            for t in list(net.parameters()) + list(net.buffers()):
+                dist.broadcast(t, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                               group=process_group)
+        dev = self.params[0].device
+        self.sizes = [p.numel() for p in self.params]
+        self.flat = torch.zeros(sum(self.sizes) + 2, dtype=torch.float32, device=dev)     # gradients | l_pix | l_freq
+        self.views = [v.view_as(p) for v, p in zip(self.flat[:-2].split(self.sizes), self.params)]
+        self.losses = {"l_pix": self.flat[-2], "l_freq": self.flat[-1]}
+        self.lq, self.gt = lq.clone(), gt.clone()
+        if not capture:
+            return
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                              # warm-up off the capture's stream: real steps, all ranks alike
+            for _ in range(warmup):
+                self._produce()
+                self._exchange()
+                self._update()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        if collective == "captured":
+            self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), None
+            with torch.cuda.graph(self.graph_a):
+                self._produce()
+                self._exchange()
+                self._update()
+        else:
+            self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_a):
+                self._produce()
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+                self._update()
+
+    def _produce(self):
+        for p in self.params:
+            p.grad = None
+        out = self.net(self.lq)
+        l_pix, l_freq = losses(out, self.gt)
+        (l_pix + l_freq).mean().backward()
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+        torch._foreach_copy_(self.views, grads)
+        self.flat[-2].copy_(l_pix.detach())
+        self.flat[-1].copy_(l_freq.detach())
+        self.flat.mul_(1.0 / self.world)                           # DDP's reducer divides before it sums
+
+    def _exchange(self):
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _update(self):
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        self.optimizer.step()
+
+    def __call__(self, lq=None, gt=None):
+        if lq is not None:
+            self.lq.copy_(lq)
+        if gt is not None:
+            self.gt.copy_(gt)
+        if not self.capture:
+            self._produce()
+            self._exchange()
+            self._update()
+        elif self.graph_b is None:
+            self.graph_a.replay()
+        else:
+            self.graph_a.replay()
+            self._exchange()
+            self.graph_b.replay()
+        return self.losses
+
+
 def loss_values(loss_dict):
     """{name: python float} of a train_step() result (synchronises: call it when logging, not every step)."""
     return {k: float(v) for k, v in loss_dict.items()}
