@@ -1984,6 +1984,81 @@ def test_graphed_train_step_matches_the_eager_step():
         wm.trainer.GraphedTrainStep(net_e, wm.trainer.make_optimizer(net_e), *batches[0])       # not capturable
 
 
+def _eager_noise():
+    """What a training loop does between two replays: kernels and allocations of its own (NaN / 1e30 fills of several sizes)."""
+    for n, v in ((8, float("nan")), (320, 1e30), (1024, float("nan")), (65536, 1e30), (1 << 20, float("nan"))):
+        t = torch.full((n,), v, device=DEV)
+        del t
+    torch.cuda.synchronize()
+
+
+def test_graph_replay_zeroes_its_accumulators_with_eager_launches_between_replays():
+    """Round 6: accumulate-into outputs were zeroed by hipMemsetAsync; captured into a HIP graph that is a memset node whose fill
+    pattern this runtime re-reads, at every launch of the graph, from memory it has recycled - any eager kernel launch between two
+    replays and the node filled the gradient buffers with other kernels' arguments (tools/repro_graph_memset_node.py).  The library
+    zeroes with a kernel now.  One accumulate-into operator of each family, captured alone, replayed with eager work in between."""
+    lib = wm._lib.load()
+    gg = gen(5)
+    B, C, H, W = 2, 32, 32, 32
+    x, gy = torch.randn(B, C, H, W, generator=gg).to(DEV), torch.randn(B, C, H, W, generator=gg).to(DEV)
+    lnw = torch.randn(C, generator=gg).to(DEV)
+
+    def dw_wgrad(buf):
+        wm.ops.check(lib.wm_dwconv3x3_wgrad(x.data_ptr(), gy.data_ptr(), buf[:9 * C].data_ptr(), buf[9 * C:].data_ptr(), B, C, H, W,
+                                            torch.cuda.current_stream().cuda_stream), "wm_dwconv3x3_wgrad")
+
+    def ln_bwd(buf):
+        gx = torch.empty_like(x)
+        wm.ops.check(lib.wm_layernorm2d_bwd(x.data_ptr(), lnw.data_ptr(), gy.data_ptr(), 1e-6, gx.data_ptr(), buf[:C].data_ptr(),
+                                            buf[C:2 * C].data_ptr(), B, H * W, C, torch.cuda.current_stream().cuda_stream),
+                     "wm_layernorm2d_bwd")
+    for name, fn, n in (("dwconv3x3_wgrad", dw_wgrad, 10 * C), ("layernorm2d_bwd", ln_bwd, 2 * C)):
+        ref = torch.empty(n, device=DEV)
+        fn(ref)
+        torch.cuda.synchronize()
+        ref_cpu = ref.cpu()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            buf = torch.empty(n, device=DEV)
+            fn(buf)
+        for r in range(4):
+            graph.replay()
+            torch.cuda.synchronize()
+            got = buf.cpu()
+            err = float((got - ref_cpu).abs().max() / ref_cpu.abs().max())
+            assert err <= 1e-5, f"{name}: replay {r} differs from the eager call by {err:.3e} (atomics reorder sums: ~1e-7 expected)"
+            _eager_noise()
+
+
+def test_graphed_train_step_with_eager_work_between_replays():
+    """The whole optimize_parameters() replayed from a graph while the caller runs kernels of its own between the replays (logging,
+    checks, data preparation): the same losses as the eager steps, finite gradients, every replay (round 6: NaN after the second)."""
+    cfg = dict(in_chn=3, wf=16, n_l_blocks=[1, 1, 1], n_h_blocks=[1, 1, 1], ffn_scale=2.0)
+    gg = gen(77)
+    batches = [(torch.rand(2, 3, 64, 64, generator=gg).to(DEV), torch.rand(2, 3, 64, 64, generator=gg).to(DEV)) for _ in range(4)]
+
+    def fresh():
+        torch.manual_seed(0)
+        net = wm.WaveMamba(**cfg).train().to(DEV)
+        return net, wm.trainer.make_optimizer(net, capturable=True)
+    net_e, opt_e = fresh()
+    for _ in range(3):
+        wm.trainer.train_step(net_e, opt_e, *batches[0], as_float=False)
+    want = [wm.trainer.loss_values(wm.trainer.train_step(net_e, opt_e, lq, gt, as_float=False)) for lq, gt in batches]
+    net_g, opt_g = fresh()
+    step = wm.trainer.GraphedTrainStep(net_g, opt_g, *batches[0])
+    for (lq, gt), w in zip(batches, want):
+        got = wm.trainer.loss_values(step(lq, gt))
+        bad = [n for n, p in net_g.named_parameters() if not bool(torch.isfinite(p.grad).all())]
+        assert not bad, f"non-finite gradients after a replay: {bad[:5]}"
+        for k in got:
+            assert abs(got[k] - w[k]) <= 1e-5 * abs(w[k]), f"{k}: graphed {got[k]} eager {w[k]}"
+        _eager_noise()
+    worst = max(float((p.detach() - q.detach()).abs().max() / (q.detach().abs().max() + 1e-12))
+                for p, q in zip(net_g.parameters(), net_e.parameters()))
+    assert worst <= 1e-3, f"parameters after 3 + 4 steps differ by {worst:.2e}"
+
+
 def test_graphed_train_step_follows_a_learning_rate_schedule():
     """a float lr would be frozen into the captured AdamW launch.  make_optimizer(capturable=True) keeps lr as a device
     tensor; a torch scheduler stepped between replays fills it in place and the replayed update follows: graphed + scheduler ==

@@ -70,6 +70,37 @@ static inline int launch_status() {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Zeroing of accumulate-into outputs: a KERNEL, never hipMemsetAsync.  Round 6: a hipMemsetAsync captured into a HIP graph
+// (torch.cuda.graph around a training step, trainer.GraphedTrainStep) becomes a memset node whose fill pattern this runtime
+// (ROCm 7.0.2 as bundled with torch 2.10) re-reads at every launch of the graph from memory it has meanwhile recycled: with any
+// eager kernel launch between two replays the node filled the gradient buffers with 16-byte records of somebody else's kernel
+// arguments (tools/repro_graph_memset_node.py: every fourth float of a depth-wise weight gradient = the low half of a temporary's
+// address, -1.5e38) - NaN parameters two replays later.  A kernel node carries its arguments by value.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint32_t* __restrict__ p, size_t nwords, int vec) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    if (vec) {                                                   // 16-byte aligned, nwords % 4 == 0
+        uint4* q = reinterpret_cast<uint4*>(p);
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords / 4; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += stride) p[i] = 0u;
+    }
+}
+
+// bytes % 4 == 0 and a 4-byte aligned pointer (every caller zeroes float buffers)
+static hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    if ((bytes & 3u) || (reinterpret_cast<uintptr_t>(p) & 3u)) return hipErrorInvalidValue;
+    const size_t nwords = bytes / 4;
+    const int vec = aligned16(p) && (nwords % 4 == 0) ? 1 : 0;
+    const size_t items = vec ? nwords / 4 : nwords;
+    size_t blocks = (items + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<uint32_t*>(p), nwords, vec);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Haar launchers
 // ------------------------------------------------------------------------------------------------
 template <typename Tf, typename Ts, bool ROUND>
@@ -451,9 +482,9 @@ static int bwd_launch(const ScanBwdArgs& a0, const BwdPlan& pl, float* seg, floa
         if (pl.nblocks > 1) bwd_launch_carry(a, pl, seg, st);
     }
     hipLaunchKernelGGL((selscan_bwd_chunk_kernel<NP, VEC, 0>), grid, block, 0, st, a);
-    hipMemsetAsync(dA, 0, (size_t)a.dim * a.N * sizeof(float), st);
-    if (dD) hipMemsetAsync(dD, 0, (size_t)a.dim * sizeof(float), st);
-    if (dbias) hipMemsetAsync(dbias, 0, (size_t)a.dim * sizeof(float), st);
+    zero_async(dA, (size_t)a.dim * a.N * sizeof(float), st);
+    if (dD) zero_async(dD, (size_t)a.dim * sizeof(float), st);
+    if (dbias) zero_async(dbias, (size_t)a.dim * sizeof(float), st);
     const int ysplit = bwd_finish_split(pl.nblocks, NP + kPartPad);
     hipLaunchKernelGGL(selscan_bwd_finish_kernel, dim3((unsigned)a.dim, (unsigned)ysplit), dim3(256), 0, st,
                        (const float*)a.part, dA, dD, dbias, a.batch, a.dim, a.N, NP + kPartPad, pl.nblocks,
@@ -492,8 +523,8 @@ int wm_selscan_bwd(const float* u, const float* delta, const float* A, const flo
     a.softplus = delta_softplus ? 1 : 0; a.atomic_bc = pl.wpg > 1 ? 1 : 0; a.accumulate = 0;
     if (a.atomic_bc) {
         const size_t nb = (size_t)batch * G * N * L * sizeof(float);
-        hipError_t e = hipMemsetAsync(dB, 0, nb, st);
-        if (e == hipSuccess) e = hipMemsetAsync(dC, 0, nb, st);
+        hipError_t e = zero_async(dB, nb, st);
+        if (e == hipSuccess) e = zero_async(dC, nb, st);
         if (e != hipSuccess) return (int)e;
     }
     const bool vec = (L % 4 == 0) && aligned16(u) && aligned16(delta) && aligned16(Bm) && aligned16(Cm) &&
@@ -1322,7 +1353,7 @@ static bool prezeroed(const void* p, size_t bytes) {
 
 static hipError_t zero_out(void* p, size_t bytes, hipStream_t st) {
     if (bytes == 0 || prezeroed(p, bytes)) return hipSuccess;
-    return hipMemsetAsync(p, 0, bytes, st);
+    return zero_async(p, bytes, st);
 }
 
 // Zero two small gradient buffers: ONE memset node when the caller allocated them back to back (ops.py does: a training step
@@ -1568,8 +1599,8 @@ int wm_conv2d_wgrad(const float* gy, const float* x, float* dW, float* db, void*
     if (!dW) return WM_ENULL;
     hipStream_t st = (hipStream_t)stream;
     if (B == 0 || H == 0 || W == 0) {
-        hipError_t e = hipMemsetAsync(dW, 0, (size_t)Cout * Cin * ks * ks * sizeof(float), st);
-        if (e == hipSuccess && db) e = hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), st);
+        hipError_t e = zero_async(dW, (size_t)Cout * Cin * ks * ks * sizeof(float), st);
+        if (e == hipSuccess && db) e = zero_async(db, (size_t)Cout * sizeof(float), st);
         return e == hipSuccess ? WM_OK : (int)e;
     }
     const size_t need = wm_conv2d_wgrad_workspace_bytes(B, Cin, Cout, H, W, ks);

@@ -173,17 +173,22 @@ class GraphedDDPTrainStep:
                 self._exchange()
                 self._update()
         torch.cuda.current_stream(dev).wait_stream(side)
+        # no collective of the warm-up may still be in flight, and the captures are THREAD-LOCAL: ProcessGroupNCCL's watchdog
+        # thread polls its work events (hipEventQuery) while this thread captures; under the default global capture mode that
+        # call is an error in the watchdog and ends the process
+        torch.cuda.synchronize(dev)
+        mode = {"capture_error_mode": "thread_local"}
         if collective == "captured":
             self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), None
-            with torch.cuda.graph(self.graph_a):
+            with torch.cuda.graph(self.graph_a, **mode):
                 self._produce()
                 self._exchange()
                 self._update()
         else:
             self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_a):
+            with torch.cuda.graph(self.graph_a, **mode):
                 self._produce()
-            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), **mode):
                 self._update()
 
     def _produce(self):
