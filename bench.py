@@ -305,7 +305,10 @@ def graph_replay(step, steps, device):
             step()                                              # warm the private-pool allocations
         torch.cuda.current_stream().wait_stream(side)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # (a process group's watchdog thread polls events while this thread captures: thread-local capture mode, trainer.py)
+        mode = {"capture_error_mode": "thread_local"} if dist.is_initialized() else {}
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, **mode):
             out = step()
         g.replay()
         torch.cuda.synchronize()

@@ -347,6 +347,15 @@ size_t wm_conv2d_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, i
 int wm_conv2d_wgrad(const float* gy, const float* x, float* dW, float* db, void* workspace, size_t workspace_bytes, int B, int Cin,
                     int Cout, int H, int W, int ks, void* stream);
 
+/* The two loss terms of FeMaSRModel.optimize_parameters (basicsr/models/femasr_model.py:171-179): nn.L1Loss() on the prediction and
+ * FFTLoss (basicsr/losses/losses.py:306-313: an L1 mean over the stacked real / imaginary parts of rfft2 = the same mean over the
+ * interleaved floats of the complex tensor).  out[0] = mean_i |a_i - b_i| (zeroed here; one atomic per workgroup: ~1e-7 run to run);
+ * ga_i = gout[0] * sign(a_i - b_i) / n (sign(0) = 0, like ATen).  a, b, ga: n fp32 elements, dense; gout: one device float.
+ * (ATen's own reduction zeroes its semaphores with hipMemsetAsync, which must not be captured into a HIP graph on this runtime:
+ * see the note on zero-initialised outputs below.) */
+int wm_l1_mean_fwd(const float* a, const float* b, float* out, int64_t n, void* stream);
+int wm_l1_mean_bwd(const float* a, const float* b, const float* gout, float* ga, int64_t n, void* stream);
+
 /* sums (C) = sum over batch and plane of x (B, C, H, W): the bias gradient of a convolution (training). */
 int wm_plane_sums(const float* x, float* sums, int B, int C, int H, int W, void* stream);
 
@@ -418,9 +427,11 @@ int wm_prof_collect(int* launches /*[WM_PROF_NKERNELS]*/, double* total_ms /*[WM
 
 /* Zero-initialised accumulator outputs.  The entry points whose kernels ADD into an output with atomics - wm_dwconv3x3_wgrad
  * (dW, db), wm_layernorm2d_bwd and wm_layernorm_tok_bwd (dweight, dbias), wm_linear_wgrad (dW), wm_plane_sums (sums),
- * wm_scale_add_bwd (gscale), wm_conv2d_f16_steps (amax) - zero that output first with a memset node on the stream.  A caller that
+ * wm_scale_add_bwd (gscale), wm_conv2d_f16_steps (amax), wm_l1_mean_fwd (out) - zero that output first, on the stream, with a small
+ * KERNEL (round 6; never hipMemsetAsync: captured into a HIP graph that is a memset node, and ROCm 7.0.2 fills with a pattern it
+ * re-reads from recycled memory when the graph is launched again after eager work - profiles/r06/graph_memset_node.md).  A caller that
  * hands these buffers out of memory it has ALREADY zeroed (one memset for many buffers: the host side's bump arena,
- * ops._zeros_small) registers the range; a buffer lying entirely inside a registered range is then taken as zero and the node is
+ * ops._zeros_small) registers the range; a buffer lying entirely inside a registered range is then taken as zero and the launch is
  * skipped (a BASELINE config-3 training step had 323 of them, 1.4 ms of stream time).  The caller's contract: every buffer it
  * passes from a registered range is zero at that point of the stream, and the range is unregistered before its memory is freed.
  * register: WM_EINVAL for an empty range or one that overlaps a registered range; unregister: WM_EINVAL for an unknown base.

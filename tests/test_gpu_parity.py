@@ -2030,12 +2030,68 @@ def test_graph_replay_zeroes_its_accumulators_with_eager_launches_between_replay
             _eager_noise()
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 64, 64), (1, 3, 37, 53), (8, 3, 512, 512), (2, 3, 128, 65, 2), (5,)])
+def test_l1_mean_vs_float64(shape):
+    """ops.l1_mean = nn.L1Loss() / the reduction of FFTLoss (femasr_model.py:171-179, losses.py:306-313) on HIP kernels: value
+    against the float64 mean, gradients in both arguments against ATen's (sign(a - b) * g / n, exact), odd sizes and an
+    unaligned view included; bit-stable enough for logging (atomics: ~1e-7 run to run)."""
+    gg = gen(3)
+    a = torch.rand(*shape, generator=gg).to(DEV).requires_grad_(True)
+    b = torch.rand(*shape, generator=gg).to(DEV).requires_grad_(True)
+    with torch.no_grad():
+        if a.numel() > 4:
+            a.view(-1)[1] = b.view(-1)[1]                        # an exact tie: sign(0) = 0
+    out = wm.ops.l1_mean(a, b)
+    assert out.shape == ()
+    want = (a.detach().double() - b.detach().double()).abs().mean()
+    assert abs(float(out) - float(want)) <= 2e-6 * float(want)
+    (out * 3.0).backward()
+    ga, gb = a.grad.clone(), b.grad.clone()
+    a2, b2 = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    (F.l1_loss(a2, b2) * 3.0).backward()
+    assert torch.equal(ga, a2.grad) and torch.equal(gb, b2.grad)
+    again = [float(wm.ops.l1_mean(a, b)) for _ in range(3)]
+    assert max(abs(v - float(out)) for v in again) <= 1e-6 * float(want)
+    with pytest.raises(RuntimeError):
+        wm.ops.l1_mean(a, b.reshape(-1)[: max(1, b.numel() - 1)])
+    with pytest.raises(RuntimeError):
+        wm.ops.l1_mean(a.cpu(), b.cpu())
+
+
+def test_trainer_losses_equal_the_reference_composition():
+    """trainer.losses on the GPU (HIP reductions, view_as_real) = the reference's composition (F.l1_loss, stacked real / imag
+    parts) in value and in the gradient that reaches the prediction."""
+    gg = gen(9)
+    pred = torch.rand(2, 3, 96, 160, generator=gg).to(DEV).requires_grad_(True)
+    gt = torch.rand(2, 3, 96, 160, generator=gg).to(DEV)
+    l_pix, l_freq = wm.trainer.losses(pred, gt)
+    (l_pix + l_freq).mean().backward()
+    p2 = pred.detach().clone().requires_grad_(True)
+    pf, tf = torch.fft.rfft2(p2), torch.fft.rfft2(gt)
+    r_pix = F.l1_loss(p2, gt)
+    r_freq = 0.1 * F.l1_loss(torch.stack([pf.real, pf.imag], dim=-1), torch.stack([tf.real, tf.imag], dim=-1))
+    (r_pix + r_freq).mean().backward()
+    assert abs(float(l_pix) - float(r_pix)) <= 2e-6 * float(r_pix) and abs(float(l_freq) - float(r_freq)) <= 2e-6 * float(r_freq)
+    assert_close(pred.grad, p2.grad, 1e-5, "d loss / d prediction")
+
+
 def test_graphed_train_step_with_eager_work_between_replays():
     """The whole optimize_parameters() replayed from a graph while the caller runs kernels of its own between the replays (logging,
     checks, data preparation): the same losses as the eager steps, finite gradients, every replay (round 6: NaN after the second)."""
-    cfg = dict(in_chn=3, wf=16, n_l_blocks=[1, 1, 1], n_h_blocks=[1, 1, 1], ffn_scale=2.0)
+    _graphed_with_eager_work(dict(in_chn=3, wf=16, n_l_blocks=[1, 1, 1], n_h_blocks=[1, 1, 1], ffn_scale=2.0), 64)
+
+
+def test_graphed_train_step_with_eager_work_between_replays_shipped_config():
+    """... and the shipped configuration at 256 x 256 (round 6: with ATen's l1_loss in the step - its reduction zeroes semaphores with
+    a memset node - the weights of a replay stayed right and its REPORTED l_pix went from 0.33 to 1.10)."""
+    # (Adam's first updates are lr * sign-like in every gradient element: tensors whose gradient noise straddles zero move by up to
+    # 2 lr per step either way, hence the looser bar on the parameters of the 591-tensor network; the losses carry the 1e-5 bar)
+    _graphed_with_eager_work(dict(in_chn=3, wf=32, n_l_blocks=[1, 2, 4], n_h_blocks=[1, 1, 2], ffn_scale=2.0), 256, wbar=5e-2)
+
+
+def _graphed_with_eager_work(cfg, size, wbar=1e-3):
     gg = gen(77)
-    batches = [(torch.rand(2, 3, 64, 64, generator=gg).to(DEV), torch.rand(2, 3, 64, 64, generator=gg).to(DEV)) for _ in range(4)]
+    batches = [(torch.rand(2, 3, size, size, generator=gg).to(DEV), torch.rand(2, 3, size, size, generator=gg).to(DEV)) for _ in range(4)]
 
     def fresh():
         torch.manual_seed(0)
@@ -2056,7 +2112,7 @@ def test_graphed_train_step_with_eager_work_between_replays():
         _eager_noise()
     worst = max(float((p.detach() - q.detach()).abs().max() / (q.detach().abs().max() + 1e-12))
                 for p, q in zip(net_g.parameters(), net_e.parameters()))
-    assert worst <= 1e-3, f"parameters after 3 + 4 steps differ by {worst:.2e}"
+    assert worst <= wbar, f"parameters after 3 + 4 steps differ by {worst:.2e}"
 
 
 def test_graphed_train_step_follows_a_learning_rate_schedule():

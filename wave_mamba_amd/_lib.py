@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("WAVEMAMBA_HIP_LIB") or os.path.join(HERE, "libwavemam
 WM_F32, WM_BF16 = 0, 1
 WM_OK, WM_EINVAL, WM_ENULL, WM_EALIGN, WM_EWORKSPACE, WM_EUNSUPPORTED, WM_EHIP = 0, -1, -2, -3, -4, -5, -6
 WM_PROF_NKERNELS = 20
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 _c = ctypes
 _p, _i, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t
@@ -57,6 +57,8 @@ SIGNATURES = {
     "wm_conv2d_wgrad_workspace_bytes": (_sz, [_i] * 6),
     "wm_conv2d_wgrad": (_i, [_p, _p, _p, _p, _p, _sz] + [_i] * 6 + [_p]),
     "wm_plane_sums": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "wm_l1_mean_fwd": (_i, [_p, _p, _p, _i64, _p]),
+    "wm_l1_mean_bwd": (_i, [_p, _p, _p, _p, _i64, _p]),
     "wm_gate_fwd": (_i, [_p] * 3 + [_i, _i] + [_i64] * 4 + [_p]),
     "wm_gate_bwd": (_i, [_p] * 5 + [_i, _i] + [_i64] * 6 + [_p]),
     "wm_scale_add_fwd": (_i, [_p] * 4 + [_i, _i, _i64, _p]),

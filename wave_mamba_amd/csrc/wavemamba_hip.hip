@@ -29,6 +29,7 @@
 #include "gates.hip.h"
 #include "conv_wgrad.hip.h"
 #include "patchify.hip.h"
+#include "loss.hip.h"
 
 namespace wm {
 
@@ -253,7 +254,7 @@ using namespace wm;
 // ================================================================================================
 extern "C" {
 
-int wm_abi_version(void) { return 30; }
+int wm_abi_version(void) { return 31; }
 
 #ifndef WM_BUILD_ID
 #define WM_BUILD_ID "unknown"
@@ -1651,6 +1652,35 @@ int wm_plane_sums(const float* x, float* sums, int B, int C, int H, int W, void*
     if (bpp > cap) bpp = cap;
     if (bpp < 1) bpp = 1;
     hipLaunchKernelGGL(plane_sums_kernel, dim3((unsigned)bpp, (unsigned)planes), dim3(256), 0, st, x, sums, C, HW, vec);
+    return launch_status();
+}
+
+// mean |a - b| over n elements -> out[0] (zeroed here, by a kernel); ga = gout[0] * sign(a - b) / n
+int wm_l1_mean_fwd(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    if (n < 0) return WM_EINVAL;
+    if (!out) return WM_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    const hipError_t e = zero_out(out, sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    if (n == 0) return WM_OK;                                     // (torch returns nan for an empty mean; callers never ask)
+    if (!a || !b) return WM_ENULL;
+    const int vec = (n % 4 == 0) && aligned16(a) && aligned16(b) ? 1 : 0;
+    long long blocks = ((vec ? n / 4 : n) + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(l1_mean_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, out, (long long)n, 1.0f / (float)n, vec);
+    return launch_status();
+}
+int wm_l1_mean_bwd(const float* a, const float* b, const float* gout, float* ga, int64_t n, void* stream) {
+    if (n < 0) return WM_EINVAL;
+    if (n == 0) return WM_OK;
+    if (!a || !b || !gout || !ga) return WM_ENULL;
+    const int vec = (n % 4 == 0) && aligned16(a) && aligned16(b) && aligned16(ga) ? 1 : 0;
+    long long blocks = ((vec ? n / 4 : n) + 256 * 4 - 1) / (256 * 4);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(l1_mean_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, gout, ga, (long long)n,
+                       1.0f / (float)n, vec);
     return launch_status();
 }
 

@@ -1302,6 +1302,42 @@ def plane_sums(x):
     return out
 
 
+class _L1Mean(torch.autograd.Function):
+    """mean |a - b| of two dense fp32 tensors of one shape (nn.L1Loss() and the reduction of FFTLoss, femasr_model.py:171-179;
+    losses.py:306-313): forward and backward on the HIP kernels of loss.hip.h.  (ATen's reduction zeroes its semaphores with
+    hipMemsetAsync - a memset node in a captured training step, which this runtime must not be given: the reported loss of a
+    replay went wrong, profiles/r06/graph_memset_node.md.)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = _lib.load()
+        ctx.save_for_backward(a, b)
+        out = _zeros_small(1, a.device)
+        with torch.cuda.device(a.device):
+            check(lib.wm_l1_mean_fwd(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "wm_l1_mean_fwd")
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        a, b = ctx.saved_tensors
+        g = g.contiguous().float()
+        ga = torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            check(lib.wm_l1_mean_bwd(_ptr(a), _ptr(b), _ptr(g), _ptr(ga), a.numel(), _stream()), "wm_l1_mean_bwd")
+        return (ga if ctx.needs_input_grad[0] else None), (-ga if ctx.needs_input_grad[1] else None)
+
+
+def l1_mean(a, b):
+    """F.l1_loss(a, b) (mean reduction) for CUDA fp32 tensors of one shape, differentiable in both arguments."""
+    _require_cuda("l1_mean", a, b)
+    if a.shape != b.shape:
+        raise RuntimeError(f"l1_mean: shapes differ: {tuple(a.shape)} vs {tuple(b.shape)}")
+    if a.numel() == 0:
+        raise RuntimeError("l1_mean: empty input")
+    return _L1Mean.apply(a.contiguous().float(), b.contiguous().float())
+
+
 class _Conv2dTrain(torch.autograd.Function):
     """Dense 3x3 / 1x1 convolution (stride 1, 'same' padding) for training: forward and input gradient on the
     matrix-core kernels (the input gradient is the same convolution with the weight transposed and flipped) - the fp16 form

@@ -12,14 +12,30 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 
+def _on_hip(a, b):
+    return a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape
+
+
+def l1(pred, target):
+    """nn.L1Loss() (femasr_model.py:30, :171).  GPU fp32 tensors: the HIP reduction (ops.l1_mean) - no ATen semaphore memset in the
+    step, so the step can be captured into a HIP graph and the REPORTED loss of a replay stays right."""
+    if _on_hip(pred, target):
+        from . import ops
+        return ops.l1_mean(pred, target)
+    return F.l1_loss(pred, target)
+
+
 def fft_l1(pred, target):
-    """FFTLoss (losses.py:306-313): L1 between the stacked real/imag parts of rfft2."""
+    """FFTLoss (losses.py:306-313): L1 between the stacked real/imag parts of rfft2.  On the GPU the same mean is taken over the
+    interleaved (re, im) floats of the complex tensors (`view_as_real`: the stacked copies are never made)."""
     pf, tf = torch.fft.rfft2(pred), torch.fft.rfft2(target)
+    if pf.is_cuda and pf.dtype == torch.complex64 and tf.dtype == torch.complex64:
+        return l1(torch.view_as_real(pf), torch.view_as_real(tf))
     return F.l1_loss(torch.stack([pf.real, pf.imag], dim=-1), torch.stack([tf.real, tf.imag], dim=-1))
 
 
 def losses(output, gt, fft_weight=0.1):
-    return F.l1_loss(output, gt), fft_weight * fft_l1(output, gt)
+    return l1(output, gt), fft_weight * fft_l1(output, gt)
 
 
 def make_optimizer(net, lr=5e-4, weight_decay=1e-3, betas=(0.9, 0.99), capturable=False):
@@ -96,7 +112,13 @@ class GraphedTrainStep:
         torch.cuda.current_stream(lq.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        mode = {}
+        if dist.is_available() and dist.is_initialized():
+            # a (one-rank) process group exists: its watchdog thread polls events while this thread captures, which the default
+            # global capture mode turns into a fatal error in the watchdog (see GraphedDDPTrainStep)
+            torch.cuda.synchronize(lq.device)
+            mode = {"capture_error_mode": "thread_local"}
+        with torch.cuda.graph(self.graph, **mode):
             out = net(self.lq)
             l_pix, l_freq = losses(out, self.gt)
             (l_pix + l_freq).mean().backward()
