@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """wm_lfss_out_conv_fwd (the ffn's depth-wise 3x3 + gelu gate + conv3 + scaled skip, one kernel) at the three UHD levels, ms per call
-(HIP events) and a checksum of the output.  WM_LFSS_OUT_LINEAR=1 selects the linear group order (before round 4's banded order).  The row-window form (R = 2) runs on maps of
->= 2^20 positions; the WM_LFSS_OUT_ROWS switch and the R = 3 instantiations were deleted in round 6."""
+(HIP events) and a checksum of the output.  Levels 1 and 2 (W % 64 == 0) run the accumulating row-window form (R = 4, round 6), level 3
+the one-row banded form; profiles/r06/lfss_out_conv_forms.txt holds the forms measured against each other."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -651,137 +651,167 @@ __global__ __launch_bounds__(256, 4) void lfss_out_conv_mfma_kernel(
     }
 }
 
-// ---- lfss_out_conv, row-window form (round 4, end): R output rows of a 64-column strip per wave pass ------------------------
-// PMC over the UHD step (profiles/r04/pmc_step_traffic_per_kernel.txt) shows lfss_out_conv_mfma_kernel HBM-bound on 2.3 x its
-// algorithmic bytes: every wave fetches the three tap rows of its output row itself and the second-level cache does not serve the
-// re-reads (64 channel planes 8 MB apart).  Here a wave owns a strip of 64 columns and R consecutive output rows: per group of four
-// channel pairs it loads the R + 2 tap rows ONCE ((R + 2) / R of f instead of 3 x, 9 (R + 2) / R load instructions per output value
-// and channel instead of 9 ... 27) and writes the R rows' gelu(gate) * value products to R per-wave LDS tiles, from which the
-// matrix stage of lfss_out_conv_mfma_kernel runs row by row: the same operands in the same instruction order, BIT-identical
-// outputs.  Two-wave workgroups (R x 16 KB of product tiles each).  W % 64 == 0; rows past the image are masked by the
-// buffer range check (reads) and skipped (stores).
+// ---- lfss_out_conv, accumulating row-window form (round 6) -------------------------------------------------------------------
+// PMC over the UHD step (profiles/r04/pmc_step_traffic_per_kernel.txt) showed the one-row form HBM-bound on 2.3 x its algorithmic
+// bytes: every wave fetches the three tap rows of its output row itself.  Rounds 4-5 kept R = 2 output rows' product tiles
+// [32 gated channels][64 positions] in LDS (R x 8 KB per wave: R = 3 already left too few waves) and fetched every tap row three times (left / centre / right: 9 (R + 2) / R load instructions per output value and
+// channel).  Here the 32 x 32 closing product ACCUMULATES over groups of eight gated channels - the K order of lfss_out, so the sums
+// stay bit-identical - in R x 2 register tiles, which leaves 2 R KB of products in LDS per wave, and a tap row is ONE coalesced
+// load: the left / right neighbours come from the adjacent lanes (DPP wave_shr:1 / wave_shl:1), the two values a strip lacks (the
+// column before its first and after its last) from one more load that only touches two cache lines.  2 (R + 2) / R load
+// instructions per output value and channel, (R + 2) / R of f; a wave walks `bpw` consecutive bands of ITS strip, so the two rows
+// two bands share come from the cache the wave has just filled.  W % 64 == 0.
+__device__ __forceinline__ float dpp_from_lower_lane(float own_if_first, float v) {       // lane i <- lane i - 1; lane 0 keeps `own_if_first`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, own_if_first), __builtin_bit_cast(int, v),
+                                                                 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_upper_lane(float own_if_last, float v) {         // lane i <- lane i + 1; lane 63 keeps `own_if_last`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, own_if_last), __builtin_bit_cast(int, v),
+                                                                 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
 template <int R, typename TP>
-__global__ __launch_bounds__(128, 2) void lfss_out_conv_rows_kernel(
+__global__ __launch_bounds__(256, 2) void lfss_out_conv_acc_kernel(
     const TP* __restrict__ f, const float* __restrict__ cw /*(D, 3, 3)*/, const float* __restrict__ cbias /*(D) or null*/,
     const float* __restrict__ tok1, const float* __restrict__ W3 /*(C, C)*/, const float* __restrict__ b3,
     const float* __restrict__ skip2, float* __restrict__ out, int out_nchw, int B, int H, int W, int nstrips, int nbands,
-    long long units, int upw) {
+    int bpw /* bands per walk */, int nchunks /* walks per strip */, long long nwalks) {
     constexpr int C = 32, D = 64, E = (int)sizeof(TP);
     __shared__ __attribute__((aligned(16))) float s_b3[C];
     __shared__ __attribute__((aligned(16))) float s_skip[C];
     __shared__ __attribute__((aligned(16))) float s_A3[(C / 2) * 64];
     __shared__ __attribute__((aligned(16))) float s_cw[D * 12];
-    __shared__ __attribute__((aligned(16))) float s_g[2 * R * C * 64];           // per wave: R tiles [channel][position]
+    __shared__ __attribute__((aligned(16))) float s_g[4 * 8 * R * 64];           // per wave: [gated channel of the group][row][position]
     const long long L = (long long)H * W;
     const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x < C) { s_b3[threadIdx.x] = b3[threadIdx.x]; s_skip[threadIdx.x] = skip2[threadIdx.x]; }
-    for (int e = threadIdx.x; e < (C / 2) * 64; e += 128) {
+    for (int e = threadIdx.x; e < (C / 2) * 64; e += 256) {
         const int j = e >> 6, l = e & 63;
         s_A3[aop_slot(j, l)] = W3[(l & 31) * C + acc_chan(j, l >> 5)];
     }
-    for (int e = threadIdx.x; e < D * 12; e += 128) {
+    for (int e = threadIdx.x; e < D * 12; e += 256) {
         const int c = e / 12, q = e - 12 * c;
         s_cw[e] = q < 9 ? cw[c * 9 + q] : (q == 9 && cbias ? cbias[c] : 0.0f);
     }
     __syncthreads();
-    float* sg = s_g + wv * (R * C * 64) + lane;
-    const long long u0 = (long long)blockIdx.x * 2 * upw + wv;       // the block's two waves walk adjacent strips together
-    for (int ui = 0; ui < upw; ++ui) {
-        const long long u = u0 + 2 * ui;
-        if (u >= units) break;
-        const int strip = (int)(u % nstrips);
-        const long long ub = u / nstrips;
-        const int band = (int)(ub % nbands);
-        const long long b = ub / nbands;
-        const int r0 = band * R;
-        const long long p = (long long)r0 * W + (long long)strip * 64 + lane;      // the lane's position in output row r0 (< L)
-        const bool ml = !(strip == 0 && lane == 0), mr = !(strip == nstrips - 1 && lane == 63);     // left / right tap inside the image
-        const TP* fb = f + b * D * L;
-        int off[R + 2];
-#pragma unroll
-        for (int dr = 0; dr < R + 2; ++dr) off[dr] = (int)((p + (long long)(dr - 1) * W) * E);     // rows r0 - 1 .. r0 + R (range check = zero rows)
-        __builtin_amdgcn_wave_barrier();                             // the previous unit's operand reads are done (in-order LDS)
-        // A ROLLED loop over groups of four channel pairs (as in dwconv_gate_positions: unrolled, every load of the strip is hoisted
-        // above its first use and a thousand registers spill)
+    const long long wk = (long long)blockIdx.x * 4 + wv;         // walk = (batch, chunk of bands, strip), strips fastest
+    if (wk >= nwalks) return;
+    const int strip = (int)(wk % nstrips);
+    const long long wb = wk / nstrips;
+    const int chunk = (int)(wb % nchunks);
+    const long long b = wb / nchunks;
+    float* sg = s_g + wv * (8 * R * 64);
+    const TP* fb = f + b * D * L;
+    const bool hok = lane < 32 ? strip != 0 : strip != nstrips - 1;      // the lane's halo element lies inside the image
+    const int hcol = strip * 64 + (lane < 32 ? -1 : 64);
+    const int band_end = min(nbands, (chunk + 1) * bpw);
 #pragma unroll 1
-        for (int c0 = 0; c0 < 32; c0 += 4) {
-            float t[4][2][R + 2][3];
+    for (int band = chunk * bpw; band < band_end; ++band) {
+        const int r0 = band * R;
+        int off[R + 2], hoff[R + 2];
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc)
+        for (int dr = 0; dr < R + 2; ++dr) {                      // rows r0 - 1 .. r0 + R (outside the image: range check = zeros)
+            const long long rowp = (long long)(r0 + dr - 1) * W;
+            off[dr] = (int)((rowp + strip * 64 + lane) * E);
+            hoff[dr] = (int)((rowp + hcol) * E);
+        }
+        lfss_v16f acc[R][2];
 #pragma unroll
-                for (int v = 0; v < 2; ++v) {
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(               // wave-uniform
-                        const_cast<TP*>(fb + (long long)(c0 + cc + 32 * v) * L), 0, (int)(L * E), 0x00020000);
+        for (int gq = 0; gq < 4; ++gq) {
+            const float4 bb = *reinterpret_cast<const float4*>(&s_b3[8 * gq + 4 * h]);
+            acc[0][0][4 * gq] = bb.x; acc[0][0][4 * gq + 1] = bb.y; acc[0][0][4 * gq + 2] = bb.z; acc[0][0][4 * gq + 3] = bb.w;
+        }
+        acc[0][1] = acc[0][0];
 #pragma unroll
-                    for (int dr = 0; dr < R + 2; ++dr) {
-                        const float a = buf_ld<TP>(rs, off[dr] - E), bq = buf_ld<TP>(rs, off[dr]), e = buf_ld<TP>(rs, off[dr] + E);
-                        t[cc][v][dr][0] = ml ? a : 0.0f; t[cc][v][dr][1] = bq; t[cc][v][dr][2] = mr ? e : 0.0f;
-                    }
-                }
+        for (int rr = 1; rr < R; ++rr) { acc[rr][0] = acc[0][0]; acc[rr][1] = acc[0][0]; }
+        // (a double-buffered form - the next channel's loads in flight under this one's products - measured the same at UHD level 1
+        // and 7 % slower at level 2, with four spilled registers: not kept)
+#pragma unroll 1
+        for (int j4 = 0; j4 < 4; ++j4) {
+            __builtin_amdgcn_wave_barrier();                     // the previous group's operand reads are done (in-order LDS)
+#pragma unroll 1
+            for (int cs = 0; cs < 4; ++cs) {                      // two gated channels = four planes per batch of loads
+                float ctr[2][2][R + 2], hal[2][2][R + 2];
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                float w[2][12];
-#pragma unroll
-                for (int v = 0; v < 2; ++v) {
-                    const float* wk = s_cw + (c0 + cc + 32 * v) * 12;                                  // [9 taps | bias | 0 0]
-                    const float4 w0 = *reinterpret_cast<const float4*>(wk), w1 = *reinterpret_cast<const float4*>(wk + 4),
-                                 w2 = *reinterpret_cast<const float4*>(wk + 8);
-                    w[v][0] = w0.x; w[v][1] = w0.y; w[v][2] = w0.z; w[v][3] = w0.w; w[v][4] = w1.x; w[v][5] = w1.y;
-                    w[v][6] = w1.z; w[v][7] = w1.w; w[v][8] = w2.x; w[v][9] = w2.y;
-                }
-#pragma unroll
-                for (int rr = 0; rr < R; ++rr) {
-                    float fc[2];
+                for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
                     for (int v = 0; v < 2; ++v) {
-                        float a = w[v][9];                           // the depth-wise kernel's order: bias, then taps row by row
+                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(               // wave-uniform
+                            const_cast<TP*>(fb + (long long)(8 * j4 + 2 * cs + cc + 32 * v) * L), 0, (int)(L * E), 0x00020000);
 #pragma unroll
-                        for (int k = 0; k < 9; ++k) a = fmaf(w[v][k], t[cc][v][rr + k / 3][k % 3], a);
-                        fc[v] = a;
+                        for (int dr = 0; dr < R + 2; ++dr) {
+                            ctr[cc][v][dr] = buf_ld<TP>(rs, off[dr]);
+                            hal[cc][v][dr] = buf_ld<TP>(rs, hoff[dr]);
+                        }
                     }
-                    sg[rr * (C * 64) + (c0 + cc) * 64] = gelu_erf(fc[0]) * fc[1];
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    float w[2][12];
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        const float* wk9 = s_cw + (8 * j4 + 2 * cs + cc + 32 * v) * 12;                     // [9 taps | bias | 0 0]
+                        const float4 w0 = *reinterpret_cast<const float4*>(wk9), w1 = *reinterpret_cast<const float4*>(wk9 + 4),
+                                     w2 = *reinterpret_cast<const float4*>(wk9 + 8);
+                        w[v][0] = w0.x; w[v][1] = w0.y; w[v][2] = w0.z; w[v][3] = w0.w; w[v][4] = w1.x; w[v][5] = w1.y;
+                        w[v][6] = w1.z; w[v][7] = w1.w; w[v][8] = w2.x; w[v][9] = w2.y;
+                    }
+                    float t[2][R + 2][3];
+#pragma unroll
+                    for (int v = 0; v < 2; ++v)
+#pragma unroll
+                        for (int dr = 0; dr < R + 2; ++dr) {
+                            const float hm = hok ? hal[cc][v][dr] : 0.0f;
+                            t[v][dr][0] = dpp_from_lower_lane(hm, ctr[cc][v][dr]);
+                            t[v][dr][1] = ctr[cc][v][dr];
+                            t[v][dr][2] = dpp_from_upper_lane(hm, ctr[cc][v][dr]);
+                        }
+#pragma unroll
+                    for (int rr = 0; rr < R; ++rr) {
+                        float fc[2];
+#pragma unroll
+                        for (int v = 0; v < 2; ++v) {
+                            float a = w[v][9];                       // the depth-wise kernel's order: bias, then taps row by row
+#pragma unroll
+                            for (int k = 0; k < 9; ++k) a = fmaf(w[v][k], t[v][rr + k / 3][k % 3], a);
+                            fc[v] = a;
+                        }
+                        sg[((2 * cs + cc) * R + rr) * 64 + lane] = gelu_erf(fc[0]) * fc[1];
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const float4 a4 = *reinterpret_cast<const float4*>(&s_A3[(j4 * 64 + lane) * 4]);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {                      // K-step j = 4 j4 + jj: channels acc_chan(j, h) = 8 j4 + jj + 4 h
+                const float* sr = sg + ((jj + 4 * h) * R) * 64;
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    acc[rr][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], sr[rr * 64 + n], acc[rr][0], 0, 0, 0);
+                    acc[rr][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], sr[rr * 64 + 32 + n], acc[rr][1], 0, 0, 0);
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 1
+#pragma unroll
         for (int rr = 0; rr < R; ++rr) {
-            if (r0 + rr >= H) break;                     // (wave-uniform) the last band may be short
-            const float* sr = s_g + wv * (R * C * 64) + rr * (C * 64);
-            lfss_v16f acc[2];
+            if (r0 + rr < H) {                                    // (wave-uniform) the last band may be short
+                const long long p0 = (long long)(r0 + rr) * W + (long long)strip * 64;
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const float4 bb = *reinterpret_cast<const float4*>(&s_b3[8 * gq + 4 * h]);
-                acc[0][4 * gq] = bb.x; acc[0][4 * gq + 1] = bb.y; acc[0][4 * gq + 2] = bb.z; acc[0][4 * gq + 3] = bb.w;
-            }
-            acc[1] = acc[0];
+                for (int tt = 0; tt < 2; ++tt) {
+                    const long long pos = p0 + 32 * tt + n;
+                    float tk[16], o[16];
+                    load_tile32(tok1, false, b, pos, L, h, tk);
 #pragma unroll
-            for (int j4 = 0; j4 < C / 8; ++j4) {
-                const float4 a4 = *reinterpret_cast<const float4*>(&s_A3[(j4 * 64 + lane) * 4]);
-                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {        // K-step j = channels acc_chan(j, h); tile 0 = positions n, tile 1 = 32 + n
-                    const int ch = acc_chan(4 * j4 + jj, h);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], sr[ch * 64 + n], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], sr[ch * 64 + 32 + n], acc[1], 0, 0, 0);
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const float4 s4 = *reinterpret_cast<const float4*>(&s_skip[8 * gq + 4 * h]);
+                        o[4 * gq] = fmaf(tk[4 * gq], s4.x, acc[rr][tt][4 * gq]); o[4 * gq + 1] = fmaf(tk[4 * gq + 1], s4.y, acc[rr][tt][4 * gq + 1]);
+                        o[4 * gq + 2] = fmaf(tk[4 * gq + 2], s4.z, acc[rr][tt][4 * gq + 2]); o[4 * gq + 3] = fmaf(tk[4 * gq + 3], s4.w, acc[rr][tt][4 * gq + 3]);
+                    }
+                    store_tile32(out, out_nchw != 0, b, pos, L, h, o);
                 }
-            }
-            const long long p0 = (long long)(r0 + rr) * W + (long long)strip * 64;
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const long long pos = p0 + 32 * tt + n;
-                float tk[16], o[16];
-                load_tile32(tok1, false, b, pos, L, h, tk);
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const float4 s4 = *reinterpret_cast<const float4*>(&s_skip[8 * gq + 4 * h]);
-                    o[4 * gq] = fmaf(tk[4 * gq], s4.x, acc[tt][4 * gq]); o[4 * gq + 1] = fmaf(tk[4 * gq + 1], s4.y, acc[tt][4 * gq + 1]);
-                    o[4 * gq + 2] = fmaf(tk[4 * gq + 2], s4.z, acc[tt][4 * gq + 2]); o[4 * gq + 3] = fmaf(tk[4 * gq + 3], s4.w, acc[tt][4 * gq + 3]);
-                }
-                store_tile32(out, out_nchw != 0, b, pos, L, h, o);
             }
         }
     }

@@ -1232,23 +1232,27 @@ int wm_lfss_out_conv_fwd(const void* f_, const float* conv2_weight, const float*
     const long long ngroups = (long long)B * ngl;
     const int gpw = lfss_groups_per_wave(ngroups, 2048);
     const long long waves = (ngroups + gpw - 1) / gpw;
-    // row-window form (lfss_out_conv_rows_kernel: R = 2 output rows per wave pass, (R + 2) / R of f instead of 3 x): W % 64 == 0.
-    // Measured (profiles/r04, ms per call at UHD levels 1 / 2): banded one-row form 0.464 / 0.087, R = 2 0.403 / 0.095, R = 3 0.452 /
-    // 0.128 (two-wave workgroups, one per 56 KB of product tiles: too few waves; its instantiations and the environment switch
-    // were deleted in round 6) -> R = 2 on maps of >= 2^20 positions, the one-row form below that.
-    if (W % 64 == 0 && (long long)B * L >= (1ll << 20)) {
-        constexpr int R = 2;
+    // accumulating row-window form (round 6, lfss_out_conv_acc_kernel<4>: four output rows of a 64-column strip per wave pass, the
+    // closing product accumulated in registers over groups of eight gated channels, one coalesced load per tap row + lane shifts):
+    // W % 64 == 0 and >= 2^18 positions.  Measured (profiles/r06/lfss_out_conv_forms.txt, ms per call at UHD levels 1 / 2): banded
+    // one-row form 0.464 / 0.087 (round 4), row windows in LDS R = 2 0.405 / 0.088 (round 4-5; deleted), this form R = 2 0.401 /
+    // 0.084, R = 4 0.346 / 0.069; its double-buffered variant 0.338-0.351 / 0.074 (not kept).  Bit-identical outputs in all forms.
+    if (W % 64 == 0 && (long long)B * L >= (1ll << 18)) {
+        constexpr int R = 4;
         const int nstrips = W / 64, nbands = (H + R - 1) / R;
-        const long long units = (long long)B * nbands * nstrips;
-        const int upw = lfss_groups_per_wave(units, 2048);
-        const long long nwaves = (units + upw - 1) / upw;
-        hipStream_t st2 = (hipStream_t)stream;
-        ProfScope ps2(11, st2);
-#define WM_ROWS(TP) hipLaunchKernelGGL((lfss_out_conv_rows_kernel<R, TP>), dim3((unsigned)((nwaves + 1) / 2)), dim3(128), 0, st2, \
-                                       (const TP*)f_, conv2_weight, conv2_bias, tok1, conv3_weight, conv3_bias, skip_scale2, out,   \
-                                       out_nchw, B, H, W, nstrips, nbands, units, upw)
-        if (plane_dtype == WM_F32) WM_ROWS(float); else WM_ROWS(bf16_t);
-#undef WM_ROWS
+        // bands per walk (a wave walks consecutive bands of its strip): enough walks for two rounds of the 2,048 resident waves
+        int bpw = (int)(((long long)B * nbands * nstrips + 4095) / 4096);
+        if (bpw < 1) bpw = 1;
+        if (bpw > 8) bpw = 8;
+        const int nchunks = (nbands + bpw - 1) / bpw;
+        const long long nwalks = (long long)B * nchunks * nstrips;
+        hipStream_t st3 = (hipStream_t)stream;
+        ProfScope ps3(11, st3);
+#define WM_ACC(TP) hipLaunchKernelGGL((lfss_out_conv_acc_kernel<R, TP>), dim3((unsigned)((nwalks + 3) / 4)), dim3(256), 0, st3, \
+                                      (const TP*)f_, conv2_weight, conv2_bias, tok1, conv3_weight, conv3_bias, skip_scale2, out,   \
+                                      out_nchw, B, H, W, nstrips, nbands, bpw, nchunks, nwalks)
+        if (plane_dtype == WM_F32) WM_ACC(float); else WM_ACC(bf16_t);
+#undef WM_ACC
         return launch_status();
     }
     // groups per image row for the kernel's banded (column-major) group order (0: linear order, maps whose width is not a multiple of 64)
