@@ -433,7 +433,9 @@ int wm_prof_collect(int* launches /*[WM_PROF_NKERNELS]*/, double* total_ms /*[WM
  * hands these buffers out of memory it has ALREADY zeroed (one memset for many buffers: the host side's bump arena,
  * ops._zeros_small) registers the range; a buffer lying entirely inside a registered range is then taken as zero and the launch is
  * skipped (a BASELINE config-3 training step had 323 of them, 1.4 ms of stream time).  The caller's contract: every buffer it
- * passes from a registered range is zero at that point of the stream, and the range is unregistered before its memory is freed.
+ * passes from a registered range is zero at that point of the stream (ONE-SHOT: a buffer that has been accumulated into is not zero
+ * any more - passing it again, to this or another accumulate-into entry point, adds onto its old contents without any error; hand
+ * every buffer out of the range once), and the range is unregistered before its memory is freed.
  * register: WM_EINVAL for an empty range or one that overlaps a registered range; unregister: WM_EINVAL for an unknown base.
  * Process-wide, thread-safe.  No reference counterpart (the reference's gradients come from ATen). */
 int wm_zero_arena_register(void* base, size_t bytes);

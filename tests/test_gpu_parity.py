@@ -1909,6 +1909,31 @@ def test_zero_arena_skips_the_memset_only_inside_registered_ranges():
     assert_close(out_in, ref, 1e-5, "after unregister: zeroed by the library")
 
 
+def test_zero_arena_clear_unregisters_and_restarts():
+    """ops.zero_arena_clear(): every (device, stream) entry goes, its block is unregistered (the library zeroes buffers
+    inside it itself again), the next small output comes zeroed from a fresh registered block."""
+    from wave_mamba_amd import ops
+    from wave_mamba_amd.ops import _ptr, _stream
+    lib = wm._lib.load()
+    x = torch.randn(2, 8, 16, 32, generator=gen(2)).to(DEV)
+    ref = x.double().sum((0, 2, 3)).float()
+    side = torch.cuda.Stream(DEV)
+    with torch.cuda.stream(side):
+        ops._zeros_small(8, torch.device(DEV))
+    side.synchronize()
+    old = ops._zeros_small(8, torch.device(DEV))
+    assert len(ops._ZERO_ARENAS) >= 2
+    old.fill_(1.0)
+    ops.zero_arena_clear()
+    assert len(ops._ZERO_ARENAS) == 0
+    assert lib.wm_plane_sums(_ptr(x), _ptr(old), 2, 8, 16, 32, _stream()) == 0     # no longer inside a registered range: zeroed first
+    torch.cuda.synchronize()
+    assert_close(old, ref, 1e-5, "a slice of a cleared arena is an ordinary buffer again")
+    new = ops._zeros_small(8, torch.device(DEV))
+    assert float(new.abs().max()) == 0.0 and new.untyped_storage().data_ptr() != old.untyped_storage().data_ptr()
+    assert_close(ops.plane_sums(x), ref, 1e-5, "plane_sums after the clear")
+
+
 def test_zeros_small_hands_out_zeroed_distinct_slices():
     """ops._zeros_small: slices are zero, 256-byte slots, never handed out twice - across the switch to a fresh block too - and a
     gradient computed into one (plane_sums) matches float64."""

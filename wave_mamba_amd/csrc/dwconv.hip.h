@@ -8,12 +8,23 @@
 //
 // One thread walks a 4-column strip down RH output rows with a 3-row register window, so every
 // input row is fetched once per strip (16-byte loads); the two halo columns come from the
-// neighbouring lanes by wave shuffle (the strip edges of a wave read them from memory).
+// neighbouring lanes by a DPP wave shift (the strip edges of a wave read them from memory).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "haar.hip.h"          // bf16_t, load4 / store4 / ld1 (fp32 and bf16 overloads)
 
 namespace wm {
+
+// A value from the neighbouring lane of the 64-lane wave: one DPP move (v_mov_b32 wave_shr:1 / wave_shl:1) instead of a
+// ds_bpermute through the LDS crossbar (what __shfl_up / __shfl_down compile to).  The lane without a neighbour keeps `own_if_...`.
+__device__ __forceinline__ float dpp_from_lower_lane(float own_if_first, float v) {       // lane i <- lane i - 1; lane 0 keeps `own_if_first`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, own_if_first), __builtin_bit_cast(int, v),
+                                                                 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_upper_lane(float own_if_last, float v) {         // lane i <- lane i + 1; lane 63 keeps `own_if_last`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, own_if_last), __builtin_bit_cast(int, v),
+                                                                 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
 
 constexpr int kDwRows = 16;     // output rows per thread strip (the kernels' `rows` argument: 16, or 8 / 4 where 16 leave the chip short of waves)
 
@@ -70,7 +81,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const TP* __restrict__ x
                     if (w0 + 3 < W) q.w = ld1(p + 3);
                 }
             }
-            float left = __shfl_up(q.w, 1), right = __shfl_down(q.x, 1);
+            float left = dpp_from_lower_lane(q.w, q.w), right = dpp_from_upper_lane(q.x, q.x);
             if (cl == 0) left = (rowok && w0 - 1 >= 0 && w0 - 1 < W) ? ld1(xp + (long long)r * W + w0 - 1) : 0.0f;
             if (cl == LPR - 1) right = (rowok && w0 + 4 < W) ? ld1(xp + (long long)r * W + w0 + 4) : 0.0f;
             v[0] = left; v[1] = q.x; v[2] = q.y; v[3] = q.z; v[4] = q.w; v[5] = right;
@@ -91,7 +102,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const TP* __restrict__ x
         auto finish = [&](int r, const float (&q)[4], float e, float (&v)[6]) {
             const bool rowok = r >= 0 && r < H, ok = rowok && colok;
             const float q0 = ok ? q[0] : 0.f, q1 = ok ? q[1] : 0.f, q2 = ok ? q[2] : 0.f, q3 = ok ? q[3] : 0.f;
-            float left = __shfl_up(q3, 1), right = __shfl_down(q0, 1);
+            float left = dpp_from_lower_lane(q3, q3), right = dpp_from_upper_lane(q0, q0);
             if (cl == 0) left = (rowok && w0 - 1 >= 0 && w0 - 1 < W) ? e : 0.0f;
             if (cl == LPR - 1) right = (rowok && w0 + 4 < W) ? e : 0.0f;
             v[0] = left; v[1] = q0; v[2] = q1; v[3] = q2; v[4] = q3; v[5] = right;
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
                     if (w0 + 3 < W) q.w = p[3];
                 }
             }
-            float left = __shfl_up(q.w, 1), right = __shfl_down(q.x, 1);
+            float left = dpp_from_lower_lane(q.w, q.w), right = dpp_from_upper_lane(q.x, q.x);
             if (cl == 0) left = (rowok && w0 - 1 >= 0 && w0 - 1 < W) ? xp[(long long)r * W + w0 - 1] : 0.0f;
             if (cl == LPR - 1) right = (rowok && w0 + 4 < W) ? xp[(long long)r * W + w0 + 4] : 0.0f;
             v[0] = left; v[1] = q.x; v[2] = q.y; v[3] = q.z; v[4] = q.w; v[5] = right;
@@ -208,7 +219,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
         auto finish = [&](int r, const float4& q, float e, float (&v)[6]) {
             const bool rowok = r >= 0 && r < H, ok = rowok && colok;
             const float q0 = ok ? q.x : 0.f, q1 = ok ? q.y : 0.f, q2 = ok ? q.z : 0.f, q3 = ok ? q.w : 0.f;
-            float left = __shfl_up(q3, 1), right = __shfl_down(q0, 1);
+            float left = dpp_from_lower_lane(q3, q3), right = dpp_from_upper_lane(q0, q0);
             if (cl == 0) left = (rowok && w0 - 1 >= 0 && w0 - 1 < W) ? e : 0.0f;
             if (cl == LPR - 1) right = (rowok && w0 + 4 < W) ? e : 0.0f;
             v[0] = left; v[1] = q0; v[2] = q1; v[3] = q2; v[4] = q3; v[5] = right;

@@ -661,15 +661,6 @@ __global__ __launch_bounds__(256, 4) void lfss_out_conv_mfma_kernel(
 // column before its first and after its last) from one more load that only touches two cache lines.  2 (R + 2) / R load
 // instructions per output value and channel, (R + 2) / R of f; a wave walks `bpw` consecutive bands of ITS strip, so the two rows
 // two bands share come from the cache the wave has just filled.  W % 64 == 0.
-__device__ __forceinline__ float dpp_from_lower_lane(float own_if_first, float v) {       // lane i <- lane i - 1; lane 0 keeps `own_if_first`
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, own_if_first), __builtin_bit_cast(int, v),
-                                                                 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float dpp_from_upper_lane(float own_if_last, float v) {         // lane i <- lane i + 1; lane 63 keeps `own_if_last`
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, own_if_last), __builtin_bit_cast(int, v),
-                                                                 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
-}
-
 template <int R, typename TP>
 __global__ __launch_bounds__(256, 2) void lfss_out_conv_acc_kernel(
     const TP* __restrict__ f, const float* __restrict__ cw /*(D, 3, 3)*/, const float* __restrict__ cbias /*(D) or null*/,

@@ -54,6 +54,11 @@ def _ptr(t):
 # then skips its memset for buffers inside it.  A block lives as long as any slice of it does (the slices are views of its
 # storage); it is unregistered when the next block replaces it.
 # ------------------------------------------------------------------------------------------------
+# ONE-SHOT RULE: a slice is zero exactly once - when it is handed out.  Whoever receives it (a library call that accumulates into
+# it, then autograd, which may keep it as a parameter's .grad) must never pass it to an accumulate-into entry point again: the
+# library would take it for zero (it lies in a registered range) and add onto the old contents.  Nothing in this package does;
+# a caller that keeps such tensors and wants to be safe calls zero_arena_clear() (new slices then come from a fresh block, and
+# the old block, once its last slice is gone, is unregistered and freed).
 _ZERO_ARENA_FLOATS = 1 << 20
 _ZERO_ARENAS = {}            # (device index, stream handle) -> [block, floats handed out]
 _ZERO_ARENA_LOCK = __import__("threading").Lock()
@@ -79,6 +84,17 @@ def _zeros_small(n, device):
         out = ent[0][ent[1]:ent[1] + n]
         ent[1] += step
     return out
+
+
+def zero_arena_clear():
+    """Drop every zeroed arena block (all devices, all streams): each is unregistered from the library now and freed with its last
+    slice.  For long-running processes that create and destroy streams (an entry per (device, stream) would otherwise keep a 4-MB
+    block registered for ever - ADVICE r5), and for callers that re-use gradient tensors handed out of an arena (see the one-shot
+    rule above).  Must not run concurrently with training steps on other threads (their next small output simply opens a new block)."""
+    with _ZERO_ARENA_LOCK:
+        for ent in _ZERO_ARENAS.values():
+            ent[2]()                                       # weakref.finalize: unregister (idempotent)
+        _ZERO_ARENAS.clear()
 
 
 # ------------------------------------------------------------------------------------------------
