@@ -13,12 +13,13 @@ for d in pmc_core pmc_core_bwd; do
   rm -rf $R/$d; mkdir -p $R/$d
   find $P/$d -name "*counter_collection.csv" | while read f; do n=$(echo $f | sed "s#$P/$d/##; s#/#_#g"); cp $f $R/$d/$n; done
 done
-cp $P/bench_core_bwd.txt $R/core_bwd_per_call.txt; cp $P/bench_core_bwd_first_generation.txt $R/core_bwd_per_call_first_generation.txt
+cp $P/bench_core_bwd.txt $R/core_bwd_per_call.txt
 cp $P/pmc_core_bwd_summary.txt $R/pmc_core_bwd_summary.txt
 cp $P/train_step_kernel_breakdown.txt $R/train_step_kernel_breakdown.txt
-cp $P/train_step_kernel_breakdown_first_generation_backward.txt $R/train_step_kernel_breakdown_first_generation_backward.txt
 cp $P/pmc_conv_summary.txt $R/pmc_conv_summary.txt; cp $P/bench_conv_train.txt $R/bench_conv_train.txt; cp $P/bench_lfss_rz.txt $R/bench_lfss_recomputed_gate.txt
 cp gpurun_out/final/bench_default.json $R/bench_default_line.json
+cp gpurun_out/pmc_step/pmc_step_table.txt $R/pmc_step_traffic_per_kernel.txt; cp gpurun_out/final/host_bound.txt $R/host_bound.txt
+tail -3 gpurun_out/final/tests_full.log > $R/tests_gpu_final_build.txt; tail -1 gpurun_out/final/smoke.log >> $R/tests_gpu_final_build.txt
 cat $P/build_id.txt; python -c "
 import sys; sys.path.insert(0, '.')
 from wave_mamba_amd import build; print('local source id', build.source_id())"
