@@ -33,6 +33,9 @@
 #define WM_BWD_DX_LATE 0         // experiment: keep the dx product in registers across one more workgroup barrier before adding it
 #endif
 
+#ifndef WM_BWD_ABLATE_FWD_STATE
+#define WM_BWD_ABLATE_FWD_STATE 0 // diagnostics: 1 = core_bwd_reduce_body without the forward recurrence (wrong results; what handing the forward's states over could save)
+#endif
 #ifndef WM_BWD_STAMP
 #define WM_BWD_STAMP 0           // diagnostics: cycle totals per phase of core_bwd_chunk_kernel (tools/core_bwd_stamps.py)
 #endif
@@ -298,8 +301,10 @@ __device__ __forceinline__ void core_bwd_reduce_body(const CoreBwdArgs& p, float
                             const float4 bv = *reinterpret_cast<const float4*>(&s_B[tt * NP + 4 * r]);
                             const float4 cv = *reinterpret_cast<const float4*>(&s_C[tt * NP + 4 * r]);
                             const v2f a0 = exp2_2(dt2 * A2[2 * r]), a1 = exp2_2(dt2 * A2[2 * r + 1]);
+#if !WM_BWD_ABLATE_FWD_STATE      // timing-only ablation (profiles/r06/core_bwd_summary_pass_ablation.txt): the summary pass without its forward-state half
                             h[2 * r] = a0 * h[2 * r] + du2 * (v2f){bv.x, bv.y};
                             h[2 * r + 1] = a1 * h[2 * r + 1] + du2 * (v2f){bv.z, bv.w};
+#endif
                             pf[2 * r] *= a0; pf[2 * r + 1] *= a1;
                             gl[2 * r] = pf[2 * r] * (dy2 * (v2f){cv.x, cv.y}) + gl[2 * r];
                             gl[2 * r + 1] = pf[2 * r + 1] * (dy2 * (v2f){cv.z, cv.w}) + gl[2 * r + 1];
