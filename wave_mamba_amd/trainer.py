@@ -86,8 +86,8 @@ class GraphedTrainStep:
     """train_step() captured ONCE into a HIP graph (forward, both losses, backward, AdamW) and replayed: a BASELINE config-3 step is
     ~2,500 kernel launches behind ~50 ms of Python and autograd bookkeeping - as much as the GPU needs for the kernels (54 ms), so on a
     host with slower cores the eager step waits for the host (60.6 against 54.8 ms of kernels on one box of the pool, round 5); a
-    replay costs the host one call.  Single-process training only (a DistributedDataParallel reducer inside a capture is not
-    supported here); fixed batch shape; `optimizer` must be make_optimizer(..., capturable=True): its learning rate is a device
+    replay costs the host one call.  Single-process training only (GraphedDDPTrainStep is the data-parallel form: a
+    DistributedDataParallel reducer cannot run inside a capture); fixed batch shape; `optimizer` must be make_optimizer(..., capturable=True): its learning rate is a device
     tensor, so a torch LR scheduler stepped between replays takes effect (it fills the tensor in place; a float lr is refused -
     it would be frozen into the graph).  The warm-up steps are real optimizer steps at the optimizer's current lr.
 
@@ -97,7 +97,7 @@ class GraphedTrainStep:
 
     def __init__(self, net, optimizer, lq, gt, warmup=3):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            raise RuntimeError("GraphedTrainStep: single-process training only")
+            raise RuntimeError("GraphedTrainStep: single-process training only (under torch.distributed: GraphedDDPTrainStep)")
         if not all(g.get("capturable", False) for g in optimizer.param_groups):
             raise RuntimeError("GraphedTrainStep: the optimizer must be capturable (make_optimizer(net, capturable=True))")
         if not all(isinstance(g["lr"], torch.Tensor) and g["lr"].is_cuda for g in optimizer.param_groups):
